@@ -1,0 +1,148 @@
+/* librvb -- C ABI of the MI355X-native Reverb-ASR hot path (gfx950 HIP kernels behind it).
+ *
+ * The reference (revdotcom/reverb) is pure Python and exposes no FFI; its boundary for the
+ * `recognize_wav` hot path is the Python API in asr/wenet/cli/reverb.py and the inner seam
+ * `ASRModel.decode` (asr/wenet/transformer/asr_model.py:331-432).  Each entry point below names
+ * the reference interface it replaces.  The Python host in reverb_amd/ binds these with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions: plain C, opaque handle, every function returns 0 (RVB_OK) or a negative RVB_E*
+ * code; rvb_last_error() returns the calling thread's last error string.  Host buffers are
+ * caller-owned; device memory is library-owned.  One engine per device; an engine is not
+ * thread-safe, distinct engines are.  All device work runs on the engine's own HIP stream and
+ * every function returns after its results are complete on the host.
+ */
+#ifndef RVB_H_
+#define RVB_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVB_OK 0
+#define RVB_E_ARG -1
+#define RVB_E_HIP -2
+#define RVB_E_STATE -3
+#define RVB_E_NOMEM -4
+#define RVB_E_UNSUPPORTED -5
+
+#define RVB_F32 0  /* parity mode: v_mfma_f32_16x16x4_f32, exact f32 fma chains */
+#define RVB_BF16 1 /* throughput mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate/residual */
+
+typedef struct rvb_engine rvb_engine;
+
+/* Model dimensions: the values the reference reads from config.yaml
+ * (asr/wenet/utils/init_model.py:102-183; cli/reverb.py:62-98). */
+typedef struct rvb_model_cfg {
+  int32_t dtype;         /* RVB_F32 | RVB_BF16 */
+  int32_t input_dim;     /* input_dim (80 mel bins) */
+  int32_t vocab;         /* output_dim */
+  int32_t d_model;       /* encoder_conf.output_size */
+  int32_t heads;         /* encoder_conf.attention_heads */
+  int32_t ffn_dim;       /* encoder_conf.linear_units */
+  int32_t num_blocks;    /* encoder_conf.num_blocks (first and last are language-specific if num_langs>0) */
+  int32_t cnn_kernel;    /* encoder_conf.cnn_module_kernel (odd) */
+  int32_t cnn_norm;      /* 0 layer_norm, 1 batch_norm (encoder_conf.cnn_module_norm) */
+  int32_t num_langs;     /* dataset_conf.cat_emb_conf.emb_len when pass_cat_emb, else 0 */
+  int32_t dec_heads;     /* decoder_conf.attention_heads */
+  int32_t dec_ffn_dim;   /* decoder_conf.linear_units */
+  int32_t dec_blocks;    /* decoder_conf.num_blocks   (left decoder) */
+  int32_t dec_r_blocks;  /* decoder_conf.r_num_blocks (right decoder, 0 = none) */
+  int32_t blank_id;      /* ctc_conf.ctc_blank_id */
+  int32_t sos_id;        /* vocab-1 (asr_model.py:79-82) */
+  int32_t eos_id;
+  int32_t max_chunks;    /* chunks per device batch (workspace sizing) */
+  int32_t chunk_frames;  /* max input frames per chunk (2051, cli/reverb.py:188) */
+} rvb_model_cfg;
+
+const char* rvb_last_error(void);
+const char* rvb_version(void);
+
+/* ReverbASR.__init__ / init_model / load_checkpoint (cli/reverb.py:46-98,
+ * utils/init_model.py:99-277, utils/checkpoint.py:29-80): create an engine, stream the
+ * state-dict tensors in by their reference names (fp32, host memory), then finalize. */
+int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out);
+void rvb_destroy(rvb_engine* e);
+int rvb_load_tensor(rvb_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
+/* Fold the language-specific linear layers with `cat_embs` = [verbatimicity, 1-verbatimicity]
+ * (cli/reverb.py:215-217; encoder_layer.py:378-390, decoder_layer.py:319-330), pack weights to
+ * the compute dtype, precompute the per-layer positional keys.  May be called again with other
+ * cat_embs.  Fails listing the first missing tensor. */
+int rvb_finalize(rvb_engine* e, const float* cat_embs, int n_cat);
+
+/* ReverbASR.compute_feats (cli/reverb.py:119-146): Kaldi fbank of 16 kHz mono int16 PCM.
+ * rvb_upload_pcm copies the samples to HBM; rvb_fbank computes [n_frames,80] log-mel on the
+ * device (kept resident, zero-padded to whole chunks) and optionally copies it to feats_out. */
+int64_t rvb_num_frames(int64_t n_samples);
+int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
+int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int64_t* n_frames);
+
+/* ASRModel._forward_encoder + ctc_logprobs + per-frame top-`beam` (asr_model.py:288-329,378-389,
+ * search.py:155): encode a batch of B chunks of T0 frames.  feats: host fp32 [B,T0,80], or NULL
+ * to read chunk rows [first_chunk, first_chunk+B) of the device-resident rvb_fbank output.
+ * lens: valid input frames per chunk (feats_batcher, cli/reverb.py:148-180). */
+int rvb_encode(rvb_engine* e, const float* feats, int64_t first_chunk, const int32_t* lens, int B, int T0,
+               int beam, float blank_penalty);
+int rvb_encoder_frames(rvb_engine* e, int32_t* T_out);                 /* encoder frames per chunk (512) */
+int rvb_get_encoder_lens(rvb_engine* e, int32_t* lens /* [B] */);      /* encoder_mask.sum (asr_model.py:387) */
+int rvb_get_encoder_out(rvb_engine* e, float* out /* [B,T,d] */);      /* parity tap */
+int rvb_get_ctc_logprobs(rvb_engine* e, int chunk, float* out /* [T,V] */); /* parity tap */
+int rvb_get_ctc_topk(rvb_engine* e, float* vals, int32_t* idx /* [B,T,beam] each */);
+
+/* ctc_greedy_search (search.py:106-121): tokens [B,T] (first ntok[b] valid) and the frame of each
+ * token's first emission. */
+int rvb_ctc_greedy(rvb_engine* e, int32_t* tokens, int32_t* ntok, int32_t* frames);
+
+/* ctc_prefix_beam_search (search.py:124-248), float64 host arithmetic, one host thread per chunk.
+ * Results are kept in the engine; read them with rvb_get_nbest. */
+int rvb_ctc_prefix_beam(rvb_engine* e, int beam);
+int rvb_get_nbest_count(rvb_engine* e, int chunk, int32_t* n_hyps, int32_t* max_len);
+/* tokens/times: [n_hyps][max_len] padded with -1; lens/times_lens/scores: [n_hyps] */
+int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens,
+                  double* scores);
+
+/* attention_rescoring (search.py:363-448) over the stored n-best of every chunk of the batch.
+ * Per chunk: index of the winning hypothesis, its score (fp32 accumulation as the reference),
+ * confidence, and per-token confidences [max_len] of the winner. */
+int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight);
+int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence,
+                     double* tokens_confidence /* [len of best] */);
+/* per-hypothesis decoder log-probs of the last rescoring (parity tap): for hyp i of `chunk`,
+ * out[j] = log p(w_j | ...) for j < len and out[len] = log p(eos); right=1 for the r2l decoder */
+int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out);
+
+/* Stage timing (HIP events on the engine stream).  When enabled every kernel family is bracketed;
+ * names: "fbank","subsample","gemm","attention","rownorm","glu_dwconv","ctc_topk","embed",
+ * "lse_gather","search_host".  flops: algorithmic FLOPs launched (gemm/attention only). */
+int rvb_set_profiling(rvb_engine* e, int enabled);
+int rvb_reset_timings(rvb_engine* e);
+int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, int64_t* launches);
+
+/* ---- raw kernel entry points for unit tests (host buffers in, host buffers out) ---- */
+int rvb_test_gemm(int dtype, const float* A, const float* W, const float* bias, const float* res, float* C,
+                  int M, int N, int K, float alpha, int act, int out_f32,
+                  int conv, int cT1, int cF1, int cC, int cB);
+int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, int mode,
+                     int silu, const float* add, float* out, int out_f32, int M, int d);
+int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
+                   const float* b, float* out, int B, int T0, int F0, int d);
+int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
+                        const int32_t* lens, float* out, int B, int T, int d, int K);
+int rvb_test_attention(int dtype, const float* q, const float* k, const float* v, const float* p,
+                       const float* bias_u, const float* bias_v, float* out, int q_rows, int kv_rows, int p_rows,
+                       int heads, int dk, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
+                       const int32_t* kv_len, int nseq, int causal);
+int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float blank_penalty, int blank_id,
+                             float* topk_val, int32_t* topk_idx, float* logp);
+int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target, float* out);
+int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats /* [frames,80] */);
+/* native prefix beam search on host arrays: top-k log-probs/indices [T,beam] of one utterance */
+int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank,
+                         int32_t* n_hyps, int32_t* tokens /* [beam][T] */, int32_t* lens, int32_t* times,
+                         int32_t* times_lens, double* scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVB_H_ */

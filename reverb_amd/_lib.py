@@ -1,0 +1,123 @@
+"""ctypes binding of librvb.so (the C ABI declared in include/rvb.h).
+
+The library is built in-tree by `reverb_amd.build` (hipcc, gfx950).  There is no CPU fallback:
+if the shared object is missing, or no HIP device is present when an engine is created, the
+error is raised to the caller.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvb.so")
+
+RVB_F32, RVB_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+NORM_LN, NORM_AFFINE = 0, 1
+
+
+class RvbError(RuntimeError):
+    pass
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "input_dim", "vocab", "d_model", "heads", "ffn_dim", "num_blocks", "cnn_kernel",
+        "cnn_norm", "num_langs", "dec_heads", "dec_ffn_dim", "dec_blocks", "dec_r_blocks", "blank_id",
+        "sos_id", "eos_id", "max_chunks", "chunk_frames")]
+
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i16p = C.POINTER(C.c_int16)
+_i64p = C.POINTER(C.c_int64)
+_eng = C.c_void_p
+
+# every exported symbol of include/rvb.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "rvb_last_error": (C.c_char_p, []),
+    "rvb_version": (C.c_char_p, []),
+    "rvb_create": (C.c_int, [C.POINTER(ModelCfg), C.c_int, C.POINTER(_eng)]),
+    "rvb_destroy": (None, [_eng]),
+    "rvb_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),
+    "rvb_finalize": (C.c_int, [_eng, _f32p, C.c_int]),
+    "rvb_num_frames": (C.c_int64, [C.c_int64]),
+    "rvb_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),
+    "rvb_encode": (C.c_int, [_eng, _f32p, C.c_int64, _i32p, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "rvb_encoder_frames": (C.c_int, [_eng, _i32p]),
+    "rvb_get_encoder_lens": (C.c_int, [_eng, _i32p]),
+    "rvb_get_encoder_out": (C.c_int, [_eng, _f32p]),
+    "rvb_get_ctc_logprobs": (C.c_int, [_eng, C.c_int, _f32p]),
+    "rvb_get_ctc_topk": (C.c_int, [_eng, _f32p, _i32p]),
+    "rvb_ctc_greedy": (C.c_int, [_eng, _i32p, _i32p, _i32p]),
+    "rvb_ctc_prefix_beam": (C.c_int, [_eng, C.c_int]),
+    "rvb_get_nbest_count": (C.c_int, [_eng, C.c_int, _i32p, _i32p]),
+    "rvb_get_nbest": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "rvb_attention_rescore": (C.c_int, [_eng, C.c_double, C.c_double]),
+    "rvb_get_rescored": (C.c_int, [_eng, C.c_int, _i32p, _f32p, _f64p, _f64p]),
+    "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
+    "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
+    "rvb_reset_timings": (C.c_int, [_eng]),
+    "rvb_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),
+    "rvb_test_gemm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
+                                   C.c_int, C.c_int]),
+    "rvb_test_conv1": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rvb_test_glu_dwconv": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int]),
+    "rvb_test_attention": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_int, C.c_int]),
+    "rvb_test_logsoftmax_topk": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _f32p]),
+    "rvb_test_lse_gather": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _f32p]),
+    "rvb_test_fbank": (C.c_int, [_i16p, C.c_int64, _f32p]),
+    "rvb_test_prefix_beam": (C.c_int, [_f32p, _i32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                       _f64p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen librvb.so and declare every prototype; raises if the build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RvbError(f"{LIB_PATH} not found: run `python -m reverb_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback for the Reverb-ASR hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().rvb_last_error()
+        raise RvbError(f"{what or 'librvb'} failed ({rc}): {msg.decode('utf8', 'replace') if msg else ''}")
+
+
+def fptr(a):
+    """float32 C-contiguous numpy array -> float* (None passes NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(_f32p)
+
+
+def iptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_i32p)
+
+
+def dptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_f64p)

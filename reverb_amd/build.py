@@ -1,0 +1,66 @@
+"""Build librvb.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+
+`python -m reverb_amd.build` or `reverb_amd.build.build()`.  hipcc cross-compiles without a GPU.
+Objects are cached under reverb_amd/csrc/_build and rebuilt when a source or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "librvb.so")
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "fbank.hip", "engine.hip", "test_api.hip", "search.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "rvb.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    bdir = os.path.join(CSRC, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + _headers()):
+        lang = ["-x", "hip"] if src.endswith(".hip") else []
+        cmd = [HIPCC] + FLAGS + lang + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=True):
+    if force:
+        for f in os.listdir(os.path.join(CSRC, "_build")) if os.path.isdir(os.path.join(CSRC, "_build")) else []:
+            os.remove(os.path.join(CSRC, "_build", f))
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if _stale(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,97 @@
+// Shared device/host helpers for librvb (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace rvb {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type of the bf16 compute mode)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+  union { uint32_t u; float f; } x;
+  x.u = ((uint32_t)v) << 16;
+  return x.f;
+}
+// round-to-nearest-even (matches torch's float->bfloat16 conversion)
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union { uint32_t u; float f; } x;
+  x.f = f;
+  if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);  // NaN
+  x.u += 0x7fffu + ((x.u >> 16) & 1u);
+  return (bf16_t)(x.u >> 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  __host__ __device__ static inline float to_f32(float v) { return v; }
+  __host__ __device__ static inline float from_f32(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  __host__ __device__ static inline float to_f32(bf16_t v) { return bf16_to_f32(v); }
+  __host__ __device__ static inline bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// One 16-byte vector of T per lane per operand = one "K chunk" of 64 bytes per matrix row:
+//   bf16 : 8 elems/lane, one v_mfma_f32_16x16x32_bf16       (K chunk = 32)
+//   f32  : 4 elems/lane, four v_mfma_f32_16x16x4_f32        (K chunk = 16)
+// A operand: lane l holds row (l&15), bytes [(l>>4)*16, +16) of the chunk; B operand likewise
+// for column (l&15).  The k <-> (lane group, element) assignment is the same for A and B, so the
+// contraction is exact whatever k order the hardware uses inside one instruction.
+// C/D: lane l holds C[(l>>4)*4 + r][l&15], r = 0..3.
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  static constexpr int KC = 32;   // elements of K per chunk
+  static constexpr int VE = 8;    // elements per 16-byte vector
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    union U { uint4 u; bf16x8_t v; };
+    U ua, ub;
+    ua.u = a; ub.u = b;
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<float> {
+  static constexpr int KC = 16;
+  static constexpr int VE = 4;
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ status codes (include/rvb.h)
+enum { OK = 0, E_ARG = -1, E_HIP = -2, E_STATE = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
+
+}  // namespace rvb
+
+#define RVB_HIP_CHECK(expr)                                                             \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      rvb::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+      return rvb::E_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+namespace rvb {
+void set_error(const std::string& msg);  // thread-local last error (api.cpp)
+}

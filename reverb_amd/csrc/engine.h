@@ -1,0 +1,109 @@
+// Engine: weights, workspace and orchestration of the Reverb-ASR hot path on one MI355X.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rvb.h"
+#include "kernels.h"
+#include "search.h"
+
+namespace rvb {
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n);   // grow-only
+  void release();
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Linear {      // y = x.W^T + b, W packed to the compute dtype [out][in]
+  DevBuf w, b;
+  int out = 0, in = 0;
+};
+struct LNorm { DevBuf g, b; float eps = 1e-5f; };
+
+struct EncLayer {
+  Linear ffm1, ffm2, ff1, ff2, qkv, att_out, pw1, pw2, lsl;
+  DevBuf pos_keys;            // T [Tpos, d] = linear_pos(pe[:Tpos])
+  DevBuf bias_u, bias_v;      // fp32 [h*dk]
+  LNorm n_ffm, n_mha, n_conv, n_ff, n_final, n_cnn;
+  DevBuf dw_w, dw_b;          // fp32 [d][K], [d]
+  bool is_lsl = false;
+};
+struct DecLayer {
+  Linear self_qkv, self_out, src_q, src_kv, src_out, ff1, ff2, lsl;
+  LNorm n1, n2, n3;
+  bool is_lsl = false;
+};
+struct Decoder {
+  DevBuf embed;               // fp32 [V][d]
+  Linear out;
+  LNorm after;
+  std::vector<DecLayer> layers;
+  bool present = false;
+};
+
+struct ProfEntry { double ms = 0, flops = 0; int64_t launches = 0; };
+
+struct RescoreResult {
+  int best = 0;
+  float score = 0.f;
+  double confidence = 0.0;
+  std::vector<double> tok_conf;
+  std::vector<std::vector<float>> logp, rlogp;   // per hyp: len+1 decoder log-probs
+};
+
+}  // namespace rvb
+
+struct rvb_engine {
+  rvb_model_cfg cfg;
+  int device = 0;
+  int dtype = 0;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+
+  std::map<std::string, rvb::HostTensor> host;   // staged state dict (fp32)
+
+  // ---- packed weights ----
+  rvb::DevBuf cmvn_mean, cmvn_istd, conv1_w, conv1_b;
+  rvb::Linear conv2, embed_out, ctc;
+  rvb::LNorm enc_after;
+  std::vector<rvb::EncLayer> enc;
+  rvb::Decoder dec_l, dec_r;
+  rvb::DevBuf pe_f32;            // fp32 [pe_rows][d] sinusoid table
+  int pe_rows = 0;
+  rvb::DevBuf fb_window, fb_twiddle, fb_melw, fb_lo, fb_hi;
+  rvb::DevBuf stage;             // fp32 staging for weight packing
+
+  // ---- audio / features ----
+  rvb::DevBuf pcm, feats;        // int16 [n], fp32 [chunks*T0pad][80]
+  int64_t n_samples = 0, n_frames = 0, feat_rows = 0;
+
+  // ---- batch state ----
+  int B = 0, T0 = 0, T1 = 0, F1 = 0, T2 = 0, F2 = 0, beam = 0;
+  std::vector<int32_t> in_lens, enc_lens;
+  rvb::DevBuf d_feats_in, X1, X2, x, xn, y, h, ao, dconv, enc_out, logits, topv, topi;
+  rvb::DevBuf d_enc_lens, d_seq_start, d_seq_len, d_aux_i32;
+  std::vector<float> h_topv;
+  std::vector<int32_t> h_topi;
+  std::vector<rvb::PrefixResult> nbest;
+  std::vector<rvb::RescoreResult> rescored;
+  // decoder workspace
+  rvb::DevBuf dx, dxn, dy, dh, dqkv, dq, dao, kvmem, d_tok, d_pos, d_tgt, d_logp;
+  rvb::DevBuf d_hq_start, d_hq_len, d_hkv_start, d_hkv_len;
+
+  // ---- profiling ----
+  bool profiling = false;
+  std::map<std::string, rvb::ProfEntry> prof;
+  struct Pending { hipEvent_t a, b; std::string name; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};

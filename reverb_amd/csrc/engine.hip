@@ -1,0 +1,987 @@
+// librvb engine: weight packing, workspace and the encode / search / rescore pipeline.
+// Orchestrates the kernels of gemm.hip, attention.hip, elementwise.hip, fbank.hip so that one call
+// processes a whole batch of 20.51 s chunks (the reference loops chunk by chunk with batch 1,
+// asr/wenet/cli/reverb.py:220-253).  Reference structure followed per stage is cited inline.
+#include "engine.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace rvb {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error() { return g_err.c_str(); }
+
+int DevBuf::ensure(size_t n) {
+  if (n <= bytes && p) return OK;
+  if (p) { hipFree(p); p = nullptr; bytes = 0; }
+  if (n == 0) n = 16;
+  hipError_t err = hipMalloc(&p, n);
+  if (err != hipSuccess) {
+    p = nullptr;
+    set_error("hipMalloc of " + std::to_string(n) + " bytes failed: " + hipGetErrorString(err));
+    return E_NOMEM;
+  }
+  bytes = n;
+  return OK;
+}
+void DevBuf::release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+
+#define RVB_TRY(expr) do { int _r = (expr); if (_r != OK) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------ profiling
+struct Scope {
+  rvb_engine* e; hipEvent_t a = nullptr, b = nullptr; std::string name;
+  Scope(rvb_engine* e_, const char* n, double flops = 0.0) : e(e_), name(n) {
+    auto& pe = e->prof[name];
+    pe.launches += 1; pe.flops += flops;
+    if (!e->profiling) return;
+    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else hipEventCreate(&ev); return ev; };
+    a = get(); b = get();
+    hipEventRecord(a, e->stream);
+  }
+  ~Scope() {
+    if (!a) return;
+    hipEventRecord(b, e->stream);
+    e->pending.push_back({a, b, name});
+  }
+};
+static void drain_prof(rvb_engine* e) {
+  if (e->pending.empty()) return;
+  hipStreamSynchronize(e->stream);
+  for (auto& p : e->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    e->prof[p.name].ms += ms;
+    e->event_pool.push_back(p.a); e->event_pool.push_back(p.b);
+  }
+  e->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------ helpers
+static int upload_f32(rvb_engine* e, DevBuf& dst, const float* src, size_t n) {
+  RVB_TRY(dst.ensure(n * 4));
+  RVB_HIP_CHECK(hipMemcpyAsync(dst.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
+  return OK;
+}
+static int upload_i32(rvb_engine* e, DevBuf& dst, const int32_t* src, size_t n) {
+  RVB_TRY(dst.ensure(n * 4 + 16));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(dst.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
+  return OK;
+}
+// fp32 host matrix -> compute dtype on device
+static int pack_T(rvb_engine* e, DevBuf& dst, const float* src, size_t n) {
+  RVB_TRY(dst.ensure(n * dt_size(e->dtype)));
+  if (e->dtype == DT_F32) {
+    RVB_HIP_CHECK(hipMemcpyAsync(dst.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
+    return OK;
+  }
+  RVB_TRY(e->stage.ensure(n * 4));
+  RVB_HIP_CHECK(hipMemcpyAsync(e->stage.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
+  return convert_f32(e->stream, e->dtype, e->stage.as<float>(), dst.p, n);
+}
+static int pack_linear(rvb_engine* e, Linear& L, const float* w, const float* b, int out, int in) {
+  L.out = out; L.in = in;
+  RVB_TRY(pack_T(e, L.w, w, (size_t)out * in));
+  if (b) RVB_TRY(upload_f32(e, L.b, b, out)); else L.b.release();
+  return OK;
+}
+
+static const HostTensor* find(rvb_engine* e, const std::string& name) {
+  auto it = e->host.find(name);
+  return it == e->host.end() ? nullptr : &it->second;
+}
+static int need(rvb_engine* e, const std::string& name, size_t numel, const HostTensor** out) {
+  const HostTensor* t = find(e, name);
+  if (!t) { set_error("missing tensor: " + name); return E_STATE; }
+  if (t->numel() != numel) {
+    set_error("tensor " + name + " has " + std::to_string(t->numel()) + " elements, expected " + std::to_string(numel));
+    return E_ARG;
+  }
+  *out = t;
+  return OK;
+}
+static int pack_named_linear(rvb_engine* e, Linear& L, const std::string& p, int out, int in, bool bias = true) {
+  const HostTensor *w, *b = nullptr;
+  RVB_TRY(need(e, p + ".weight", (size_t)out * in, &w));
+  if (bias) RVB_TRY(need(e, p + ".bias", out, &b));
+  return pack_linear(e, L, w->data.data(), b ? b->data.data() : nullptr, out, in);
+}
+static int pack_norm(rvb_engine* e, LNorm& n, const std::string& p, int d, float eps) {
+  const HostTensor *g, *b;
+  RVB_TRY(need(e, p + ".weight", d, &g));
+  RVB_TRY(need(e, p + ".bias", d, &b));
+  n.eps = eps;
+  RVB_TRY(upload_f32(e, n.g, g->data.data(), d));
+  return upload_f32(e, n.b, b->data.data(), d);
+}
+// concatenate several [rows_i, in] linears along the output dim
+static int pack_concat(rvb_engine* e, Linear& L, const std::vector<std::string>& names, int out_each, int in) {
+  std::vector<float> w((size_t)names.size() * out_each * in), b((size_t)names.size() * out_each);
+  for (size_t i = 0; i < names.size(); ++i) {
+    const HostTensor *tw, *tb;
+    RVB_TRY(need(e, names[i] + ".weight", (size_t)out_each * in, &tw));
+    RVB_TRY(need(e, names[i] + ".bias", out_each, &tb));
+    memcpy(w.data() + i * (size_t)out_each * in, tw->data.data(), (size_t)out_each * in * 4);
+    memcpy(b.data() + i * (size_t)out_each, tb->data.data(), (size_t)out_each * 4);
+  }
+  int r = pack_linear(e, L, w.data(), b.data(), (int)names.size() * out_each, in);
+  if (r == OK) hipStreamSynchronize(e->stream);   // w/b go out of scope
+  return r;
+}
+// language-specific layers folded with the category weights: W = sum_i c_i W_i, b = sum_i c_i b_i
+// (encoder_layer.py:378-390, decoder_layer.py:319-330 with 1-D cat_embs)
+static int pack_lsl(rvb_engine* e, Linear& L, const std::string& p, int d, const float* cat, int ncat) {
+  std::vector<float> w((size_t)d * d, 0.f), b(d, 0.f);
+  for (int i = 0; i < ncat; ++i) {
+    const HostTensor *tw, *tb;
+    const std::string n = p + ".language_layers." + std::to_string(i);
+    RVB_TRY(need(e, n + ".weight", (size_t)d * d, &tw));
+    RVB_TRY(need(e, n + ".bias", d, &tb));
+    const float c = cat[i];
+    if (i == 0) {
+      for (size_t k = 0; k < w.size(); ++k) w[k] = c * tw->data[k];
+      for (int k = 0; k < d; ++k) b[k] = c * tb->data[k];
+    } else {
+      for (size_t k = 0; k < w.size(); ++k) w[k] = w[k] + c * tw->data[k];
+      for (int k = 0; k < d; ++k) b[k] = b[k] + c * tb->data[k];
+    }
+  }
+  int r = pack_linear(e, L, w.data(), b.data(), d, d);
+  if (r == OK) hipStreamSynchronize(e->stream);
+  return r;
+}
+
+// sinusoid table, transformer/embedding.py:48-56 (float32 arithmetic as torch does it)
+static void make_pe(int rows, int d, std::vector<float>* pe) {
+  pe->assign((size_t)rows * d, 0.f);
+  const float c = (float)(-(std::log(10000.0) / (double)d));
+  for (int i = 0; i < d; i += 2) {
+    const float div = std::exp((float)i * c);
+    for (int pos = 0; pos < rows; ++pos) {
+      const float ang = (float)pos * div;
+      (*pe)[(size_t)pos * d + i] = std::sin(ang);
+      if (i + 1 < d) (*pe)[(size_t)pos * d + i + 1] = std::cos(ang);
+    }
+  }
+}
+
+// Kaldi mel banks / povey window / FFT twiddles (see oracle/fbank_ref.py for the restatement)
+static int make_fbank_tables(rvb_engine* e) {
+  const int WIN = 400, NFFT = 512, NBIN = 257, NMEL = 80;
+  const double PI = 3.14159265358979323846;
+  std::vector<float> win(WIN), tw(2 * 256), melw((size_t)NMEL * NBIN, 0.f);
+  std::vector<int32_t> lo(NMEL, NBIN), hi(NMEL, 0);
+  for (int i = 0; i < WIN; ++i) win[i] = (float)std::pow(0.5 - 0.5 * std::cos(2.0 * PI * i / (WIN - 1)), 0.85);
+  for (int k = 0; k < 256; ++k) { tw[2 * k] = (float)std::cos(2.0 * PI * k / NFFT); tw[2 * k + 1] = (float)(-std::sin(2.0 * PI * k / NFFT)); }
+  auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+  const double mlo = mel(20.0), mhi = mel(8000.0), delta = (mhi - mlo) / (NMEL + 1);
+  for (int m = 0; m < NMEL; ++m) {
+    const double left = mlo + m * delta, center = left + delta, right = center + delta;
+    for (int b = 0; b < NFFT / 2; ++b) {
+      const double mf = mel(16000.0 / NFFT * b);
+      const double up = (mf - left) / (center - left), down = (right - mf) / (right - center);
+      const double w = std::max(0.0, std::min(up, down));
+      if (w > 0.0) {
+        melw[(size_t)m * NBIN + b] = (float)w;
+        lo[m] = std::min(lo[m], b); hi[m] = std::max(hi[m], b + 1);
+      }
+    }
+    if (hi[m] == 0) lo[m] = 0;
+  }
+  RVB_TRY(upload_f32(e, e->fb_window, win.data(), win.size()));
+  RVB_TRY(upload_f32(e, e->fb_twiddle, tw.data(), tw.size()));
+  RVB_TRY(upload_f32(e, e->fb_melw, melw.data(), melw.size()));
+  RVB_TRY(upload_i32(e, e->fb_lo, lo.data(), lo.size()));
+  RVB_TRY(upload_i32(e, e->fb_hi, hi.data(), hi.size()));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+static int out_frames(int T0) { const int T1 = (T0 - 3) / 2 + 1; return (T1 - 3) / 2 + 1; }
+
+// ------------------------------------------------------------------------------------ gemm wrapper
+static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void* C, int ldc, int M, bool out_f32,
+                    float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.W = L.w.p; g.bias = L.b.as<float>(); g.res = res; g.C = C;
+  g.M = M; g.N = L.out; g.K = L.in; g.lda = lda; g.ldw = L.in; g.ldc = ldc; g.ldres = ldres;
+  g.alpha = alpha; g.act = act; g.out_f32 = out_f32 ? 1 : 0;
+  Scope sc(e, "gemm", 2.0 * M * (double)L.out * L.in);
+  return gemm(e->stream, e->dtype, g);
+}
+static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bool out_f32, int M, int d,
+                    int mode = NORM_LN, int silu = 0, const void* add = nullptr) {
+  NormArgs a;
+  a.x = x; a.gamma = n.g.as<float>(); a.beta = n.b.as<float>(); a.eps = n.eps; a.mode = mode; a.silu = silu;
+  a.add = add; a.out = out; a.out_f32 = out_f32 ? 1 : 0; a.M = M; a.d = d;
+  Scope sc(e, "rownorm");
+  return rownorm(e->stream, e->dtype, a);
+}
+
+// ------------------------------------------------------------------------------------ finalize
+static int pack_decoder(rvb_engine* e, Decoder& D, const std::string& p, int nblocks, const float* cat, int ncat) {
+  const int d = e->cfg.d_model, V = e->cfg.vocab, ff = e->cfg.dec_ffn_dim;
+  D.present = false;
+  if (nblocks <= 0 || !find(e, p + ".embed.0.weight")) return OK;
+  const HostTensor* emb;
+  RVB_TRY(need(e, p + ".embed.0.weight", (size_t)V * d, &emb));
+  RVB_TRY(upload_f32(e, D.embed, emb->data.data(), emb->data.size()));
+  RVB_TRY(pack_norm(e, D.after, p + ".after_norm", d, 1e-5f));
+  RVB_TRY(pack_named_linear(e, D.out, p + ".output_layer", V, d));
+  D.layers.resize(nblocks);
+  for (int j = 0; j < nblocks; ++j) {
+    DecLayer& L = D.layers[j];
+    const std::string q = p + ".decoders." + std::to_string(j);
+    L.is_lsl = find(e, q + ".language_layers.0.weight") != nullptr;
+    const float eps = L.is_lsl ? 1e-12f : 1e-5f;   // decoder_layer.py:56-58 vs :241-243
+    RVB_TRY(pack_concat(e, L.self_qkv, {q + ".self_attn.linear_q", q + ".self_attn.linear_k", q + ".self_attn.linear_v"}, d, d));
+    RVB_TRY(pack_named_linear(e, L.self_out, q + ".self_attn.linear_out", d, d));
+    RVB_TRY(pack_named_linear(e, L.src_q, q + ".src_attn.linear_q", d, d));
+    RVB_TRY(pack_concat(e, L.src_kv, {q + ".src_attn.linear_k", q + ".src_attn.linear_v"}, d, d));
+    RVB_TRY(pack_named_linear(e, L.src_out, q + ".src_attn.linear_out", d, d));
+    RVB_TRY(pack_named_linear(e, L.ff1, q + ".feed_forward.w_1", ff, d));
+    RVB_TRY(pack_named_linear(e, L.ff2, q + ".feed_forward.w_2", d, ff));
+    RVB_TRY(pack_norm(e, L.n1, q + ".norm1", d, eps));
+    RVB_TRY(pack_norm(e, L.n2, q + ".norm2", d, eps));
+    RVB_TRY(pack_norm(e, L.n3, q + ".norm3", d, eps));
+    if (L.is_lsl) RVB_TRY(pack_lsl(e, L.lsl, q, d, cat, ncat));
+  }
+  D.present = true;
+  return OK;
+}
+
+static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
+  const rvb_model_cfg& c = e->cfg;
+  const int d = c.d_model, h = c.heads, ff = c.ffn_dim, K = c.cnn_kernel, V = c.vocab, F0 = c.input_dim;
+  const int F1 = (F0 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  if (c.num_langs > 0 && ncat != c.num_langs) { set_error("finalize: cat_embs length must equal num_langs"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+
+  if (!e->finalized) {
+    const HostTensor *t, *t2;
+    RVB_TRY(need(e, "encoder.global_cmvn.mean", F0, &t));
+    RVB_TRY(upload_f32(e, e->cmvn_mean, t->data.data(), F0));
+    RVB_TRY(need(e, "encoder.global_cmvn.istd", F0, &t));
+    RVB_TRY(upload_f32(e, e->cmvn_istd, t->data.data(), F0));
+    RVB_TRY(need(e, "encoder.embed.conv.0.weight", (size_t)d * 9, &t));
+    RVB_TRY(upload_f32(e, e->conv1_w, t->data.data(), (size_t)d * 9));
+    RVB_TRY(need(e, "encoder.embed.conv.0.bias", d, &t));
+    RVB_TRY(upload_f32(e, e->conv1_b, t->data.data(), d));
+    {  // conv2 [co][ci][kh][kw] -> [co][(kh*3+kw)*d + ci]  (K-contiguous rows for the implicit GEMM)
+      RVB_TRY(need(e, "encoder.embed.conv.2.weight", (size_t)d * d * 9, &t));
+      RVB_TRY(need(e, "encoder.embed.conv.2.bias", d, &t2));
+      std::vector<float> w((size_t)d * 9 * d);
+      for (int co = 0; co < d; ++co)
+        for (int ci = 0; ci < d; ++ci)
+          for (int k = 0; k < 9; ++k) w[((size_t)co * 9 + k) * d + ci] = t->data[((size_t)co * d + ci) * 9 + k];
+      RVB_TRY(pack_linear(e, e->conv2, w.data(), t2->data.data(), d, 9 * d));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    {  // out.0 [o][c*F2+f] -> [o][f*d+c]: our conv2 output is (t, f, c) not the reference's (t, c, f)
+      RVB_TRY(need(e, "encoder.embed.out.0.weight", (size_t)d * d * F2, &t));
+      RVB_TRY(need(e, "encoder.embed.out.0.bias", d, &t2));
+      std::vector<float> w((size_t)d * d * F2);
+      for (int o = 0; o < d; ++o)
+        for (int cc = 0; cc < d; ++cc)
+          for (int f = 0; f < F2; ++f) w[(size_t)o * d * F2 + (size_t)f * d + cc] = t->data[(size_t)o * d * F2 + (size_t)cc * F2 + f];
+      RVB_TRY(pack_linear(e, e->embed_out, w.data(), t2->data.data(), d, d * F2));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    RVB_TRY(pack_norm(e, e->enc_after, "encoder.after_norm", d, 1e-5f));
+    RVB_TRY(pack_named_linear(e, e->ctc, "ctc.ctc_lo", V, d));
+
+    // sinusoid table for encoder positions and decoder positions
+    const int Tmax = out_frames(c.chunk_frames);
+    e->pe_rows = std::max(Tmax + 2, 64);
+    std::vector<float> pe;
+    make_pe(e->pe_rows, d, &pe);
+    RVB_TRY(upload_f32(e, e->pe_f32, pe.data(), pe.size()));
+    DevBuf pe_T;
+    RVB_TRY(pack_T(e, pe_T, pe.data(), pe.size()));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+
+    e->enc.resize(c.num_blocks);
+    for (int i = 0; i < c.num_blocks; ++i) {
+      EncLayer& L = e->enc[i];
+      const std::string p = "encoder.encoders." + std::to_string(i);
+      L.is_lsl = find(e, p + ".language_layers.0.weight") != nullptr;
+      RVB_TRY(pack_named_linear(e, L.ffm1, p + ".feed_forward_macaron.w_1", ff, d));
+      RVB_TRY(pack_named_linear(e, L.ffm2, p + ".feed_forward_macaron.w_2", d, ff));
+      RVB_TRY(pack_named_linear(e, L.ff1, p + ".feed_forward.w_1", ff, d));
+      RVB_TRY(pack_named_linear(e, L.ff2, p + ".feed_forward.w_2", d, ff));
+      RVB_TRY(pack_concat(e, L.qkv, {p + ".self_attn.linear_q", p + ".self_attn.linear_k", p + ".self_attn.linear_v"}, d, d));
+      RVB_TRY(pack_named_linear(e, L.att_out, p + ".self_attn.linear_out", d, d));
+      RVB_TRY(pack_named_linear(e, L.pw1, p + ".conv_module.pointwise_conv1", 2 * d, d));
+      RVB_TRY(pack_named_linear(e, L.pw2, p + ".conv_module.pointwise_conv2", d, d));
+      RVB_TRY(need(e, p + ".self_attn.pos_bias_u", d, &t));
+      RVB_TRY(upload_f32(e, L.bias_u, t->data.data(), d));
+      RVB_TRY(need(e, p + ".self_attn.pos_bias_v", d, &t));
+      RVB_TRY(upload_f32(e, L.bias_v, t->data.data(), d));
+      RVB_TRY(need(e, p + ".conv_module.depthwise_conv.weight", (size_t)d * K, &t));
+      RVB_TRY(upload_f32(e, L.dw_w, t->data.data(), (size_t)d * K));
+      RVB_TRY(need(e, p + ".conv_module.depthwise_conv.bias", d, &t));
+      RVB_TRY(upload_f32(e, L.dw_b, t->data.data(), d));
+      RVB_TRY(pack_norm(e, L.n_ffm, p + ".norm_ff_macaron", d, 1e-5f));
+      RVB_TRY(pack_norm(e, L.n_mha, p + ".norm_mha", d, 1e-5f));
+      RVB_TRY(pack_norm(e, L.n_conv, p + ".norm_conv", d, 1e-5f));
+      RVB_TRY(pack_norm(e, L.n_ff, p + ".norm_ff", d, 1e-5f));
+      RVB_TRY(pack_norm(e, L.n_final, p + ".norm_final", d, 1e-5f));
+      if (c.cnn_norm == 0) {
+        RVB_TRY(pack_norm(e, L.n_cnn, p + ".conv_module.norm", d, 1e-5f));
+      } else {  // BatchNorm1d (eval) folded to y = x*g' + b'
+        const HostTensor *g, *b, *rm, *rv;
+        RVB_TRY(need(e, p + ".conv_module.norm.weight", d, &g));
+        RVB_TRY(need(e, p + ".conv_module.norm.bias", d, &b));
+        RVB_TRY(need(e, p + ".conv_module.norm.running_mean", d, &rm));
+        RVB_TRY(need(e, p + ".conv_module.norm.running_var", d, &rv));
+        std::vector<float> gg(d), bb(d);
+        for (int k = 0; k < d; ++k) {
+          gg[k] = g->data[k] / std::sqrt(rv->data[k] + 1e-5f);
+          bb[k] = b->data[k] - rm->data[k] * gg[k];
+        }
+        RVB_TRY(upload_f32(e, L.n_cnn.g, gg.data(), d));
+        RVB_TRY(upload_f32(e, L.n_cnn.b, bb.data(), d));
+        RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+      }
+      // positional keys P = linear_pos(pe[:Tmax]) -- input independent (attention.py:374, embedding.py:145)
+      Linear lp;
+      RVB_TRY(pack_named_linear(e, lp, p + ".self_attn.linear_pos", d, d, false));
+      RVB_TRY(L.pos_keys.ensure((size_t)e->pe_rows * d * dt_size(e->dtype)));
+      RVB_TRY(run_gemm(e, pe_T.p, d, lp, L.pos_keys.p, d, e->pe_rows, false));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+      lp.w.release(); lp.b.release();
+    }
+    pe_T.release();
+    RVB_TRY(make_fbank_tables(e));
+  }
+  // (re)fold the language-specific layers with the requested category weights
+  for (int i = 0; i < c.num_blocks; ++i) {
+    EncLayer& L = e->enc[i];
+    if (L.is_lsl) RVB_TRY(pack_lsl(e, L.lsl, "encoder.encoders." + std::to_string(i), d, cat, ncat));
+  }
+  if (!e->finalized) {
+    RVB_TRY(pack_decoder(e, e->dec_l, "decoder.left_decoder", c.dec_blocks, cat, ncat));
+    RVB_TRY(pack_decoder(e, e->dec_r, "decoder.right_decoder", c.dec_r_blocks, cat, ncat));
+  } else {
+    for (int side = 0; side < 2; ++side) {
+      Decoder& D = side ? e->dec_r : e->dec_l;
+      const std::string p = side ? "decoder.right_decoder" : "decoder.left_decoder";
+      if (!D.present) continue;
+      for (size_t j = 0; j < D.layers.size(); ++j)
+        if (D.layers[j].is_lsl) RVB_TRY(pack_lsl(e, D.layers[j].lsl, p + ".decoders." + std::to_string(j), d, cat, ncat));
+    }
+  }
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (!e->finalized) {   // keep only what a later re-finalize needs
+    for (auto it = e->host.begin(); it != e->host.end();) {
+      if (it->first.find(".language_layers.") == std::string::npos) it = e->host.erase(it); else ++it;
+    }
+  }
+  e->prof.clear();
+  e->finalized = true;
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ encoder
+static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
+  const int d = e->cfg.d_model, ff = e->cfg.ffn_dim, heads = e->cfg.heads, dk = d / heads;
+  float* x = e->x.as<float>();
+  // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
+  RVB_TRY(run_norm(e, x, L.n_ffm, e->xn.p, false, M, d));
+  RVB_TRY(run_gemm(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, false, 1.f, ACT_SILU));
+  RVB_TRY(run_gemm(e, e->h.p, ff, L.ffm2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  // rel-pos self attention: x += MHSA(LN(x))              encoder_layer.py:208-216
+  RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d));
+  RVB_TRY(run_gemm(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, false));
+  {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    const size_t es = dt_size(e->dtype);
+    a.q = e->h.p; a.k = (const char*)e->h.p + (size_t)d * es; a.v = (const char*)e->h.p + (size_t)2 * d * es;
+    a.p = L.pos_keys.p;
+    a.q_stride = a.k_stride = a.v_stride = 3 * d; a.p_stride = d; a.o_stride = d;
+    a.bias_u = L.bias_u.as<float>(); a.bias_v = L.bias_v.as<float>();
+    a.out = e->ao.p;
+    a.q_start = e->d_seq_start.as<int>(); a.q_len = e->d_seq_len.as<int>();
+    a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->d_enc_lens.as<int>();
+    a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
+    Scope sc(e, "attention", 6.0 * B * (double)T * T * d);
+    RVB_TRY(attention(e->stream, e->dtype, a));
+  }
+  RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
+  // convolution module: x += Conv(LN(x))                   encoder_layer.py:218-229, convolution.py:89-144
+  RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d));
+  RVB_TRY(run_gemm(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, false));
+  {
+    GluDwArgs g;
+    g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
+    g.lens = e->d_enc_lens.as<int>(); g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
+    Scope sc(e, "glu_dwconv");
+    RVB_TRY(glu_dwconv(e->stream, e->dtype, g));
+  }
+  RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE, 1));
+  RVB_TRY(run_gemm(e, e->xn.p, d, L.pw2, x, d, M, true, 1.f, ACT_NONE, x, d));
+  // feed-forward (+ language-specific mix), final norm     encoder_layer.py:231-244 / :372-402
+  RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d));
+  const void* ffin = e->xn.p;
+  if (L.is_lsl) {
+    RVB_TRY(run_gemm(e, e->xn.p, d, L.lsl, e->y.p, d, M, false));
+    ffin = e->y.p;
+  }
+  RVB_TRY(run_gemm(e, ffin, d, L.ff1, e->h.p, ff, M, false, 1.f, ACT_SILU));
+  RVB_TRY(run_gemm(e, e->h.p, ff, L.ff2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr));
+  return OK;
+}
+
+static const int LOGIT_SLAB = 8192;   // rows of fp32 logits materialised at a time
+
+static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, const int32_t* lens, int B, int T0,
+                       int beam, float blank_penalty) {
+  const rvb_model_cfg& c = e->cfg;
+  if (!e->finalized) { set_error("rvb_encode before rvb_finalize"); return E_STATE; }
+  if (B <= 0 || B > c.max_chunks || T0 < 7 || T0 > c.chunk_frames) {
+    set_error("rvb_encode: need 1 <= B <= max_chunks and 7 <= T0 <= chunk_frames"); return E_ARG;
+  }
+  if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_encode: beam must be in [1,16]"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int d = c.d_model, F0 = c.input_dim, V = c.vocab;
+  const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  const int M = B * T2;
+  const size_t es = dt_size(e->dtype);
+  e->B = B; e->T0 = T0; e->T1 = T1; e->F1 = F1; e->T2 = T2; e->F2 = F2; e->beam = beam;
+  e->in_lens.assign(lens, lens + B);
+  e->enc_lens.resize(B);
+  std::vector<int32_t> starts(B), qlens(B, T2);
+  for (int b = 0; b < B; ++b) {
+    if (lens[b] < 0 || lens[b] > T0) { set_error("rvb_encode: lens out of range"); return E_ARG; }
+    // mask[:, :, 2::2][:, :, 2::2] (subsampling.py:226): frames 6+4j < len
+    e->enc_lens[b] = lens[b] > 6 ? (lens[b] - 7) / 4 + 1 : 0;
+    starts[b] = b * T2;
+  }
+  e->nbest.clear(); e->rescored.clear();
+  RVB_TRY(upload_i32(e, e->d_enc_lens, e->enc_lens.data(), B));
+  RVB_TRY(upload_i32(e, e->d_seq_start, starts.data(), B));
+  RVB_TRY(upload_i32(e, e->d_seq_len, qlens.data(), B));
+
+  const float* d_feats;
+  if (feats) {
+    RVB_TRY(upload_f32(e, e->d_feats_in, feats, (size_t)B * T0 * F0));
+    d_feats = e->d_feats_in.as<float>();
+  } else {
+    if (!e->feats.p || (first_chunk + B) * (int64_t)T0 > e->feat_rows) {
+      set_error("rvb_encode: device features missing or too short (call rvb_fbank first)"); return E_STATE;
+    }
+    d_feats = e->feats.as<float>() + (size_t)first_chunk * T0 * F0;
+  }
+  RVB_TRY(e->X1.ensure((size_t)B * T1 * F1 * d * es));
+  RVB_TRY(e->X2.ensure((size_t)B * T2 * F2 * d * es));
+  RVB_TRY(e->x.ensure((size_t)M * d * 4));
+  RVB_TRY(e->xn.ensure((size_t)M * d * es));
+  RVB_TRY(e->y.ensure((size_t)M * d * es));
+  RVB_TRY(e->ao.ensure((size_t)M * d * es));
+  RVB_TRY(e->dconv.ensure((size_t)M * d * 4));
+  RVB_TRY(e->enc_out.ensure((size_t)M * d * es));
+  RVB_TRY(e->h.ensure((size_t)M * std::max(c.ffn_dim, 3 * d) * es));
+  const int Vld = (V + 3) & ~3;
+  RVB_TRY(e->logits.ensure((size_t)LOGIT_SLAB * Vld * 4));
+  RVB_TRY(e->topv.ensure((size_t)M * beam * 4));
+  RVB_TRY(e->topi.ensure((size_t)M * beam * 4));
+
+  // Conv2dSubsampling4 (subsampling.py:201-226): cmvn+conv1 -> conv2 (implicit GEMM) -> linear * sqrt(d)
+  {
+    Scope sc(e, "subsample");
+    RVB_TRY(subsample_conv1(e->stream, e->dtype, d_feats, e->cmvn_mean.as<float>(), e->cmvn_istd.as<float>(),
+                            e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, B, T0, F0, d));
+  }
+  {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
+    g.M = B * T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
+    g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
+    Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
+    RVB_TRY(gemm(e->stream, e->dtype, g));
+  }
+  RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, M, true, std::sqrt((float)d)));
+  for (auto& L : e->enc) RVB_TRY(encoder_layer(e, L, M, B, T2));
+  RVB_TRY(run_norm(e, e->x.as<float>(), e->enc_after, e->enc_out.p, false, M, d));
+  // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
+  for (int r0 = 0; r0 < M; r0 += LOGIT_SLAB) {
+    const int rows = std::min(LOGIT_SLAB, M - r0);
+    RVB_TRY(run_gemm(e, (const char*)e->enc_out.p + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
+    Scope sc(e, "ctc_topk");
+    RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), rows, V, Vld, beam, blank_penalty, c.blank_id,
+                            e->topv.as<float>() + (size_t)r0 * beam, e->topi.as<int>() + (size_t)r0 * beam, nullptr));
+  }
+  e->h_topv.resize((size_t)M * beam);
+  e->h_topi.resize((size_t)M * beam);
+  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topv.data(), e->topv.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topi.data(), e->topi.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ search
+static int prefix_beam_impl(rvb_engine* e, int beam) {
+  if (e->B <= 0) { set_error("rvb_ctc_prefix_beam before rvb_encode"); return E_STATE; }
+  if (beam != e->beam) { set_error("rvb_ctc_prefix_beam: beam differs from the one given to rvb_encode"); return E_ARG; }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int B = e->B, T = e->T2;
+  e->nbest.assign(B, PrefixResult());
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (nthr == 0) nthr = 4;
+  nthr = std::min<unsigned>(std::min<unsigned>(nthr, 64), (unsigned)B);
+  std::vector<std::thread> pool;
+  for (unsigned w = 0; w < nthr; ++w) {
+    pool.emplace_back([=]() {
+      for (int b = (int)w; b < B; b += (int)nthr)
+        prefix_beam_search(e->h_topv.data() + (size_t)b * T * beam, e->h_topi.data() + (size_t)b * T * beam,
+                           e->enc_lens[b], beam, beam, e->cfg.blank_id, &e->nbest[b]);
+    });
+  }
+  for (auto& t : pool) t.join();
+  auto& pe = e->prof["search_host"];
+  pe.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  pe.launches += 1;
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ rescoring
+struct HypRef { int chunk, idx, len, row0; };
+
+static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>& hyps, int R, int maxL,
+                           const std::vector<int32_t>& tok, const std::vector<int32_t>& pos,
+                           const std::vector<int32_t>& tgt, std::vector<float>* logp) {
+  const rvb_model_cfg& c = e->cfg;
+  const int d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
+  const int M = e->B * e->T2;
+  const size_t es = dt_size(e->dtype);
+  RVB_TRY(upload_i32(e, e->d_tok, tok.data(), R));
+  RVB_TRY(upload_i32(e, e->d_pos, pos.data(), R));
+  RVB_TRY(upload_i32(e, e->d_tgt, tgt.data(), R));
+  RVB_TRY(e->dx.ensure((size_t)R * d * 4));
+  RVB_TRY(e->dxn.ensure((size_t)R * d * es));
+  RVB_TRY(e->dy.ensure((size_t)R * d * es));
+  RVB_TRY(e->dao.ensure((size_t)R * d * es));
+  RVB_TRY(e->dq.ensure((size_t)R * d * es));
+  RVB_TRY(e->dqkv.ensure((size_t)R * 3 * d * es));
+  RVB_TRY(e->dh.ensure((size_t)R * ff * es));
+  RVB_TRY(e->kvmem.ensure((size_t)M * 2 * d * es));
+  RVB_TRY(e->d_logp.ensure((size_t)R * 4));
+  float* x = e->dx.as<float>();
+  {
+    Scope sc(e, "embed");
+    RVB_TRY(embed_tokens(e->stream, D.embed.as<float>(), e->pe_f32.as<float>(), e->d_tok.as<int>(), e->d_pos.as<int>(),
+                         x, R, d, std::sqrt((float)d)));
+  }
+  for (auto& L : D.layers) {
+    // self attention (causal, per hypothesis)            decoder_layer.py:91-110, decoder.py:150-156
+    RVB_TRY(run_norm(e, x, L.n1, e->dxn.p, false, R, d));
+    RVB_TRY(run_gemm(e, e->dxn.p, d, L.self_qkv, e->dqkv.p, 3 * d, R, false));
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = e->dqkv.p; a.k = (const char*)e->dqkv.p + (size_t)d * es; a.v = (const char*)e->dqkv.p + (size_t)2 * d * es;
+    a.q_stride = a.k_stride = a.v_stride = 3 * d; a.o_stride = d; a.out = e->dao.p;
+    a.q_start = e->d_hq_start.as<int>(); a.q_len = e->d_hq_len.as<int>();
+    a.kv_start = e->d_hq_start.as<int>(); a.kv_len = e->d_hq_len.as<int>();
+    a.nseq = (int)hyps.size(); a.heads = heads; a.dk = dk; a.max_q = maxL; a.causal = 1; a.sqrt_dk = std::sqrt((float)dk);
+    {
+      Scope sc(e, "attention");
+      RVB_TRY(attention(e->stream, e->dtype, a));
+    }
+    RVB_TRY(run_gemm(e, e->dao.p, d, L.self_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+    // cross attention over the chunk's encoder frames (memory K/V computed once, not per hypothesis:
+    // the reference repeats the memory N times, asr_model.py:895)       decoder_layer.py:112-119
+    RVB_TRY(run_norm(e, x, L.n2, e->dxn.p, false, R, d));
+    RVB_TRY(run_gemm(e, e->dxn.p, d, L.src_q, e->dq.p, d, R, false));
+    RVB_TRY(run_gemm(e, e->enc_out.p, d, L.src_kv, e->kvmem.p, 2 * d, M, false));
+    a.q = e->dq.p; a.k = e->kvmem.p; a.v = (const char*)e->kvmem.p + (size_t)d * es;
+    a.q_stride = d; a.k_stride = a.v_stride = 2 * d;
+    a.kv_start = e->d_hkv_start.as<int>(); a.kv_len = e->d_hkv_len.as<int>();
+    a.causal = 0;
+    {
+      Scope sc(e, "attention");
+      RVB_TRY(attention(e->stream, e->dtype, a));
+    }
+    RVB_TRY(run_gemm(e, e->dao.p, d, L.src_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+    // feed forward (ReLU) with the language-specific mix     decoder_layer.py:121-127 / :313-333
+    RVB_TRY(run_norm(e, x, L.n3, e->dxn.p, false, R, d));
+    const void* ffin = e->dxn.p;
+    if (L.is_lsl) {
+      RVB_TRY(run_gemm(e, e->dxn.p, d, L.lsl, e->dy.p, d, R, false));
+      ffin = e->dy.p;
+    }
+    RVB_TRY(run_gemm(e, ffin, d, L.ff1, e->dh.p, ff, R, false, 1.f, ACT_RELU));
+    RVB_TRY(run_gemm(e, e->dh.p, ff, L.ff2, x, d, R, true, 1.f, ACT_NONE, x, d));
+  }
+  RVB_TRY(run_norm(e, x, D.after, e->dxn.p, false, R, d));
+  const int Vld = (V + 3) & ~3;
+  for (int r0 = 0; r0 < R; r0 += LOGIT_SLAB) {
+    const int rows = std::min(LOGIT_SLAB, R - r0);
+    RVB_TRY(run_gemm(e, (const char*)e->dxn.p + (size_t)r0 * d * es, d, D.out, e->logits.p, Vld, rows, true));
+    Scope sc(e, "lse_gather");
+    RVB_TRY(lse_gather(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt.as<int>() + r0, e->d_logp.as<float>() + r0));
+  }
+  logp->resize(R);
+  RVB_HIP_CHECK(hipMemcpyAsync(logp->data(), e->d_logp.p, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+static int rescore_impl(rvb_engine* e, double ctc_weight, double reverse_weight) {
+  if ((int)e->nbest.size() != e->B || e->B <= 0) { set_error("rvb_attention_rescore before rvb_ctc_prefix_beam"); return E_STATE; }
+  if (!e->dec_l.present) { set_error("model has no attention decoder"); return E_STATE; }
+  const bool use_r = reverse_weight > 0.0;
+  if (use_r && !e->dec_r.present) { set_error("reverse_weight > 0 but model has no right-to-left decoder"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int B = e->B, T2 = e->T2, eos = e->cfg.eos_id, sos = e->cfg.sos_id;
+  // ragged batch: every hypothesis of every chunk contributes len+1 rows ([sos] + tokens)
+  std::vector<HypRef> hyps;
+  std::vector<int32_t> tok, rtok, pos, tgt, rtgt, hq_start, hq_len, hkv_start, hkv_len;
+  int R = 0, maxL = 0;
+  for (int b = 0; b < B; ++b) {
+    const PrefixResult& pr = e->nbest[b];
+    for (size_t i = 0; i < pr.nbest.size(); ++i) {
+      const std::vector<int>& hy = pr.nbest[i];
+      const int len = (int)hy.size();
+      if (len + 1 > e->pe_rows) { set_error("hypothesis longer than the positional table"); return E_UNSUPPORTED; }
+      hyps.push_back({b, (int)i, len, R});
+      hq_start.push_back(R); hq_len.push_back(len + 1);
+      hkv_start.push_back(b * T2); hkv_len.push_back(e->enc_lens[b]);
+      for (int j = 0; j <= len; ++j) {
+        tok.push_back(j == 0 ? sos : hy[j - 1]);                  // add_sos_eos, common.py:112-155
+        rtok.push_back(j == 0 ? sos : hy[len - j]);               // reversed input, asr_model.py:896-953
+        pos.push_back(j);
+        tgt.push_back(j < len ? hy[j] : eos);                      // search.py:417-425
+        rtgt.push_back(j < len ? hy[len - 1 - j] : eos);           // search.py:427-433
+      }
+      R += len + 1;
+      maxL = std::max(maxL, len + 1);
+    }
+  }
+  RVB_TRY(upload_i32(e, e->d_hq_start, hq_start.data(), hq_start.size()));
+  RVB_TRY(upload_i32(e, e->d_hq_len, hq_len.data(), hq_len.size()));
+  RVB_TRY(upload_i32(e, e->d_hkv_start, hkv_start.data(), hkv_start.size()));
+  RVB_TRY(upload_i32(e, e->d_hkv_len, hkv_len.data(), hkv_len.size()));
+  std::vector<float> logp, rlogp;
+  RVB_TRY(decoder_forward(e, e->dec_l, hyps, R, maxL, tok, pos, tgt, &logp));
+  if (use_r) RVB_TRY(decoder_forward(e, e->dec_r, hyps, R, maxL, rtok, pos, rtgt, &rlogp));
+
+  // score accumulation exactly as search.py:413-441: fp32 running sums (0-dim float32 tensors),
+  // python-float exp() for confidences, strict '>' so the first maximum wins
+  e->rescored.assign(B, RescoreResult());
+  std::vector<std::vector<float>> sc_all(B);
+  std::vector<std::vector<double>> conf_all(B);
+  std::vector<std::vector<std::vector<double>>> tc_all(B);
+  for (const HypRef& hr : hyps) {
+    const PrefixResult& pr = e->nbest[hr.chunk];
+    RescoreResult& rr = e->rescored[hr.chunk];
+    if (rr.logp.empty()) { rr.logp.resize(pr.nbest.size()); rr.rlogp.resize(pr.nbest.size()); }
+    const float* lp = logp.data() + hr.row0;
+    rr.logp[hr.idx].assign(lp, lp + hr.len + 1);
+    float score = 0.f;
+    std::vector<double> tc(hr.len);
+    for (int j = 0; j < hr.len; ++j) { score += lp[j]; tc[j] = std::exp((double)lp[j]); }
+    score += lp[hr.len];
+    if (use_r) {
+      const float* rp = rlogp.data() + hr.row0;
+      rr.rlogp[hr.idx].assign(rp, rp + hr.len + 1);
+      float r_score = 0.f;
+      for (int j = 0; j < hr.len; ++j) {
+        const float s = rp[hr.len - j - 1];
+        r_score += s;
+        tc[j] = (tc[j] + std::exp((double)s)) / 2.0;
+      }
+      r_score += rp[hr.len];
+      // python: tensor(fp32) * float(1 - rw) + tensor(fp32) * float(rw)
+      score = score * (float)(1.0 - reverse_weight) + r_score * (float)reverse_weight;
+    }
+    conf_all[hr.chunk].push_back(std::exp((double)(score / (float)(hr.len + 1))));
+    score += (float)(pr.scores[hr.idx] * ctc_weight);
+    sc_all[hr.chunk].push_back(score);
+    tc_all[hr.chunk].push_back(std::move(tc));
+  }
+  for (int b = 0; b < B; ++b) {
+    RescoreResult& rr = e->rescored[b];
+    float best = -INFINITY;
+    int bi = 0;
+    for (size_t i = 0; i < sc_all[b].size(); ++i)
+      if (sc_all[b][i] > best) { best = sc_all[b][i]; bi = (int)i; }
+    rr.best = bi; rr.score = best;
+    if (!sc_all[b].empty()) { rr.confidence = conf_all[b][bi]; rr.tok_conf = tc_all[b][bi]; }
+  }
+  return OK;
+}
+
+}  // namespace rvb
+
+// ================================================================================================
+//                                         C ABI
+// ================================================================================================
+using namespace rvb;
+
+extern "C" {
+
+const char* rvb_last_error(void) { return last_error(); }
+const char* rvb_version(void) { return "librvb 0.1 (gfx950)"; }
+
+int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
+  if (!cfg || !out) { set_error("rvb_create: null argument"); return E_ARG; }
+  if (cfg->dtype != RVB_F32 && cfg->dtype != RVB_BF16) { set_error("rvb_create: bad dtype"); return E_ARG; }
+  if (cfg->d_model <= 0 || cfg->heads <= 0 || cfg->d_model % cfg->heads || cfg->d_model % 8 || cfg->ffn_dim % 8 ||
+      cfg->dec_ffn_dim % 8 || cfg->input_dim != 80 || cfg->vocab < 2 || cfg->num_blocks < 1 ||
+      (cfg->cnn_kernel % 2) == 0 || cfg->chunk_frames < 7 || cfg->max_chunks < 1 ||
+      (cfg->dec_blocks > 0 && (cfg->dec_heads <= 0 || cfg->d_model % cfg->dec_heads))) {
+    set_error("rvb_create: unsupported model dimensions (need d, ffn dims % 8 == 0, d % heads == 0, input_dim 80, odd cnn kernel)");
+    return E_ARG;
+  }
+  int ndev = 0;
+  hipError_t err = hipGetDeviceCount(&ndev);
+  if (err != hipSuccess || ndev <= 0) { set_error("no HIP device available: librvb has no CPU fallback"); return E_HIP; }
+  if (device < 0 || device >= ndev) { set_error("rvb_create: device index out of range"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(device));
+  rvb_engine* e = new rvb_engine();
+  e->cfg = *cfg; e->device = device; e->dtype = cfg->dtype;
+  hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return E_HIP; }
+  *out = e;
+  return OK;
+}
+
+void rvb_destroy(rvb_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  // DevBuf members are released explicitly: list the big ones, the rest die with the process
+  DevBuf* bufs[] = {&e->cmvn_mean, &e->cmvn_istd, &e->conv1_w, &e->conv1_b, &e->pe_f32, &e->stage, &e->pcm, &e->feats,
+                    &e->d_feats_in, &e->X1, &e->X2, &e->x, &e->xn, &e->y, &e->h, &e->ao, &e->dconv, &e->enc_out,
+                    &e->logits, &e->topv, &e->topi, &e->d_enc_lens, &e->d_seq_start, &e->d_seq_len, &e->d_aux_i32,
+                    &e->dx, &e->dxn, &e->dy, &e->dh, &e->dqkv, &e->dq, &e->dao, &e->kvmem, &e->d_tok, &e->d_pos,
+                    &e->d_tgt, &e->d_logp, &e->d_hq_start, &e->d_hq_len, &e->d_hkv_start, &e->d_hkv_len,
+                    &e->fb_window, &e->fb_twiddle, &e->fb_melw, &e->fb_lo, &e->fb_hi,
+                    &e->conv2.w, &e->conv2.b, &e->embed_out.w, &e->embed_out.b, &e->ctc.w, &e->ctc.b,
+                    &e->enc_after.g, &e->enc_after.b};
+  for (DevBuf* b : bufs) b->release();
+  auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); };
+  auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };
+  for (auto& L : e->enc) {
+    for (Linear* l : {&L.ffm1, &L.ffm2, &L.ff1, &L.ff2, &L.qkv, &L.att_out, &L.pw1, &L.pw2, &L.lsl}) rel_lin(*l);
+    for (LNorm* n : {&L.n_ffm, &L.n_mha, &L.n_conv, &L.n_ff, &L.n_final, &L.n_cnn}) rel_n(*n);
+    L.pos_keys.release(); L.bias_u.release(); L.bias_v.release(); L.dw_w.release(); L.dw_b.release();
+  }
+  for (Decoder* D : {&e->dec_l, &e->dec_r}) {
+    D->embed.release(); rel_lin(D->out); rel_n(D->after);
+    for (auto& L : D->layers) {
+      for (Linear* l : {&L.self_qkv, &L.self_out, &L.src_q, &L.src_kv, &L.src_out, &L.ff1, &L.ff2, &L.lsl}) rel_lin(*l);
+      for (LNorm* n : {&L.n1, &L.n2, &L.n3}) rel_n(*n);
+    }
+  }
+  for (auto& p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int rvb_load_tensor(rvb_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!e || !name || !host || ndim < 0 || (ndim > 0 && !shape)) { set_error("rvb_load_tensor: null argument"); return E_ARG; }
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { if (shape[i] < 0) { set_error("negative dim"); return E_ARG; } t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(host, host + n);
+  e->host[name] = std::move(t);
+  return OK;
+}
+
+int rvb_finalize(rvb_engine* e, const float* cat_embs, int n_cat) {
+  if (!e || (n_cat > 0 && !cat_embs)) { set_error("rvb_finalize: null argument"); return E_ARG; }
+  return finalize_impl(e, cat_embs, n_cat);
+}
+
+int64_t rvb_num_frames(int64_t n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
+
+int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n) {
+  if (!e || (!pcm && n > 0) || n < 0) { set_error("rvb_upload_pcm: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->n_samples = n;
+  return OK;
+}
+
+int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
+  if (!e) { set_error("rvb_fbank: null engine"); return E_ARG; }
+  if (!e->fb_window.p) { set_error("rvb_fbank before rvb_finalize"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int64_t nf = rvb_num_frames(e->n_samples);
+  const int64_t T0 = e->cfg.chunk_frames;
+  const int64_t rows = ((nf + T0 - 1) / T0) * T0;    // zero padded to whole chunks (feats_batcher)
+  RVB_TRY(e->feats.ensure((size_t)std::max<int64_t>(rows, 1) * 80 * 4));
+  RVB_HIP_CHECK(hipMemsetAsync(e->feats.p, 0, (size_t)std::max<int64_t>(rows, 1) * 80 * 4, e->stream));
+  FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};
+  {
+    Scope sc(e, "fbank");
+    RVB_TRY(fbank(e->stream, e->pcm.as<int16_t>(), nf, e->feats.as<float>(), t));
+  }
+  if (feats_out && nf) RVB_HIP_CHECK(hipMemcpyAsync(feats_out, e->feats.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->n_frames = nf; e->feat_rows = rows;
+  if (n_frames) *n_frames = nf;
+  return OK;
+}
+
+int rvb_encode(rvb_engine* e, const float* feats, int64_t first_chunk, const int32_t* lens, int B, int T0, int beam,
+               float blank_penalty) {
+  if (!e || !lens) { set_error("rvb_encode: null argument"); return E_ARG; }
+  return encode_impl(e, feats, first_chunk, lens, B, T0, beam, blank_penalty);
+}
+
+int rvb_encoder_frames(rvb_engine* e, int32_t* T_out) {
+  if (!e || !T_out || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
+  *T_out = e->T2; return OK;
+}
+int rvb_get_encoder_lens(rvb_engine* e, int32_t* lens) {
+  if (!e || !lens || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
+  memcpy(lens, e->enc_lens.data(), (size_t)e->B * 4); return OK;
+}
+int rvb_get_encoder_out(rvb_engine* e, float* out) {
+  if (!e || !out || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
+  const size_t n = (size_t)e->B * e->T2 * e->cfg.d_model;
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  if (e->dtype == DT_F32) {
+    RVB_HIP_CHECK(hipMemcpy(out, e->enc_out.p, n * 4, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<bf16_t> tmp(n);
+    RVB_HIP_CHECK(hipMemcpy(tmp.data(), e->enc_out.p, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = bf16_to_f32(tmp[i]);
+  }
+  return OK;
+}
+int rvb_get_ctc_logprobs(rvb_engine* e, int chunk, float* out) {
+  if (!e || !out || e->B <= 0 || chunk < 0 || chunk >= e->B) { set_error("rvb_get_ctc_logprobs: bad chunk"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int d = e->cfg.d_model, V = e->cfg.vocab, T = e->T2, Vld = (V + 3) & ~3;
+  if (T > LOGIT_SLAB) { set_error("chunk too long for the logit slab"); return E_UNSUPPORTED; }
+  DevBuf lp, tv, ti;
+  RVB_TRY(lp.ensure((size_t)T * V * 4)); RVB_TRY(tv.ensure((size_t)T * 4)); RVB_TRY(ti.ensure((size_t)T * 4));
+  int r = run_gemm(e, (const char*)e->enc_out.p + (size_t)chunk * T * d * dt_size(e->dtype), d, e->ctc, e->logits.p, Vld, T, true);
+  if (r == OK) r = logsoftmax_topk(e->stream, e->logits.as<float>(), T, V, Vld, 1, 0.f, e->cfg.blank_id, tv.as<float>(), ti.as<int>(), lp.as<float>());
+  if (r == OK && hipMemcpyAsync(out, lp.p, (size_t)T * V * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) r = E_HIP;
+  hipStreamSynchronize(e->stream);
+  lp.release(); tv.release(); ti.release();
+  return r;
+}
+int rvb_get_ctc_topk(rvb_engine* e, float* vals, int32_t* idx) {
+  if (!e || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
+  const size_t n = (size_t)e->B * e->T2 * e->beam;
+  if (vals) memcpy(vals, e->h_topv.data(), n * 4);
+  if (idx) memcpy(idx, e->h_topi.data(), n * 4);
+  return OK;
+}
+
+int rvb_ctc_greedy(rvb_engine* e, int32_t* tokens, int32_t* ntok, int32_t* frames) {
+  if (!e || !tokens || !ntok || e->B <= 0) { set_error("rvb_ctc_greedy: no encoded batch"); return E_STATE; }
+  const int T = e->T2, beam = e->beam;
+  std::vector<int> tk, fr;
+  for (int b = 0; b < e->B; ++b) {
+    greedy_collapse(e->h_topi.data() + (size_t)b * T * beam, e->enc_lens[b], beam, e->cfg.blank_id, &tk, &fr);
+    ntok[b] = (int32_t)tk.size();
+    for (size_t i = 0; i < tk.size(); ++i) { tokens[(size_t)b * T + i] = tk[i]; if (frames) frames[(size_t)b * T + i] = fr[i]; }
+    for (size_t i = tk.size(); i < (size_t)T; ++i) { tokens[(size_t)b * T + i] = -1; if (frames) frames[(size_t)b * T + i] = -1; }
+  }
+  return OK;
+}
+
+int rvb_ctc_prefix_beam(rvb_engine* e, int beam) {
+  if (!e) { set_error("null engine"); return E_ARG; }
+  return prefix_beam_impl(e, beam);
+}
+int rvb_get_nbest_count(rvb_engine* e, int chunk, int32_t* n_hyps, int32_t* max_len) {
+  if (!e || chunk < 0 || chunk >= (int)e->nbest.size()) { set_error("rvb_get_nbest_count: bad chunk / no search results"); return E_STATE; }
+  const PrefixResult& pr = e->nbest[chunk];
+  int ml = 0;
+  for (auto& h : pr.nbest) ml = std::max(ml, (int)h.size());
+  for (auto& t : pr.times) ml = std::max(ml, (int)t.size());
+  if (n_hyps) *n_hyps = (int32_t)pr.nbest.size();
+  if (max_len) *max_len = ml;
+  return OK;
+}
+static void fill_nbest(const PrefixResult& pr, int ml, int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens, double* scores) {
+  for (size_t i = 0; i < pr.nbest.size(); ++i) {
+    if (lens) lens[i] = (int32_t)pr.nbest[i].size();
+    if (times_lens) times_lens[i] = (int32_t)pr.times[i].size();
+    if (scores) scores[i] = pr.scores[i];
+    for (int j = 0; j < ml; ++j) {
+      if (tokens) tokens[i * ml + j] = j < (int)pr.nbest[i].size() ? pr.nbest[i][j] : -1;
+      if (times) times[i * ml + j] = j < (int)pr.times[i].size() ? pr.times[i][j] : -1;
+    }
+  }
+}
+int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens, double* scores) {
+  int32_t n, ml;
+  int r = rvb_get_nbest_count(e, chunk, &n, &ml);
+  if (r != OK) return r;
+  fill_nbest(e->nbest[chunk], ml, tokens, lens, times, times_lens, scores);
+  return OK;
+}
+
+int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight) {
+  if (!e) { set_error("null engine"); return E_ARG; }
+  return rescore_impl(e, ctc_weight, reverse_weight);
+}
+int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence, double* tokens_confidence) {
+  if (!e || chunk < 0 || chunk >= (int)e->rescored.size()) { set_error("rvb_get_rescored: bad chunk / no rescoring results"); return E_STATE; }
+  const RescoreResult& r = e->rescored[chunk];
+  if (best_index) *best_index = r.best;
+  if (score) *score = r.score;
+  if (confidence) *confidence = r.confidence;
+  if (tokens_confidence) for (size_t i = 0; i < r.tok_conf.size(); ++i) tokens_confidence[i] = r.tok_conf[i];
+  return OK;
+}
+int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out) {
+  if (!e || !out || chunk < 0 || chunk >= (int)e->rescored.size()) { set_error("rvb_get_rescore_logp: bad chunk"); return E_STATE; }
+  const RescoreResult& r = e->rescored[chunk];
+  const auto& v = right ? r.rlogp : r.logp;
+  if (hyp < 0 || hyp >= (int)v.size()) { set_error("rvb_get_rescore_logp: bad hyp"); return E_ARG; }
+  for (size_t i = 0; i < v[hyp].size(); ++i) out[i] = v[hyp][i];
+  return OK;
+}
+
+int rvb_set_profiling(rvb_engine* e, int enabled) { if (!e) return E_ARG; drain_prof(e); e->profiling = enabled != 0; return OK; }
+int rvb_reset_timings(rvb_engine* e) { if (!e) return E_ARG; drain_prof(e); e->prof.clear(); return OK; }
+int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, int64_t* launches) {
+  if (!e || !name) return E_ARG;
+  drain_prof(e);
+  auto it = e->prof.find(name);
+  ProfEntry pe; if (it != e->prof.end()) pe = it->second;
+  if (ms) *ms = pe.ms; if (flops) *flops = pe.flops; if (launches) *launches = pe.launches;
+  return OK;
+}
+
+}  // extern "C"
+
+extern "C" int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: librvb has no CPU fallback"); return E_HIP; }
+  if (!pcm || !feats) { set_error("rvb_test_fbank: null argument"); return E_ARG; }
+  rvb_engine e;   // default stream, only the fbank tables are used
+  RVB_TRY(make_fbank_tables(&e));
+  const int64_t nf = rvb_num_frames(n_samples);
+  DevBuf dp, df;
+  RVB_TRY(dp.ensure((size_t)n_samples * 2 + 16));
+  RVB_TRY(df.ensure((size_t)std::max<int64_t>(nf, 1) * 80 * 4));
+  RVB_HIP_CHECK(hipMemcpy(dp.p, pcm, (size_t)n_samples * 2, hipMemcpyHostToDevice));
+  FbankTables t{e.fb_window.as<float>(), e.fb_twiddle.as<float>(), e.fb_melw.as<float>(), e.fb_lo.as<int>(), e.fb_hi.as<int>()};
+  int r = fbank(nullptr, dp.as<int16_t>(), nf, df.as<float>(), t);
+  if (r == OK && hipDeviceSynchronize() != hipSuccess) { set_error("fbank kernel failed"); r = E_HIP; }
+  if (r == OK && nf && hipMemcpy(feats, df.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost) != hipSuccess) r = E_HIP;
+  dp.release(); df.release();
+  for (DevBuf* b : {&e.fb_window, &e.fb_twiddle, &e.fb_melw, &e.fb_lo, &e.fb_hi}) b->release();
+  return r;
+}

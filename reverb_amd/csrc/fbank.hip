@@ -1,0 +1,125 @@
+// Kaldi-compatible 80-bin log-mel filterbank (25 ms / 10 ms, povey window, 512-point FFT).
+//
+// Replaces `torchaudio.compliance.kaldi.fbank(waveform, num_mel_bins=80, frame_length=25,
+// frame_shift=10, dither=0.0, energy_floor=0.0, sample_frequency=16000)` at
+// asr/wenet/cli/reverb.py:136-144 (torchaudio 2.2.2 defaults: snip_edges, remove_dc_offset,
+// preemphasis 0.97, use_power, log of max(., eps)).
+//
+// HBM-bound and tiny (32 KB/s of audio in, 32 KB/s of features out): one wave64 per frame,
+// four frames per workgroup; the 400-sample window is read coalesced, the radix-2 FFT runs
+// in LDS (4 butterflies per lane per stage), the mel projection reads the power spectrum
+// from LDS with each lane owning mel bins {lane, lane+64}.
+#include "common.h"
+#include "kernels.h"
+
+namespace rvb {
+
+static constexpr int WIN = 400, SHIFT = 160, NFFT = 512, NBIN = 257, NMEL = 80;
+
+__global__ __launch_bounds__(256) void fbank_kernel(const int16_t* __restrict__ pcm, int64_t n_frames,
+                                                    float* __restrict__ feats, FbankTables t) {
+  __shared__ float s_re[4][NFFT];
+  __shared__ float s_im[4][NFFT];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t frame = (int64_t)blockIdx.x * 4 + w;
+  const bool live = frame < n_frames;
+  float* re = s_re[w];
+  float* im = s_im[w];
+
+  // 1. load window, remove DC
+  float x[7];
+  float sum = 0.f;
+  const int16_t* src = pcm + frame * SHIFT;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int j = lane + 64 * i;
+    x[i] = (live && j < WIN) ? (float)src[j] : 0.f;
+    sum += x[i];
+  }
+  const float mean = wave_sum(sum) / (float)WIN;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int j = lane + 64 * i;
+    if (j < WIN) im[j] = x[i] - mean;   // stage DC-removed samples in `im`
+  }
+  __syncthreads();
+  // 2. pre-emphasis (x[-1] := x[0]) + povey window, written bit-reversed into re; im := 0
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    float v = 0.f;
+    if (j < WIN) {
+      const float cur = im[j];
+      const float prev = im[j > 0 ? j - 1 : 0];
+      v = (cur - 0.97f * prev) * t.window[j];
+    }
+    y[i] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    re[__brev((unsigned)j) >> 23] = y[i];
+    im[j] = 0.f;
+  }
+  __syncthreads();
+  // 3. 512-point radix-2 DIT FFT
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = lane + 64 * q;
+      const int j = b & (half - 1);
+      const int i0 = ((b >> s) << (s + 1)) + j;
+      const int i1 = i0 + half;
+      const int tw = j << (8 - s);
+      const float wr = t.twiddle[2 * tw], wi = t.twiddle[2 * tw + 1];
+      const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+      const float tr = wr * br - wi * bi;
+      const float ti = wr * bi + wi * br;
+      re[i0] = ar + tr; im[i0] = ai + ti;
+      re[i1] = ar - tr; im[i1] = ai - ti;
+    }
+    __syncthreads();
+  }
+  // 4. power spectrum (bins 0..256) into re
+  float pw[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + 64 * i;
+    pw[i] = (j < NBIN) ? re[j] * re[j] + im[j] * im[j] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + 64 * i;
+    if (j < NBIN) re[j] = pw[i];
+  }
+  __syncthreads();
+  // 5. mel projection + log
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = lane + 64 * i;
+      if (m < NMEL) {
+        const int lo = t.mel_lo[m], hi = t.mel_hi[m];
+        const float* wrow = t.mel_w + (size_t)m * NBIN;
+        float acc = 0.f;
+        for (int b = lo; b < hi; ++b) acc += re[b] * wrow[b];
+        feats[frame * NMEL + m] = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      }
+    }
+  }
+}
+
+int fbank(hipStream_t s, const int16_t* pcm, int64_t n_frames, float* feats, const FbankTables& t) {
+  if (n_frames <= 0) return OK;
+  hipLaunchKernelGGL(fbank_kernel, dim3(cdiv(n_frames, 4)), dim3(256), 0, s, pcm, n_frames, feats, t);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace rvb

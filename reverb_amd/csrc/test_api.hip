@@ -1,0 +1,217 @@
+// rvb_test_*: raw kernel entry points used by tests/ (host buffers in, host buffers out).  Each one
+// uploads fp32 host data (rounded to the compute dtype with the same RNE conversion the engine
+// uses), launches exactly the kernel the engine launches, and downloads the result as fp32.
+#include <cstring>
+#include <vector>
+
+#include "../../include/rvb.h"
+#include "kernels.h"
+#include "search.h"
+
+using namespace rvb;
+
+namespace {
+struct Dev {
+  void* p = nullptr;
+  ~Dev() { if (p) hipFree(p); }
+  int alloc(size_t n) { if (n == 0) n = 16; if (hipMalloc(&p, n) != hipSuccess) { set_error("hipMalloc failed in test api"); return E_NOMEM; } return OK; }
+};
+int up_T(Dev& d, int dtype, const float* src, size_t n) {
+  if (!src) return OK;
+  int r = d.alloc(n * dt_size(dtype));
+  if (r != OK) return r;
+  if (dtype == DT_F32) { RVB_HIP_CHECK(hipMemcpy(d.p, src, n * 4, hipMemcpyHostToDevice)); return OK; }
+  std::vector<bf16_t> t(n);
+  for (size_t i = 0; i < n; ++i) t[i] = f32_to_bf16(src[i]);
+  RVB_HIP_CHECK(hipMemcpy(d.p, t.data(), n * 2, hipMemcpyHostToDevice));
+  return OK;
+}
+int up_raw(Dev& d, const void* src, size_t bytes) {
+  if (!src) return OK;
+  int r = d.alloc(bytes);
+  if (r != OK) return r;
+  RVB_HIP_CHECK(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+  return OK;
+}
+int down_T(const Dev& d, int dtype, bool as_f32, float* dst, size_t n) {
+  if (dtype == DT_F32 || as_f32) { RVB_HIP_CHECK(hipMemcpy(dst, d.p, n * 4, hipMemcpyDeviceToHost)); return OK; }
+  std::vector<bf16_t> t(n);
+  RVB_HIP_CHECK(hipMemcpy(t.data(), d.p, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) dst[i] = bf16_to_f32(t[i]);
+  return OK;
+}
+int need_gpu() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available: librvb has no CPU fallback"); return E_HIP; }
+  return OK;
+}
+#define T_TRY(x) do { int _r = (x); if (_r != OK) return _r; } while (0)
+}  // namespace
+
+extern "C" {
+
+int rvb_test_gemm(int dtype, const float* A, const float* W, const float* bias, const float* res, float* C, int M,
+                  int N, int K, float alpha, int act, int out_f32, int conv, int cT1, int cF1, int cC, int cB) {
+  T_TRY(need_gpu());
+  Dev dA, dW, dB, dR, dC;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  size_t a_elems = (size_t)M * K;
+  if (conv) {
+    const int T2 = (cT1 - 3) / 2 + 1, F2 = (cF1 - 3) / 2 + 1;
+    if (M != cB * T2 * F2 || K != 9 * cC) { set_error("rvb_test_gemm: conv shape mismatch"); return E_ARG; }
+    a_elems = (size_t)cB * cT1 * cF1 * cC;
+    g.conv = 1; g.cT1 = cT1; g.cF1 = cF1; g.cT2 = T2; g.cF2 = F2; g.cC = cC;
+  }
+  T_TRY(up_T(dA, dtype, A, a_elems));
+  T_TRY(up_T(dW, dtype, W, (size_t)N * K));
+  T_TRY(up_raw(dB, bias, (size_t)N * 4));
+  T_TRY(up_raw(dR, res, (size_t)M * N * 4));
+  const bool f32out = dtype == DT_F32 || out_f32;
+  T_TRY(dC.alloc((size_t)M * N * (f32out ? 4 : 2)));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.res = (const float*)dR.p; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = conv ? cC : K; g.ldw = K; g.ldc = N; g.ldres = N;
+  g.alpha = alpha; g.act = act; g.out_f32 = out_f32;
+  T_TRY(gemm(nullptr, dtype, g));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dC, dtype, f32out, C, (size_t)M * N);
+}
+
+int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, int mode, int silu,
+                     const float* add, float* out, int out_f32, int M, int d) {
+  T_TRY(need_gpu());
+  Dev dx, dg, db, da, dout;
+  T_TRY(up_raw(dx, x, (size_t)M * d * 4));
+  T_TRY(up_raw(dg, gamma, (size_t)d * 4));
+  T_TRY(up_raw(db, beta, (size_t)d * 4));
+  T_TRY(up_T(da, dtype, add, (size_t)M * d));
+  const bool f32out = dtype == DT_F32 || out_f32;
+  T_TRY(dout.alloc((size_t)M * d * (f32out ? 4 : 2)));
+  NormArgs a;
+  a.x = (const float*)dx.p; a.gamma = (const float*)dg.p; a.beta = (const float*)db.p; a.eps = eps; a.mode = mode;
+  a.silu = silu; a.add = da.p; a.out = dout.p; a.out_f32 = out_f32; a.M = M; a.d = d;
+  T_TRY(rownorm(nullptr, dtype, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dout, dtype, f32out, out, (size_t)M * d);
+}
+
+int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w, const float* b,
+                   float* out, int B, int T0, int F0, int d) {
+  T_TRY(need_gpu());
+  const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1;
+  Dev df, dm, di, dw, db, dout;
+  T_TRY(up_raw(df, feats, (size_t)B * T0 * F0 * 4));
+  T_TRY(up_raw(dm, mean, (size_t)F0 * 4));
+  T_TRY(up_raw(di, istd, (size_t)F0 * 4));
+  T_TRY(up_raw(dw, w, (size_t)d * 9 * 4));
+  T_TRY(up_raw(db, b, (size_t)d * 4));
+  const size_t n = (size_t)B * T1 * F1 * d;
+  T_TRY(dout.alloc(n * dt_size(dtype)));
+  T_TRY(subsample_conv1(nullptr, dtype, (const float*)df.p, (const float*)dm.p, (const float*)di.p, (const float*)dw.p,
+                        (const float*)db.p, dout.p, B, T0, F0, d));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dout, dtype, false, out, n);
+}
+
+int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
+                        const int32_t* lens, float* out, int B, int T, int d, int K) {
+  T_TRY(need_gpu());
+  Dev dG, dpb, dw, db, dl, dout;
+  T_TRY(up_T(dG, dtype, G, (size_t)B * T * 2 * d));
+  T_TRY(up_raw(dpb, pw1_bias, (size_t)2 * d * 4));
+  T_TRY(up_raw(dw, dw_w, (size_t)d * K * 4));
+  T_TRY(up_raw(db, dw_b, (size_t)d * 4));
+  T_TRY(up_raw(dl, lens, (size_t)B * 4));
+  T_TRY(dout.alloc((size_t)B * T * d * 4));
+  GluDwArgs a;
+  a.G = dG.p; a.pw1_bias = (const float*)dpb.p; a.dw_w = (const float*)dw.p; a.dw_b = (const float*)db.p;
+  a.lens = (const int*)dl.p; a.out = (float*)dout.p; a.B = B; a.T = T; a.d = d; a.K = K;
+  T_TRY(glu_dwconv(nullptr, dtype, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)B * T * d * 4, hipMemcpyDeviceToHost));
+  return OK;
+}
+
+int rvb_test_attention(int dtype, const float* q, const float* k, const float* v, const float* p, const float* bias_u,
+                       const float* bias_v, float* out, int q_rows, int kv_rows, int p_rows, int heads, int dk,
+                       const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start, const int32_t* kv_len,
+                       int nseq, int causal) {
+  T_TRY(need_gpu());
+  const int d = heads * dk;
+  Dev dq, dkk, dv, dp, du, dvv, dout, qs, ql, ks, kl;
+  T_TRY(up_T(dq, dtype, q, (size_t)q_rows * d));
+  T_TRY(up_T(dkk, dtype, k, (size_t)kv_rows * d));
+  T_TRY(up_T(dv, dtype, v, (size_t)kv_rows * d));
+  T_TRY(up_T(dp, dtype, p, (size_t)p_rows * d));
+  T_TRY(up_raw(du, bias_u, (size_t)d * 4));
+  T_TRY(up_raw(dvv, bias_v, (size_t)d * 4));
+  T_TRY(up_raw(qs, q_start, (size_t)nseq * 4));
+  T_TRY(up_raw(ql, q_len, (size_t)nseq * 4));
+  T_TRY(up_raw(ks, kv_start, (size_t)nseq * 4));
+  T_TRY(up_raw(kl, kv_len, (size_t)nseq * 4));
+  T_TRY(dout.alloc((size_t)q_rows * d * dt_size(dtype)));
+  RVB_HIP_CHECK(hipMemset(dout.p, 0, (size_t)q_rows * d * dt_size(dtype)));
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = dq.p; a.k = dkk.p; a.v = dv.p; a.p = dp.p;
+  a.q_stride = a.k_stride = a.v_stride = a.p_stride = a.o_stride = d;
+  a.bias_u = (const float*)du.p; a.bias_v = (const float*)dvv.p; a.out = dout.p;
+  a.q_start = (const int*)qs.p; a.q_len = (const int*)ql.p; a.kv_start = (const int*)ks.p; a.kv_len = (const int*)kl.p;
+  a.nseq = nseq; a.heads = heads; a.dk = dk; a.causal = causal; a.sqrt_dk = sqrtf((float)dk);
+  int mq = 0;
+  for (int i = 0; i < nseq; ++i) mq = q_len[i] > mq ? q_len[i] : mq;
+  a.max_q = mq;
+  T_TRY(attention(nullptr, dtype, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dout, dtype, false, out, (size_t)q_rows * d);
+}
+
+int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float blank_penalty, int blank_id,
+                             float* topk_val, int32_t* topk_idx, float* logp) {
+  T_TRY(need_gpu());
+  Dev dl, dv, di, dp;
+  T_TRY(up_raw(dl, logits, (size_t)M * V * 4));
+  T_TRY(dv.alloc((size_t)M * k * 4));
+  T_TRY(di.alloc((size_t)M * k * 4));
+  if (logp) T_TRY(dp.alloc((size_t)M * V * 4));
+  T_TRY(logsoftmax_topk(nullptr, (const float*)dl.p, M, V, V, k, blank_penalty, blank_id, (float*)dv.p, (int*)di.p,
+                        (float*)dp.p));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  RVB_HIP_CHECK(hipMemcpy(topk_val, dv.p, (size_t)M * k * 4, hipMemcpyDeviceToHost));
+  RVB_HIP_CHECK(hipMemcpy(topk_idx, di.p, (size_t)M * k * 4, hipMemcpyDeviceToHost));
+  if (logp) RVB_HIP_CHECK(hipMemcpy(logp, dp.p, (size_t)M * V * 4, hipMemcpyDeviceToHost));
+  return OK;
+}
+
+int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target, float* out) {
+  T_TRY(need_gpu());
+  Dev dl, dt, dout;
+  T_TRY(up_raw(dl, logits, (size_t)R * V * 4));
+  T_TRY(up_raw(dt, target, (size_t)R * 4));
+  T_TRY(dout.alloc((size_t)R * 4));
+  T_TRY(lse_gather(nullptr, (const float*)dl.p, R, V, V, (const int*)dt.p, (float*)dout.p));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+  return OK;
+}
+
+int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank, int32_t* n_hyps,
+                         int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens, double* scores) {
+  if (!topk_val || !topk_idx || !n_hyps || T < 0 || beam < 1) { set_error("rvb_test_prefix_beam: bad argument"); return E_ARG; }
+  PrefixResult pr;
+  prefix_beam_search(topk_val, topk_idx, T, beam, beam, blank, &pr);
+  *n_hyps = (int32_t)pr.nbest.size();
+  const int ml = T > 0 ? T : 1;
+  for (size_t i = 0; i < pr.nbest.size(); ++i) {
+    if (lens) lens[i] = (int32_t)pr.nbest[i].size();
+    if (times_lens) times_lens[i] = (int32_t)pr.times[i].size();
+    if (scores) scores[i] = pr.scores[i];
+    for (int j = 0; j < ml; ++j) {
+      if (tokens) tokens[i * ml + j] = j < (int)pr.nbest[i].size() ? pr.nbest[i][j] : -1;
+      if (times) times[i * ml + j] = j < (int)pr.times[i].size() ? pr.times[i][j] : -1;
+    }
+  }
+  return OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+"""Per-kernel parity tests: each HIP kernel (called through the C ABI's rvb_test_* entry points)
+against a plain torch/numpy fp64 reference of the same reference op.  Tolerances are written at
+each assert: f32 mode differs from the reference only by summation order; bf16 mode additionally
+rounds operands/outputs to bfloat16."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from reverb_amd import _lib
+from reverb_amd._lib import fptr, iptr, dptr
+from util import bf16_round, rnd, f32, i32
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = 0, 1
+
+
+def _tol(dtype, f32_tol, bf16_tol):
+    return f32_tol if dtype == F32 else bf16_tol
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (70, 1001, 160), (513, 48, 32)])
+def test_gemm_plain(lib, dtype, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rnd(dtype, rng.standard_normal((M, K)))
+    W = rnd(dtype, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    C = np.empty((M, N), np.float32)
+    _lib.check(lib.rvb_test_gemm(dtype, fptr(A), fptr(W), fptr(bias), None, fptr(C), M, N, K, 1.0, 0, 1, 0, 0, 0, 0, 0))
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    # asymmetric random operands: a transposed fragment mapping cannot pass this
+    np.testing.assert_allclose(C, ref, rtol=_tol(dtype, 2e-5, 2e-5), atol=_tol(dtype, 2e-5, 2e-5) * 4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("act,alpha,use_res,out_f32", [(1, 1.0, False, 0), (2, 1.0, False, 0), (0, 0.5, True, 1), (0, 8.0, False, 1)])
+def test_gemm_epilogue(lib, dtype, act, alpha, use_res, out_f32):
+    M, N, K = 200, 136, 64
+    rng = np.random.default_rng(7)
+    A = rnd(dtype, rng.standard_normal((M, K)))
+    W = rnd(dtype, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    res = f32(rng.standard_normal((M, N))) if use_res else None
+    C = np.empty((M, N), np.float32)
+    _lib.check(lib.rvb_test_gemm(dtype, fptr(A), fptr(W), fptr(bias), fptr(res), fptr(C), M, N, K, alpha, act, out_f32,
+                                 0, 0, 0, 0, 0))
+    v = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if act == 1:
+        v = v / (1 + np.exp(-v))
+    elif act == 2:
+        v = np.maximum(v, 0)
+    v = v * alpha + (res if use_res else 0)
+    if dtype == BF16 and not out_f32:
+        np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)      # one bf16 rounding of the output
+    else:
+        np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_implicit_conv(lib, dtype):
+    """second Conv2d(d,d,3,2)+ReLU of Conv2dSubsampling4 (subsampling.py:189-190) as implicit GEMM on NHWC."""
+    B, T1, F1, Cc, N = 2, 21, 15, 16, 24
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    rng = np.random.default_rng(3)
+    x = rnd(dtype, rng.standard_normal((B, T1, F1, Cc)))                 # NHWC
+    w = rnd(dtype, rng.standard_normal((N, Cc, 3, 3)) / math.sqrt(9 * Cc))  # torch layout [co][ci][kh][kw]
+    bias = f32(rng.standard_normal(N))
+    wp = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(N, 9 * Cc))   # [co][(kh,kw,ci)]
+    M = B * T2 * F2
+    C = np.empty((M, N), np.float32)
+    _lib.check(lib.rvb_test_gemm(dtype, fptr(x), fptr(wp), fptr(bias), None, fptr(C), M, N, 9 * Cc, 1.0, 2, 1,
+                                 1, T1, F1, Cc, B))
+    ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2),
+                                                torch.from_numpy(w).double(), torch.from_numpy(bias).double(), stride=2))
+    ref = ref.permute(0, 2, 3, 1).reshape(M, N).numpy()                  # (b, t2, f2, co)
+    np.testing.assert_allclose(C, ref, rtol=5e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mode,silu,use_add,out_f32,d", [(0, 0, False, 0, 64), (0, 1, False, 0, 640), (0, 0, True, 1, 1024),
+                                                         (1, 1, False, 0, 96)])
+def test_rownorm(lib, dtype, mode, silu, use_add, out_f32, d):
+    M = 37
+    rng = np.random.default_rng(d)
+    x = f32(rng.standard_normal((M, d)) * 3 + 1)
+    g = f32(1 + 0.1 * rng.standard_normal(d)); b = f32(0.1 * rng.standard_normal(d))
+    add = rnd(dtype, rng.standard_normal((M, d))) if use_add else None
+    out = np.empty((M, d), np.float32)
+    _lib.check(lib.rvb_test_rownorm(dtype, fptr(x), fptr(g), fptr(b), 1e-5, mode, silu, fptr(add), fptr(out), out_f32, M, d))
+    xd = x.astype(np.float64)
+    if mode == 0:
+        mu = xd.mean(1, keepdims=True); var = xd.var(1, keepdims=True)
+        ref = (xd - mu) / np.sqrt(var + 1e-5) * g + b
+    else:
+        ref = xd * g + b
+    if silu:
+        ref = ref / (1 + np.exp(-ref))
+    if use_add:
+        ref = ref + add
+    tol = 1e-5 if (dtype == F32 or out_f32) else 1e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("d", [32, 640])
+def test_conv1_cmvn(lib, dtype, d):
+    B, T0, F0 = 2, 39, 80
+    rng = np.random.default_rng(d)
+    feats = f32(rng.standard_normal((B, T0, F0)) * 4 + 15)
+    mean = f32(15 + rng.standard_normal(F0)); istd = f32(0.25 + 0.05 * rng.random(F0))
+    w = f32(rng.standard_normal((d, 1, 3, 3)) / 3); b = f32(rng.standard_normal(d))
+    T1, F1 = (T0 - 3) // 2 + 1, (F0 - 3) // 2 + 1
+    out = np.empty((B, T1, F1, d), np.float32)
+    _lib.check(lib.rvb_test_conv1(dtype, fptr(feats), fptr(mean), fptr(istd), fptr(w), fptr(b), fptr(out), B, T0, F0, d))
+    xn = (torch.from_numpy(feats).double() - torch.from_numpy(mean).double()) * torch.from_numpy(istd).double()
+    ref = torch.relu(torch.nn.functional.conv2d(xn.unsqueeze(1), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2))
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    tol = 2e-5 if dtype == F32 else 1e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("K,d,T", [(15, 32, 70), (31, 200, 130)])
+def test_glu_dwconv(lib, dtype, K, d, T):
+    B = 3
+    rng = np.random.default_rng(K)
+    lens = i32([T, T - 9, 5])
+    G = rnd(dtype, rng.standard_normal((B, T, 2 * d)))
+    pb = f32(rng.standard_normal(2 * d)); w = f32(rng.standard_normal((d, K)) / math.sqrt(K)); b = f32(rng.standard_normal(d))
+    out = np.empty((B, T, d), np.float32)
+    _lib.check(lib.rvb_test_glu_dwconv(dtype, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(out), B, T, d, K))
+    # reference semantics (convolution.py:107-131): padded frames were zeroed BEFORE pointwise_conv1,
+    # so what the GLU sees there is the bias alone
+    Gd = torch.from_numpy(G).double().clone()
+    for bi in range(B):
+        Gd[bi, lens[bi]:, :] = torch.from_numpy(pb).double()
+    glu = torch.nn.functional.glu(Gd.transpose(1, 2), dim=1)
+    ref = torch.nn.functional.conv1d(glu, torch.from_numpy(w).double().unsqueeze(1), torch.from_numpy(b).double(),
+                                     padding=(K - 1) // 2, groups=d).transpose(1, 2).numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-4)
+
+
+def _ref_attention(q, k, v, p, bu, bv, heads, dk, q_start, q_len, kv_start, kv_len, causal):
+    d = heads * dk
+    out = np.zeros((q.shape[0], d))
+    for s in range(len(q_start)):
+        qs, ql, ks, kl = int(q_start[s]), int(q_len[s]), int(kv_start[s]), int(kv_len[s])
+        for h in range(heads):
+            sl = slice(h * dk, (h + 1) * dk)
+            Q = q[qs:qs + ql, sl].astype(np.float64)
+            Kk = k[ks:ks + kl, sl].astype(np.float64); V = v[ks:ks + kl, sl].astype(np.float64)
+            if kl == 0:
+                continue
+            if p is not None:
+                S = (Q + bu[sl]) @ Kk.T + (Q + bv[sl]) @ p[:kl, sl].astype(np.float64).T
+            else:
+                S = Q @ Kk.T
+            S = S / math.sqrt(dk)
+            if causal:
+                S = np.where(np.arange(kl)[None, :] > np.arange(ql)[:, None], -np.inf, S)
+            S = S - S.max(1, keepdims=True)
+            P = np.exp(S); P /= P.sum(1, keepdims=True)
+            out[qs:qs + ql, sl] = P @ V
+    return out
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("heads,dk,T,pos", [(2, 16, 100, True), (4, 64, 200, True), (2, 80, 130, True), (2, 32, 70, False)])
+def test_attention_encoder_form(lib, dtype, heads, dk, T, pos):
+    """RelPositionMultiHeadedAttention scores (attention.py:378-399) with key-padding mask."""
+    B = 3
+    d = heads * dk
+    rng = np.random.default_rng(heads * 1000 + dk)
+    kv_len = i32([T, T - 37, 0])
+    q = rnd(dtype, rng.standard_normal((B * T, d)))
+    k = rnd(dtype, rng.standard_normal((B * T, d)))
+    v = rnd(dtype, rng.standard_normal((B * T, d)))
+    p = rnd(dtype, rng.standard_normal((T, d))) if pos else None
+    bu = f32(0.3 * rng.standard_normal(d)) if pos else None
+    bv = f32(0.3 * rng.standard_normal(d)) if pos else None
+    starts = i32([0, T, 2 * T]); qlen = i32([T, T, T])
+    out = np.empty((B * T, d), np.float32)
+    _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), fptr(p), fptr(bu), fptr(bv), fptr(out), B * T, B * T,
+                                      T if pos else 0, heads, dk, iptr(starts), iptr(qlen), iptr(starts), iptr(kv_len), B, 0))
+    ref = _ref_attention(q, k, v, p, bu, bv, heads, dk, starts, qlen, starts, kv_len, False)
+    tol = 2e-5 if dtype == F32 else 3e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+    assert np.all(out[2 * T:] == 0)     # fully masked chunk -> zeros (attention.py:112-114)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_decoder_forms(lib, dtype):
+    """causal ragged self attention and cross attention over a chunk memory (decoder.py:150-156)."""
+    heads, dk = 4, 32
+    d = heads * dk
+    rng = np.random.default_rng(11)
+    qlen = i32([5, 83, 1, 130]); qstart = i32(np.concatenate([[0], np.cumsum(qlen)[:-1]]))
+    R = int(qlen.sum())
+    q = rnd(dtype, rng.standard_normal((R, d))); k = rnd(dtype, rng.standard_normal((R, d))); v = rnd(dtype, rng.standard_normal((R, d)))
+    out = np.empty((R, d), np.float32)
+    _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), None, None, None, fptr(out), R, R, 0, heads, dk,
+                                      iptr(qstart), iptr(qlen), iptr(qstart), iptr(qlen), 4, 1))
+    ref = _ref_attention(q, k, v, None, None, None, heads, dk, qstart, qlen, qstart, qlen, True)
+    tol = 2e-5 if dtype == F32 else 3e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+    # cross attention: 2 chunks of 90 memory frames, valid 90 / 41
+    Tm = 90
+    mem_k = rnd(dtype, rng.standard_normal((2 * Tm, d))); mem_v = rnd(dtype, rng.standard_normal((2 * Tm, d)))
+    kvs = i32([0, 0, Tm, Tm]); kvl = i32([90, 90, 41, 41])
+    _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(mem_k), fptr(mem_v), None, None, None, fptr(out), R, 2 * Tm, 0,
+                                      heads, dk, iptr(qstart), iptr(qlen), iptr(kvs), iptr(kvl), 4, 0))
+    ref = _ref_attention(q, mem_k, mem_v, None, None, None, heads, dk, qstart, qlen, kvs, kvl, False)
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
+def test_logsoftmax_topk(lib):
+    M, V, k = 37, 1001, 10
+    rng = np.random.default_rng(5)
+    x = f32(rng.standard_normal((M, V)) * 3)
+    x[3, 17] = x[3, 400] = x[3].max() + 1.0          # exact tie: lower index first
+    tv = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int32); lp = np.empty((M, V), np.float32)
+    _lib.check(lib.rvb_test_logsoftmax_topk(fptr(x), M, V, k, 0.0, 0, fptr(tv), iptr(ti), fptr(lp)))
+    ref = torch.from_numpy(x).double().log_softmax(-1)
+    np.testing.assert_allclose(lp, ref.numpy(), rtol=0, atol=2e-6)
+    rv, ri = ref.float().topk(k, dim=-1)
+    assert ti[3, 0] == 17 and ti[3, 1] == 400
+    rows = [r for r in range(M) if r != 3]
+    np.testing.assert_array_equal(ti[rows], ri.numpy()[rows])
+    np.testing.assert_allclose(tv, rv.numpy(), rtol=0, atol=2e-6)
+    # blank penalty (asr_model.py:322-325)
+    _lib.check(lib.rvb_test_logsoftmax_topk(fptr(x), M, V, k, 2.5, 0, fptr(tv), iptr(ti), fptr(lp)))
+    x2 = x.copy(); x2[:, 0] -= 2.5
+    np.testing.assert_allclose(lp, torch.from_numpy(x2).double().log_softmax(-1).numpy(), rtol=0, atol=2e-6)
+
+
+def test_lse_gather(lib):
+    R, V = 29, 10001
+    rng = np.random.default_rng(9)
+    x = f32(rng.standard_normal((R, V)) * 2)
+    tgt = i32(rng.integers(0, V, R))
+    out = np.empty(R, np.float32)
+    _lib.check(lib.rvb_test_lse_gather(fptr(x), R, V, iptr(tgt), fptr(out)))
+    ref = torch.from_numpy(x).double().log_softmax(-1).numpy()[np.arange(R), tgt]
+    np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)
+
+
+def test_fbank_vs_oracle(lib):
+    from oracle import fbank_ref
+    from reverb_amd import synth
+    pcm = synth.synth_audio(3.3, seed=7)
+    nf = fbank_ref.num_frames(len(pcm))
+    feats = np.empty((nf, 80), np.float32)
+    _lib.check(lib.rvb_test_fbank(pcm.ctypes.data_as(_lib._i16p), len(pcm), fptr(feats)))
+    ref = fbank_ref.fbank(pcm)
+    assert ref.shape == feats.shape
+    # fp32 radix-2 FFT vs pocketfft: log-mel agrees to 1e-3 abs (SURVEY.md 8d fbank tolerance)
+    np.testing.assert_allclose(feats, ref, rtol=0, atol=1e-3)
+    # low-amplitude input: every bin hits the log floor path or tiny energies
+    quiet = (pcm // 4000).astype(np.int16)
+    _lib.check(lib.rvb_test_fbank(quiet.ctypes.data_as(_lib._i16p), len(quiet), fptr(feats)))
+    np.testing.assert_allclose(feats, fbank_ref.fbank(quiet), rtol=0, atol=2e-3)
