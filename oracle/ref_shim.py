@@ -41,8 +41,11 @@ def install():
     """Make `import wenet` resolve to the reference. Idempotent."""
     if not reference_available():
         raise RuntimeError("reference not present at %s" % REFERENCE_ASR)
-    if "wenet" in sys.modules and getattr(sys.modules["wenet"], "__file__", "").startswith(REFERENCE_ASR):
+    if "wenet" in sys.modules and (getattr(sys.modules["wenet"], "__file__", "") or "").startswith(REFERENCE_ASR):
         return
+    # the repo ships its own `wenet` compatibility package; make sure the name resolves to the reference
+    for k in [k for k in sys.modules if k == "wenet" or k.startswith("wenet.")]:
+        del sys.modules[k]
     import torch
     import torch.nn.modules.conv as C
     # squeezeformer/conv2d.py imports typing names from torch.nn.modules.conv

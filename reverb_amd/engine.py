@@ -1,0 +1,254 @@
+"""Python host of the librvb engine: loads a Reverb-ASR state dict into HBM through the C ABI
+and exposes `ASRModel.decode`-shaped decoding (asr/wenet/transformer/asr_model.py:331-432).
+
+PyTorch is used only to read `.pt` checkpoints; all compute is in librvb's HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import ModelCfg, RvbError, check, dptr, fptr, iptr
+from .search import DecodeResult
+
+DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32,
+          "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16}
+SUPPORTED_MODES = ("ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring")
+
+
+def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_frames: int) -> ModelCfg:
+    """config.yaml -> rvb_model_cfg; refuses the model families / options the hot path does not cover
+     instead of silently computing something else."""
+    ec, dc = configs["encoder_conf"], configs.get("decoder_conf", {})
+    if configs.get("encoder", "conformer") != "conformer":
+        raise RvbError(f"encoder {configs.get('encoder')!r} is not supported (Reverb-ASR is a conformer)")
+    want = dict(input_layer="conv2d", pos_enc_layer_type="rel_pos", selfattention_layer_type="rel_selfattn",
+                activation_type="swish", normalize_before=True, use_cnn_module=True, macaron_style=True)
+    defaults = dict(input_layer="conv2d", pos_enc_layer_type="rel_pos", selfattention_layer_type="rel_selfattn",
+                    activation_type="swish", normalize_before=True, use_cnn_module=True, macaron_style=True)
+    for k, v in want.items():
+        if ec.get(k, defaults[k]) != v:
+            raise RvbError(f"encoder_conf.{k}={ec.get(k)!r} is not supported (need {v!r})")
+    if ec.get("causal", False):
+        raise RvbError("causal convolution (streaming models) is not supported yet")
+    ds = configs.get("dataset_conf", {})
+    lsl = bool(ds.get("pass_cat_emb", False))
+    if ds.get("add_cat_emb", False):
+        raise RvbError("dataset_conf.add_cat_emb is not supported")
+    nlang = int(ds["cat_emb_conf"]["emb_len"]) if lsl else 0
+    vocab = int(configs["output_dim"])
+    blank = int(configs.get("ctc_conf", {}).get("ctc_blank_id", 0))
+    cfg = ModelCfg()
+    cfg.dtype = DTYPES[dtype]
+    cfg.input_dim = int(configs["input_dim"])
+    cfg.vocab = vocab
+    cfg.d_model = int(ec["output_size"])
+    cfg.heads = int(ec["attention_heads"])
+    cfg.ffn_dim = int(ec["linear_units"])
+    cfg.num_blocks = int(ec["num_blocks"])
+    cfg.cnn_kernel = int(ec.get("cnn_module_kernel", 15))
+    cfg.cnn_norm = 0 if ec.get("cnn_module_norm", "batch_norm") == "layer_norm" else 1
+    cfg.num_langs = nlang
+    cfg.dec_heads = int(dc.get("attention_heads", 4))
+    cfg.dec_ffn_dim = int(dc.get("linear_units", 2048))
+    cfg.dec_blocks = int(dc.get("num_blocks", 0))
+    cfg.dec_r_blocks = int(dc.get("r_num_blocks", 0))
+    cfg.blank_id = blank
+    cfg.sos_id = vocab - 1
+    cfg.eos_id = vocab - 1
+    cfg.max_chunks = int(max_chunks)
+    cfg.chunk_frames = int(chunk_frames)
+    return cfg
+
+
+def _as_numpy_f32(v) -> Optional[np.ndarray]:
+    if hasattr(v, "detach"):          # torch tensor
+        if not v.dtype.is_floating_point:
+            return None
+        v = v.detach().cpu().float().numpy()
+    v = np.asarray(v)
+    if v.dtype.kind != "f":
+        return None
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class Engine:
+    """One librvb engine = one MI355X.  Not thread-safe (use one engine per thread/GPU)."""
+
+    def __init__(self, configs: dict, state_dict, dtype: str = "bf16", device: int = 0, max_chunks: int = 64,
+                 chunk_frames: int = 2051, cat_embs: Sequence[float] = (1.0, 0.0)):
+        self.lib = _lib.load()
+        self.configs = configs
+        self.dtype = dtype
+        self.cfg = model_cfg_from_configs(configs, dtype, max_chunks, chunk_frames)
+        self.handle = C.c_void_p()
+        check(self.lib.rvb_create(C.byref(self.cfg), int(device), C.byref(self.handle)), "rvb_create")
+        if "model0" in state_dict and isinstance(state_dict["model0"], dict):     # checkpoint.py:38-41
+            state_dict = state_dict["model0"]
+        for name, value in state_dict.items():
+            arr = _as_numpy_f32(value)
+            if arr is None:
+                continue                # e.g. BatchNorm num_batches_tracked
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            check(self.lib.rvb_load_tensor(self.handle, name.encode(), fptr(arr), shape, arr.ndim), f"load {name}")
+        self._cat = None
+        self.set_cat_embs(cat_embs)
+        self.batch = 0
+        self.enc_frames = 0
+
+    # -------------------------------------------------------------------------------- lifecycle
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.rvb_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cat_embs(self, cat_embs: Sequence[float]):
+        """[verbatimicity, 1-verbatimicity] (cli/reverb.py:215-217): refolds the language-specific layers."""
+        cat = np.ascontiguousarray(np.asarray(cat_embs, dtype=np.float32).reshape(-1))
+        if self._cat is not None and np.array_equal(cat, self._cat):
+            return
+        n = self.cfg.num_langs
+        if n and len(cat) != n:
+            raise RvbError(f"cat_embs must have {n} entries")
+        check(self.lib.rvb_finalize(self.handle, fptr(cat), len(cat) if n else 0), "rvb_finalize")
+        self._cat = cat
+
+    # -------------------------------------------------------------------------------- front end
+    def upload_pcm(self, pcm: np.ndarray):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
+        check(self.lib.rvb_upload_pcm(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm)), "rvb_upload_pcm")
+        self._n_samples = len(pcm)
+
+    def fbank(self, return_feats: bool = False):
+        """Kaldi fbank of the uploaded PCM; features stay resident in HBM.  Returns n_frames
+        (and the (n_frames, 80) float32 array when asked)."""
+        n = C.c_int64(0)
+        out = None
+        if return_feats:
+            out = np.empty((int(self.lib.rvb_num_frames(self._n_samples)), 80), np.float32)
+        check(self.lib.rvb_fbank(self.handle, fptr(out), C.byref(n)), "rvb_fbank")
+        self.n_frames = int(n.value)
+        return (self.n_frames, out) if return_feats else self.n_frames
+
+    # -------------------------------------------------------------------------------- decode
+    def encode(self, feats: Optional[np.ndarray], lens, beam: int, blank_penalty: float = 0.0, first_chunk: int = 0,
+               T0: Optional[int] = None):
+        lens = np.ascontiguousarray(np.asarray(lens, dtype=np.int32).reshape(-1))
+        B = len(lens)
+        if feats is not None:
+            feats = np.ascontiguousarray(feats, dtype=np.float32)
+            assert feats.ndim == 3 and feats.shape[0] == B and feats.shape[2] == self.cfg.input_dim
+            T0 = feats.shape[1]
+        elif T0 is None:
+            T0 = self.cfg.chunk_frames
+        check(self.lib.rvb_encode(self.handle, fptr(feats), int(first_chunk), iptr(lens), B, int(T0), int(beam),
+                                  float(blank_penalty)), "rvb_encode")
+        t = C.c_int32(0)
+        check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
+        self.batch, self.enc_frames, self.beam = B, int(t.value), int(beam)
+
+    def encoder_lens(self) -> np.ndarray:
+        out = np.empty(self.batch, np.int32)
+        check(self.lib.rvb_get_encoder_lens(self.handle, iptr(out)))
+        return out
+
+    def encoder_out(self) -> np.ndarray:
+        out = np.empty((self.batch, self.enc_frames, self.cfg.d_model), np.float32)
+        check(self.lib.rvb_get_encoder_out(self.handle, fptr(out)))
+        return out
+
+    def ctc_logprobs(self, chunk: int) -> np.ndarray:
+        out = np.empty((self.enc_frames, self.cfg.vocab), np.float32)
+        check(self.lib.rvb_get_ctc_logprobs(self.handle, int(chunk), fptr(out)))
+        return out
+
+    def ctc_topk(self):
+        v = np.empty((self.batch, self.enc_frames, self.beam), np.float32)
+        i = np.empty((self.batch, self.enc_frames, self.beam), np.int32)
+        check(self.lib.rvb_get_ctc_topk(self.handle, fptr(v), iptr(i)))
+        return v, i
+
+    def greedy(self) -> List[DecodeResult]:
+        T = self.enc_frames
+        tok = np.empty((self.batch, T), np.int32); n = np.empty(self.batch, np.int32); fr = np.empty((self.batch, T), np.int32)
+        check(self.lib.rvb_ctc_greedy(self.handle, iptr(tok), iptr(n), iptr(fr)), "rvb_ctc_greedy")
+        res = []
+        for b in range(self.batch):
+            r = DecodeResult(tok[b, :n[b]].tolist())
+            r.ctc_frames = fr[b, :n[b]].tolist()
+            res.append(r)
+        return res
+
+    def _nbest(self, chunk: int):
+        nh, ml = C.c_int32(0), C.c_int32(0)
+        check(self.lib.rvb_get_nbest_count(self.handle, chunk, C.byref(nh), C.byref(ml)))
+        nh, ml = nh.value, max(ml.value, 1)
+        tok = np.empty((nh, ml), np.int32); lens = np.empty(nh, np.int32)
+        tim = np.empty((nh, ml), np.int32); tl = np.empty(nh, np.int32); sc = np.empty(nh, np.float64)
+        check(self.lib.rvb_get_nbest(self.handle, chunk, iptr(tok), iptr(lens), iptr(tim), iptr(tl), dptr(sc)))
+        nbest = [tuple(tok[i, :lens[i]].tolist()) for i in range(nh)]
+        times = [tim[i, :tl[i]].tolist() for i in range(nh)]
+        return nbest, sc.tolist(), times
+
+    def prefix_beam(self) -> List[DecodeResult]:
+        check(self.lib.rvb_ctc_prefix_beam(self.handle, self.beam), "rvb_ctc_prefix_beam")
+        res = []
+        for b in range(self.batch):
+            nbest, scores, times = self._nbest(b)
+            res.append(DecodeResult(tokens=nbest[0], score=scores[0], times=times[0], nbest=nbest, nbest_scores=scores,
+                                    nbest_times=times))
+        return res
+
+    def rescore(self, prefix_results: List[DecodeResult], ctc_weight: float, reverse_weight: float) -> List[DecodeResult]:
+        check(self.lib.rvb_attention_rescore(self.handle, float(ctc_weight), float(reverse_weight)), "rvb_attention_rescore")
+        res = []
+        for b, pr in enumerate(prefix_results):
+            bi, sc, cf = C.c_int32(0), C.c_float(0), C.c_double(0)
+            check(self.lib.rvb_get_rescored(self.handle, b, C.byref(bi), C.byref(sc), C.byref(cf), None))
+            tc = np.empty(max(len(pr.nbest[bi.value]), 1), np.float64)
+            check(self.lib.rvb_get_rescored(self.handle, b, None, None, None, dptr(tc)))
+            res.append(DecodeResult(pr.nbest[bi.value], float(sc.value), confidence=float(cf.value),
+                                    times=pr.nbest_times[bi.value],
+                                    tokens_confidence=tc[:len(pr.nbest[bi.value])].tolist()))
+        return res
+
+    def rescore_logp(self, chunk: int, hyp: int, length: int, right: bool = False) -> np.ndarray:
+        out = np.empty(length + 1, np.float32)
+        check(self.lib.rvb_get_rescore_logp(self.handle, chunk, hyp, 1 if right else 0, fptr(out)))
+        return out
+
+    def search(self, methods: Sequence[str], ctc_weight: float, reverse_weight: float) -> Dict[str, List[DecodeResult]]:
+        """Search stages of ASRModel.decode (asr_model.py:399-425) on the last encoded batch."""
+        results: Dict[str, List[DecodeResult]] = {}
+        for m in methods:
+            if m not in SUPPORTED_MODES:
+                raise RvbError(f"decoding mode {m!r} is not built yet (supported: {', '.join(SUPPORTED_MODES)})")
+        if "ctc_greedy_search" in methods:
+            results["ctc_greedy_search"] = self.greedy()
+        if "ctc_prefix_beam_search" in methods or "attention_rescoring" in methods:
+            pref = self.prefix_beam()
+            if "ctc_prefix_beam_search" in methods:
+                results["ctc_prefix_beam_search"] = pref
+            if "attention_rescoring" in methods:
+                results["attention_rescoring"] = self.rescore(pref, ctc_weight, reverse_weight)
+        return results
+
+    # -------------------------------------------------------------------------------- timings
+    def set_profiling(self, on: bool):
+        check(self.lib.rvb_set_profiling(self.handle, 1 if on else 0))
+
+    def reset_timings(self):
+        check(self.lib.rvb_reset_timings(self.handle))
+
+    def timing(self, name: str):
+        ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        check(self.lib.rvb_get_timing(self.handle, name.encode(), C.byref(ms), C.byref(fl), C.byref(n)))
+        return {"ms": ms.value, "flops": fl.value, "launches": n.value}
