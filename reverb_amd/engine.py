@@ -241,6 +241,26 @@ class Engine:
                 results["attention_rescoring"] = self.rescore(pref, ctc_weight, reverse_weight)
         return results
 
+    def decode_resident(self, n_frames: int, modes, chunk_size: int, beam_size: int, ctc_weight: float,
+                        reverse_weight: float, blank_penalty: float = 0.0) -> Dict[str, List[DecodeResult]]:
+        """Decode the device-resident features of the last fbank() call: fixed, non-overlapping
+        chunks with a length-masked zero-padded tail (feats_batcher, cli/reverb.py:148-180),
+        `max_chunks` chunks per launch, results concatenated in chunk order."""
+        if chunk_size != self.cfg.chunk_frames:
+            raise RvbError("resident decoding needs chunk_size == engine chunk_frames")
+        n_chunks = -(-n_frames // chunk_size)
+        lens = np.full(n_chunks, chunk_size, np.int32)
+        if n_chunks:
+            lens[-1] = n_frames - (n_chunks - 1) * chunk_size
+        out: Dict[str, List[DecodeResult]] = {m: [] for m in modes}
+        for s in range(0, n_chunks, self.cfg.max_chunks):
+            e = min(n_chunks, s + self.cfg.max_chunks)
+            self.encode(None, lens[s:e], beam_size, blank_penalty, first_chunk=s, T0=chunk_size)
+            part = self.search(modes, ctc_weight, reverse_weight)
+            for m in modes:
+                out[m].extend(part[m])
+        return out
+
     # -------------------------------------------------------------------------------- timings
     def set_profiling(self, on: bool):
         check(self.lib.rvb_set_profiling(self.handle, 1 if on else 0))

@@ -203,22 +203,8 @@ class ReverbASR:
 
     def decode_resident(self, n_frames: int, modes, chunk_size: int, beam_size: int, ctc_weight: float,
                         reverse_weight: float, blank_penalty: float = 0.0):
-        """Decode the device-resident features of the last fbank call, `max_chunks` chunks per launch."""
-        eng = self.engine
-        if chunk_size != eng.cfg.chunk_frames:
-            raise ValueError("resident decoding needs chunk_size == engine chunk_frames")
-        n_chunks = ceil(n_frames / chunk_size)
-        lens = np.full(n_chunks, chunk_size, np.int32)
-        if n_chunks:
-            lens[-1] = n_frames - (n_chunks - 1) * chunk_size
-        out = {m: [] for m in modes}
-        for s in range(0, n_chunks, eng.cfg.max_chunks):
-            e = min(n_chunks, s + eng.cfg.max_chunks)
-            eng.encode(None, lens[s:e], beam_size, blank_penalty, first_chunk=s, T0=chunk_size)
-            part = eng.search(modes, ctc_weight, reverse_weight)
-            for m in modes:
-                out[m].extend(part[m])
-        return out
+        return self.engine.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight,
+                                           blank_penalty)
 
     def transcribe(self, audio_file, mode: str = "ctc_prefix_beam_search", format: str = "txt",
                    verbatimicity: float = 1.0, chunk_size: int = 2051, batch_size: int = 1, beam_size: int = 10,

@@ -1,0 +1,60 @@
+"""Rebuild the exact inputs of a golden case (weights, audio, chunked features) from its json."""
+import json
+import os
+
+import numpy as np
+
+from oracle import fbank_ref
+from reverb_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["tiny_ln", "tiny_ln_r2l", "tiny_bn", "small_ln", "r268_chunk"]
+MODES = ["ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring"]
+
+
+class Case:
+    def __init__(self, name):
+        self.name = name
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.js = json.load(f)
+        self.arrays = np.load(os.path.join(GOLDEN, name + ".npz"))
+        c = self.js["case"]
+        self.c = c
+        self.cfg = synth.make_config(c["dims"], c["norm"])
+        self.beam, self.ctc_weight, self.reverse_weight, self.cat = c["beam"], c["ctc_weight"], c["reverse_weight"], c["cat"]
+        self.chunk = c["chunk"]
+        self._sd = None
+        self._feats = None
+
+    @property
+    def sd(self):
+        if self._sd is None:
+            self._sd = synth.make_state_dict(self.cfg, self.c["seed"], self.js["gamma"], self.js["beta"])
+        return self._sd
+
+    @property
+    def pcm(self):
+        return synth.synth_audio(self.c["seconds"], seed=1234 + self.c["seed"])
+
+    def chunked_feats(self):
+        """(x [nch, chunk, 80], lens) exactly as oracle/gen_golden.py fed the reference."""
+        if self._feats is None:
+            feats = fbank_ref.fbank(self.pcm)
+            n = feats.shape[0]
+            tail = self.c.get("tail_frames")
+            if tail is not None:
+                n = (n // self.chunk) * self.chunk + tail
+                feats = feats[:n]
+            nch = -(-n // self.chunk)
+            x = np.zeros((nch, self.chunk, 80), np.float32)
+            lens = np.zeros(nch, np.int32)
+            for i in range(nch):
+                part = feats[i * self.chunk:(i + 1) * self.chunk]
+                x[i, :len(part)] = part
+                lens[i] = len(part)
+            assert lens.tolist() == self.js["lens"]
+            self._feats = (x, lens)
+        return self._feats
+
+    def golden(self, mode):
+        return self.js["modes"][mode]

@@ -1,0 +1,188 @@
+"""End-to-end parity of the HIP engine (through the C ABI) against the golden vectors generated
+from the unmodified reference, and against the oracle on the same seeded inputs.
+
+f32 mode (v_mfma_f32_16x16x4_f32, exact f32 fma chains) must reproduce token ids, n-best lists and
+CTC peak times exactly; floating point taps within the tolerances written at each assert
+(summation order is the only difference).  bf16 mode is judged by cosine similarity and token
+error rate (bit-exact ids are only attainable on the f32 path)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from golden_util import CASES, MODES, Case
+from reverb_amd import synth
+from reverb_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, dtype, max_chunks=4):
+    return Engine(case.cfg, case.sd, dtype=dtype, device=0, max_chunks=max_chunks, chunk_frames=case.chunk,
+                  cat_embs=case.cat)
+
+
+def _edit_distance(a, b):
+    dp = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        prev, dp[0] = dp[0], i
+        for j in range(1, len(b) + 1):
+            cur = dp[j]
+            dp[j] = min(dp[j] + 1, dp[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+            prev = cur
+    return dp[-1]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_f32_engine_matches_reference_golden(name):
+    case = Case(name)
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "f32")
+    eng.encode(x, lens, case.beam)
+    enc_lens = eng.encoder_lens()
+    assert enc_lens.tolist() == case.js["encoder_lens"]
+    enc = eng.encoder_out()
+    gold = case.arrays["encoder_out"]
+    if case.c.get("light"):
+        enc = enc[:, ::16, ::8]
+    for b, n in enumerate(enc_lens):
+        nn = len(range(0, n, 16)) if case.c.get("light") else n
+        # LayerNorm-ed activations are O(1): 2e-3 abs is ~1e-3 relative (f32 sums in a different order)
+        np.testing.assert_allclose(enc[b, :nn], gold[b, :nn], rtol=2e-3, atol=2e-3)
+    tv, ti = eng.ctc_topk()
+    gv, gi = case.arrays["topk_val"], case.arrays["topk_idx"]
+    mism = 0
+    for b, n in enumerate(enc_lens):
+        np.testing.assert_allclose(tv[b, :n, 0], gv[b, :n, 0], rtol=0, atol=2e-3)
+        mism += int((ti[b, :n] != gi[b, :n]).sum())
+    assert mism <= 0.002 * max(1, int(enc_lens.sum()) * case.beam)     # swaps only between near-tied candidates
+    if "ctc_probs_chunk0" in case.arrays and case.cfg["output_dim"] <= 64:
+        lp = eng.ctc_logprobs(0)
+        np.testing.assert_allclose(lp[:enc_lens[0]], case.arrays["ctc_probs_chunk0"][:enc_lens[0]], rtol=0, atol=2e-3)
+
+    res = eng.search(MODES, case.ctc_weight, case.reverse_weight)
+    for b in range(len(lens)):
+        g = case.golden("ctc_greedy_search")[b]
+        assert res["ctc_greedy_search"][b].tokens == g["tokens"], f"greedy tokens differ in chunk {b}"
+        assert res["ctc_greedy_search"][b].times is None
+        p, gp = res["ctc_prefix_beam_search"][b], case.golden("ctc_prefix_beam_search")[b]
+        assert [list(h) for h in p.nbest] == gp["nbest"]
+        assert p.nbest_times == gp["nbest_times"]
+        np.testing.assert_allclose(p.nbest_scores, gp["nbest_scores"], rtol=0, atol=2e-2)
+        assert list(p.tokens) == gp["tokens"] and list(p.times) == gp["times"]
+        r, gr = res["attention_rescoring"][b], case.golden("attention_rescoring")[b]
+        assert list(r.tokens) == gr["tokens"], f"rescoring picked another hypothesis in chunk {b}"
+        assert list(r.times) == gr["times"]
+        assert abs(r.score - gr["score"]) <= 2e-2 + 1e-4 * abs(gr["score"])
+        assert abs(r.confidence - gr["confidence"]) <= 1e-3
+        np.testing.assert_allclose(r.tokens_confidence, gr["tokens_confidence"], rtol=0, atol=2e-3)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "small_ln", "r268_chunk"])
+def test_bf16_engine_within_tolerance(name):
+    case = Case(name)
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "bf16")
+    eng.encode(x, lens, case.beam)
+    enc_lens = eng.encoder_lens()
+    enc = eng.encoder_out()
+    gold = case.arrays["encoder_out"]
+    if case.c.get("light"):
+        enc = enc[:, ::16, ::8]
+    for b, n in enumerate(enc_lens):
+        nn = len(range(0, n, 16)) if case.c.get("light") else n
+        if nn == 0:
+            continue
+        a, g = enc[b, :nn].ravel().astype(np.float64), gold[b, :nn].ravel().astype(np.float64)
+        cos = float(a @ g / (np.linalg.norm(a) * np.linalg.norm(g)))
+        assert cos > 0.999, f"encoder cos-sim {cos}"
+    res = eng.search(MODES, case.ctc_weight, case.reverse_weight)
+    err = tot = 0
+    for b in range(len(lens)):
+        g = case.golden("ctc_greedy_search")[b]["tokens"]
+        err += _edit_distance(res["ctc_greedy_search"][b].tokens, g)
+        tot += len(g)
+        r = res["attention_rescoring"][b]
+        assert len(r.times) == len(r.tokens) or case.js["outputs"]["attention_rescoring"].get("error")
+    # synthetic random-weight models have tiny CTC margins (79 vs 73 tokens under bf16 autocast)
+    assert err <= 0.25 * max(tot, 1), f"token error rate {err}/{tot}"
+    eng.close()
+
+
+def test_encode_rejects_bad_arguments_and_reports():
+    from reverb_amd._lib import RvbError
+    case = Case("tiny_ln")
+    eng = _engine(case, "f32", max_chunks=2)
+    x, lens = case.chunked_feats()
+    with pytest.raises(RvbError, match="max_chunks"):
+        eng.encode(np.zeros((3, case.chunk, 80), np.float32), [case.chunk] * 3, 4)
+    with pytest.raises(RvbError, match="beam"):
+        eng.encode(x, lens, 17)
+    with pytest.raises(RvbError):
+        eng.rescore([], 0.1, 0.0)          # no search results yet
+    eng.close()
+
+
+def test_cat_embs_refold_changes_and_restores_output():
+    """language-specific layers are folded per request (encoder_layer.py:378-390)."""
+    case = Case("tiny_ln")
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "f32")
+    eng.encode(x[:1], lens[:1], case.beam)
+    a = eng.encoder_out().copy()
+    eng.set_cat_embs([0.2, 0.8])
+    eng.encode(x[:1], lens[:1], case.beam)
+    b = eng.encoder_out().copy()
+    eng.set_cat_embs(case.cat)
+    eng.encode(x[:1], lens[:1], case.beam)
+    c = eng.encoder_out()
+    assert np.abs(a - b).max() > 1e-3
+    np.testing.assert_array_equal(a, c)
+    eng.close()
+
+
+def test_batch_composition_does_not_change_results():
+    """chunks are independent (reverb.py:148-180): batch of 2 == two batches of 1, bit for bit."""
+    case = Case("tiny_ln")
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "f32")
+    eng.encode(x, lens, case.beam)
+    both_v, both_i = eng.ctc_topk()
+    both = eng.encoder_out().copy()
+    for b in range(2):
+        eng.encode(x[b:b + 1], lens[b:b + 1], case.beam)
+        np.testing.assert_array_equal(eng.encoder_out()[0], both[b])
+        v, i = eng.ctc_topk()
+        np.testing.assert_array_equal(i[0], both_i[b])
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "small_ln"])
+def test_api_from_wav_file_matches_reference_ctm(name):
+    """load_model(dir).transcribe_modes(wav) -- PCM in, CTM out, features computed on the device --
+    against the CTM strings the reference produced from the oracle features."""
+    import reverb_amd
+    case = Case(name)
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_model_dir(os.path.join(d, "model"), name, sd=case.sd, cfg=case.cfg)
+        wav = os.path.join(d, "golden.wav")
+        synth.write_wav(wav, case.pcm)
+        asr = reverb_amd.load_model(os.path.join(d, "model"), dtype="f32", max_chunks=4)
+        modes = ["ctc_prefix_beam_search", "attention_rescoring"]
+        ctm = asr.transcribe_modes(wav, modes, format="ctm", verbatimicity=case.cat[0], chunk_size=case.chunk,
+                                   beam_size=case.beam, ctc_weight=case.ctc_weight, reverse_weight=case.reverse_weight)
+        for m, text in zip(modes, ctm):
+            want = case.js["outputs"][m]["ctm"].split("\n")
+            got = text.split("\n")
+            # device fbank differs from the oracle features by ~1e-4: allow a near-tie flip in <=2% of words
+            assert abs(len(got) - len(want)) <= max(1, len(want) // 50)
+            same = sum(1 for a, b in zip(got, want) if a.split()[:5] == b.split()[:5])
+            assert same >= 0.9 * len(want), f"{m}: {same}/{len(want)} CTM lines equal"
+        txt = asr.transcribe(wav, mode="ctc_greedy_search", verbatimicity=case.cat[0])
+        assert isinstance(txt, str) and len(txt) > 0
+        feats = asr.compute_feats(wav, num_mel_bins=80)
+        from oracle import fbank_ref
+        np.testing.assert_allclose(feats[0].numpy(), fbank_ref.fbank(case.pcm), rtol=0, atol=1e-3)
+        asr.engine.close()
