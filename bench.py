@@ -48,39 +48,6 @@ def parse():
     return p.parse_args()
 
 
-def gather_results(dist, torch, device, hyps, world):
-    """One all-gather(v) of the per-chunk results over RCCL/xGMI (SURVEY.md 8e option (i)):
-    tokens + CTC peak frames + confidences, padded to the longest hypothesis of any rank."""
-    n = len(hyps)
-    lmax = max([len(h.tokens) for h in hyps] + [1])
-    meta = torch.tensor([n, lmax], device=device, dtype=torch.int64)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    nmax = max(int(m[0]) for m in metas)
-    lall = max(int(m[1]) for m in metas)
-    pack = np.full((nmax, 2 * lall + 2), -1, np.int32)
-    conf = np.zeros((nmax, lall + 2), np.float32)
-    for i, h in enumerate(hyps):
-        k = len(h.tokens)
-        pack[i, 0] = k
-        pack[i, 1] = len(h.times)
-        pack[i, 2:2 + k] = h.tokens
-        pack[i, 2 + lall:2 + lall + len(h.times)] = h.times
-        conf[i, 0] = h.score
-        conf[i, 1] = h.confidence
-        conf[i, 2:2 + k] = h.tokens_confidence
-    tp = torch.from_numpy(pack).to(device)
-    tc = torch.from_numpy(conf).to(device)
-    outs_p = [torch.empty_like(tp) for _ in range(world)]
-    outs_c = [torch.empty_like(tc) for _ in range(world)]
-    dist.all_gather(outs_p, tp)
-    dist.all_gather(outs_c, tc)
-    total = 0
-    for r in range(world):
-        total += int((outs_p[r][:int(metas[r][0]), 0]).sum().item())
-    return total
-
-
 def cpu_baseline(cfg, sd, feats_chunks, lens, args):
     """The oracle (CPU restatement of the reference, plain torch fp32, batch 1 as the reference does,
     recognize_wav.py:60-64) timed on the host cores on a bounded sample of the same workload."""
@@ -119,6 +86,7 @@ def main():
     torch.cuda.set_device(device)
 
     from reverb_amd import synth
+    from reverb_amd.dist import all_gather_results
     from reverb_amd.engine import Engine
 
     chunk = 2051
@@ -137,8 +105,9 @@ def main():
         nf = eng.fbank()
         hyps = eng.decode_resident(nf, modes, chunk, args.beam, args.ctc_weight, args.reverse_weight)["attention_rescoring"]
         ntok = sum(len(h.tokens) for h in hyps)
-        if world > 1:
-            ntok = gather_results(dist, torch, device, hyps, world)
+        if world > 1:     # one all-gather of the per-chunk results over RCCL/xGMI
+            hyps = all_gather_results(hyps, device)
+            ntok = sum(len(h.tokens) for h in hyps)
         return hyps, ntok
 
     for _ in range(args.warmup):

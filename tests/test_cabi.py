@@ -1,0 +1,58 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/rvb.h
+declares; without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAVE_GPU, ROOT
+from reverb_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rvb.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rvb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"librvb.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in reverb_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_frame_count(lib):
+    assert b"gfx950" in lib.rvb_version()
+    assert lib.rvb_num_frames(399) == 0 and lib.rvb_num_frames(400) == 1 and lib.rvb_num_frames(57600000) == 359998
+
+
+def test_struct_layout_matches_header():
+    text = open(os.path.join(ROOT, "include", "rvb.h")).read()
+    body = text[text.index("typedef struct rvb_model_cfg {"):text.index("} rvb_model_cfg;")]
+    fields = re.findall(r"int32_t\s+([a-z_0-9]+);", body)
+    assert fields == [f[0] for f in _lib.ModelCfg._fields_]
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(lib):
+    from reverb_amd import synth
+    from reverb_amd.engine import Engine
+    cfg = synth.make_config("tiny")
+    with pytest.raises(_lib.RvbError, match="no HIP device"):
+        Engine(cfg, {}, dtype="f32")
+    out = np.zeros(4, np.float32)
+    rc = lib.rvb_test_gemm(0, _lib.fptr(out), _lib.fptr(out), None, None, _lib.fptr(out), 1, 1, 4, 1.0, 0, 1, 0, 0, 0, 0, 0)
+    assert rc != 0 and b"no CPU fallback" in lib.rvb_last_error()
+
+
+def test_bad_arguments_are_reported_not_crashed(lib):
+    cfg = _lib.ModelCfg()
+    h = ctypes.c_void_p()
+    assert lib.rvb_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1      # RVB_E_ARG: all-zero dims
+    assert b"unsupported model dimensions" in lib.rvb_last_error() or b"dtype" in lib.rvb_last_error()
+    assert lib.rvb_create(None, 0, ctypes.byref(h)) == -1

@@ -1,0 +1,83 @@
+"""Multi-GPU path on CPU: the chunk partition, the waveform slicing with its 240-sample halo, and
+the result all-gather (world_size 2, gloo backend -- the same torch.distributed calls run over
+RCCL on the GPUs)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import fbank_ref
+from reverb_amd import dist as rdist
+from reverb_amd import synth
+from reverb_amd.search import DecodeResult
+
+
+def test_chunk_ranges_cover_everything_in_order():
+    for n in (0, 1, 7, 8, 176, 1405):
+        for w in (1, 2, 4, 8):
+            r = rdist.chunk_ranges(n, w)
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    assert rdist.chunk_ranges(1405, 8)[0] == (0, 176) and rdist.chunk_ranges(1405, 8)[7] == (1230, 1405)
+
+
+def test_sample_slices_reproduce_the_whole_file_features():
+    """fbank of each rank's PCM slice == the rank's rows of the whole-file fbank (bit for bit)."""
+    pcm = synth.synth_audio(23.7, seed=5)
+    chunk = 500
+    whole = fbank_ref.fbank(pcm)
+    n_chunks = -(-whole.shape[0] // chunk)
+    rows = []
+    for c0, c1 in rdist.chunk_ranges(n_chunks, 3):
+        s0, s1 = rdist.sample_range(len(pcm), chunk, c0, c1)
+        part = fbank_ref.fbank(pcm[s0:s1])
+        assert part.shape[0] == min(c1 * chunk, whole.shape[0]) - c0 * chunk
+        rows.append(part)
+    np.testing.assert_array_equal(np.concatenate(rows), whole)
+    assert rdist.sample_range(len(pcm), chunk, n_chunks, n_chunks + 2) == (0, 0)
+
+
+def _fake_results(rank):
+    rng = np.random.default_rng(rank)
+    out = []
+    for i in range(3 + 2 * rank):
+        k = int(rng.integers(0, 9))
+        toks = rng.integers(1, 40, k).tolist()
+        out.append(DecodeResult(tuple(toks), float(-rng.random() * 30), confidence=float(rng.random()),
+                                times=sorted(rng.integers(0, 512, k).tolist()),
+                                tokens_confidence=rng.random(k).tolist()))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    merged = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"))
+    q.put((rank, [(list(h.tokens), h.times, h.score, h.confidence, h.tokens_confidence) for h in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_results_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [(list(h.tokens), h.times, h.score, h.confidence, h.tokens_confidence)
+            for r in range(2) for h in _fake_results(r)]
+    assert got[0] == want and got[1] == want        # every rank holds all results, in chunk order
