@@ -142,6 +142,11 @@ int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, 
                          int32_t* n_hyps, int32_t* tokens /* [beam][T] */, int32_t* lens, int32_t* times,
                          int32_t* times_lens, double* scores);
 
+/* GEMM kernel selection / micro-benchmark hooks (tests and tuning only) */
+int rvb_test_set_gemm_variant(int variant /* 0 auto, 1 gemm.hip 128x128, 2 gemm2.hip 256x256 LDS-DMA */);
+int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, int iters, int act, int out_f32, int with_res,
+                        double* ms_out, double* max_abs_diff_vs_variant1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   char* sV = smem + L::OFF_V;
   char* sW = smem + L::OFF_W + wave * 16 * L::ROW_V;
 
+  const float inv_sqrt_dk = 1.0f / a.sqrt_dk;   // bf16 mode multiplies; f32 mode divides like the reference
   int kend = kvlen;
   if (a.causal) kend = min(kvlen, q0 + 64);
   for (int kt0 = 0; kt0 < kend; kt0 += KT) {
@@ -108,17 +109,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       const int r = i / VPR, c = i - r * VPR;
       const int key = kt0 + r;
       const bool ok = key < kvlen && c * VE < dk;
-      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        kv4 = *(const uint4*)(K + (size_t)(ks + key) * a.k_stride + head * dk + c * VE);
-        vv4 = *(const uint4*)(V + (size_t)(ks + key) * a.v_stride + head * dk + c * VE);
-      }
+      uint4 kv4 = make_uint4(0, 0, 0, 0);
+      if (ok) kv4 = *(const uint4*)(K + (size_t)(ks + key) * a.k_stride + head * dk + c * VE);
       *(uint4*)(sK + r * L::ROW_K + c * 16) = kv4;
       if constexpr (HAS_POS) {
         uint4 pv4 = make_uint4(0, 0, 0, 0);
         if (ok) pv4 = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
         *(uint4*)(sP + r * L::ROW_K + c * 16) = pv4;
       }
+    }
+    // V^T: consecutive lanes take consecutive keys, so the 2-/4-byte transposed LDS writes of a wave
+    // fall on consecutive addresses (the key-major mapping above would put 8 lanes on one bank)
+    for (int i = tid; i < KT * VPR; i += 256) {
+      const int c = i / KT, r = i - c * KT;
+      const int key = kt0 + r;
+      uint4 vv4 = make_uint4(0, 0, 0, 0);
+      if (key < kvlen && c * VE < dk) vv4 = *(const uint4*)(V + (size_t)(ks + key) * a.v_stride + head * dk + c * VE);
       T tv[VE];
       *(uint4*)tv = vv4;
 #pragma unroll
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) {
         const int key = kt0 + nf * 16 + lrow;
-        float v = s[nf][r] / a.sqrt_dk;
+        float v = sizeof(T) == 2 ? s[nf][r] * inv_sqrt_dk : s[nf][r] / a.sqrt_dk;
         if (key >= kvlen || (a.causal && key > qrow)) v = -INFINITY;
         s[nf][r] = v;
         mx = fmaxf(mx, v);
@@ -163,10 +169,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) s[nf][r] = 0.f;
       } else {
-        al = (m_run[r] == -INFINITY) ? 0.f : expf(m_run[r] - m_new);
+        al = (m_run[r] == -INFINITY) ? 0.f : (sizeof(T) == 2 ? __expf(m_run[r] - m_new) : expf(m_run[r] - m_new));
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          const float pv = expf(s[nf][r] - m_new);   // exp(-inf) = 0 for masked keys
+          const float pv = sizeof(T) == 2 ? __expf(s[nf][r] - m_new) : expf(s[nf][r] - m_new);   // exp(-inf) = 0 for masked keys
           s[nf][r] = pv;
           ps += pv;
         }

@@ -160,34 +160,54 @@ int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
 // ------------------------------------------------------------------------------------------------
 // GLU + depthwise conv along time (per chunk), LDS halo tile of 64 time steps x 64 channels
 // ------------------------------------------------------------------------------------------------
-static constexpr int DW_TT = 64, DW_CT = 64, DW_KMAX = 63;
+static constexpr int DW_TT = 64, DW_CT = 128, DW_KMAX = 31;
 
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> {
+  __device__ static inline void load(const bf16_t* p, float& x, float& y) {
+    const uint32_t u = *(const uint32_t*)p;
+    x = bf16_to_f32((bf16_t)(u & 0xffffu)); y = bf16_to_f32((bf16_t)(u >> 16));
+  }
+};
+template <> struct Pair<float> {
+  __device__ static inline void load(const float* p, float& x, float& y) {
+    const float2 u = *(const float2*)p;
+    x = u.x; y = u.y;
+  }
+};
+
+// block = 64 time steps x 128 channels; a lane owns 2 adjacent channels (4-/8-byte loads, 8-byte stores)
 template <typename T>
 __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
-  __shared__ float s_g[DW_TT + DW_KMAX - 1][DW_CT];
-  __shared__ float s_w[DW_KMAX][DW_CT];
+  __shared__ float2 s_g[DW_TT + DW_KMAX - 1][DW_CT / 2];
+  __shared__ float2 s_w[DW_KMAX][DW_CT / 2];
   const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
-  const int ch = c0 + c;
-  const bool cok = ch < a.d;
+  const int ch = c0 + 2 * c;
+  const bool cok = ch < a.d;            // d is even: both channels of the pair are in range together
   const int K = a.K, pad = (K - 1) / 2;
   const int len = a.lens[b];
   const T* G = (const T*)a.G;
-  float gpad = 0.f;   // GLU of the pointwise-conv1 bias: what a zero-masked (padded) frame produces
+  float2 gpad = make_float2(0.f, 0.f);  // GLU of the pointwise-conv1 bias: what a zero-masked (padded) frame yields
   if (cok) {
-    const float pa = a.pw1_bias[ch], pb = a.pw1_bias[a.d + ch];
-    gpad = pa / (1.0f + expf(-pb));
+    gpad.x = a.pw1_bias[ch] / (1.0f + expf(-a.pw1_bias[a.d + ch]));
+    gpad.y = a.pw1_bias[ch + 1] / (1.0f + expf(-a.pw1_bias[a.d + ch + 1]));
   }
-  for (int k = slot; k < K; k += 4) s_w[k][c] = cok ? a.dw_w[(size_t)ch * K + k] : 0.f;
+  for (int k = slot; k < K; k += 4)
+    s_w[k][c] = cok ? make_float2(a.dw_w[(size_t)ch * K + k], a.dw_w[(size_t)(ch + 1) * K + k]) : make_float2(0.f, 0.f);
   const int rows = DW_TT + K - 1;
+#pragma unroll 4
   for (int r = slot; r < rows; r += 4) {
     const int t = t0 - pad + r;
-    float g = 0.f;
+    float2 g = make_float2(0.f, 0.f);
     if (cok && t >= 0 && t < a.T) {
       if (t < len) {
         const T* gr = G + ((size_t)b * a.T + t) * 2 * a.d;
-        const float ga = Cvt<T>::to_f32(gr[ch]), gb = Cvt<T>::to_f32(gr[a.d + ch]);
-        g = ga / (1.0f + expf(-gb));
+        float a0, a1, b0, b1;
+        Pair<T>::load(gr + ch, a0, a1);
+        Pair<T>::load(gr + a.d + ch, b0, b1);
+        g.x = a0 / (1.0f + expf(-b0));
+        g.y = a1 / (1.0f + expf(-b1));
       } else {
         g = gpad;
       }
@@ -196,25 +216,29 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
   }
   __syncthreads();
   if (!cok) return;
-  float acc[DW_TT / 4];
-  const float bv = a.dw_b[ch];
+  float2 acc[DW_TT / 4];
+  const float2 bv = make_float2(a.dw_b[ch], a.dw_b[ch + 1]);
 #pragma unroll
   for (int i = 0; i < DW_TT / 4; ++i) acc[i] = bv;
   for (int k = 0; k < K; ++k) {
-    const float wk = s_w[k][c];
+    const float2 wk = s_w[k][c];
 #pragma unroll
-    for (int i = 0; i < DW_TT / 4; ++i) acc[i] += wk * s_g[slot + 4 * i + k][c];
+    for (int i = 0; i < DW_TT / 4; ++i) {
+      const float2 g = s_g[slot + 4 * i + k][c];
+      acc[i].x += wk.x * g.x;
+      acc[i].y += wk.y * g.y;
+    }
   }
 #pragma unroll
   for (int i = 0; i < DW_TT / 4; ++i) {
     const int t = t0 + slot + 4 * i;
-    if (t < a.T) a.out[((size_t)b * a.T + t) * a.d + ch] = acc[i];
+    if (t < a.T) *(float2*)(a.out + ((size_t)b * a.T + t) * a.d + ch) = acc[i];
   }
 }
 
 int glu_dwconv(hipStream_t s, int dtype, const GluDwArgs& a) {
   if (a.B <= 0 || a.T <= 0) return OK;
-  if (a.K > DW_KMAX || (a.K % 2) == 0) { set_error("glu_dwconv: kernel must be odd and <= 63"); return E_ARG; }
+  if (a.K > DW_KMAX || (a.K % 2) == 0 || (a.d % 2)) { set_error("glu_dwconv: kernel must be odd and <= 31, d even"); return E_ARG; }
   dim3 grid(cdiv(a.T, DW_TT), cdiv(a.d, DW_CT), a.B);
   if (dtype == DT_BF16) hipLaunchKernelGGL(glu_dw_kernel<bf16_t>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(256), 0, s, a);
@@ -236,106 +260,6 @@ int embed_tokens(hipStream_t s, const float* E, const float* pe, const int* tok,
                  int rows, int d, float scale) {
   if (rows <= 0) return OK;
   hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, s, E, pe, tok, pos, out, rows, d, scale);
-  RVB_HIP_CHECK(hipGetLastError());
-  return OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// log-softmax + top-k per row: one wave per row.  Each lane keeps a sorted top-16 of its strided
-// slice in registers (static indices only), then the wave pops the global maximum k times.
-// ------------------------------------------------------------------------------------------------
-static constexpr int TOPK_MAX = 16;
-
-__device__ inline float row_logit(const float* x, int i, float pen, int blank) {
-  float v = x[i];
-  if (i == blank) v -= pen;
-  return v;
-}
-
-__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int M, int V, int ld,
-                                                              int k, float pen, int blank, float* __restrict__ tv,
-                                                              int* __restrict__ ti, float* __restrict__ lp) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* x = logits + (size_t)row * ld;
-  float bv[TOPK_MAX];
-  int bi[TOPK_MAX];
-#pragma unroll
-  for (int i = 0; i < TOPK_MAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
-  float mx = -INFINITY;
-  for (int i = lane; i < V; i += 64) {
-    float v = row_logit(x, i, pen, blank);
-    mx = fmaxf(mx, v);
-    if (v > bv[TOPK_MAX - 1]) {
-      int vi = i;
-#pragma unroll
-      for (int j = 0; j < TOPK_MAX; ++j) {
-        if (v > bv[j]) {   // strict: on ties the earlier (lower) index stays ahead
-          const float tvv = bv[j]; const int tii = bi[j];
-          bv[j] = v; bi[j] = vi; v = tvv; vi = tii;
-        }
-      }
-    }
-  }
-  mx = wave_max(mx);
-  float se = 0.f;
-  for (int i = lane; i < V; i += 64) se += expf(row_logit(x, i, pen, blank) - mx);
-  se = wave_sum(se);
-  const float lse = mx + logf(se);
-  if (lp) {
-    float* o = lp + (size_t)row * V;
-    for (int i = lane; i < V; i += 64) o[i] = row_logit(x, i, pen, blank) - lse;
-  }
-  for (int r = 0; r < k; ++r) {
-    float hv = bv[0];
-    int hi = bi[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(hv, o, 64);
-      const int oi = __shfl_xor(hi, o, 64);
-      if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
-    }
-    if (bi[0] == hi && bv[0] == hv) {   // the unique winner pops its head
-#pragma unroll
-      for (int j = 0; j < TOPK_MAX - 1; ++j) { bv[j] = bv[j + 1]; bi[j] = bi[j + 1]; }
-      bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
-    }
-    if (lane == 0) {
-      tv[(size_t)row * k + r] = hv - lse;
-      ti[(size_t)row * k + r] = hi;
-    }
-  }
-}
-
-int logsoftmax_topk(hipStream_t s, const float* logits, int M, int V, int ld, int k, float blank_penalty,
-                    int blank_id, float* topk_val, int* topk_idx, float* logp_out) {
-  if (M <= 0) return OK;
-  if (k < 1 || k > TOPK_MAX || k > V) { set_error("logsoftmax_topk: beam must be in [1,16] and <= vocab"); return E_ARG; }
-  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, logits, M, V, ld, k,
-                     blank_penalty, blank_id, topk_val, topk_idx, logp_out);
-  RVB_HIP_CHECK(hipGetLastError());
-  return OK;
-}
-
-__global__ __launch_bounds__(256) void lse_gather_kernel(const float* __restrict__ logits, int R, int V, int ld,
-                                                         const int* __restrict__ target, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const float* x = logits + (size_t)row * ld;
-  float mx = -INFINITY;
-  for (int i = lane; i < V; i += 64) mx = fmaxf(mx, x[i]);
-  mx = wave_max(mx);
-  float se = 0.f;
-  for (int i = lane; i < V; i += 64) se += expf(x[i] - mx);
-  se = wave_sum(se);
-  if (lane == 0) out[row] = x[target[row]] - mx - logf(se);
-}
-
-int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out) {
-  if (R <= 0) return OK;
-  hipLaunchKernelGGL(lse_gather_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, R, V, ld, target, out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -536,7 +536,7 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
   e->nbest.assign(B, PrefixResult());
   unsigned nthr = std::thread::hardware_concurrency();
   if (nthr == 0) nthr = 4;
-  nthr = std::min<unsigned>(std::min<unsigned>(nthr, 64), (unsigned)B);
+  nthr = std::min<unsigned>(std::min<unsigned>(nthr, 256), (unsigned)B);
   std::vector<std::thread> pool;
   for (unsigned w = 0; w < nthr; ++w) {
     pool.emplace_back([=]() {

@@ -182,6 +182,8 @@ static int launch(hipStream_t s, const GemmArgs& p) {
   return OK;
 }
 
+int g_gemm_variant = 0;
+
 int gemm(hipStream_t s, int dtype, const GemmArgs& p) {
   const int ve = dtype == DT_BF16 ? 8 : 4;
   if (p.M < 0 || p.N <= 0 || p.K <= 0 || (p.K % ve) || (p.lda % ve) || (p.ldw % ve) ||
@@ -190,6 +192,10 @@ int gemm(hipStream_t s, int dtype, const GemmArgs& p) {
     return E_ARG;
   }
   if (p.M == 0) return OK;
+  // auto: the 256x256 LDS-DMA kernel for bf16 (1.5-2x); f32 stays on the 128x128 kernel, which already
+  // runs at ~70 % of the 157 TFLOP/s f32 MFMA peak (profiles/r01_gemm_microbench.md)
+  if (g_gemm_variant != 1 && (dtype == DT_BF16 || g_gemm_variant == 2) && gemm2_applicable(dtype, p))
+    return gemm2(s, dtype, p);
   if (dtype == DT_BF16) {
     if (p.out_f32) return p.conv ? launch<bf16_t, float, true>(s, p) : launch<bf16_t, float, false>(s, p);
     return p.conv ? launch<bf16_t, bf16_t, true>(s, p) : launch<bf16_t, bf16_t, false>(s, p);

@@ -1,0 +1,330 @@
+// Large-shape MFMA GEMM for gfx950 (same contract as gemm.hip, used when K is a multiple of the
+// 128-byte K step):  256x256 output tile, 8 waves (2 along M x 4 along N, 128x64 per wave =
+// 8x4 MFMA 16x16 fragments), operands go HBM -> LDS directly with `global_load_lds_dwordx4`
+// (LDS-DMA, no VGPR round trip, no ds_write pass), two LDS stages of 64 KiB, one barrier per K step:
+//
+//     wait(own DMA of tile t) ; barrier ; ds_read fragments of tile t ; issue DMA of tile t+1 ;
+//     MFMAs of tile t   <- the DMA of t+1 lands underneath
+//
+// The LDS image is lane-linear (8 rows x 128 B per wave-instruction); bank conflicts of the
+// 128-byte rows are removed by an XOR swizzle applied to the SOURCE column and to the read:
+// LDS[row][c] = G[row][c ^ ((row>>1)&7)]  (16-byte columns), which makes every 16-lane group of a
+// ds_read_b128 touch 16 distinct 16-byte slots of the 256-byte bank row.
+// Out-of-range rows are clamped (their results are never stored); K tails are not supported here
+// (gemm.hip handles them).
+#include "common.h"
+#include "kernels.h"
+
+namespace rvb {
+
+static constexpr int B2M = 256, B2N = 256;
+static constexpr int ROW2 = 128;                         // bytes of K per tile row
+static constexpr int STAGE2 = (B2M + B2N) * ROW2;        // 64 KiB
+static constexpr int GEMM2_LDS = 2 * STAGE2;             // 128 KiB
+
+__device__ inline float act_apply2(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+__device__ inline void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, typename OutT, bool CONV>
+__global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VE = Mma16<T>::VE;
+  constexpr int BKE = ROW2 / (int)sizeof(T);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_n = (p.N + B2N - 1) / B2N;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * B2M, n0 = tn * B2N;
+
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA source pointers: wave w stages rows [32w, 32w+32) of A and of W, 8 rows per instruction
+  const int lrow = lane >> 3, lcol = lane & 7;
+  const T* a_src[4];
+  const T* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lrow;
+    const int gcol = (lcol ^ ((row >> 1) & 7)) * VE;     // swizzled 16-byte source column
+    int m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    if (CONV) {
+      const int tf = p.cT2 * p.cF2;
+      const int b = m / tf;
+      const int rem = m - b * tf;
+      const int t2 = rem / p.cF2, f2 = rem - t2 * p.cF2;
+      a_src[i] = A + (((size_t)b * p.cT1 + 2 * t2) * p.cF1 + 2 * f2) * (size_t)p.cC + gcol;
+    } else {
+      a_src[i] = A + (size_t)m * p.lda + gcol;
+    }
+    int n = n0 + row;
+    if (n >= p.N) n = p.N - 1;
+    w_src[i] = W + (size_t)n * p.ldw + gcol;
+  }
+
+  auto issue = [&](int kt, int buf) {
+    size_t koff = (size_t)kt * BKE;
+    if (CONV) {   // the whole 128-byte K step lies inside one (kh,kw) tap: cC % BKE == 0
+      const int k0 = kt * BKE;
+      const int kk = k0 / p.cC;
+      const int cin = k0 - kk * p.cC;
+      const int kh = kk / 3, kw = kk - kh * 3;
+      koff = ((size_t)kh * p.cF1 + kw) * p.cC + cin;
+    }
+    // eight 1-KiB LDS-DMA pieces (4 of A, 4 of W) in ONE asm statement: hipcc's waitcnt pass does not
+    // see them (it would otherwise drain vmcnt(0) before every ds_read that follows a DMA issue), so
+    // the explicit `s_waitcnt vmcnt(0)` at the top of the K loop is what orders them.  M0 carries the
+    // wave-uniform LDS destination; it is saved and restored because the compiler owns it.
+    const unsigned ldsA = lds_base + (unsigned)(buf * STAGE2 + (wave * 32) * ROW2);
+    const T* pa0 = a_src[0] + koff; const T* pa1 = a_src[1] + koff; const T* pa2 = a_src[2] + koff; const T* pa3 = a_src[3] + koff;
+    const size_t wk = (size_t)kt * BKE;
+    const T* pw0 = w_src[0] + wk; const T* pw1 = w_src[1] + wk; const T* pw2 = w_src[2] + wk; const T* pw3 = w_src[3] + wk;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_add_u32 m0, m0, 0x7400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, off\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pw0), "v"(pw1), "v"(pw2), "v"(pw3), "s"(ldsA)
+        : "memory", "scc");
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, lgrp = lane >> 4;
+  const int swz = (frow >> 1) & 7;
+  int roff[2];     // byte offset of this lane's 16-byte vector inside a row, per 64-byte chunk
+  roff[0] = ((0 * 4 + lgrp) ^ swz) << 4;
+  roff[1] = ((1 * 4 + lgrp) ^ swz) << 4;
+
+  const int nk = p.K / BKE;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt have landed
+    __syncthreads();                                   // ... and so have everybody else's
+    const char* sA = smem + cur * STAGE2 + (wr * 128 + frow) * ROW2;
+    const char* sB = smem + cur * STAGE2 + B2M * ROW2 + (wc * 64 + frow) * ROW2;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);   // other stage: last read one K step ago, every wave is past the barrier
+    uint4 a0[8], b0[4], a1[8], b1[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a0[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a1[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Mma16<T>::run(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Mma16<T>::run(a1[i], b1[j], acc[i][j]);
+  }
+
+  // ---- epilogue ----
+  // Accumulator fragments hold 4 rows x 1 column per lane: stored directly they make 2-byte/4-byte
+  // scattered writes (32-64 B runs).  Each wave instead transposes one 16x64 slab at a time through
+  // the idle LDS stage so that a lane owns 16 consecutive columns of one row: residual reads and
+  // output writes become 16-byte vectors, 4 lanes covering a 64-column row segment.
+  // bf16 mode uses the hardware exp for SiLU (the result is rounded to bf16 anyway).
+  OutT* __restrict__ C = (OutT*)p.C;
+  const int crow = (lane >> 4) * 4;
+  const int ccol = lane & 15;
+  const bool full = (m0 + B2M <= p.M) && (n0 + B2N <= p.N);
+  const bool vec_ok = ((p.ldc * (int)sizeof(OutT)) % 16 == 0) && (((size_t)p.C & 15) == 0) &&
+                      (p.res == nullptr || ((p.ldres % 4) == 0 && ((size_t)p.res & 15) == 0));
+  if (vec_ok) {
+    constexpr int SROW = 64 * 4 + 16;                      // padded slab row (bytes)
+    char* slab = smem + ((nk & 1) ? STAGE2 : 0) + wave * (16 * SROW);   // the stage NOT used by the last K step
+    const int orow = lane >> 2;                            // row of the slab this lane finishes
+    const int ocol = (lane & 3) * 16;                      // first of its 16 columns
+    const int col0 = n0 + wc * 64 + ocol;
+    float bias16[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias16[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
+    const bool seg_full = col0 + 16 <= p.N;
+    auto finish_v = [&](auto actf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = *(const float4*)(slab + orow * SROW + (ocol + q * 4) * 4);
+          v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+        }
+        const int row = m0 + wr * 128 + i * 16 + orow;
+        if (row >= p.M || col0 >= p.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = actf(v[e] + bias16[e]) * p.alpha;
+        OutT* cp = C + (size_t)row * p.ldc + col0;
+        if (seg_full) {
+          if (p.res) {
+            const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + col0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 t = rp[q];
+              v[q * 4 + 0] += t.x; v[q * 4 + 1] += t.y; v[q * 4 + 2] += t.z; v[q * 4 + 3] += t.w;
+            }
+          }
+          if constexpr (sizeof(OutT) == 2) {
+            uint4 o0, o1;
+            o0.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o0.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o0.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+            o0.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+            o1.x = (uint32_t)f32_to_bf16(v[8]) | ((uint32_t)f32_to_bf16(v[9]) << 16);
+            o1.y = (uint32_t)f32_to_bf16(v[10]) | ((uint32_t)f32_to_bf16(v[11]) << 16);
+            o1.z = (uint32_t)f32_to_bf16(v[12]) | ((uint32_t)f32_to_bf16(v[13]) << 16);
+            o1.w = (uint32_t)f32_to_bf16(v[14]) | ((uint32_t)f32_to_bf16(v[15]) << 16);
+            ((uint4*)cp)[0] = o0;
+            ((uint4*)cp)[1] = o1;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              ((float4*)cp)[q] = make_float4(v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+          }
+        } else {            // ragged last column segment of the matrix
+          for (int e = 0; e < 16 && col0 + e < p.N; ++e) {
+            float o = v[e];
+            if (p.res) o += p.res[(size_t)row * p.ldres + col0 + e];
+            cp[e] = Cvt<OutT>::from_f32(o);
+          }
+        }
+      }
+    };
+    if (p.act == ACT_SILU) {
+      if constexpr (sizeof(T) == 2) finish_v([](float x) { return __fdividef(x, 1.0f + __expf(-x)); });
+      else finish_v([](float x) { return x / (1.0f + expf(-x)); });
+    } else if (p.act == ACT_RELU) {
+      finish_v([](float x) { return fmaxf(x, 0.0f); });
+    } else {
+      finish_v([](float x) { return x; });
+    }
+    return;
+  }
+  // unaligned output / residual rows: element-wise stores
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wc * 64 + j * 16 + ccol;
+    bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+  }
+  auto finish = [&](auto actf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 128 + i * 16 + crow + r;
+        if (!full && row >= p.M) continue;
+        const float* rrow = p.res ? p.res + (size_t)row * p.ldres : nullptr;
+        OutT* crow_p = C + (size_t)row * p.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = n0 + wc * 64 + j * 16 + ccol;
+          if (!full && col >= p.N) continue;
+          float v = actf(acc[i][j][r] + bv[j]) * p.alpha;
+          if (rrow) v += rrow[col];
+          crow_p[col] = Cvt<OutT>::from_f32(v);
+        }
+      }
+    }
+  };
+  if (p.act == ACT_SILU) {
+    if constexpr (sizeof(T) == 2) finish([](float v) { return __fdividef(v, 1.0f + __expf(-v)); });
+    else finish([](float v) { return v / (1.0f + expf(-v)); });
+  } else if (p.act == ACT_RELU) {
+    finish([](float v) { return fmaxf(v, 0.0f); });
+  } else {
+    finish([](float v) { return v; });
+  }
+}
+
+template <typename T, typename OutT, bool CONV>
+static int launch2(hipStream_t s, const GemmArgs& p) {
+  static bool attr_set = false;
+  auto kern = gemm2_kernel<T, OutT, CONV>;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS));
+    attr_set = true;
+  }
+  const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), GEMM2_LDS, s, p);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+bool gemm2_applicable(int dtype, const GemmArgs& p) {
+  const int bke = dtype == DT_BF16 ? 64 : 32;
+  if (p.K % bke || p.lda % (bke / 8) || p.ldw % (bke / 8)) return false;
+  if (p.conv && (p.cC % bke)) return false;
+  if (p.M < 128 || p.N < 64) return false;      // tiny problems: the 128x128 kernel wastes less
+  return true;
+}
+
+int gemm2(hipStream_t s, int dtype, const GemmArgs& p) {
+  if (dtype == DT_BF16) {
+    if (p.out_f32) return p.conv ? launch2<bf16_t, float, true>(s, p) : launch2<bf16_t, float, false>(s, p);
+    return p.conv ? launch2<bf16_t, bf16_t, true>(s, p) : launch2<bf16_t, bf16_t, false>(s, p);
+  }
+  return p.conv ? launch2<float, float, true>(s, p) : launch2<float, float, false>(s, p);
+}
+
+}  // namespace rvb

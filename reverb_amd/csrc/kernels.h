@@ -26,6 +26,10 @@ struct GemmArgs {
   int cT1, cF1, cT2, cF2, cC;
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
+// gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)
+bool gemm2_applicable(int dtype, const GemmArgs& a);
+int gemm2(hipStream_t s, int dtype, const GemmArgs& a);
+extern int g_gemm_variant;   // 0 = auto, 1 = always gemm.hip kernel, 2 = gemm2.hip whenever applicable
 
 // ---------------------------------------------------------------- fbank.hip
 struct FbankTables {

@@ -15,25 +15,29 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
-#include <unordered_map>
 
 namespace rvb {
 
 static const double NEG_INF = -std::numeric_limits<double>::infinity();
 
 static inline double log_add2(double a, double b) {
-  if (a == NEG_INF && b == NEG_INF) return NEG_INF;
+  // exact shortcuts: with one operand at -inf the reference computes max + log(0 + 1) = max + 0.0
+  if (a == NEG_INF) return b;
+  if (b == NEG_INF) return a;
   const double mx = a > b ? a : b;
   return mx + std::log(std::exp(a - mx) + std::exp(b - mx));
 }
 
 namespace {
+// The reference copies Python lists of peak frames on every update; here a list is an index into a
+// per-utterance arena of (parent, frame) nodes, so "copy", "copy and append" and "copy and replace
+// the last element" are O(1) and share their common prefix.  -1 is the empty list.
 struct PS {
   double s = NEG_INF, ns = NEG_INF, v_s = NEG_INF, v_ns = NEG_INF, cur_token_prob = NEG_INF;
-  std::vector<int> times_s, times_ns;
+  int times_s = -1, times_ns = -1;
   double score() const { return log_add2(s, ns); }
   double viterbi() const { return v_s > v_ns ? v_s : v_ns; }
-  const std::vector<int>& times() const { return v_s > v_ns ? times_s : times_ns; }
+  int times() const { return v_s > v_ns ? times_s : times_ns; }
 };
 struct Hyp {
   int id;
@@ -45,20 +49,29 @@ struct Hyp {
 void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int beam, int blank,
                         PrefixResult* out) {
   // trie of prefixes: node 0 = empty prefix
-  std::vector<int> parent(1, -1), last(1, -1);
-  std::unordered_map<uint64_t, int> child;
-  child.reserve(4096);
+  // children of a node form a singly linked sibling list (a prefix has few live extensions)
+  std::vector<int> parent(1, -1), last(1, -1), first_child(1, -1), next_sib(1, -1);
+  parent.reserve(16384); last.reserve(16384); first_child.reserve(16384); next_sib.reserve(16384);
   auto extend = [&](int id, int tok) -> int {
-    const uint64_t key = ((uint64_t)(uint32_t)id << 32) | (uint32_t)tok;
-    auto it = child.find(key);
-    if (it != child.end()) return it->second;
+    for (int c = first_child[id]; c >= 0; c = next_sib[c])
+      if (last[c] == tok) return c;
     const int nid = (int)parent.size();
     parent.push_back(id);
     last.push_back(tok);
-    child.emplace(key, nid);
+    first_child.push_back(-1);
+    next_sib.push_back(first_child[id]);
+    first_child[id] = nid;
     return nid;
   };
 
+  std::vector<int> tn_parent, tn_val;   // arena of time-list nodes
+  tn_parent.reserve(8192); tn_val.reserve(8192);
+  auto t_push = [&](int list, int v) -> int {
+    tn_parent.push_back(list); tn_val.push_back(v);
+    return (int)tn_parent.size() - 1;
+  };
+  std::vector<int> sel;
+  std::vector<char> taken;
   std::vector<Hyp> cur(1), nxt;
   cur[0].id = 0;
   cur[0].ps.s = 0.0; cur[0].ps.ns = NEG_INF; cur[0].ps.v_s = 0.0; cur[0].ps.v_ns = 0.0;
@@ -99,8 +112,8 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
               // reference assigns a misspelled attribute here (`vs_ns`): v_ns stays as it was
               if (n1.cur_token_prob < prob) {
                 n1.cur_token_prob = prob;
-                n1.times_ns = ps.times_ns;
-                if (!n1.times_ns.empty()) n1.times_ns.back() = t;
+                // copy of the list with its last element replaced by t
+                n1.times_ns = ps.times_ns >= 0 ? t_push(tn_parent[ps.times_ns], t) : -1;
               }
             }
           }
@@ -111,8 +124,7 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
           if (n2.v_ns < ps.v_s + prob) {
             n2.v_ns = ps.v_s + prob;
             n2.cur_token_prob = prob;
-            n2.times_ns = ps.times_s;
-            n2.times_ns.push_back(t);
+            n2.times_ns = t_push(ps.times_s, t);
           }
         } else {
           const int nid = extend(pid, u);
@@ -123,17 +135,27 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
           if (n.v_ns < vit) {
             n.v_ns = vit;
             n.cur_token_prob = prob;
-            n.times_ns = ps.times();
-            n.times_ns.push_back(t);
+            n.times_ns = t_push(ps.times(), t);
           }
         }
       }
     }
     for (auto& h : nxt) h.score_cache = h.ps.score();
-    std::stable_sort(nxt.begin(), nxt.end(),
-                     [](const Hyp& a, const Hyp& b) { return a.score_cache > b.score_cache; });
-    if ((int)nxt.size() > beam) nxt.resize(beam);
-    cur.swap(nxt);
+    // sorted(..., reverse=True)[:beam] of the reference: descending score, equal scores keep their
+    // insertion order.  Only the first `beam` are needed: repeated selection of the first maximum.
+    const int keep = std::min<int>(beam, (int)nxt.size());
+    sel.clear();
+    taken.assign(nxt.size(), 0);
+    for (int k = 0; k < keep; ++k) {
+      int best = -1;
+      for (int i = 0; i < (int)nxt.size(); ++i)
+        if (!taken[i] && (best < 0 || nxt[i].score_cache > nxt[best].score_cache)) best = i;
+      if (best < 0) break;
+      taken[best] = 1;
+      sel.push_back(best);
+    }
+    cur.clear();
+    for (int i : sel) cur.push_back(nxt[i]);
   }
 
   out->nbest.clear(); out->scores.clear(); out->times.clear();
@@ -143,7 +165,10 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
     std::reverse(toks.begin(), toks.end());
     out->nbest.push_back(std::move(toks));
     out->scores.push_back(h.ps.score());
-    out->times.push_back(h.ps.times());
+    std::vector<int> tm;
+    for (int n = h.ps.times(); n >= 0; n = tn_parent[n]) tm.push_back(tn_val[n]);
+    std::reverse(tm.begin(), tm.end());
+    out->times.push_back(std::move(tm));
   }
 }
 

@@ -215,3 +215,80 @@ int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// GEMM micro-benchmark: random operands generated on the device, `variant` timed with HIP events,
+// result compared against the gemm.hip kernel (variant 1) on sampled rows.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ void fill_random(T* p, size_t n, unsigned seed, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u ^ seed;
+    x ^= x >> 16; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    p[i] = Cvt<T>::from_f32(((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale);
+  }
+}
+template <typename T> void fill(void* p, size_t n, unsigned seed, float scale) {
+  hipLaunchKernelGGL(fill_random<T>, dim3(2048), dim3(256), 0, nullptr, (T*)p, n, seed, scale);
+}
+}  // namespace
+
+extern "C" int rvb_test_set_gemm_variant(int v) { g_gemm_variant = v; return OK; }
+
+extern "C" int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, int iters, int act, int out_f32,
+                                   int with_res, double* ms_out, double* max_abs_diff) {
+  T_TRY(need_gpu());
+  Dev dA, dW, dB, dR, dC, dC1;
+  const size_t es = dt_size(dtype);
+  const bool f32out = dtype == DT_F32 || out_f32;
+  T_TRY(dA.alloc((size_t)M * K * es)); T_TRY(dW.alloc((size_t)N * K * es)); T_TRY(dB.alloc((size_t)N * 4));
+  T_TRY(dR.alloc((size_t)M * N * 4)); T_TRY(dC.alloc((size_t)M * N * (f32out ? 4 : 2)));
+  T_TRY(dC1.alloc((size_t)M * N * (f32out ? 4 : 2)));
+  if (dtype == DT_BF16) { fill<bf16_t>(dA.p, (size_t)M * K, 1u, 1.0f); fill<bf16_t>(dW.p, (size_t)N * K, 2u, 1.0f / sqrtf((float)K)); }
+  else { fill<float>(dA.p, (size_t)M * K, 1u, 1.0f); fill<float>(dW.p, (size_t)N * K, 2u, 1.0f / sqrtf((float)K)); }
+  fill<float>(dB.p, N, 3u, 1.0f);
+  fill<float>(dR.p, (size_t)M * N, 4u, 1.0f);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.res = with_res ? (const float*)dR.p : nullptr; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldres = N; g.alpha = 0.5f; g.act = act; g.out_f32 = out_f32;
+  const int saved = g_gemm_variant;
+  g_gemm_variant = variant;
+  int r = gemm(nullptr, dtype, g);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  if (r == OK) {
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && r == OK; ++i) r = gemm(nullptr, dtype, g);
+    hipEventRecord(e1, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("gemm bench kernel failed"); r = E_HIP; }
+  }
+  float ms = 0.f;
+  if (r == OK) hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (ms_out) *ms_out = iters > 0 ? ms / iters : 0.0;
+  if (r == OK && max_abs_diff) {
+    g_gemm_variant = 1;
+    g.C = dC1.p;
+    r = gemm(nullptr, dtype, g);
+    if (r == OK && hipDeviceSynchronize() != hipSuccess) r = E_HIP;
+    if (r == OK) {
+      const int rows = M < 512 ? M : 512;
+      std::vector<float> a((size_t)rows * N), b((size_t)rows * N);
+      double md = 0.0;
+      for (int part = 0; part < 2 && r == OK; ++part) {
+        const size_t off = part == 0 ? 0 : (size_t)(M - rows) * N;
+        Dev va, vb;   // views
+        va.p = (char*)dC.p + off * (f32out ? 4 : 2); vb.p = (char*)dC1.p + off * (f32out ? 4 : 2);
+        r = down_T(va, dtype, f32out, a.data(), a.size());
+        if (r == OK) r = down_T(vb, dtype, f32out, b.data(), b.size());
+        va.p = nullptr; vb.p = nullptr;
+        for (size_t i = 0; i < a.size(); ++i) { const double d = fabs((double)a[i] - (double)b[i]); if (d > md || d != d) md = d; }
+      }
+      *max_abs_diff = md;
+    }
+  }
+  g_gemm_variant = saved;
+  return r;
+}
