@@ -103,34 +103,54 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const float inv_sqrt_dk = 1.0f / a.sqrt_dk;   // bf16 mode multiplies; f32 mode divides like the reference
   int kend = kvlen;
   if (a.causal) kend = min(kvlen, q0 + 64);
-  for (int kt0 = 0; kt0 < kend; kt0 += KT) {
-    // ---- stage K, P rows and V^T ----
-    for (int i = tid; i < KT * VPR; i += 256) {
-      const int r = i / VPR, c = i - r * VPR;
-      const int key = kt0 + r;
-      const bool ok = key < kvlen && c * VE < dk;
-      uint4 kv4 = make_uint4(0, 0, 0, 0);
-      if (ok) kv4 = *(const uint4*)(K + (size_t)(ks + key) * a.k_stride + head * dk + c * VE);
-      *(uint4*)(sK + r * L::ROW_K + c * 16) = kv4;
-      if constexpr (HAS_POS) {
-        uint4 pv4 = make_uint4(0, 0, 0, 0);
-        if (ok) pv4 = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
-        *(uint4*)(sP + r * L::ROW_K + c * 16) = pv4;
+  // Staging: tile t+1 is fetched HBM -> VGPR while tile t is being multiplied (issue early, write to
+  // LDS late); K and P rows are stored as they come, V is stored transposed (consecutive lanes take
+  // consecutive keys so the 2-/4-byte transposed writes of a wave are conflict-free).
+  constexpr int NV = (KT * VPR + 255) / 256;
+  constexpr bool PREFETCH = NV <= 4;           // f32 with 128-wide heads would need 96 staging VGPRs
+  uint4 rk[NV], rp[HAS_POS ? NV : 1], rv[NV];
+  auto gload = [&](int kt0) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + 256 * n;
+      rk[n] = make_uint4(0, 0, 0, 0); rv[n] = make_uint4(0, 0, 0, 0);
+      if constexpr (HAS_POS) rp[n] = make_uint4(0, 0, 0, 0);
+      if (i < KT * VPR) {
+        const int r = i / VPR, c = i - r * VPR;
+        const int key = kt0 + r;
+        if (key < kvlen && c * VE < dk) {
+          rk[n] = *(const uint4*)(K + (size_t)(ks + key) * a.k_stride + head * dk + c * VE);
+          if constexpr (HAS_POS) rp[n] = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
+        }
+        const int c2 = i / KT, r2 = i - c2 * KT;
+        const int key2 = kt0 + r2;
+        if (key2 < kvlen && c2 * VE < dk)
+          rv[n] = *(const uint4*)(V + (size_t)(ks + key2) * a.v_stride + head * dk + c2 * VE);
       }
     }
-    // V^T: consecutive lanes take consecutive keys, so the 2-/4-byte transposed LDS writes of a wave
-    // fall on consecutive addresses (the key-major mapping above would put 8 lanes on one bank)
-    for (int i = tid; i < KT * VPR; i += 256) {
-      const int c = i / KT, r = i - c * KT;
-      const int key = kt0 + r;
-      uint4 vv4 = make_uint4(0, 0, 0, 0);
-      if (key < kvlen && c * VE < dk) vv4 = *(const uint4*)(V + (size_t)(ks + key) * a.v_stride + head * dk + c * VE);
-      T tv[VE];
-      *(uint4*)tv = vv4;
+  };
+  auto lstore = [&]() {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) *(T*)(sV + (c * VE + e) * L::ROW_V + r * sizeof(T)) = tv[e];
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + 256 * n;
+      if (i < KT * VPR) {
+        const int r = i / VPR, c = i - r * VPR;
+        *(uint4*)(sK + r * L::ROW_K + c * 16) = rk[n];
+        if constexpr (HAS_POS) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
+        const int c2 = i / KT, r2 = i - c2 * KT;
+        T tv[VE];
+        *(uint4*)tv = rv[n];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) *(T*)(sV + (c2 * VE + e) * L::ROW_V + r2 * sizeof(T)) = tv[e];
+      }
     }
+  };
+  if (PREFETCH && kend > 0) gload(0);
+  for (int kt0 = 0; kt0 < kend; kt0 += KT) {
+    if (!PREFETCH) gload(kt0);
+    lstore();
     __syncthreads();
+    if (PREFETCH && kt0 + KT < kend) gload(kt0 + KT);   // lands under the MFMAs / softmax below
 
     // ---- S = Qu.K^T (+ Qv.P^T) : 4 fragments of 16 keys ----
     f32x4_t s[4];
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         *(T*)(sW + (crow + r) * L::ROW_V + (nf * 16 + lrow) * sizeof(T)) = Cvt<T>::from_f32(s[nf][r]);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the patch is private to this wave: LDS ops of one wave execute in order
     // ---- O += P.V ----
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {

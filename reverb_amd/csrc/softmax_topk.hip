@@ -3,25 +3,31 @@
 //   logsoftmax_topk   asr/wenet/transformer/ctc.py:106-114, asr_model.py:318-329 (blank penalty),
 //                     search.py:111,155 (torch.topk per frame)
 //   lse_gather        asr_model.py:969 + search.py:417-437 (only the needed log-probs)
-// One wave64 per row.  The row is read ONCE: 16-byte vectors, four per lane in flight per batch
-// (1024 logits per wave per batch), online max/sum-exp per lane merged across the wave at the end.
-// Each lane keeps a sorted top-16 of its slice in registers (static indices only); the wave then
-// pops the global maximum k times (ties -> lower index, matching a stable descending order).
+// One wave64 per row, 16-byte loads, four vectors per lane in flight.
+//   pass A : online max / sum-exp per lane (merged across the wave at the end) and the maximum of
+//            each lane's slice; the k-th largest of the 64 lane maxima is a lower bound t of the
+//            row's k-th largest logit (they are k distinct elements >= t).
+//   pass B : the row is read again (40 KB, L2 resident) and the few elements >= t are compacted into
+//            a per-wave LDS list with ballot/popcount.
+//   pass C : k rounds of wave arg-max over the candidates; order = value descending, ties by lower
+//            index (a stable descending order, as torch.topk on CPU returns it).
+// Rows with more than 256 candidates (massive ties) fall back to k exclusion scans.
 #include "common.h"
 #include "kernels.h"
 
 namespace rvb {
 
 static constexpr int TOPK_MAX = 16;
-static constexpr int UNR = 4;      // float4 vectors per lane per batch
+static constexpr int UNR = 4;        // float4 vectors per lane per batch
+static constexpr int CAND = 256;     // candidate slots per row
 
 struct RowStat {
   float m = -INFINITY, s = 0.f;
-  __device__ inline void add_batch(const float* x, int n) {   // n values, any may be -inf
+  __device__ inline void add_batch(const float* x, int n) {   // n <= 16 values, any may be -inf
     float bm = x[0];
 #pragma unroll
     for (int i = 1; i < 4 * UNR; ++i) if (i < n) bm = fmaxf(bm, x[i]);
-    if (bm > m) { s *= expf(m - bm); m = bm; }     // m = -inf first time: s = 0 * exp(-inf) = 0
+    if (bm > m) { s *= expf(m - bm); m = bm; }     // first time m = -inf: s = 0 * exp(-inf) = 0
     if (m == -INFINITY) return;
 #pragma unroll
     for (int i = 0; i < 4 * UNR; ++i) if (i < n) s += expf(x[i] - m);
@@ -33,98 +39,149 @@ struct RowStat {
   }
 };
 
-template <bool TOPK>
-__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, int M, int V, int ld, int k,
-                                                      float pen, int blank, float* __restrict__ tv,
-                                                      int* __restrict__ ti, float* __restrict__ lp,
-                                                      const int* __restrict__ target, float* __restrict__ gathered) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* x = logits + (size_t)row * ld;
-  float bv[TOPK ? TOPK_MAX : 1];
-  int bi[TOPK ? TOPK_MAX : 1];
-  if constexpr (TOPK) {
+// (value desc, index asc) ordering
+__device__ inline bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
+
+__device__ inline void wave_argbest(float& v, int& i) {
 #pragma unroll
-    for (int i = 0; i < TOPK_MAX; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (better(ov, oi, v, i)) { v = ov; i = oi; }
   }
-  RowStat st;
-  const bool vec = ((ld & 3) == 0) && (((size_t)logits & 15) == 0);
-  const int nvec = vec ? (V >> 2) : 0;
-  for (int v0 = 0; v0 < nvec; v0 += 64 * UNR) {
+}
+
+struct RowReader {
+  const float* x; int V, nvec, blank; float pen;
+  // loads batch `b` (1024 logits of the row) into e[16]; returns number of valid leading... all 16
+  // slots are filled, out-of-range ones with -inf; idx(slot) gives the logit index of a slot
+  __device__ inline void load(int v0, int lane, float* e) const {
     float4 q[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int vi = v0 + u * 64 + lane;
       q[u] = vi < nvec ? ((const float4*)x)[vi] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
-    float e[4 * UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) { e[4 * u] = q[u].x; e[4 * u + 1] = q[u].y; e[4 * u + 2] = q[u].z; e[4 * u + 3] = q[u].w; }
     if (pen != 0.f) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if ((v0 + u * 64 + lane) * 4 + c == blank) e[4 * u + c] -= pen;
+      for (int s = 0; s < 4 * UNR; ++s) if (idx(v0, lane, s) == blank) e[s] -= pen;
     }
+  }
+  __device__ inline int idx(int v0, int lane, int slot) const { return (v0 + (slot >> 2) * 64 + lane) * 4 + (slot & 3); }
+  __device__ inline float tail(int i) const { float v = x[i]; if (i == blank) v -= pen; return v; }
+};
+
+template <bool TOPK>
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, int M, int V, int ld, int k,
+                                                      float pen, int blank, float* __restrict__ tv,
+                                                      int* __restrict__ ti, float* __restrict__ lp,
+                                                      const int* __restrict__ target, float* __restrict__ gathered) {
+  __shared__ float s_cv[4][TOPK ? CAND : 1];
+  __shared__ int s_ci[4][TOPK ? CAND : 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= M) return;
+  RowReader rd;
+  rd.x = logits + (size_t)row * ld; rd.V = V; rd.blank = blank; rd.pen = pen;
+  const bool vec = ((ld & 3) == 0) && (((size_t)logits & 15) == 0);
+  rd.nvec = vec ? (V >> 2) : 0;
+  const int tail0 = rd.nvec * 4;
+
+  // ---- pass A ----
+  RowStat st;
+  float lane_max = -INFINITY;
+  for (int v0 = 0; v0 < rd.nvec; v0 += 64 * UNR) {
+    float e[4 * UNR];
+    rd.load(v0, lane, e);
     st.add_batch(e, 4 * UNR);
     if constexpr (TOPK) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v = e[4 * u + c];
-          if (v > bv[TOPK_MAX - 1]) {
-            int vi = (v0 + u * 64 + lane) * 4 + c;
-#pragma unroll
-            for (int j = 0; j < TOPK_MAX; ++j) {
-              // strict '>' keeps an earlier equal value ahead; a lane visits its indices in
-              // increasing order, so on ties the lower index stays first
-              if (v > bv[j]) { const float tvv = bv[j]; const int tii = bi[j]; bv[j] = v; bi[j] = vi; v = tvv; vi = tii; }
-            }
-          }
-        }
+      for (int s = 0; s < 4 * UNR; ++s) lane_max = fmaxf(lane_max, e[s]);
     }
   }
-  for (int i = nvec * 4 + lane; i < V; i += 64) {      // unaligned rows / the last V % 4 logits
-    float v = x[i];
-    if (i == blank) v -= pen;
+  for (int i = tail0 + lane; i < V; i += 64) {
     float one[4 * UNR];
-    one[0] = v;
+    one[0] = rd.tail(i);
     st.add_batch(one, 1);
-    if constexpr (TOPK) {
-      if (v > bv[TOPK_MAX - 1]) {
-        int vi = i;
-#pragma unroll
-        for (int j = 0; j < TOPK_MAX; ++j)
-          if (v > bv[j] || (v == bv[j] && vi < bi[j])) { const float tvv = bv[j]; const int tii = bi[j]; bv[j] = v; bi[j] = vi; v = tvv; vi = tii; }
-      }
-    }
+    lane_max = fmaxf(lane_max, one[0]);
   }
   const float lse = st.wave_lse();
   if constexpr (!TOPK) {
-    if (lane == 0) gathered[row] = x[target[row]] - lse;
+    if (lane == 0) gathered[row] = rd.x[target[row]] - lse;
     return;
   } else {
     if (lp) {
       float* o = lp + (size_t)row * V;
-      for (int i = lane; i < V; i += 64) o[i] = (i == blank ? x[i] - pen : x[i]) - lse;
+      for (int i = lane; i < V; i += 64) o[i] = rd.tail(i) - lse;
     }
-    for (int r = 0; r < k; ++r) {
-      float hv = bv[0];
-      int hi = bi[0];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(hv, o, 64);
-        const int oi = __shfl_xor(hi, o, 64);
-        if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
+    // threshold: k-th largest lane maximum
+    float thr;
+    {
+      float h = lane_max;
+      float cur = 0.f;
+      for (int r = 0; r < k; ++r) {
+        cur = wave_max(h);
+        const unsigned long long mk = __ballot(h == cur);
+        if (lane == (int)__builtin_ctzll(mk)) h = -INFINITY;   // retire one holder of the maximum
       }
-      if (bi[0] == hi) {   // the unique winner pops its head
+      thr = cur;
+    }
+    // ---- pass B: compact candidates (>= thr) ----
+    int count = 0;   // wave-uniform
+    auto push = [&](bool pred, float v, int i) {
+      const unsigned long long mk = __ballot(pred);
+      if (mk == 0) return;
+      const int pos = count + (int)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+      if (pred && pos < CAND) { s_cv[w][pos] = v; s_ci[w][pos] = i; }
+      count += (int)__builtin_popcountll(mk);
+    };
+    for (int v0 = 0; v0 < rd.nvec; v0 += 64 * UNR) {
+      float e[4 * UNR];
+      rd.load(v0, lane, e);
 #pragma unroll
-        for (int j = 0; j < TOPK_MAX - 1; ++j) { bv[j] = bv[j + 1]; bi[j] = bi[j + 1]; }
-        bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
+      for (int s = 0; s < 4 * UNR; ++s)
+        push((v0 + (s >> 2) * 64 + lane) < rd.nvec && e[s] >= thr, e[s], rd.idx(v0, lane, s));
+    }
+    for (int i0 = tail0; i0 < V; i0 += 64) {
+      const int i = i0 + lane;
+      const float v = i < V ? rd.tail(i) : -INFINITY;
+      push(i < V && v >= thr, v, i);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (count <= CAND) {
+      // ---- pass C: k arg-max rounds over <= 256 candidates (4 per lane) ----
+      float cv[4]; int ci[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = lane + 64 * j;
+        cv[j] = p < count ? s_cv[w][p] : -INFINITY;
+        ci[j] = p < count ? s_ci[w][p] : 0x7fffffff;
       }
-      if (lane == 0) { tv[(size_t)row * k + r] = hv - lse; ti[(size_t)row * k + r] = hi; }
+      for (int r = 0; r < k; ++r) {
+        float bv = cv[0]; int bi = ci[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (better(cv[j], ci[j], bv, bi)) { bv = cv[j]; bi = ci[j]; }
+        wave_argbest(bv, bi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (ci[j] == bi) { cv[j] = -INFINITY; ci[j] = 0x7fffffff; }
+        if (lane == 0) { tv[(size_t)row * k + r] = bv - lse; ti[(size_t)row * k + r] = bi; }
+      }
+    } else {
+      // ---- fallback (massive ties): k exclusion scans of the whole row ----
+      float pv = INFINITY; int pi = -1;
+      for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < V; i += 64) {
+          const float v = rd.tail(i);
+          const bool after_prev = v < pv || (v == pv && i > pi);
+          if (after_prev && better(v, i, bv, bi)) { bv = v; bi = i; }
+        }
+        wave_argbest(bv, bi);
+        pv = bv; pi = bi;
+        if (lane == 0) { tv[(size_t)row * k + r] = bv - lse; ti[(size_t)row * k + r] = bi; }
+      }
     }
   }
 }

@@ -223,13 +223,17 @@ def test_logsoftmax_topk(lib, V):
     rng = np.random.default_rng(5)
     x = f32(rng.standard_normal((M, V)) * 3)
     x[3, 17] = x[3, 400] = x[3].max() + 1.0          # exact tie: lower index first
+    x[5, :] = 0.25                                    # all-equal row: > 256 candidates -> exclusion-scan fallback
+    x[6, :] = 0.5; x[6, 700:] = 0.75                  # 300-way tie at the top
     tv = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int32); lp = np.empty((M, V), np.float32)
     _lib.check(lib.rvb_test_logsoftmax_topk(fptr(x), M, V, k, 0.0, 0, fptr(tv), iptr(ti), fptr(lp)))
     ref = torch.from_numpy(x).double().log_softmax(-1)
     np.testing.assert_allclose(lp, ref.numpy(), rtol=0, atol=2e-6)
     rv, ri = ref.float().topk(k, dim=-1)
     assert ti[3, 0] == 17 and ti[3, 1] == 400
-    rows = [r for r in range(M) if r != 3]
+    assert ti[5].tolist() == list(range(k))                 # ties -> ascending index (stable descending order)
+    assert ti[6].tolist() == list(range(700, 700 + k))
+    rows = [r for r in range(M) if r not in (3, 5, 6)]      # torch's own tie order is unspecified
     np.testing.assert_array_equal(ti[rows], ri.numpy()[rows])
     np.testing.assert_allclose(tv, rv.numpy(), rtol=0, atol=2e-6)
     # blank penalty (asr_model.py:322-325)
