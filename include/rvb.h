@@ -108,6 +108,10 @@ int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int3
 int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight);
 int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence,
                      double* tokens_confidence /* [len of best] */);
+/* all chunks of the batch at once: the winning hypothesis of each chunk, arrays padded to [B][T]
+ * (T = rvb_encoder_frames) with -1 / 0 */
+int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_t* times_lens, int32_t* times,
+                           float* scores, double* confidences, double* tokens_confidence);
 /* per-hypothesis decoder log-probs of the last rescoring (parity tap): for hyp i of `chunk`,
  * out[j] = log p(w_j | ...) for j < len and out[len] = log p(eos); right=1 for the r2l decoder */
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   // LDS late); K and P rows are stored as they come, V is stored transposed (consecutive lanes take
   // consecutive keys so the 2-/4-byte transposed writes of a wave are conflict-free).
   constexpr int NV = (KT * VPR + 255) / 256;
-  constexpr bool PREFETCH = NV <= 4;           // f32 with 128-wide heads would need 96 staging VGPRs
+  constexpr bool PREFETCH = false;   // measured: holding tile t+1 in VGPRs costs a wave of occupancy and is slower (33.2 vs 29.8 ms)
   uint4 rk[NV], rp[HAS_POS ? NV : 1], rv[NV];
   auto gload = [&](int kt0) {
 #pragma unroll

@@ -92,8 +92,13 @@ struct rvb_engine {
   std::vector<int32_t> in_lens, enc_lens;
   rvb::DevBuf d_feats_in, X1, X2, x, xn, y, h, ao, dconv, enc_out, logits, topv, topi;
   rvb::DevBuf d_enc_lens, d_seq_start, d_seq_len, d_aux_i32;
-  std::vector<float> h_topv;
-  std::vector<int32_t> h_topi;
+  float* h_topv = nullptr;         // pinned host copies of the per-frame top-k (async D2H per slice)
+  int32_t* h_topi = nullptr;
+  size_t h_top_cap = 0;
+  struct Slice { int c0, nb; hipEvent_t ev; bool done; };
+  std::vector<Slice> slices;       // slices of the last rvb_encode, in chunk order
+  std::vector<hipEvent_t> slice_event_pool;
+  const int* cur_lens = nullptr;   // device pointer: valid encoder frames of the slice being encoded
   std::vector<rvb::PrefixResult> nbest;
   std::vector<rvb::RescoreResult> rescored;
   // decoder workspace

@@ -408,7 +408,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
     a.bias_u = L.bias_u.as<float>(); a.bias_v = L.bias_v.as<float>();
     a.out = e->ao.p;
     a.q_start = e->d_seq_start.as<int>(); a.q_len = e->d_seq_len.as<int>();
-    a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->d_enc_lens.as<int>();
+    a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->cur_lens;
     a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
     Scope sc(e, "attention", 6.0 * B * (double)T * T * d);
     RVB_TRY(attention(e->stream, e->dtype, a));
@@ -420,7 +420,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
   {
     GluDwArgs g;
     g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
-    g.lens = e->d_enc_lens.as<int>(); g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
+    g.lens = e->cur_lens; g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
     Scope sc(e, "glu_dwconv");
     RVB_TRY(glu_dwconv(e->stream, e->dtype, g));
   }
@@ -441,6 +441,8 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
 
 static const int LOGIT_SLAB = 8192;   // rows of fp32 logits materialised at a time
 
+static int wait_slices(rvb_engine* e, int i);
+
 static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, const int32_t* lens, int B, int T0,
                        int beam, float blank_penalty) {
   const rvb_model_cfg& c = e->cfg;
@@ -450,6 +452,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   }
   if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_encode: beam must be in [1,16]"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(wait_slices(e, -1));      // a previous batch may still be in flight
   const int d = c.d_model, F0 = c.input_dim, V = c.vocab;
   const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   const int M = B * T2;
@@ -479,51 +482,88 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     }
     d_feats = e->feats.as<float>() + (size_t)first_chunk * T0 * F0;
   }
-  RVB_TRY(e->X1.ensure((size_t)B * T1 * F1 * d * es));
-  RVB_TRY(e->X2.ensure((size_t)B * T2 * F2 * d * es));
-  RVB_TRY(e->x.ensure((size_t)M * d * 4));
-  RVB_TRY(e->xn.ensure((size_t)M * d * es));
-  RVB_TRY(e->y.ensure((size_t)M * d * es));
-  RVB_TRY(e->ao.ensure((size_t)M * d * es));
-  RVB_TRY(e->dconv.ensure((size_t)M * d * 4));
+  // Sub-batch pipeline: the batch is encoded in up to 4 slices on the engine stream; each slice ends with
+  // an async D2H copy of its per-frame top-k into pinned memory and an event.  rvb_encode returns once
+  // everything is enqueued; the host CTC search of slice i (rvb_ctc_prefix_beam) then runs while the
+  // GPU is still encoding slice i+1.  Workspaces are sized for one slice.
+  const int nsplit = B >= 64 ? 4 : (B >= 16 ? 2 : 1);
+  const int SB = (B + nsplit - 1) / nsplit;
+  const int Ms = SB * T2;
+  RVB_TRY(e->X1.ensure((size_t)SB * T1 * F1 * d * es));
+  RVB_TRY(e->X2.ensure((size_t)SB * T2 * F2 * d * es));
+  RVB_TRY(e->x.ensure((size_t)Ms * d * 4));
+  RVB_TRY(e->xn.ensure((size_t)Ms * d * es));
+  RVB_TRY(e->y.ensure((size_t)Ms * d * es));
+  RVB_TRY(e->ao.ensure((size_t)Ms * d * es));
+  RVB_TRY(e->dconv.ensure((size_t)Ms * d * 4));
   RVB_TRY(e->enc_out.ensure((size_t)M * d * es));
-  RVB_TRY(e->h.ensure((size_t)M * std::max(c.ffn_dim, 3 * d) * es));
+  RVB_TRY(e->h.ensure((size_t)Ms * std::max(c.ffn_dim, 3 * d) * es));
   const int Vld = (V + 3) & ~3;
   RVB_TRY(e->logits.ensure((size_t)LOGIT_SLAB * Vld * 4));
   RVB_TRY(e->topv.ensure((size_t)M * beam * 4));
   RVB_TRY(e->topi.ensure((size_t)M * beam * 4));
+  if (e->h_top_cap < (size_t)M * beam) {
+    if (e->h_topv) hipHostFree(e->h_topv);
+    if (e->h_topi) hipHostFree(e->h_topi);
+    e->h_topv = nullptr; e->h_topi = nullptr; e->h_top_cap = 0;
+    RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topv, (size_t)M * beam * 4, hipHostMallocDefault));
+    RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topi, (size_t)M * beam * 4, hipHostMallocDefault));
+    e->h_top_cap = (size_t)M * beam;
+  }
+  e->slices.clear();
+  for (int c0 = 0; c0 < B; c0 += SB) {
+    const int nb = std::min(SB, B - c0);
+    const int m = nb * T2;
+    const int row0 = c0 * T2;
+    e->cur_lens = e->d_enc_lens.as<int>() + c0;       // per-chunk arrays of this slice (starts are slice-relative)
+    // Conv2dSubsampling4 (subsampling.py:201-226): cmvn+conv1 -> conv2 (implicit GEMM) -> linear * sqrt(d)
+    {
+      Scope sc(e, "subsample");
+      RVB_TRY(subsample_conv1(e->stream, e->dtype, d_feats + (size_t)c0 * T0 * F0, e->cmvn_mean.as<float>(),
+                              e->cmvn_istd.as<float>(), e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, nb, T0, F0, d));
+    }
+    {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
+      g.M = nb * T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
+      g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
+      Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
+      RVB_TRY(gemm(e->stream, e->dtype, g));
+    }
+    RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, m, true, std::sqrt((float)d)));
+    for (auto& L : e->enc) RVB_TRY(encoder_layer(e, L, m, nb, T2));
+    void* eo = (char*)e->enc_out.p + (size_t)row0 * d * es;
+    RVB_TRY(run_norm(e, e->x.as<float>(), e->enc_after, eo, false, m, d));
+    // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
+    for (int r0 = 0; r0 < m; r0 += LOGIT_SLAB) {
+      const int rows = std::min(LOGIT_SLAB, m - r0);
+      RVB_TRY(run_gemm(e, (const char*)eo + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
+      Scope sc(e, "ctc_topk");
+      RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), rows, V, Vld, beam, blank_penalty, c.blank_id,
+                              e->topv.as<float>() + (size_t)(row0 + r0) * beam, e->topi.as<int>() + (size_t)(row0 + r0) * beam, nullptr));
+    }
+    RVB_HIP_CHECK(hipMemcpyAsync(e->h_topv + (size_t)row0 * beam, e->topv.as<float>() + (size_t)row0 * beam, (size_t)m * beam * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipMemcpyAsync(e->h_topi + (size_t)row0 * beam, e->topi.as<int>() + (size_t)row0 * beam, (size_t)m * beam * 4, hipMemcpyDeviceToHost, e->stream));
+    hipEvent_t ev;
+    if (!e->slice_event_pool.empty()) { ev = e->slice_event_pool.back(); e->slice_event_pool.pop_back(); }
+    else RVB_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    RVB_HIP_CHECK(hipEventRecord(ev, e->stream));
+    e->slices.push_back({c0, nb, ev, false});
+  }
+  return OK;
+}
 
-  // Conv2dSubsampling4 (subsampling.py:201-226): cmvn+conv1 -> conv2 (implicit GEMM) -> linear * sqrt(d)
-  {
-    Scope sc(e, "subsample");
-    RVB_TRY(subsample_conv1(e->stream, e->dtype, d_feats, e->cmvn_mean.as<float>(), e->cmvn_istd.as<float>(),
-                            e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, B, T0, F0, d));
+// wait until slice `i` (or every slice when i < 0) of the last rvb_encode has reached the host
+static int wait_slices(rvb_engine* e, int i) {
+  for (size_t k = 0; k < e->slices.size(); ++k) {
+    if (i >= 0 && (int)k != i) continue;
+    auto& sl = e->slices[k];
+    if (sl.done) continue;
+    RVB_HIP_CHECK(hipEventSynchronize(sl.ev));
+    e->slice_event_pool.push_back(sl.ev);
+    sl.done = true;
   }
-  {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
-    g.M = B * T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
-    g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
-    Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
-    RVB_TRY(gemm(e->stream, e->dtype, g));
-  }
-  RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, M, true, std::sqrt((float)d)));
-  for (auto& L : e->enc) RVB_TRY(encoder_layer(e, L, M, B, T2));
-  RVB_TRY(run_norm(e, e->x.as<float>(), e->enc_after, e->enc_out.p, false, M, d));
-  // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
-  for (int r0 = 0; r0 < M; r0 += LOGIT_SLAB) {
-    const int rows = std::min(LOGIT_SLAB, M - r0);
-    RVB_TRY(run_gemm(e, (const char*)e->enc_out.p + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
-    Scope sc(e, "ctc_topk");
-    RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), rows, V, Vld, beam, blank_penalty, c.blank_id,
-                            e->topv.as<float>() + (size_t)r0 * beam, e->topi.as<int>() + (size_t)r0 * beam, nullptr));
-  }
-  e->h_topv.resize((size_t)M * beam);
-  e->h_topi.resize((size_t)M * beam);
-  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topv.data(), e->topv.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
-  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topi.data(), e->topi.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
-  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   return OK;
 }
 
@@ -531,23 +571,29 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
 static int prefix_beam_impl(rvb_engine* e, int beam) {
   if (e->B <= 0) { set_error("rvb_ctc_prefix_beam before rvb_encode"); return E_STATE; }
   if (beam != e->beam) { set_error("rvb_ctc_prefix_beam: beam differs from the one given to rvb_encode"); return E_ARG; }
-  const auto t0 = std::chrono::steady_clock::now();
   const int B = e->B, T = e->T2;
   e->nbest.assign(B, PrefixResult());
-  unsigned nthr = std::thread::hardware_concurrency();
-  if (nthr == 0) nthr = 4;
-  nthr = std::min<unsigned>(std::min<unsigned>(nthr, 256), (unsigned)B);
-  std::vector<std::thread> pool;
-  for (unsigned w = 0; w < nthr; ++w) {
-    pool.emplace_back([=]() {
-      for (int b = (int)w; b < B; b += (int)nthr)
-        prefix_beam_search(e->h_topv.data() + (size_t)b * T * beam, e->h_topi.data() + (size_t)b * T * beam,
-                           e->enc_lens[b], beam, beam, e->cfg.blank_id, &e->nbest[b]);
-    });
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  double busy_ms = 0.0;
+  for (size_t si = 0; si < e->slices.size(); ++si) {
+    RVB_TRY(wait_slices(e, (int)si));            // GPU keeps encoding the later slices meanwhile
+    const auto t0 = std::chrono::steady_clock::now();
+    const int c0 = e->slices[si].c0, nb = e->slices[si].nb;
+    const unsigned nthr = std::min<unsigned>(std::min<unsigned>(hw, 256), (unsigned)nb);
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthr; ++w) {
+      pool.emplace_back([=]() {
+        for (int b = c0 + (int)w; b < c0 + nb; b += (int)nthr)
+          prefix_beam_search(e->h_topv + (size_t)b * T * beam, e->h_topi + (size_t)b * T * beam, e->enc_lens[b], beam,
+                             beam, e->cfg.blank_id, &e->nbest[b]);
+      });
+    }
+    for (auto& t : pool) t.join();
+    busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  for (auto& t : pool) t.join();
   auto& pe = e->prof["search_host"];
-  pe.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  pe.ms += busy_ms;
   pe.launches += 1;
   return OK;
 }
@@ -637,6 +683,7 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>&
 static int rescore_impl(rvb_engine* e, double ctc_weight, double reverse_weight) {
   if ((int)e->nbest.size() != e->B || e->B <= 0) { set_error("rvb_attention_rescore before rvb_ctc_prefix_beam"); return E_STATE; }
   if (!e->dec_l.present) { set_error("model has no attention decoder"); return E_STATE; }
+  RVB_TRY(wait_slices(e, -1));
   const bool use_r = reverse_weight > 0.0;
   if (use_r && !e->dec_r.present) { set_error("reverse_weight > 0 but model has no right-to-left decoder"); return E_STATE; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
@@ -782,6 +829,10 @@ void rvb_destroy(rvb_engine* e) {
       for (LNorm* n : {&L.n1, &L.n2, &L.n3}) rel_n(*n);
     }
   }
+  if (e->h_topv) hipHostFree(e->h_topv);
+  if (e->h_topi) hipHostFree(e->h_topi);
+  for (auto& sl : e->slices) if (!sl.done) hipEventDestroy(sl.ev);
+  for (auto ev : e->slice_event_pool) hipEventDestroy(ev);
   for (auto& p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   hipStreamDestroy(e->stream);
@@ -854,6 +905,8 @@ int rvb_get_encoder_out(rvb_engine* e, float* out) {
   if (!e || !out || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
   const size_t n = (size_t)e->B * e->T2 * e->cfg.d_model;
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(wait_slices(e, -1));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   if (e->dtype == DT_F32) {
     RVB_HIP_CHECK(hipMemcpy(out, e->enc_out.p, n * 4, hipMemcpyDeviceToHost));
   } else {
@@ -868,6 +921,7 @@ int rvb_get_ctc_logprobs(rvb_engine* e, int chunk, float* out) {
   RVB_HIP_CHECK(hipSetDevice(e->device));
   const int d = e->cfg.d_model, V = e->cfg.vocab, T = e->T2, Vld = (V + 3) & ~3;
   if (T > LOGIT_SLAB) { set_error("chunk too long for the logit slab"); return E_UNSUPPORTED; }
+  RVB_TRY(wait_slices(e, -1));
   DevBuf lp, tv, ti;
   RVB_TRY(lp.ensure((size_t)T * V * 4)); RVB_TRY(tv.ensure((size_t)T * 4)); RVB_TRY(ti.ensure((size_t)T * 4));
   int r = run_gemm(e, (const char*)e->enc_out.p + (size_t)chunk * T * d * dt_size(e->dtype), d, e->ctc, e->logits.p, Vld, T, true);
@@ -880,17 +934,19 @@ int rvb_get_ctc_logprobs(rvb_engine* e, int chunk, float* out) {
 int rvb_get_ctc_topk(rvb_engine* e, float* vals, int32_t* idx) {
   if (!e || e->B <= 0) { set_error("no encoded batch"); return E_STATE; }
   const size_t n = (size_t)e->B * e->T2 * e->beam;
-  if (vals) memcpy(vals, e->h_topv.data(), n * 4);
-  if (idx) memcpy(idx, e->h_topi.data(), n * 4);
+  RVB_TRY(wait_slices(e, -1));
+  if (vals) memcpy(vals, e->h_topv, n * 4);
+  if (idx) memcpy(idx, e->h_topi, n * 4);
   return OK;
 }
 
 int rvb_ctc_greedy(rvb_engine* e, int32_t* tokens, int32_t* ntok, int32_t* frames) {
   if (!e || !tokens || !ntok || e->B <= 0) { set_error("rvb_ctc_greedy: no encoded batch"); return E_STATE; }
   const int T = e->T2, beam = e->beam;
+  RVB_TRY(wait_slices(e, -1));
   std::vector<int> tk, fr;
   for (int b = 0; b < e->B; ++b) {
-    greedy_collapse(e->h_topi.data() + (size_t)b * T * beam, e->enc_lens[b], beam, e->cfg.blank_id, &tk, &fr);
+    greedy_collapse(e->h_topi + (size_t)b * T * beam, e->enc_lens[b], beam, e->cfg.blank_id, &tk, &fr);
     ntok[b] = (int32_t)tk.size();
     for (size_t i = 0; i < tk.size(); ++i) { tokens[(size_t)b * T + i] = tk[i]; if (frames) frames[(size_t)b * T + i] = fr[i]; }
     for (size_t i = tk.size(); i < (size_t)T; ++i) { tokens[(size_t)b * T + i] = -1; if (frames) frames[(size_t)b * T + i] = -1; }
@@ -942,6 +998,27 @@ int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score
   if (score) *score = r.score;
   if (confidence) *confidence = r.confidence;
   if (tokens_confidence) for (size_t i = 0; i < r.tok_conf.size(); ++i) tokens_confidence[i] = r.tok_conf[i];
+  return OK;
+}
+int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_t* times_lens, int32_t* times,
+                           float* scores, double* confidences, double* tokens_confidence) {
+  if (!e || (int)e->rescored.size() != e->B || e->B <= 0 || !lens || !tokens) { set_error("rvb_get_rescored_batch: no rescoring results"); return E_STATE; }
+  const int T = e->T2;
+  for (int b = 0; b < e->B; ++b) {
+    const RescoreResult& r = e->rescored[b];
+    const PrefixResult& pr = e->nbest[b];
+    const std::vector<int>& tk = pr.nbest[r.best];
+    const std::vector<int>& tm = pr.times[r.best];
+    lens[b] = (int32_t)tk.size();
+    if (times_lens) times_lens[b] = (int32_t)tm.size();
+    if (scores) scores[b] = r.score;
+    if (confidences) confidences[b] = r.confidence;
+    for (int j = 0; j < T; ++j) {
+      tokens[(size_t)b * T + j] = j < (int)tk.size() ? tk[j] : -1;
+      if (times) times[(size_t)b * T + j] = j < (int)tm.size() ? tm[j] : -1;
+      if (tokens_confidence) tokens_confidence[(size_t)b * T + j] = j < (int)r.tok_conf.size() ? r.tok_conf[j] : 0.0;
+    }
+  }
   return OK;
 }
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out) {

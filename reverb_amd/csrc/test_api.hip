@@ -1,6 +1,7 @@
 // rvb_test_*: raw kernel entry points used by tests/ (host buffers in, host buffers out).  Each one
 // uploads fp32 host data (rounded to the compute dtype with the same RNE conversion the engine
 // uses), launches exactly the kernel the engine launches, and downloads the result as fp32.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -242,17 +243,20 @@ extern "C" int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, 
   Dev dA, dW, dB, dR, dC, dC1;
   const size_t es = dt_size(dtype);
   const bool f32out = dtype == DT_F32 || out_f32;
-  T_TRY(dA.alloc((size_t)M * K * es)); T_TRY(dW.alloc((size_t)N * K * es)); T_TRY(dB.alloc((size_t)N * 4));
+  // RVB_BENCH_PAD=<elements>: pad the leading dimensions of A and W (probe for channel camping of 2^n row strides)
+  const int pad = getenv("RVB_BENCH_PAD") ? atoi(getenv("RVB_BENCH_PAD")) : 0;
+  const int ldk = K + pad;
+  T_TRY(dA.alloc((size_t)M * ldk * es)); T_TRY(dW.alloc((size_t)N * ldk * es)); T_TRY(dB.alloc((size_t)N * 4));
   T_TRY(dR.alloc((size_t)M * N * 4)); T_TRY(dC.alloc((size_t)M * N * (f32out ? 4 : 2)));
   T_TRY(dC1.alloc((size_t)M * N * (f32out ? 4 : 2)));
-  if (dtype == DT_BF16) { fill<bf16_t>(dA.p, (size_t)M * K, 1u, 1.0f); fill<bf16_t>(dW.p, (size_t)N * K, 2u, 1.0f / sqrtf((float)K)); }
-  else { fill<float>(dA.p, (size_t)M * K, 1u, 1.0f); fill<float>(dW.p, (size_t)N * K, 2u, 1.0f / sqrtf((float)K)); }
+  if (dtype == DT_BF16) { fill<bf16_t>(dA.p, (size_t)M * ldk, 1u, 1.0f); fill<bf16_t>(dW.p, (size_t)N * ldk, 2u, 1.0f / sqrtf((float)K)); }
+  else { fill<float>(dA.p, (size_t)M * ldk, 1u, 1.0f); fill<float>(dW.p, (size_t)N * ldk, 2u, 1.0f / sqrtf((float)K)); }
   fill<float>(dB.p, N, 3u, 1.0f);
   fill<float>(dR.p, (size_t)M * N, 4u, 1.0f);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.res = with_res ? (const float*)dR.p : nullptr; g.C = dC.p;
-  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldres = N; g.alpha = 0.5f; g.act = act; g.out_f32 = out_f32;
+  g.M = M; g.N = N; g.K = K; g.lda = ldk; g.ldw = ldk; g.ldc = N; g.ldres = N; g.alpha = 0.5f; g.act = act; g.out_f32 = out_f32;
   const int saved = g_gemm_variant;
   g_gemm_variant = variant;
   int r = gemm(nullptr, dtype, g);

@@ -220,6 +220,17 @@ class Engine:
                                     tokens_confidence=tc[:len(pr.nbest[bi.value])].tolist()))
         return res
 
+    def _rescore_bulk(self, ctc_weight: float, reverse_weight: float) -> List[DecodeResult]:
+        check(self.lib.rvb_attention_rescore(self.handle, float(ctc_weight), float(reverse_weight)), "rvb_attention_rescore")
+        B, T = self.batch, self.enc_frames
+        lens = np.empty(B, np.int32); tok = np.empty((B, T), np.int32); tl = np.empty(B, np.int32)
+        tim = np.empty((B, T), np.int32); sc = np.empty(B, np.float32); cf = np.empty(B, np.float64)
+        tc = np.empty((B, T), np.float64)
+        check(self.lib.rvb_get_rescored_batch(self.handle, iptr(lens), iptr(tok), iptr(tl), iptr(tim), fptr(sc), dptr(cf),
+                                              dptr(tc)), "rvb_get_rescored_batch")
+        return [DecodeResult(tuple(tok[b, :lens[b]].tolist()), float(sc[b]), confidence=float(cf[b]),
+                             times=tim[b, :tl[b]].tolist(), tokens_confidence=tc[b, :lens[b]].tolist()) for b in range(B)]
+
     def rescore_logp(self, chunk: int, hyp: int, length: int, right: bool = False) -> np.ndarray:
         out = np.empty(length + 1, np.float32)
         check(self.lib.rvb_get_rescore_logp(self.handle, chunk, hyp, 1 if right else 0, fptr(out)))
@@ -233,7 +244,11 @@ class Engine:
                 raise RvbError(f"decoding mode {m!r} is not built yet (supported: {', '.join(SUPPORTED_MODES)})")
         if "ctc_greedy_search" in methods:
             results["ctc_greedy_search"] = self.greedy()
-        if "ctc_prefix_beam_search" in methods or "attention_rescoring" in methods:
+        if "attention_rescoring" in methods and "ctc_prefix_beam_search" not in methods:
+            # fast path: n-best lists stay in the engine, one bulk read of the winners
+            check(self.lib.rvb_ctc_prefix_beam(self.handle, self.beam), "rvb_ctc_prefix_beam")
+            results["attention_rescoring"] = self._rescore_bulk(ctc_weight, reverse_weight)
+        elif "ctc_prefix_beam_search" in methods or "attention_rescoring" in methods:
             pref = self.prefix_beam()
             if "ctc_prefix_beam_search" in methods:
                 results["ctc_prefix_beam_search"] = pref

@@ -186,3 +186,33 @@ def test_api_from_wav_file_matches_reference_ctm(name):
         from oracle import fbank_ref
         np.testing.assert_allclose(feats[0].numpy(), fbank_ref.fbank(case.pcm), rtol=0, atol=1e-3)
         asr.engine.close()
+
+
+def test_slice_pipeline_and_bulk_results_equal_plain_path():
+    """>= 16 chunks are encoded in slices with the host search overlapped; results must not depend on it,
+    and the rescoring-only fast path (bulk getter) must equal the per-chunk path."""
+    case = Case("tiny_ln")
+    rng = np.random.default_rng(0)
+    T0, B = 263, 20
+    feats = case.chunked_feats()[0][0]                       # (2051, 80) real log-mel of chunk 0
+    x = np.stack([feats[(37 * i) % 1700:(37 * i) % 1700 + T0] for i in range(B)]).astype(np.float32)
+    lens = np.full(B, T0, np.int32); lens[-1] = 120; lens[3] = 5
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=32, chunk_frames=T0, cat_embs=case.cat)
+    eng.encode(x, lens, 6)                                   # 2 slices of 10
+    enc_all = eng.encoder_out().copy()
+    _, idx_all = eng.ctc_topk()
+    full = eng.search(MODES, 0.1, 0.0)
+    eng.encode(x, lens, 6)
+    fast = eng.search(["attention_rescoring"], 0.1, 0.0)["attention_rescoring"]
+    for a, b in zip(full["attention_rescoring"], fast):
+        assert list(a.tokens) == list(b.tokens) and list(a.times) == list(b.times)
+        assert a.score == b.score and a.confidence == b.confidence and a.tokens_confidence == b.tokens_confidence
+    for s in range(0, B, 10):                                # the same chunks as two plain batches
+        eng.encode(x[s:s + 10], lens[s:s + 10], 6)
+        np.testing.assert_array_equal(eng.encoder_out(), enc_all[s:s + 10])
+        np.testing.assert_array_equal(eng.ctc_topk()[1], idx_all[s:s + 10])
+        part = eng.search(MODES, 0.1, 0.0)
+        for m in MODES:
+            for a, b in zip(part[m], full[m][s:s + 10]):
+                assert list(a.tokens) == list(b.tokens)
+    eng.close()
