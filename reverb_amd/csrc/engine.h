@@ -98,6 +98,7 @@ struct rvb_engine {
   struct Slice { int c0, nb; hipEvent_t ev; bool done; };
   std::vector<Slice> slices;       // slices of the last rvb_encode, in chunk order
   std::vector<hipEvent_t> slice_event_pool;
+  int xattn_max_rows = 0;          // most decoder rows of any chunk (cross-attention query sequence length)
   const int* cur_lens = nullptr;   // device pointer: valid encoder frames of the slice being encoded
   std::vector<rvb::PrefixResult> nbest;
   std::vector<rvb::RescoreResult> rescored;
