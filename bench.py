@@ -136,10 +136,15 @@ def main():
         stages = {k: eng.timing(k) for k in ("fbank", "subsample", "gemm", "attention", "rownorm", "glu_dwconv",
                                              "ctc_topk", "embed", "lse_gather", "search_host")}
         roof = None
+        traffic = None      # HBM bytes per GEMM launch from a PMC pass of this command (scripts/pmc_traffic.py)
+        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{args.model}_{args.hours:g}h_{args.dtype}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as tf:
+                traffic = round(json.load(tf)["traffic_bytes_per_launch"], 1)
         if g["ms"] > 0:
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                     "kernel": "rvb::gemm_kernel (all GEMM launches of the timed steps)",
                     "launches": g["launches"], "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
                     "flops_per_launch": round(g["flops"] / max(g["launches"], 1), 1)}
