@@ -1,0 +1,82 @@
+/* rvd.h -- C ABI of the MI355X-native diarization hot path (same shared library as rvb.h: librvb.so).
+ *
+ * What it replaces.  /root/reference/diarization/infer_pyannote3.0.py:33-42 builds
+ * `pyannote.audio.Pipeline.from_pretrained("Revai/reverb-diarization-v1")`, moves it to the GPU and
+ * calls `pipeline(audio)`.  Inside that call the two neural networks are the hot path:
+ *
+ *   segmentation   PyanNet (SincNet + 4 x BiLSTM(128) + 2 x Linear(128) + 7-class powerset head) on every
+ *                  10 s window, hop 1 s        (pyannote.audio Inference.slide -> model.forward)
+ *   embedding      WeSpeaker ResNet34 + masked statistics pooling on every (window, local speaker) pair
+ *
+ * The glue between them (powerset decoding, speaker counting, clustering, reconstruction, RTTM) is host
+ * code in reverb_amd/diarization.py.  A maintainer binds this header with ctypes exactly as
+ * reverb_amd/_lib.py does (INTEGRATION.md shows the pyannote-side stub).
+ *
+ * Conventions: every function returns 0 on success or a negative RVB_E_* code (rvb.h); the message is in
+ * rvd_last_error().  Host pointers are plain C arrays.  All tensors are loaded as fp32 in the layout and
+ * under the names of the pyannote checkpoints' state dicts, prefixed "segmentation." / "embedding.".
+ * There is no CPU fallback: rvd_create fails when no HIP device is present.
+ */
+#ifndef RVD_H
+#define RVD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvd_engine rvd_engine;
+
+typedef struct rvd_model_cfg {
+  int32_t dtype;            /* RVB_F32 (0) exact-parity mode, RVB_BF16 (1) bf16 MFMA inputs, fp32 accumulate */
+  int32_t sample_rate;      /* 16000 */
+  int32_t window_samples;   /* 160000 (10 s) */
+  int32_t step_samples;     /* 16000  (segmentation_step 0.1 x window) */
+  int32_t sinc_filters;     /* 80 (40 cos + 40 sin), kernel 251, stride 10 */
+  int32_t sinc_channels;    /* 60: Conv1d(80,60,5), Conv1d(60,60,5) */
+  int32_t lstm_hidden;      /* 128 (bidirectional) */
+  int32_t lstm_layers;      /* 4 */
+  int32_t linear_dim;       /* 128 */
+  int32_t linear_layers;    /* 2 */
+  int32_t num_classes;      /* 7 powerset classes (3 speakers, <= 2 simultaneously) */
+  int32_t emb_channels;     /* 32: ResNet34 m_channels; 0 = no embedding model loaded */
+  int32_t emb_dim;          /* 256 */
+} rvd_model_cfg;
+
+const char* rvd_last_error(void);
+
+int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out);
+void rvd_destroy(rvd_engine* e);
+/* stage one fp32 tensor of a checkpoint, e.g. "segmentation.sincnet.conv1d.1.weight" */
+int rvd_load_tensor(rvd_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
+/* pack weights for the device (sinc filters from low_hz_/band_hz_, conv weights as GEMM operands,
+ * BatchNorm folded into the ResNet convolutions) and free the staged copies */
+int rvd_finalize(rvd_engine* e);
+
+/* windows pyannote's Inference.slide makes of n samples: the full ones plus one zero-padded tail */
+int64_t rvd_num_windows(const rvd_engine* e, int64_t n_samples);
+/* frames the segmentation model emits per window (589 for 10 s) */
+int rvd_frames_per_window(const rvd_engine* e);
+
+/* 16-bit mono PCM at cfg.sample_rate -> HBM; evaluates the sinc filter bank once for all windows */
+int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n_samples);
+
+/* segmentation model on windows [first, first+n): logp_out host fp32 [n][frames][num_classes] */
+int rvd_segment(rvd_engine* e, int64_t first_window, int n_windows, float* logp_out);
+/* debug taps of the last rvd_segment: "sincnet" [n][frames][sinc_channels], "lstm" [n][frames][2*hidden] */
+int rvd_get_tap(rvd_engine* e, const char* name, float* out);
+
+/* embedding model: for each of n items, window index win[i] and a frame mask[i][frames] (weights in [0,1],
+ * resampled to the ResNet's time axis as pyannote does); emb_out host fp32 [n][emb_dim] */
+int rvd_embed(rvd_engine* e, const int64_t* win, const float* mask, int n, float* emb_out);
+/* debug: the 80-bin log-mel features of one window as fed to the ResNet, [frames][80]; returns frames in *n */
+int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_frames);
+
+int rvd_set_profiling(rvd_engine* e, int enabled);
+int rvd_reset_timings(rvd_engine* e);
+int rvd_get_timing(rvd_engine* e, const char* name, double* ms, double* flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

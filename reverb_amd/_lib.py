@@ -82,6 +82,34 @@ SIGNATURES = {
                                        _f64p]),
 }
 
+
+
+class DiarCfg(C.Structure):
+    """rvd_model_cfg of include/rvd.h."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "sample_rate", "window_samples", "step_samples", "sinc_filters", "sinc_channels", "lstm_hidden",
+        "lstm_layers", "linear_dim", "linear_layers", "num_classes", "emb_channels", "emb_dim")]
+
+
+# every exported symbol of include/rvd.h (diarization networks; same shared library)
+DIAR_SIGNATURES = {
+    "rvd_last_error": (C.c_char_p, []),
+    "rvd_create": (C.c_int, [C.POINTER(DiarCfg), C.c_int, C.POINTER(_eng)]),
+    "rvd_destroy": (None, [_eng]),
+    "rvd_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),
+    "rvd_finalize": (C.c_int, [_eng]),
+    "rvd_num_windows": (C.c_int64, [_eng, C.c_int64]),
+    "rvd_frames_per_window": (C.c_int, [_eng]),
+    "rvd_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvd_segment": (C.c_int, [_eng, C.c_int64, C.c_int, _f32p]),
+    "rvd_get_tap": (C.c_int, [_eng, C.c_char_p, _f32p]),
+    "rvd_embed": (C.c_int, [_eng, _i64p, _f32p, C.c_int, _f32p]),
+    "rvd_get_emb_fbank": (C.c_int, [_eng, C.c_int64, _f32p, _i32p]),
+    "rvd_set_profiling": (C.c_int, [_eng, C.c_int]),
+    "rvd_reset_timings": (C.c_int, [_eng]),
+    "rvd_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),
+}
+
 _lib = None
 
 
@@ -94,7 +122,7 @@ def load():
         raise RvbError(f"{LIB_PATH} not found: run `python -m reverb_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback for the Reverb-ASR hot path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DIAR_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -93,5 +93,6 @@ enum { OK = 0, E_ARG = -1, E_HIP = -2, E_STATE = -3, E_NOMEM = -4, E_UNSUPPORTED
   } while (0)
 
 namespace rvb {
-void set_error(const std::string& msg);  // thread-local last error (api.cpp)
+void set_error(const std::string& msg);  // thread-local last error (engine.hip)
+const char* last_error();
 }

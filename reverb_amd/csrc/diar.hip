@@ -1,0 +1,389 @@
+// Diarization segmentation kernels (PyanNet = SincNet + BiLSTM + linears, pyannote/segmentation-3.0 as
+// fine-tuned by reverb-diarization-v1; call site /root/reference/diarization/infer_pyannote3.0.py:33-42).
+//
+// The pipeline slides a 10 s window every 1 s, so every sample is seen by 10 windows.  SincNet's first
+// layer is instance-norm(waveform) -> 80 fixed band-pass filters (251 taps, stride 10): because the
+// window hop (16 000 samples) is a multiple of the stride, the filter bank is evaluated ONCE on the raw
+// waveform (sinc_conv) and each window applies its own normalisation as an affine correction
+// (pool_norm, first block) -- 10x fewer FLOPs and no per-window copies of the audio.
+#include "kernels.h"
+
+namespace rvb {
+
+// ------------------------------------------------------------------------------------ pcm -> float
+__global__ void pcm_to_float_kernel(const int16_t* __restrict__ pcm, int64_t n, float* __restrict__ out, int64_t n_pad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) out[i] = i < n ? (float)pcm[i] * (1.0f / 32768.0f) : 0.0f;
+}
+int pcm_to_float(hipStream_t s, const int16_t* pcm, int64_t n, float* out, int64_t n_pad) {
+  if (n_pad <= 0) return OK;
+  hipLaunchKernelGGL(pcm_to_float_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, pcm, n, out, n_pad);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ sinc filter bank
+// 64 frames x 80 filters per block; filters (80 KB) and the 881 samples they cover live in LDS.  Thread
+// (filter f, slot) walks its 16 frames four at a time: per tap one conflict-free LDS read of the weight
+// (row stride 251 words is odd) and four broadcast reads of samples feed four FMAs.
+static constexpr int SC_FT = 64, SC_NF = 80, SC_KS = 251, SC_THREADS = 320;
+
+__global__ __launch_bounds__(SC_THREADS) void sinc_conv_kernel(const float* __restrict__ wave, const float* __restrict__ filt,
+                                                               float* __restrict__ craw, int64_t n_frames, int nf,
+                                                               int ksize, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sc_smem[];
+  float* sf = sc_smem;                       // [nf][ksize]
+  float* sx = sc_smem + SC_NF * SC_KS;       // [(FT-1)*stride + ksize]
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * SC_FT;
+  const int nsamp = (SC_FT - 1) * stride + ksize;
+  const int64_t last = (n_frames - 1) * stride + ksize;   // samples available
+  for (int i = tid; i < nf * ksize; i += SC_THREADS) sf[i] = filt[i];
+  for (int i = tid; i < nsamp; i += SC_THREADS) {
+    const int64_t g = t0 * stride + i;
+    sx[i] = g < last ? wave[g] : 0.0f;
+  }
+  __syncthreads();
+  const int f = tid % SC_NF, slot = tid / SC_NF;
+  if (f >= nf) return;
+  const float* wf = sf + f * ksize;
+#pragma unroll 1
+  for (int g = 0; g < 4; ++g) {
+    const int fr = slot * 16 + g * 4;
+    const float* x0 = sx + fr * stride;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < ksize; ++k) {
+      const float w = wf[k];
+      a0 = fmaf(x0[k], w, a0);
+      a1 = fmaf(x0[k + stride], w, a1);
+      a2 = fmaf(x0[k + 2 * stride], w, a2);
+      a3 = fmaf(x0[k + 3 * stride], w, a3);
+    }
+    const int64_t t = t0 + fr;
+    if (t < n_frames) craw[t * nf + f] = a0;
+    if (t + 1 < n_frames) craw[(t + 1) * nf + f] = a1;
+    if (t + 2 < n_frames) craw[(t + 2) * nf + f] = a2;
+    if (t + 3 < n_frames) craw[(t + 3) * nf + f] = a3;
+  }
+}
+
+int sinc_conv(hipStream_t s, const float* wave, const float* filt, float* craw, int64_t n_frames, int nf, int ksize,
+              int stride) {
+  if (nf > SC_NF || ksize > SC_KS || stride < 1 || stride > 16) { set_error("sinc_conv: unsupported filter bank shape"); return E_UNSUPPORTED; }
+  if (n_frames <= 0) return OK;
+  const size_t lds = (size_t)(SC_NF * SC_KS + (SC_FT - 1) * 16 + SC_KS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sinc_conv_kernel, dim3(cdiv(n_frames, SC_FT)), dim3(SC_THREADS), lds, s, wave, filt, craw, n_frames,
+                     nf, ksize, stride);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ window statistics
+__device__ inline double block_sum_d(double v, double* red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void window_stats_kernel(const float* __restrict__ wave, int64_t first, int64_t step, int len,
+                                                           float eps, float* __restrict__ stats) {
+  __shared__ double red[4];
+  const float* x = wave + (first + blockIdx.x) * step;
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
+    if (i + 4 <= len) {
+      const float4 v = *(const float4*)(x + i);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (int j = i; j < len; ++j) { s += x[j]; ss += (double)x[j] * x[j]; }
+    }
+  }
+  s = block_sum_d(s, red);
+  ss = block_sum_d(ss, red);
+  if (threadIdx.x == 0) {
+    const double mean = s / len;
+    double var = ss / len - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * blockIdx.x] = (float)mean;
+    stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+int window_stats(hipStream_t s, const float* wave, int64_t first, int nwin, int64_t step, int len, float eps, float* stats) {
+  if (nwin <= 0) return OK;
+  if (step % 4) { set_error("window_stats: step must be a multiple of 4 samples"); return E_ARG; }
+  hipLaunchKernelGGL(window_stats_kernel, dim3(nwin), dim3(256), 0, s, wave, first, step, len, eps, stats);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ pool + instance norm + leaky relu
+// One block per window.  Thread (channel c, slot) strides over the pooled frames; pass 1 accumulates the
+// per-channel mean / variance (fp64 partials), pass 2 recomputes the pooled value and writes the
+// normalised activation (cheaper than a round trip of the pooled tensor through HBM).
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(256) void pool_norm_kernel(PoolNormArgs p) {
+  __shared__ double s_sum[256], s_sq[256];
+  __shared__ float s_scale[128], s_shift[128];
+  const int w = blockIdx.x;
+  const int CP = p.ld_out;
+  const int nslots = 256 / CP;
+  const int c = threadIdx.x % CP, slot = threadIdx.x / CP;
+  const bool active = slot < nslots && c < p.C;
+  const int TP = p.frames_in / 3;
+
+  float a = 0.f, off = 0.f;
+  const float* cr = nullptr;
+  const T* x = nullptr;
+  if (FIRST) {
+    const float mean = p.stats[2 * w], rstd = p.stats[2 * w + 1];
+    a = p.wn_gamma * rstd;
+    if (active) off = (p.wn_beta - a * mean) * p.fsum[c];
+    cr = p.craw + (p.craw_frame0 + (int64_t)w * p.craw_frames_per_step) * p.C + c;
+  } else {
+    x = (const T*)p.x + (size_t)w * p.rows_in * p.ld_in + c;
+  }
+  auto pooled = [&](int tp) -> float {
+    if (FIRST) {
+      const float* q = cr + (size_t)(3 * tp) * p.C;
+      const float v0 = fabsf(fmaf(a, q[0], off)), v1 = fabsf(fmaf(a, q[p.C], off)), v2 = fabsf(fmaf(a, q[2 * p.C], off));
+      return fmaxf(v0, fmaxf(v1, v2));
+    } else {
+      const T* q = x + (size_t)(3 * tp) * p.ld_in;
+      return fmaxf(Cvt<T>::to_f32(q[0]), fmaxf(Cvt<T>::to_f32(q[p.ld_in]), Cvt<T>::to_f32(q[2 * p.ld_in])));
+    }
+  };
+
+  double s = 0.0, ss = 0.0;
+  if (active)
+    for (int tp = slot; tp < TP; tp += nslots) { const float v = pooled(tp); s += v; ss += (double)v * v; }
+  s_sum[threadIdx.x] = s; s_sq[threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < CP) {
+    if (threadIdx.x < p.C) {
+      double ts = 0.0, tq = 0.0;
+      for (int k = 0; k < nslots; ++k) { ts += s_sum[k * CP + threadIdx.x]; tq += s_sq[k * CP + threadIdx.x]; }
+      const double mean = ts / TP;
+      double var = tq / TP - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+      const float g = p.gamma[threadIdx.x] * rstd;
+      s_scale[threadIdx.x] = g;
+      s_shift[threadIdx.x] = p.beta[threadIdx.x] - (float)mean * g;
+    } else {
+      s_scale[threadIdx.x] = 0.f; s_shift[threadIdx.x] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (slot >= nslots) return;
+  T* out = (T*)p.out + (size_t)w * TP * CP + c;
+  if (c >= p.C) {
+    for (int tp = slot; tp < TP; tp += nslots) out[(size_t)tp * CP] = Cvt<T>::from_f32(0.f);
+    return;
+  }
+  const float sc = s_scale[c], sh = s_shift[c];
+  for (int tp = slot; tp < TP; tp += nslots) {
+    float v = fmaf(pooled(tp), sc, sh);
+    v = v > 0.f ? v : 0.01f * v;
+    out[(size_t)tp * CP] = Cvt<T>::from_f32(v);
+  }
+}
+
+int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a) {
+  if (a.W <= 0) return OK;
+  if (a.ld_out > 128 || a.ld_out < a.C || a.C < 1) { set_error("pool_norm: channels must be <= ld_out <= 128"); return E_ARG; }
+  const bool first = a.x == nullptr;
+  if (dtype == DT_BF16) {
+    if (first) hipLaunchKernelGGL((pool_norm_kernel<bf16_t, true>), dim3(a.W), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_norm_kernel<bf16_t, false>), dim3(a.W), dim3(256), 0, s, a);
+  } else {
+    if (first) hipLaunchKernelGGL((pool_norm_kernel<float, true>), dim3(a.W), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_norm_kernel<float, false>), dim3(a.W), dim3(256), 0, s, a);
+  }
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ LSTM recurrence
+// One block = 16 windows x one direction, 4 waves; wave v owns hidden units [32v, 32v+32) and therefore the
+// four gate columns {q*128 + unit} of each: the i/f/g/o pre-activations of a (window, unit) pair land in
+// the same lane of four accumulator fragments, so the cell update is lane-local.  The recurrent weights
+// (4H x H) stay in registers as MFMA B fragments for all 589 steps (bf16: 128 VGPRs per lane); h_t goes
+// through a double-buffered 4 KB LDS tile to become the next step's A operand; the input projection of
+// step t+1 is prefetched while step t runs.
+template <typename T> struct GateMath;
+template <> struct GateMath<float> {
+  __device__ static inline float sig(float x) { return 1.0f / (1.0f + expf(-x)); }
+  __device__ static inline float tanh_(float x) { return tanhf(x); }
+};
+template <> struct GateMath<bf16_t> {
+  __device__ static inline float sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+  __device__ static inline float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x)); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void lstm_kernel(const T* __restrict__ xproj, const T* __restrict__ whh, T* __restrict__ out,
+                                                   int W, int TT) {
+  constexpr int H = 128, NB = 16;
+  constexpr int KC = Mma16<T>::KC, VE = Mma16<T>::VE, NCH = H / KC;
+  constexpr int HSB = H * (int)sizeof(T) + 16;          // padded LDS row stride (bytes)
+  constexpr bool WREG = sizeof(T) == 2;
+  __shared__ __attribute__((aligned(16))) char hs[2][NB * HSB];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int dir = blockIdx.y;
+  const int w0 = blockIdx.x * NB;
+  const int col = lane & 15, grp = lane >> 4;
+  const T* whd = whh + (size_t)dir * 4 * H * H;
+
+  auto wptr = [&](int q, int hf, int kc) { return (const uint4*)(whd + (size_t)(q * H + 32 * wv + 16 * hf + col) * H + kc * KC + grp * VE); };
+  uint4 wreg[WREG ? 4 : 1][2][WREG ? NCH : 1];
+  if (WREG) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) wreg[WREG ? q : 0][hf][WREG ? kc : 0] = *wptr(q, hf, kc);
+  }
+
+  size_t xrow[4];
+  bool wok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int wi = w0 + 4 * grp + r;
+    wok[r] = wi < W;
+    xrow[r] = (size_t)(wok[r] ? wi : W - 1) * TT;
+  }
+  const int ucol = 32 * wv + col;     // + 16*hf
+  float xpv[4][2][4];
+  auto load_xp = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const T* xp = xproj + (xrow[r] + t) * (size_t)(8 * H) + dir * 4 * H + ucol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) xpv[q][hf][r] = Cvt<T>::to_f32(xp[q * H + 16 * hf]);
+    }
+  };
+
+  for (int i = threadIdx.x; i < NB * HSB / 4; i += 256) ((uint32_t*)hs[0])[i] = 0u;
+  float cst[2][4];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cst[hf][r] = 0.f;
+  load_xp(dir ? TT - 1 : 0);
+  __syncthreads();
+
+  for (int s = 0; s < TT; ++s) {
+    const int t = dir ? TT - 1 - s : s;
+    const int cur = s & 1;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) acc[q][hf] = (f32x4_t){xpv[q][hf][0], xpv[q][hf][1], xpv[q][hf][2], xpv[q][hf][3]};
+    if (s + 1 < TT) load_xp(dir ? t - 1 : t + 1);
+
+    const char* ha = hs[cur] + col * HSB + grp * 16;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      const uint4 a = *(const uint4*)(ha + kc * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const uint4 b = WREG ? wreg[WREG ? q : 0][hf][WREG ? kc : 0] : *wptr(q, hf, kc);
+          Mma16<T>::run(a, b, acc[q][hf]);
+        }
+    }
+    char* hn = hs[cur ^ 1];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int unit = ucol + 16 * hf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = GateMath<T>::sig(acc[0][hf][r]);
+        const float fg = GateMath<T>::sig(acc[1][hf][r]);
+        const float gg = GateMath<T>::tanh_(acc[2][hf][r]);
+        const float og = GateMath<T>::sig(acc[3][hf][r]);
+        const float c = fg * cst[hf][r] + ig * gg;
+        cst[hf][r] = c;
+        const T hv = Cvt<T>::from_f32(og * GateMath<T>::tanh_(c));
+        *(T*)(hn + (4 * grp + r) * HSB + unit * sizeof(T)) = hv;
+        if (wok[r]) out[(xrow[r] + t) * (size_t)(2 * H) + dir * H + unit] = hv;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh, void* out, int W, int T) {
+  if (W <= 0 || T <= 0) return OK;
+  const dim3 grid(cdiv(W, 16), 2);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(lstm_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xproj, (const bf16_t*)whh, (bf16_t*)out, W, T);
+  else hipLaunchKernelGGL(lstm_kernel<float>, grid, dim3(256), 0, s, (const float*)xproj, (const float*)whh, (float*)out, W, T);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ classifier + log-softmax
+template <typename T>
+__global__ __launch_bounds__(256) void classifier_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ logp, int64_t M,
+                                                         int in, int C) {
+  __shared__ float sw[16 * 256];
+  for (int i = threadIdx.x; i < C * in; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = (c < C) ? b[c] : 0.f;
+  const T* xr = x + row * ldx;
+  constexpr int VE = 16 / sizeof(T);
+  for (int k0 = 0; k0 < in; k0 += VE) {
+    const uint4 raw = *(const uint4*)(xr + k0);
+    const T* xe = (const T*)&raw;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float xv = Cvt<T>::to_f32(xe[e]);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < C) acc[c] = fmaf(xv, sw[c * in + k0 + e], acc[c]);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) if (c < C) mx = fmaxf(mx, acc[c]);
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) if (c < C) se += expf(acc[c] - mx);
+  const float lse = mx + logf(se);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) if (c < C) logp[row * C + c] = acc[c] - lse;
+}
+
+int classifier_logsoftmax(hipStream_t s, int dtype, const void* x, int ldx, const float* w, const float* b, float* logp,
+                          int64_t M, int in, int C) {
+  if (C > 16 || in > 256 || (in % 8) || (ldx % 8)) { set_error("classifier_logsoftmax: needs C <= 16, in <= 256, in and ldx multiples of 8"); return E_ARG; }
+  if (M <= 0) return OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(classifier_kernel<bf16_t>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, logp, M, in, C);
+  else hipLaunchKernelGGL(classifier_kernel<float>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const float*)x, ldx, w, b, logp, M, in, C);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace rvb

@@ -1,0 +1,465 @@
+// rvd_* : diarization engine (segmentation + embedding networks of the pyannote pipeline the reference
+// runs in diarization/infer_pyannote3.0.py:33-42) on one MI355X.  Kernels: diar.hip, resnet.hip, gemm*.hip.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rvd.h"
+#include "engine.h"
+
+using namespace rvb;
+
+#define RVD_TRY(expr) do { int _r = (expr); if (_r != OK) return _r; } while (0)
+
+namespace {
+struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
+constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
+}  // namespace
+
+struct rvd_engine {
+  rvd_model_cfg cfg;
+  int device = 0, dtype = 0;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+  std::map<std::string, HostTensor> host;
+
+  // derived frame counts of one window
+  int f1 = 0, p1 = 0, f2 = 0, p2 = 0, f3 = 0, p3 = 0, cpad = 0;
+
+  // segmentation weights
+  DevBuf filt, fsum;
+  float wn_gamma = 1.f, wn_beta = 0.f;
+  LNorm norm[3];
+  Linear conv2, conv3;
+  std::vector<LstmLayer> lstm;
+  std::vector<Linear> lin;
+  DevBuf cls_w, cls_b;
+  DevBuf stage;
+
+  // audio
+  DevBuf pcm, wave, craw;
+  int64_t n_samples = 0, n_pad = 0, n_windows = 0, craw_frames = 0;
+
+  // workspace of rvd_segment
+  DevBuf stats, a1, c2, a2, c3, a3, xproj, hA, hB, l0, l1, logp;
+  int last_W = 0;
+  const void* last_lstm = nullptr;
+
+  // profiling
+  bool profiling = false;
+  std::map<std::string, ProfEntry> prof;
+  struct Pending { hipEvent_t a, b; std::string name; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+struct DScope {
+  rvd_engine* e; hipEvent_t a = nullptr, b = nullptr; std::string name;
+  DScope(rvd_engine* e_, const char* n, double flops = 0.0) : e(e_), name(n) {
+    auto& pe = e->prof[name];
+    pe.launches += 1; pe.flops += flops;
+    if (!e->profiling) return;
+    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else hipEventCreate(&ev); return ev; };
+    a = get(); b = get();
+    hipEventRecord(a, e->stream);
+  }
+  ~DScope() { if (a) { hipEventRecord(b, e->stream); e->pending.push_back({a, b, name}); } }
+};
+void drain(rvd_engine* e) {
+  if (e->pending.empty()) return;
+  hipStreamSynchronize(e->stream);
+  for (auto& p : e->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    e->prof[p.name].ms += ms;
+    e->event_pool.push_back(p.a); e->event_pool.push_back(p.b);
+  }
+  e->pending.clear();
+}
+
+int up_f32(rvd_engine* e, DevBuf& dst, const float* src, size_t n) {
+  RVD_TRY(dst.ensure(n * 4));
+  RVB_HIP_CHECK(hipMemcpyAsync(dst.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));   // src may be a temporary
+  return OK;
+}
+int pack_T(rvd_engine* e, DevBuf& dst, const float* src, size_t n) {
+  RVD_TRY(dst.ensure(n * dt_size(e->dtype)));
+  if (e->dtype == DT_F32) return up_f32(e, dst, src, n);
+  RVD_TRY(up_f32(e, e->stage, src, n));
+  RVD_TRY(convert_f32(e->stream, e->dtype, e->stage.as<float>(), dst.p, n));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+int need(rvd_engine* e, const std::string& name, size_t numel, const HostTensor** out) {
+  auto it = e->host.find(name);
+  if (it == e->host.end()) { set_error("missing tensor: " + name); return E_STATE; }
+  if (it->second.numel() != numel) {
+    set_error("tensor " + name + " has " + std::to_string(it->second.numel()) + " elements, expected " + std::to_string(numel));
+    return E_ARG;
+  }
+  *out = &it->second;
+  return OK;
+}
+int pack_norm(rvd_engine* e, LNorm& n, const std::string& p, int d) {
+  const HostTensor *g, *b;
+  RVD_TRY(need(e, p + ".weight", d, &g));
+  RVD_TRY(need(e, p + ".bias", d, &b));
+  n.eps = 1e-5f;
+  RVD_TRY(up_f32(e, n.g, g->data.data(), d));
+  return up_f32(e, n.b, b->data.data(), d);
+}
+
+// asteroid_filterbanks ParamSincFB.filters(): 40 cos + 40 sin band-pass filters from (low_hz_, band_hz_)
+void sinc_filters(const float* low_hz_, const float* band_hz_, int npair, int sr, std::vector<float>* out, std::vector<float>* fsum) {
+  const int K = SINC_K, half = K / 2;
+  out->assign((size_t)2 * npair * K, 0.f);
+  fsum->assign((size_t)2 * npair, 0.f);
+  const double min_low = 50.0, min_band = 50.0;
+  for (int f = 0; f < npair; ++f) {
+    const float low = (float)min_low + std::fabs(low_hz_[f]);
+    float high = low + (float)min_band + std::fabs(band_hz_[f]);
+    high = std::fmin(std::fmax(high, (float)min_low), (float)sr / 2.f);
+    const float band = high - low;
+    float* fc = out->data() + (size_t)f * K;
+    float* fs = out->data() + (size_t)(npair + f) * K;
+    for (int i = 0; i < half; ++i) {
+      const float win = (float)(0.54 - 0.46 * std::cos(2.0 * M_PI * i / (K - 1)));
+      const float n = (float)(2.0 * M_PI) * ((float)(i - half) / (float)sr);
+      const float fl = low * n, fh = high * n;
+      const float lc = ((std::sin(fh) - std::sin(fl)) / (n / 2.f)) * win;
+      const float ls = ((std::cos(fl) - std::cos(fh)) / (n / 2.f)) * win;
+      fc[i] = lc / (2.f * band); fc[K - 1 - i] = lc / (2.f * band);
+      fs[i] = ls / (2.f * band); fs[K - 1 - i] = -ls / (2.f * band);
+    }
+    fc[half] = (2.f * band) / (2.f * band);
+    fs[half] = 0.f;
+  }
+  for (int f = 0; f < 2 * npair; ++f) {
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += (*out)[(size_t)f * K + k];
+    (*fsum)[f] = (float)s;
+  }
+}
+
+// Conv1d weight [out][in][k] -> GEMM operand [out_pad][k][in_pad] (row m of the activation matrix is frame t,
+// its K = k*in_pad columns run on into frames t+1..t+4, which are contiguous in memory)
+int pack_conv1d(rvd_engine* e, Linear& L, const std::string& p, int out, int in, int out_pad, int in_pad) {
+  const HostTensor *w, *b;
+  RVD_TRY(need(e, p + ".weight", (size_t)out * in * CONV_K, &w));
+  RVD_TRY(need(e, p + ".bias", out, &b));
+  std::vector<float> pw((size_t)out_pad * CONV_K * in_pad, 0.f), pb(out_pad, 0.f);
+  for (int o = 0; o < out; ++o) {
+    pb[o] = b->data[o];
+    for (int c = 0; c < in; ++c)
+      for (int k = 0; k < CONV_K; ++k) pw[((size_t)o * CONV_K + k) * in_pad + c] = w->data[((size_t)o * in + c) * CONV_K + k];
+  }
+  L.out = out_pad; L.in = CONV_K * in_pad;
+  RVD_TRY(pack_T(e, L.w, pw.data(), pw.size()));
+  return up_f32(e, L.b, pb.data(), pb.size());
+}
+
+int run_gemm(rvd_engine* e, const char* name, const void* A, int lda, const Linear& L, void* C, int ldc, int64_t M, int act) {
+  DScope sc(e, name, 2.0 * (double)M * L.out * L.in);
+  GemmArgs g{};
+  g.A = A; g.W = L.w.p; g.bias = L.b.p ? L.b.as<float>() : nullptr; g.res = nullptr; g.C = C;
+  g.M = (int)M; g.N = L.out; g.K = L.in; g.lda = lda; g.ldw = L.in; g.ldc = ldc; g.ldres = 0;
+  g.alpha = 1.f; g.act = act; g.out_f32 = 0; g.conv = 0;
+  return gemm(e->stream, e->dtype, g);
+}
+
+int finalize_impl(rvd_engine* e) {
+  const rvd_model_cfg& c = e->cfg;
+  const std::string S = "segmentation.";
+  const HostTensor *t1, *t2;
+  // --- SincNet ---
+  RVD_TRY(need(e, S + "sincnet.wav_norm1d.weight", 1, &t1));
+  RVD_TRY(need(e, S + "sincnet.wav_norm1d.bias", 1, &t2));
+  e->wn_gamma = t1->data[0]; e->wn_beta = t2->data[0];
+  const int npair = c.sinc_filters / 2;
+  RVD_TRY(need(e, S + "sincnet.conv1d.0.filterbank.low_hz_", npair, &t1));
+  RVD_TRY(need(e, S + "sincnet.conv1d.0.filterbank.band_hz_", npair, &t2));
+  std::vector<float> filt, fsum;
+  sinc_filters(t1->data.data(), t2->data.data(), npair, c.sample_rate, &filt, &fsum);
+  RVD_TRY(up_f32(e, e->filt, filt.data(), filt.size()));
+  RVD_TRY(up_f32(e, e->fsum, fsum.data(), fsum.size()));
+  RVD_TRY(pack_norm(e, e->norm[0], S + "sincnet.norm1d.0", c.sinc_filters));
+  RVD_TRY(pack_norm(e, e->norm[1], S + "sincnet.norm1d.1", c.sinc_channels));
+  RVD_TRY(pack_norm(e, e->norm[2], S + "sincnet.norm1d.2", c.sinc_channels));
+  RVD_TRY(pack_conv1d(e, e->conv2, S + "sincnet.conv1d.1", c.sinc_channels, c.sinc_filters, e->cpad, c.sinc_filters));
+  RVD_TRY(pack_conv1d(e, e->conv3, S + "sincnet.conv1d.2", c.sinc_channels, c.sinc_channels, e->cpad, e->cpad));
+  // --- LSTM: both directions' input projections as one [8H][in_pad] operand, bias = b_ih + b_hh ---
+  const int H = c.lstm_hidden;
+  e->lstm.resize(c.lstm_layers);
+  for (int l = 0; l < c.lstm_layers; ++l) {
+    const int in = l == 0 ? c.sinc_channels : 2 * H;
+    const int in_pad = l == 0 ? e->cpad : 2 * H;
+    std::vector<float> wih((size_t)8 * H * in_pad, 0.f), bias((size_t)8 * H, 0.f), whh((size_t)8 * H * H);
+    for (int d = 0; d < 2; ++d) {
+      const std::string suf = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+      const HostTensor *wi, *wh, *bi, *bh;
+      RVD_TRY(need(e, S + "lstm.weight_ih" + suf, (size_t)4 * H * in, &wi));
+      RVD_TRY(need(e, S + "lstm.weight_hh" + suf, (size_t)4 * H * H, &wh));
+      RVD_TRY(need(e, S + "lstm.bias_ih" + suf, (size_t)4 * H, &bi));
+      RVD_TRY(need(e, S + "lstm.bias_hh" + suf, (size_t)4 * H, &bh));
+      for (int r = 0; r < 4 * H; ++r) {
+        std::memcpy(&wih[((size_t)d * 4 * H + r) * in_pad], &wi->data[(size_t)r * in], (size_t)in * 4);
+        bias[(size_t)d * 4 * H + r] = bi->data[r] + bh->data[r];
+      }
+      std::memcpy(&whh[(size_t)d * 4 * H * H], wh->data.data(), (size_t)4 * H * H * 4);
+    }
+    LstmLayer& L = e->lstm[l];
+    L.in_pad = in_pad;
+    L.ih.out = 8 * H; L.ih.in = in_pad;
+    RVD_TRY(pack_T(e, L.ih.w, wih.data(), wih.size()));
+    RVD_TRY(up_f32(e, L.ih.b, bias.data(), bias.size()));
+    RVD_TRY(pack_T(e, L.whh, whh.data(), whh.size()));
+  }
+  // --- linears + classifier ---
+  e->lin.resize(c.linear_layers);
+  for (int i = 0; i < c.linear_layers; ++i) {
+    const int in = i == 0 ? 2 * H : c.linear_dim;
+    const std::string p = S + "linear." + std::to_string(i);
+    RVD_TRY(need(e, p + ".weight", (size_t)c.linear_dim * in, &t1));
+    RVD_TRY(need(e, p + ".bias", c.linear_dim, &t2));
+    e->lin[i].out = c.linear_dim; e->lin[i].in = in;
+    RVD_TRY(pack_T(e, e->lin[i].w, t1->data.data(), t1->data.size()));
+    RVD_TRY(up_f32(e, e->lin[i].b, t2->data.data(), t2->data.size()));
+  }
+  const int cls_in = c.linear_layers ? c.linear_dim : 2 * H;
+  RVD_TRY(need(e, S + "classifier.weight", (size_t)c.num_classes * cls_in, &t1));
+  RVD_TRY(need(e, S + "classifier.bias", c.num_classes, &t2));
+  RVD_TRY(up_f32(e, e->cls_w, t1->data.data(), t1->data.size()));
+  RVD_TRY(up_f32(e, e->cls_b, t2->data.data(), t2->data.size()));
+  e->host.clear();
+  e->stage.release();
+  e->finalized = true;
+  return OK;
+}
+
+int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
+  const rvd_model_cfg& c = e->cfg;
+  if (!e->finalized || e->n_windows == 0) { set_error("rvd_segment: finalize the model and upload audio first"); return E_STATE; }
+  if (first < 0 || W <= 0 || first + W > e->n_windows) { set_error("rvd_segment: window range outside the uploaded audio"); return E_ARG; }
+  const size_t ts = dt_size(e->dtype);
+  const int H = c.lstm_hidden, CP = e->cpad, NF = c.sinc_filters;
+  const int64_t R1 = (int64_t)W * e->p1, R2 = (int64_t)W * e->p2, R3 = (int64_t)W * e->p3;
+  if (R1 > 0x7fffffffLL / 4) { set_error("rvd_segment: too many windows in one call (limit 100k frames rows)"); return E_ARG; }
+  RVD_TRY(e->stats.ensure((size_t)W * 8));
+  RVD_TRY(e->a1.ensure((size_t)(R1 + 8) * NF * ts));
+  RVD_TRY(e->c2.ensure((size_t)R1 * CP * ts));
+  RVD_TRY(e->a2.ensure((size_t)(R2 + 8) * CP * ts));
+  RVD_TRY(e->c3.ensure((size_t)R2 * CP * ts));
+  RVD_TRY(e->a3.ensure((size_t)R3 * CP * ts));
+  RVD_TRY(e->xproj.ensure((size_t)R3 * 8 * H * ts));
+  RVD_TRY(e->hA.ensure((size_t)R3 * 2 * H * ts));
+  RVD_TRY(e->hB.ensure((size_t)R3 * 2 * H * ts));
+  RVD_TRY(e->l0.ensure((size_t)R3 * c.linear_dim * ts));
+  RVD_TRY(e->l1.ensure((size_t)R3 * c.linear_dim * ts));
+  RVD_TRY(e->logp.ensure((size_t)R3 * c.num_classes * 4));
+
+  { DScope sc(e, "window_stats");
+    RVD_TRY(window_stats(e->stream, e->wave.as<float>(), first, W, c.step_samples, c.window_samples, 1e-5f, e->stats.as<float>())); }
+  PoolNormArgs pn{};
+  pn.W = W; pn.eps = 1e-5f;
+  { DScope sc(e, "pool_norm");
+    pn.x = nullptr; pn.frames_in = e->f1; pn.C = NF; pn.ld_out = NF;
+    pn.gamma = e->norm[0].g.as<float>(); pn.beta = e->norm[0].b.as<float>(); pn.out = e->a1.p;
+    pn.craw = e->craw.as<float>(); pn.craw_frame0 = first * (c.step_samples / SINC_STRIDE);
+    pn.craw_frames_per_step = c.step_samples / SINC_STRIDE;
+    pn.stats = e->stats.as<float>(); pn.fsum = e->fsum.as<float>(); pn.wn_gamma = e->wn_gamma; pn.wn_beta = e->wn_beta;
+    RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
+  RVD_TRY(run_gemm(e, "sincnet_conv", e->a1.p, NF, e->conv2, e->c2.p, CP, R1, ACT_NONE));
+  { DScope sc(e, "pool_norm");
+    pn.x = e->c2.p; pn.rows_in = e->p1; pn.ld_in = CP; pn.frames_in = e->f2; pn.C = c.sinc_channels; pn.ld_out = CP;
+    pn.gamma = e->norm[1].g.as<float>(); pn.beta = e->norm[1].b.as<float>(); pn.out = e->a2.p;
+    RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
+  RVD_TRY(run_gemm(e, "sincnet_conv", e->a2.p, CP, e->conv3, e->c3.p, CP, R2, ACT_NONE));
+  { DScope sc(e, "pool_norm");
+    pn.x = e->c3.p; pn.rows_in = e->p2; pn.ld_in = CP; pn.frames_in = e->f3; pn.C = c.sinc_channels; pn.ld_out = CP;
+    pn.gamma = e->norm[2].g.as<float>(); pn.beta = e->norm[2].b.as<float>(); pn.out = e->a3.p;
+    RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
+
+  const void* x = e->a3.p;
+  int ldx = CP;
+  for (int l = 0; l < c.lstm_layers; ++l) {
+    RVD_TRY(run_gemm(e, "lstm_inproj", x, ldx, e->lstm[l].ih, e->xproj.p, 8 * H, R3, ACT_NONE));
+    void* out = (l & 1) ? e->hB.p : e->hA.p;
+    { DScope sc(e, "lstm_recurrence", 2.0 * (double)R3 * 8 * H * H);
+      RVD_TRY(lstm_recurrence(e->stream, e->dtype, e->xproj.p, e->lstm[l].whh.p, out, W, e->p3)); }
+    x = out; ldx = 2 * H;
+  }
+  e->last_lstm = x;
+  for (int i = 0; i < c.linear_layers; ++i) {
+    void* out = (i & 1) ? e->l1.p : e->l0.p;
+    RVD_TRY(run_gemm(e, "linear", x, ldx, e->lin[i], out, c.linear_dim, R3, ACT_LRELU));
+    x = out; ldx = c.linear_dim;
+  }
+  { DScope sc(e, "classifier");
+    RVD_TRY(classifier_logsoftmax(e->stream, e->dtype, x, ldx, e->cls_w.as<float>(), e->cls_b.as<float>(), e->logp.as<float>(),
+                                  R3, ldx, c.num_classes)); }
+  e->last_W = W;
+  if (logp_out) {
+    DScope sc(e, "d2h");
+    RVB_HIP_CHECK(hipMemcpyAsync(logp_out, e->logp.p, (size_t)R3 * c.num_classes * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+// device T [rows][ld] -> host fp32 [rows][cols]
+int fetch_T(rvd_engine* e, const void* src, int64_t rows, int ld, int cols, float* out) {
+  const size_t ts = dt_size(e->dtype);
+  std::vector<char> tmp((size_t)rows * ld * ts);
+  RVB_HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < rows; ++r)
+    for (int cc = 0; cc < cols; ++cc)
+      out[r * cols + cc] = e->dtype == DT_BF16 ? bf16_to_f32(((const bf16_t*)tmp.data())[r * ld + cc]) : ((const float*)tmp.data())[r * ld + cc];
+  return OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rvd_last_error(void) { return rvb::last_error(); }
+
+int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
+  if (!cfg || !out) { set_error("rvd_create: null argument"); return E_ARG; }
+  *out = nullptr;
+  if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) { set_error("rvd_create: dtype must be RVB_F32 or RVB_BF16"); return E_ARG; }
+  if (cfg->lstm_hidden != 128 || cfg->sinc_filters != 80 || cfg->sinc_filters % 8 || cfg->sinc_channels < 1 || cfg->sinc_channels > 64 ||
+      cfg->lstm_layers < 1 || cfg->linear_layers < 0 || cfg->linear_layers > 2 || (cfg->linear_layers && cfg->linear_dim % 8) ||
+      cfg->linear_dim > 256 || cfg->num_classes < 1 || cfg->num_classes > 16 || cfg->sample_rate != 16000 ||
+      cfg->step_samples % (SINC_STRIDE * 4) || cfg->step_samples <= 0 || cfg->window_samples < 4000) {
+    set_error("rvd_create: unsupported model dimensions (this build: 80 sinc filters, <= 64 conv channels, LSTM hidden 128, 16 kHz)");
+    return E_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) {
+    set_error("rvd_create: no HIP device " + std::to_string(device) + " (this library has no CPU fallback)");
+    return E_HIP;
+  }
+  RVB_HIP_CHECK(hipSetDevice(device));
+  rvd_engine* e = new rvd_engine();
+  e->cfg = *cfg; e->device = device; e->dtype = cfg->dtype;
+  RVB_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->f1 = (cfg->window_samples - SINC_K) / SINC_STRIDE + 1; e->p1 = e->f1 / 3;
+  e->f2 = e->p1 - (CONV_K - 1); e->p2 = e->f2 / 3;
+  e->f3 = e->p2 - (CONV_K - 1); e->p3 = e->f3 / 3;
+  e->cpad = 64;
+  *out = e;
+  return OK;
+}
+
+void rvd_destroy(rvd_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  drain(e);
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  DevBuf* bufs[] = {&e->filt, &e->fsum, &e->cls_w, &e->cls_b, &e->stage, &e->pcm, &e->wave, &e->craw, &e->stats, &e->a1, &e->c2,
+                    &e->a2, &e->c3, &e->a3, &e->xproj, &e->hA, &e->hB, &e->l0, &e->l1, &e->logp, &e->conv2.w, &e->conv2.b,
+                    &e->conv3.w, &e->conv3.b};
+  for (auto* b : bufs) b->release();
+  for (auto& n : e->norm) { n.g.release(); n.b.release(); }
+  for (auto& l : e->lstm) { l.ih.w.release(); l.ih.b.release(); l.whh.release(); }
+  for (auto& l : e->lin) { l.w.release(); l.b.release(); }
+  hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int rvd_load_tensor(rvd_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!e || !name || !host || ndim < 0 || (ndim && !shape)) { set_error("rvd_load_tensor: null argument"); return E_ARG; }
+  if (e->finalized) { set_error("rvd_load_tensor: engine already finalized"); return E_STATE; }
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(host, host + t.numel());
+  e->host[name] = std::move(t);
+  return OK;
+}
+
+int rvd_finalize(rvd_engine* e) {
+  if (!e) { set_error("rvd_finalize: null engine"); return E_ARG; }
+  if (e->finalized) { set_error("rvd_finalize: already finalized"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return finalize_impl(e);
+}
+
+int64_t rvd_num_windows(const rvd_engine* e, int64_t n) {
+  if (!e || n <= 0) return 0;
+  const int64_t win = e->cfg.window_samples, step = e->cfg.step_samples;
+  const int64_t full = n >= win ? (n - win) / step + 1 : 0;
+  const bool tail = n < win || (n - win) % step > 0;
+  return full + (tail ? 1 : 0);
+}
+int rvd_frames_per_window(const rvd_engine* e) { return e ? e->p3 : 0; }
+
+int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n) {
+  if (!e || !pcm || n <= 0) { set_error("rvd_upload_pcm: null or empty audio"); return E_ARG; }
+  if (!e->finalized) { set_error("rvd_upload_pcm: finalize the model first"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const rvd_model_cfg& c = e->cfg;
+  e->n_samples = n;
+  e->n_windows = rvd_num_windows(e, n);
+  e->n_pad = (e->n_windows - 1) * c.step_samples + c.window_samples;
+  e->craw_frames = (e->n_pad - SINC_K) / SINC_STRIDE + 1;
+  RVD_TRY(e->pcm.ensure((size_t)n * 2));
+  RVD_TRY(e->wave.ensure((size_t)e->n_pad * 4));
+  RVD_TRY(e->craw.ensure((size_t)e->craw_frames * c.sinc_filters * 4));
+  { DScope sc(e, "h2d");
+    RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream)); }
+  { DScope sc(e, "pcm_to_float");
+    RVD_TRY(pcm_to_float(e->stream, e->pcm.as<int16_t>(), n, e->wave.as<float>(), e->n_pad)); }
+  { DScope sc(e, "sinc_conv", 2.0 * (double)e->craw_frames * c.sinc_filters * SINC_K);
+    RVD_TRY(sinc_conv(e->stream, e->wave.as<float>(), e->filt.as<float>(), e->craw.as<float>(), e->craw_frames, c.sinc_filters,
+                      SINC_K, SINC_STRIDE)); }
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+int rvd_segment(rvd_engine* e, int64_t first_window, int n_windows, float* logp_out) {
+  if (!e) { set_error("rvd_segment: null engine"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return segment_impl(e, first_window, n_windows, logp_out);
+}
+
+int rvd_get_tap(rvd_engine* e, const char* name, float* out) {
+  if (!e || !name || !out) { set_error("rvd_get_tap: null argument"); return E_ARG; }
+  if (e->last_W <= 0) { set_error("rvd_get_tap: no rvd_segment call yet"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int64_t R3 = (int64_t)e->last_W * e->p3;
+  if (!strcmp(name, "sincnet")) return fetch_T(e, e->a3.p, R3, e->cpad, e->cfg.sinc_channels, out);
+  if (!strcmp(name, "lstm")) return fetch_T(e, e->last_lstm, R3, 2 * e->cfg.lstm_hidden, 2 * e->cfg.lstm_hidden, out);
+  set_error(std::string("rvd_get_tap: unknown tap ") + name);
+  return E_ARG;
+}
+
+int rvd_embed(rvd_engine* e, const int64_t* win, const float* mask, int n, float* emb_out) {
+  if (!e || !win || !emb_out || n < 0) { set_error("rvd_embed: null argument"); return E_ARG; }
+  set_error("rvd_embed: the embedding model is not part of this build yet");
+  return E_UNSUPPORTED;
+}
+int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_frames) {
+  set_error("rvd_get_emb_fbank: the embedding model is not part of this build yet");
+  return E_UNSUPPORTED;
+}
+
+int rvd_set_profiling(rvd_engine* e, int enabled) { if (!e) return E_ARG; drain(e); e->profiling = enabled != 0; return OK; }
+int rvd_reset_timings(rvd_engine* e) { if (!e) return E_ARG; drain(e); e->prof.clear(); return OK; }
+int rvd_get_timing(rvd_engine* e, const char* name, double* ms, double* flops, int64_t* launches) {
+  if (!e || !name) return E_ARG;
+  drain(e);
+  auto it = e->prof.find(name);
+  if (it == e->prof.end()) { if (ms) *ms = 0; if (flops) *flops = 0; if (launches) *launches = 0; return OK; }
+  if (ms) *ms = it->second.ms;
+  if (flops) *flops = it->second.flops;
+  if (launches) *launches = it->second.launches;
+  return OK;
+}
+
+}  // extern "C"

@@ -28,6 +28,7 @@ static constexpr int GEMM_LDS = 2 * (BM + BN) * LDSB;  // double buffered: 73,72
 __device__ inline float act_apply(float v, int act) {
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
   if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_LRELU) return v > 0.0f ? v : 0.01f * v;
   return v;
 }
 

@@ -316,7 +316,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
   const int bke = dtype == DT_BF16 ? 64 : 32;
   if (p.K % bke || p.lda % (bke / 8) || p.ldw % (bke / 8)) return false;
   if (p.conv && (p.cC % bke)) return false;
-  if (p.M < 128 || p.N < 64) return false;      // tiny problems: the 128x128 kernel wastes less
+  if (p.M < 128 || p.N < 64 || p.act == ACT_LRELU) return false;      // tiny problems: the 128x128 kernel wastes less
   return true;
 }
 

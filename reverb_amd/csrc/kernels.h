@@ -6,7 +6,7 @@
 namespace rvb {
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LRELU = 3 /* leaky_relu, slope 0.01 (gemm.hip kernel only) */ };
 
 inline size_t dt_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
@@ -105,5 +105,46 @@ struct AttnArgs {
   float sqrt_dk;   // scores are divided by this (attention.py:384,395: `/ math.sqrt(self.d_k)`)
 };
 int attention(hipStream_t s, int dtype, const AttnArgs& a);
+
+}  // namespace rvb
+
+// ================================================================ diar.hip (pyannote segmentation path)
+namespace rvb {
+
+// int16 PCM -> float (/32768), zero-filled up to n_pad samples
+int pcm_to_float(hipStream_t s, const int16_t* pcm, int64_t n, float* out, int64_t n_pad);
+
+// Sinc band-pass bank on the raw waveform, shared by every window that overlaps a frame:
+// craw[t][f] = sum_k wave[stride*t + k] * filt[f][k]        fp32 [n_frames][nf], nf <= 80, ksize <= 251
+int sinc_conv(hipStream_t s, const float* wave, const float* filt, float* craw, int64_t n_frames, int nf,
+              int ksize, int stride);
+
+// per window (start = (first+w)*step samples, `len` samples): stats[w] = {mean, 1/sqrt(var+eps)} (biased var)
+int window_stats(hipStream_t s, const float* wave, int64_t first, int nwin, int64_t step, int len, float eps,
+                 float* stats);
+
+// MaxPool1d(3,3) + InstanceNorm1d(affine) + LeakyReLU over the frames of each window (SincNet block tail).
+struct PoolNormArgs {
+  const void* x;        // T [W*rows_in, ld_in] conv output (bias applied);  first block: null
+  int rows_in, ld_in;   // rows per window in x (>= frames_in)
+  int frames_in;        // valid conv frames per window; pooled frames = frames_in / 3
+  int C, ld_out;        // channels; output row stride (pad channels written as 0)
+  const float* gamma; const float* beta; float eps;
+  void* out;            // T [W*frames_out, ld_out]
+  int W;
+  // first block (x == null): value = | a*(craw[frame0 + t][c] - mean*fsum[c]) + b*fsum[c] |, a = wn_gamma*rstd,
+  // i.e. the sinc conv of the instance-normalised window, from the shared raw conv
+  const float* craw; int64_t craw_frame0; int craw_frames_per_step;
+  const float* stats; const float* fsum; float wn_gamma, wn_beta;
+};
+int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a);
+
+// One bidirectional LSTM layer's recurrence (hidden 128).  xproj T [W*T, 8H] = x.Wih^T + b_ih + b_hh for
+// (forward | reverse) gates i,f,g,o; whh T [2][4H][H]; out T [W*T, 2H].
+int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh, void* out, int W, int T);
+
+// logp[r][:] = log_softmax(x[r].Wc^T + bc)   x T [M, ldx], Wc fp32 [C][in], C <= 16
+int classifier_logsoftmax(hipStream_t s, int dtype, const void* x, int ldx, const float* w, const float* b,
+                          float* logp, int64_t M, int in, int C);
 
 }  // namespace rvb

@@ -56,3 +56,26 @@ def test_bad_arguments_are_reported_not_crashed(lib):
     assert lib.rvb_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1      # RVB_E_ARG: all-zero dims
     assert b"unsupported model dimensions" in lib.rvb_last_error() or b"dtype" in lib.rvb_last_error()
     assert lib.rvb_create(None, 0, ctypes.byref(h)) == -1
+
+
+def test_diarization_header_symbols_and_struct():
+    """include/rvd.h (diarization networks): every declared function is exported and bound."""
+    from reverb_amd import _lib as L
+    lib = L.load()
+    text = open(os.path.join(ROOT, "include", "rvd.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rvd_[a-z0-9_]+)\s*\(", code)))
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"librvb.so does not export {n}"
+    assert sorted(L.DIAR_SIGNATURES) == names
+    body = code[code.index("typedef struct rvd_model_cfg {"):code.index("} rvd_model_cfg;")]
+    assert re.findall(r"int32_t\s+([a-z_0-9]+);", body) == [f[0] for f in L.DiarCfg._fields_]
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_diarization_fails_loudly_without_gpu():
+    from reverb_amd import synth_diar
+    from reverb_amd.diar_engine import DiarEngine
+    with pytest.raises(_lib.RvbError, match="no HIP device"):
+        DiarEngine(synth_diar.make_diar_config(), {}, dtype="f32")
