@@ -177,13 +177,14 @@ def resnet34_trunk(sd: SD, feats: torch.Tensor) -> torch.Tensor:
 
 
 def tstp(x: torch.Tensor, weights: Optional[torch.Tensor]) -> torch.Tensor:
-    """Temporal statistics pooling with (optional) frame weights: x (B,C,F,T) -> (B, 2*C*F)."""
+    """pyannote.audio.models.blocks.pooling.StatsPool behind wespeaker's TSTP: x (B,C,F,T) -> (B, 2*C*F),
+    (C,F) flattened channel-major, frame weights resampled to T by nearest interpolation."""
     B = x.shape[0]
     x = x.reshape(B, -1, x.shape[-1])
     if weights is None:
         return torch.cat([x.mean(-1), x.std(-1, unbiased=True)], dim=-1)
     w = F.interpolate(weights.unsqueeze(1), size=x.shape[-1], mode="nearest")        # (B,1,T')
-    v1 = w.sum(-1)
+    v1 = w.sum(-1) + 1e-8
     mean = (x * w).sum(-1) / v1
     dx2 = (x - mean.unsqueeze(-1)) ** 2
     v2 = (w * w).sum(-1)

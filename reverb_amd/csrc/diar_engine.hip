@@ -16,6 +16,11 @@ using namespace rvb;
 namespace {
 struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
 constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
+// ResNet34 trunk: conv weights packed [tap][Cin/CK][Cout][CK] with BatchNorm folded in
+struct ConvW { DevBuf w, b; int cin = 0, cout = 0, taps = 9, stride = 1; };
+struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
+constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
+constexpr int EMB_BATCH = 48;      // windows per trunk pass (activations ~36 MB per window in bf16)
 }  // namespace
 
 struct rvd_engine {
@@ -46,6 +51,19 @@ struct rvd_engine {
   DevBuf stats, a1, c2, a2, c3, a3, xproj, hA, hB, l0, l1, logp;
   int last_W = 0;
   const void* last_lstm = nullptr;
+
+  // embedding model
+  bool has_emb = false;
+  DevBuf stem_w, stem_b;
+  std::vector<std::vector<ResBlock>> stages;
+  Linear seg1;
+  DevBuf fb_window, fb_twiddle, fb_melw, fb_lo, fb_hi;
+  DevBuf pcm_pad, emb_fb;                 // int16 [n_pad], fp32 [emb_frames][80] hamming log-mel of the whole file
+  int64_t emb_frames = 0;
+  int nfr = 0;                            // fbank frames per window (998)
+  DevBuf act[4][4];                       // per stage: three rotating activation buffers + the shortcut
+  int act_cap = 0;
+  DevBuf e_win, e_mean, e_item_b, e_mask, e_stats, e_out;
 
   // profiling
   bool profiling = false;
@@ -172,6 +190,8 @@ int run_gemm(rvd_engine* e, const char* name, const void* A, int lda, const Line
   return gemm(e->stream, e->dtype, g);
 }
 
+int finalize_embedding(rvd_engine* e);
+
 int finalize_impl(rvd_engine* e) {
   const rvd_model_cfg& c = e->cfg;
   const std::string S = "segmentation.";
@@ -235,6 +255,7 @@ int finalize_impl(rvd_engine* e) {
   RVD_TRY(need(e, S + "classifier.bias", c.num_classes, &t2));
   RVD_TRY(up_f32(e, e->cls_w, t1->data.data(), t1->data.size()));
   RVD_TRY(up_f32(e, e->cls_b, t2->data.data(), t2->data.size()));
+  if (c.emb_channels > 0) RVD_TRY(finalize_embedding(e));
   e->host.clear();
   e->stage.release();
   e->finalized = true;
@@ -308,6 +329,226 @@ int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
     RVB_HIP_CHECK(hipMemcpyAsync(logp_out, e->logp.p, (size_t)R3 * c.num_classes * 4, hipMemcpyDeviceToHost, e->stream));
   }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ embedding model
+int make_hamming_fbank_tables(rvd_engine* e) {
+  const int NFFT = 512, NBIN = 257;
+  const double PI = 3.14159265358979323846;
+  std::vector<float> win(FB_WIN), tw(2 * 256), melw((size_t)FB_MEL * NBIN, 0.f);
+  std::vector<int32_t> lo(FB_MEL, NBIN), hi(FB_MEL, 0);
+  for (int i = 0; i < FB_WIN; ++i) win[i] = (float)(0.54 - 0.46 * std::cos(2.0 * PI * i / (FB_WIN - 1)));
+  for (int k = 0; k < 256; ++k) { tw[2 * k] = (float)std::cos(2.0 * PI * k / NFFT); tw[2 * k + 1] = (float)(-std::sin(2.0 * PI * k / NFFT)); }
+  auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+  const double mlo = mel(20.0), mhi = mel(8000.0), delta = (mhi - mlo) / (FB_MEL + 1);
+  for (int m = 0; m < FB_MEL; ++m) {
+    const double left = mlo + m * delta, center = left + delta, right = center + delta;
+    for (int b = 0; b < NFFT / 2; ++b) {
+      const double mf = mel(16000.0 / NFFT * b);
+      const double w = std::max(0.0, std::min((mf - left) / (center - left), (right - mf) / (right - center)));
+      if (w > 0.0) { melw[(size_t)m * NBIN + b] = (float)w; lo[m] = std::min(lo[m], b); hi[m] = std::max(hi[m], b + 1); }
+    }
+    if (hi[m] == 0) lo[m] = 0;
+  }
+  RVD_TRY(up_f32(e, e->fb_window, win.data(), win.size()));
+  RVD_TRY(up_f32(e, e->fb_twiddle, tw.data(), tw.size()));
+  RVD_TRY(up_f32(e, e->fb_melw, melw.data(), melw.size()));
+  RVD_TRY(up_f32(e, e->fb_lo, (const float*)lo.data(), lo.size()));   // raw 4-byte copies
+  return up_f32(e, e->fb_hi, (const float*)hi.data(), hi.size());
+}
+
+// Conv2d weight [cout][cin][k][k] + eval-mode BatchNorm -> [tap][cin/CK][cout][CK] (T) and bias (fp32)
+int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::string& bn, int cout, int cin, int k, int stride) {
+  const HostTensor *w, *g, *b, *m, *v;
+  RVD_TRY(need(e, conv + ".weight", (size_t)cout * cin * k * k, &w));
+  RVD_TRY(need(e, bn + ".weight", cout, &g));
+  RVD_TRY(need(e, bn + ".bias", cout, &b));
+  RVD_TRY(need(e, bn + ".running_mean", cout, &m));
+  RVD_TRY(need(e, bn + ".running_var", cout, &v));
+  const int CK = 64 / (int)dt_size(e->dtype);
+  if (cin % CK) { set_error("embedding conv " + conv + ": input channels must be a multiple of " + std::to_string(CK)); return E_UNSUPPORTED; }
+  const int taps = k * k, nch = cin / CK;
+  std::vector<float> pw((size_t)taps * cin * cout), pb(cout);
+  for (int o = 0; o < cout; ++o) {
+    const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f);
+    pb[o] = b->data[o] - m->data[o] * sc;
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < taps; ++t)
+        pw[(((size_t)t * nch + ci / CK) * cout + o) * CK + ci % CK] = w->data[((size_t)o * cin + ci) * taps + t] * sc;
+  }
+  c.cin = cin; c.cout = cout; c.taps = taps; c.stride = stride;
+  RVD_TRY(pack_T(e, c.w, pw.data(), pw.size()));
+  return up_f32(e, c.b, pb.data(), pb.size());
+}
+
+int finalize_embedding(rvd_engine* e) {
+  const rvd_model_cfg& c = e->cfg;
+  const std::string S = "embedding.resnet.";
+  const int m = c.emb_channels;
+  if (m != 32) { set_error("embedding: this build supports m_channels = 32 (ResNet34 of pyannote/wespeaker-voxceleb-resnet34-LM)"); return E_UNSUPPORTED; }
+  // stem: Conv2d(1, m, 3) + BN folded, fp32 weights [m][9]
+  const HostTensor *w, *g, *b, *mu, *v;
+  RVD_TRY(need(e, S + "conv1.weight", (size_t)m * 9, &w));
+  RVD_TRY(need(e, S + "bn1.weight", m, &g));
+  RVD_TRY(need(e, S + "bn1.bias", m, &b));
+  RVD_TRY(need(e, S + "bn1.running_mean", m, &mu));
+  RVD_TRY(need(e, S + "bn1.running_var", m, &v));
+  std::vector<float> sw((size_t)m * 9), sb(m);
+  for (int o = 0; o < m; ++o) {
+    const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f);
+    sb[o] = b->data[o] - mu->data[o] * sc;
+    for (int t = 0; t < 9; ++t) sw[(size_t)o * 9 + t] = w->data[(size_t)o * 9 + t] * sc;
+  }
+  RVD_TRY(up_f32(e, e->stem_w, sw.data(), sw.size()));
+  RVD_TRY(up_f32(e, e->stem_b, sb.data(), sb.size()));
+  const int nblk[4] = {3, 4, 6, 3};
+  e->stages.assign(4, {});
+  int cin = m;
+  for (int li = 0; li < 4; ++li) {
+    const int cout = m << li;
+    e->stages[li].resize(nblk[li]);
+    for (int bi = 0; bi < nblk[li]; ++bi) {
+      ResBlock& B = e->stages[li][bi];
+      const int stride = (bi == 0 && li > 0) ? 2 : 1;
+      const std::string p = S + "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      RVD_TRY(pack_conv_bn(e, B.c1, p + ".conv1", p + ".bn1", cout, cin, 3, stride));
+      RVD_TRY(pack_conv_bn(e, B.c2, p + ".conv2", p + ".bn2", cout, cout, 3, 1));
+      B.has_sc = stride != 1 || cin != cout;
+      if (B.has_sc) RVD_TRY(pack_conv_bn(e, B.sc, p + ".shortcut.0", p + ".shortcut.1", cout, cin, 1, stride));
+      cin = cout;
+    }
+  }
+  const int stats = (FB_MEL / 8) * (m << 3) * 2;
+  RVD_TRY(need(e, S + "seg_1.weight", (size_t)c.emb_dim * stats, &w));
+  RVD_TRY(need(e, S + "seg_1.bias", c.emb_dim, &b));
+  e->seg1.out = c.emb_dim; e->seg1.in = stats;
+  RVD_TRY(pack_T(e, e->seg1.w, w->data.data(), w->data.size()));
+  RVD_TRY(up_f32(e, e->seg1.b, b->data.data(), b->data.size()));
+  RVD_TRY(make_hamming_fbank_tables(e));
+  e->nfr = (c.window_samples - FB_WIN) / FB_SHIFT + 1;
+  e->has_emb = true;
+  return OK;
+}
+
+struct StageDims { int F, T, C; };
+StageDims stage_dims(const rvd_engine* e, int li) {
+  int F = FB_MEL, T = e->nfr;
+  for (int i = 0; i < li; ++i) { F = (F - 1) / 2 + 1; T = (T - 1) / 2 + 1; }
+  return {F, T, e->cfg.emb_channels << li};
+}
+
+int ensure_emb_workspace(rvd_engine* e, int B) {
+  if (B <= e->act_cap) return OK;
+  const size_t ts = dt_size(e->dtype);
+  for (int li = 0; li < 4; ++li) {
+    const StageDims d = stage_dims(e, li);
+    const size_t bytes = (size_t)B * (d.F + 2) * (d.T + 2) * d.C * ts;
+    for (int k = 0; k < 4; ++k) {
+      if (k == 3 && li == 0) continue;            // stage 1 has no projection shortcut
+      RVD_TRY(e->act[li][k].ensure(bytes));
+      RVB_HIP_CHECK(hipMemsetAsync(e->act[li][k].p, 0, bytes, e->stream));   // the zero border is never written again
+    }
+  }
+  e->act_cap = B;
+  return OK;
+}
+
+int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di, const void* res, void* out, const StageDims& dq, int B, int relu) {
+  ConvArgs a{};
+  a.in = in; a.w = c.w.p; a.bias = c.b.as<float>(); a.res = res; a.out = out;
+  a.B = B; a.Fi = di.F; a.Ti = di.T; a.Cin = c.cin; a.Fo = dq.F; a.To = dq.T; a.Cout = c.cout;
+  a.stride = c.stride; a.taps = c.taps; a.relu = relu;
+  DScope sc(e, "emb_conv", 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
+  return conv2d(e->stream, e->dtype, a);
+}
+
+// trunk on B distinct windows (device list e->e_win); leaves the stage-4 output in *trunk_out
+int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
+  const rvd_model_cfg& c = e->cfg;
+  const int fps = c.step_samples / FB_SHIFT;
+  { DScope sc(e, "emb_cmn");
+    RVD_TRY(emb_window_mean(e->stream, e->emb_fb.as<float>(), e->e_win.as<int64_t>(), B, fps, e->nfr, e->e_mean.as<float>())); }
+  const StageDims d0 = stage_dims(e, 0);
+  { DScope sc(e, "emb_stem", 2.0 * (double)B * d0.F * d0.T * d0.C * 9);
+    RVD_TRY(emb_conv1(e->stream, e->dtype, e->emb_fb.as<float>(), e->e_win.as<int64_t>(), e->e_mean.as<float>(), e->stem_w.as<float>(),
+                      e->stem_b.as<float>(), e->act[0][0].p, B, d0.F, d0.T, fps, d0.C)); }
+  const void* x = e->act[0][0].p;
+  StageDims dx = d0;
+  int xi = 0;                                   // index of x among the stage's rotating buffers
+  for (int li = 0; li < 4; ++li) {
+    const StageDims d = stage_dims(e, li);
+    for (size_t bi = 0; bi < e->stages[li].size(); ++bi) {
+      const ResBlock& Bk = e->stages[li][bi];
+      if (bi == 0 && li > 0) xi = -1;           // x lives in the previous stage's buffers
+      const int ti = xi < 0 ? 0 : (xi + 1) % 3;
+      const int oi = xi < 0 ? 1 : (xi + 2) % 3;
+      void* tmp = e->act[li][ti].p;
+      void* out = e->act[li][oi].p;
+      RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+      const void* res = x;
+      if (Bk.has_sc) {
+        RVD_TRY(run_conv(e, Bk.sc, x, dx, nullptr, e->act[li][3].p, d, B, 0));
+        res = e->act[li][3].p;
+      }
+      RVD_TRY(run_conv(e, Bk.c2, tmp, d, res, out, d, B, 1));
+      x = out; dx = d; xi = oi;
+    }
+  }
+  *trunk_out = x;
+  return OK;
+}
+
+int embed_impl(rvd_engine* e, const int64_t* win, const float* mask, int n, float* emb_out) {
+  const rvd_model_cfg& c = e->cfg;
+  if (!e->has_emb) { set_error("rvd_embed: no embedding model was loaded (cfg.emb_channels == 0)"); return E_STATE; }
+  if (e->n_windows == 0) { set_error("rvd_embed: upload audio first"); return E_STATE; }
+  const int frames = e->p3;
+  const StageDims d3 = stage_dims(e, 3);
+  const int stats = 2 * d3.C * d3.F;
+  int i0 = 0;
+  while (i0 < n) {
+    // next group of items covering at most EMB_BATCH distinct windows (items of one window are adjacent)
+    std::vector<int64_t> uniq;
+    std::vector<int32_t> item_b;
+    int i1 = i0;
+    while (i1 < n) {
+      if (win[i1] < 0 || win[i1] >= e->n_windows) { set_error("rvd_embed: window index outside the uploaded audio"); return E_ARG; }
+      int u = -1;
+      for (int k = (int)uniq.size() - 1; k >= 0 && k >= (int)uniq.size() - 4; --k) if (uniq[k] == win[i1]) { u = k; break; }
+      if (u < 0) {
+        if ((int)uniq.size() == EMB_BATCH) break;
+        uniq.push_back(win[i1]); u = (int)uniq.size() - 1;
+      }
+      item_b.push_back(u);
+      ++i1;
+    }
+    const int B = (int)uniq.size(), ni = i1 - i0;
+    RVD_TRY(ensure_emb_workspace(e, B));
+    RVD_TRY(e->e_win.ensure((size_t)B * 8));
+    RVD_TRY(e->e_mean.ensure((size_t)B * FB_MEL * 4));
+    RVD_TRY(e->e_item_b.ensure((size_t)ni * 4));
+    RVD_TRY(e->e_mask.ensure((size_t)ni * frames * 4));
+    RVD_TRY(e->e_stats.ensure((size_t)ni * stats * dt_size(e->dtype)));
+    RVD_TRY(e->e_out.ensure((size_t)ni * c.emb_dim * 4));
+    RVB_HIP_CHECK(hipMemcpyAsync(e->e_win.p, uniq.data(), (size_t)B * 8, hipMemcpyHostToDevice, e->stream));
+    RVB_HIP_CHECK(hipMemcpyAsync(e->e_item_b.p, item_b.data(), (size_t)ni * 4, hipMemcpyHostToDevice, e->stream));
+    RVB_HIP_CHECK(hipMemcpyAsync(e->e_mask.p, mask + (size_t)i0 * frames, (size_t)ni * frames * 4, hipMemcpyHostToDevice, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));    // uniq / item_b are locals
+    const void* trunk = nullptr;
+    RVD_TRY(run_trunk(e, B, &trunk));
+    { DScope sc(e, "emb_pool");
+      RVD_TRY(tstp_pool(e->stream, e->dtype, trunk, e->e_item_b.as<int>(), e->e_mask.as<float>(), frames, ni, d3.F, d3.T, d3.C, e->e_stats.p)); }
+    { DScope sc(e, "emb_linear", 2.0 * (double)ni * stats * c.emb_dim);
+      GemmArgs g{};
+      g.A = e->e_stats.p; g.W = e->seg1.w.p; g.bias = e->seg1.b.as<float>(); g.C = e->e_out.p;
+      g.M = ni; g.N = c.emb_dim; g.K = stats; g.lda = stats; g.ldw = stats; g.ldc = c.emb_dim; g.alpha = 1.f; g.act = ACT_NONE;
+      g.out_f32 = 1;
+      RVD_TRY(gemm(e->stream, e->dtype, g)); }
+    RVB_HIP_CHECK(hipMemcpyAsync(emb_out + (size_t)i0 * c.emb_dim, e->e_out.p, (size_t)ni * c.emb_dim * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    i0 = i1;
+  }
   return OK;
 }
 
@@ -418,6 +659,17 @@ int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n) {
   { DScope sc(e, "sinc_conv", 2.0 * (double)e->craw_frames * c.sinc_filters * SINC_K);
     RVD_TRY(sinc_conv(e->stream, e->wave.as<float>(), e->filt.as<float>(), e->craw.as<float>(), e->craw_frames, c.sinc_filters,
                       SINC_K, SINC_STRIDE)); }
+  if (e->has_emb) {
+    // hamming log-mel of the zero-extended file, shared by all windows (frame j of window w = frame w*step/160 + j)
+    e->emb_frames = (e->n_pad - FB_WIN) / FB_SHIFT + 1;
+    RVD_TRY(e->pcm_pad.ensure((size_t)e->n_pad * 2));
+    RVD_TRY(e->emb_fb.ensure((size_t)e->emb_frames * FB_MEL * 4));
+    RVB_HIP_CHECK(hipMemsetAsync(e->pcm_pad.p, 0, (size_t)e->n_pad * 2, e->stream));
+    RVB_HIP_CHECK(hipMemcpyAsync(e->pcm_pad.p, e->pcm.p, (size_t)n * 2, hipMemcpyDeviceToDevice, e->stream));
+    DScope sc(e, "emb_fbank");
+    FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};
+    RVD_TRY(fbank(e->stream, e->pcm_pad.as<int16_t>(), e->emb_frames, e->emb_fb.as<float>(), t));
+  }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   return OK;
 }
@@ -440,13 +692,19 @@ int rvd_get_tap(rvd_engine* e, const char* name, float* out) {
 }
 
 int rvd_embed(rvd_engine* e, const int64_t* win, const float* mask, int n, float* emb_out) {
-  if (!e || !win || !emb_out || n < 0) { set_error("rvd_embed: null argument"); return E_ARG; }
-  set_error("rvd_embed: the embedding model is not part of this build yet");
-  return E_UNSUPPORTED;
+  if (!e || !win || !mask || !emb_out || n < 0) { set_error("rvd_embed: null argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return embed_impl(e, win, mask, n, emb_out);
 }
 int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_frames) {
-  set_error("rvd_get_emb_fbank: the embedding model is not part of this build yet");
-  return E_UNSUPPORTED;
+  if (!e || !out) { set_error("rvd_get_emb_fbank: null argument"); return E_ARG; }
+  if (!e->has_emb || e->n_windows == 0) { set_error("rvd_get_emb_fbank: needs an embedding model and uploaded audio"); return E_STATE; }
+  if (window < 0 || window >= e->n_windows) { set_error("rvd_get_emb_fbank: window outside the uploaded audio"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int64_t f0 = window * (e->cfg.step_samples / FB_SHIFT);
+  RVB_HIP_CHECK(hipMemcpy(out, e->emb_fb.as<float>() + f0 * FB_MEL, (size_t)e->nfr * FB_MEL * 4, hipMemcpyDeviceToHost));
+  if (n_frames) *n_frames = e->nfr;
+  return OK;
 }
 
 int rvd_set_profiling(rvd_engine* e, int enabled) { if (!e) return E_ARG; drain(e); e->profiling = enabled != 0; return OK; }

@@ -147,4 +147,31 @@ int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh
 int classifier_logsoftmax(hipStream_t s, int dtype, const void* x, int ldx, const float* w, const float* b,
                           float* logp, int64_t M, int in, int C);
 
+// ---------------------------------------------------------------- resnet.hip (speaker-embedding ResNet34)
+// mean[b][bin] over the nfr fbank frames of window win[b] (frames start at win*frames_per_step)
+int emb_window_mean(hipStream_t s, const float* fb, const int64_t* win, int B, int frames_per_step, int nfr, float* mean);
+// stem conv (1 -> C channels, 3x3 pad 1, folded BN, ReLU) from the shared fbank; out T [B][F+2][NT+2][C]
+int emb_conv1(hipStream_t s, int dtype, const float* fb, const int64_t* win, const float* mean, const float* w,
+              const float* bias, void* out, int B, int F, int NT, int frames_per_step, int C);
+
+// NHWC convolution with a one-pixel zero border on input and output:
+// out[b][fo+1][to+1][:] = relu?( sum_taps in[b][s*fo+kh][s*to+kw][:] . w[tap] + bias + res[b][fo+1][to+1][:] )
+struct ConvArgs {
+  const void* in;     // T [B][Fi+2][Ti+2][Cin]
+  const void* w;      // T [taps][Cin/CK][Cout][CK], CK = 64 bytes of input channels (BN folded)
+  const float* bias;  // [Cout]
+  const void* res;    // T [B][Fo+2][To+2][Cout] or null
+  void* out;          // T [B][Fo+2][To+2][Cout]
+  int B, Fi, Ti, Cin, Fo, To, Cout;
+  int stride;         // 1 | 2
+  int taps;           // 9 (3x3, pad 1) | 1 (1x1)
+  int relu;
+};
+int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
+
+// weighted mean/std over time of the trunk output x T [B][F+2][TT+2][C] for each item (item_b = batch row,
+// mask [n_items][mask_len] resampled to TT by nearest); stats T [n_items][2*C*F]
+int tstp_pool(hipStream_t s, int dtype, const void* x, const int* item_b, const float* mask, int mask_len, int n_items,
+              int F, int TT, int C, void* stats);
+
 }  // namespace rvb

@@ -108,6 +108,13 @@ class DiarEngine:
                                       fptr(out[b0:b0 + nb])), "rvd_embed")
         return out
 
+    def emb_fbank(self, window: int) -> np.ndarray:
+        """80-bin hamming log-mel frames of one window as the ResNet sees them before mean subtraction."""
+        out = np.empty((1200, 80), np.float32)
+        n = C.c_int32()
+        _check(self.lib.rvd_get_emb_fbank(self._h, int(window), fptr(out), C.byref(n)), "rvd_get_emb_fbank")
+        return out[:n.value].copy()
+
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
         _check(self.lib.rvd_set_profiling(self._h, 1 if on else 0), "rvd_set_profiling")

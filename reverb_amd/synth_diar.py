@@ -77,8 +77,8 @@ def make_embedding_sd(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
     def conv(name, cout, cin, k):
         sd[name + ".weight"] = (rng.standard_normal((cout, cin, k, k)) * math.sqrt(2.0 / (cin * k * k))).astype(np.float32)
 
-    def bn(name, ch):
-        sd[name + ".weight"] = rng.uniform(0.6, 1.2, ch).astype(np.float32)
+    def bn(name, ch, lo=0.6, hi=1.2):
+        sd[name + ".weight"] = rng.uniform(lo, hi, ch).astype(np.float32)
         sd[name + ".bias"] = (0.1 * rng.standard_normal(ch)).astype(np.float32)
         sd[name + ".running_mean"] = (0.1 * rng.standard_normal(ch)).astype(np.float32)
         sd[name + ".running_var"] = rng.uniform(0.5, 1.5, ch).astype(np.float32)
@@ -91,7 +91,7 @@ def make_embedding_sd(cfg: dict = None, seed: int = 0) -> Dict[str, np.ndarray]:
             p = f"resnet.layer{li}.{b}"
             s = stride if b == 0 else 1
             conv(p + ".conv1", cout, cin, 3); bn(p + ".bn1", cout)
-            conv(p + ".conv2", cout, cout, 3); bn(p + ".bn2", cout)
+            conv(p + ".conv2", cout, cout, 3); bn(p + ".bn2", cout, 0.15, 0.4)   # small residual branches, as in trained nets
             if s != 1 or cin != cout:
                 conv(p + ".shortcut.0", cout, cin, 1); bn(p + ".shortcut.1", cout)
             cin = cout

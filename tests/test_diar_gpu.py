@@ -103,3 +103,78 @@ def test_short_audio_single_padded_window(case):
     got = eng.segment()
     assert np.abs(got - want).max() < 1e-2
     eng.close()
+
+
+# ------------------------------------------------------------------------------------ embedding network
+@pytest.fixture(scope="module")
+def emb_case(case):
+    cfg = case["cfg"]
+    emb_sd = SD.make_embedding_sd(cfg, 0)
+    rng = np.random.default_rng(5)
+    W = case["x"].shape[0]
+    wins, masks = [], []
+    for w in (0, 2, W - 1):                       # W-1 is the zero-padded tail window
+        for k in range(3):
+            m = np.zeros(R.NUM_FRAMES, np.float32)
+            if k == 0:
+                m[rng.integers(0, 200):rng.integers(300, 589)] = 1.0        # one contiguous turn
+            elif k == 1:
+                m[:] = (rng.random(R.NUM_FRAMES) < 0.4)                       # scattered frames
+            elif w == 2:
+                pass                                                          # inactive speaker: all-zero mask
+            else:
+                m[:] = rng.random(R.NUM_FRAMES).astype(np.float32)           # soft weights
+            wins.append(w); masks.append(m)
+    wins = np.array(wins, np.int64); masks = np.stack(masks)
+    sd = R.to_torch_sd(emb_sd)
+    feats = {w: torch.from_numpy(R.hamming_fbank(case["x"][w, 0].numpy())) for w in sorted(set(wins.tolist()))}
+    with torch.no_grad():
+        trunk = {w: R.resnet34_trunk(sd, f[None]) for w, f in feats.items()}
+        want = torch.cat([F_linear_stats(sd, trunk[int(w)], torch.from_numpy(m)[None]) for w, m in zip(wins, masks)]).numpy()
+    return dict(cfg=cfg, emb_sd=emb_sd, wins=wins, masks=masks, feats={w: f.numpy() for w, f in feats.items()}, want=want)
+
+
+def F_linear_stats(sd, trunk, weights):
+    return torch.nn.functional.linear(R.tstp(trunk, weights), sd["resnet.seg_1.weight"], sd["resnet.seg_1.bias"])
+
+
+def test_embedding_fbank_shared_across_windows(case, emb_case):
+    from reverb_amd.diar_engine import DiarEngine
+    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="f32")
+    eng.upload(case["pcm"])
+    for w, want in emb_case["feats"].items():
+        got = eng.emb_fbank(w)
+        assert got.shape == (998, 80)
+        got = got - got.mean(0, keepdims=True)        # the oracle returns mean-normalised features
+        assert np.abs(got - want).max() < 2e-3, w
+    eng.close()
+
+
+def test_embedding_f32_matches_oracle(case, emb_case):
+    from reverb_amd.diar_engine import DiarEngine
+    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="f32")
+    eng.upload(case["pcm"])
+    got = eng.embed(emb_case["wins"], emb_case["masks"])
+    want = emb_case["want"]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 2e-3 * scale, np.abs(got - want).max() / scale
+    # an inactive speaker (all-zero mask) pools to zero statistics: the embedding is the bias of seg_1
+    idx = int(np.where(emb_case["masks"].sum(1) == 0)[0][0])
+    assert np.abs(got[idx] - emb_case["emb_sd"]["resnet.seg_1.bias"]).max() < 1e-5
+    # item order / grouping does not matter
+    perm = np.array([3, 4, 5, 0, 1, 2, 6, 7, 8])
+    again = eng.embed(emb_case["wins"][perm], emb_case["masks"][perm])
+    assert np.array_equal(again, got[perm])
+    eng.close()
+
+
+def test_embedding_bf16_close_to_oracle(case, emb_case):
+    from reverb_amd.diar_engine import DiarEngine
+    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+    eng.upload(case["pcm"])
+    got = eng.embed(emb_case["wins"], emb_case["masks"])
+    want = emb_case["want"]
+    active = emb_case["masks"].sum(1) > 0
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos[active].min() > 0.995, cos
+    eng.close()
