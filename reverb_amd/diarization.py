@@ -1,0 +1,457 @@
+"""Speaker diarization pipeline with the calling convention of `pyannote.audio.Pipeline`, as used by
+the reference (/root/reference/diarization/infer_pyannote3.0.py:33-42):
+
+    pipeline = Pipeline.from_pretrained(model_dir)        # :33
+    pipeline.to(torch.device("cuda"))                      # :36
+    annotation = pipeline("a.wav")                         # :40
+    annotation.write_rttm(f)                               # :42
+
+The two neural networks run in librvb.so's HIP kernels (reverb_amd/diar_engine.py, include/rvd.h);
+this file is the host logic between and after them, restating pyannote.audio 3.x
+`SpeakerDiarization.apply` with the hyper-parameters of pyannote/speaker-diarization-3.1, which
+Revai/reverb-diarization-v1 inherits (fine-tuned segmentation model, same pipeline):
+powerset decoding, speaker counting, overlap-excluding masks, centroid-linkage agglomerative
+clustering (scipy, as pyannote itself uses), reconstruction, binarisation, RTTM.
+
+pyannote.audio is a third-party dependency that is not vendored in /root/reference and not
+installed here: the restatement is from its published algorithm and is
+**parity-unpinned** against the package itself; the functions are pure numpy so that
+tests/test_diarization_host.py can check them on hand-made inputs.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import namedtuple
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+POWERSET = [(), (0,), (1,), (2,), (0, 1), (0, 2), (1, 2)]      # 3 local speakers, at most 2 at once
+
+DEFAULT_PARAMS = dict(
+    clustering=dict(method="centroid", min_cluster_size=12, threshold=0.7045654963945799),
+    segmentation=dict(min_duration_off=0.0),
+    embedding_exclude_overlap=True,
+)
+
+# receptive field of the segmentation model (pyannote >= 3.1 `model.receptive_field`): 991 samples wide,
+# one frame every 270 samples
+FRAME_DURATION = 991 / 16000.0
+FRAME_STEP = 270 / 16000.0
+
+
+# ------------------------------------------------------------------------------------------------ result type
+class Segment(namedtuple("Segment", ["start", "end"])):
+    @property
+    def duration(self):
+        return self.end - self.start
+
+    @property
+    def middle(self):
+        return 0.5 * (self.start + self.end)
+
+
+class Annotation:
+    """The slice of pyannote.core.Annotation the reference touches: itertracks / write_rttm / labels."""
+
+    def __init__(self, uri: Optional[str] = None):
+        self.uri = uri
+        self._tracks: List[Tuple[Segment, object, str]] = []
+
+    def add(self, segment: Segment, track, label):
+        self._tracks.append((segment, track, label))
+
+    def __setitem__(self, key, label):
+        segment, track = key
+        self.add(Segment(*segment), track, label)
+
+    def __len__(self):
+        return len(self._tracks)
+
+    def __bool__(self):
+        return True
+
+    def itertracks(self, yield_label: bool = False):
+        for seg, track, label in sorted(self._tracks, key=lambda x: (x[0].start, x[0].end, str(x[1]))):
+            yield (seg, track, label) if yield_label else (seg, track)
+
+    def labels(self):
+        return sorted({label for _, _, label in self._tracks}, key=lambda x: (str(type(x)), x))
+
+    def rename_labels(self, mapping: Dict) -> "Annotation":
+        out = Annotation(self.uri)
+        for seg, track, label in self._tracks:
+            out.add(seg, track, mapping.get(label, label))
+        return out
+
+    def write_rttm(self, file):
+        """pyannote.core.Annotation.write_rttm line format."""
+        uri = self.uri if self.uri else "<NA>"
+        if isinstance(uri, str) and " " in uri:
+            raise ValueError(f'Space-separated RTTM file format does not allow file URIs containing spaces (got: "{uri}").')
+        for segment, _, label in self.itertracks(yield_label=True):
+            if isinstance(label, str) and " " in label:
+                raise ValueError(f'Space-separated RTTM file format does not allow labels containing spaces (got: "{label}").')
+            file.write(f"SPEAKER {uri} 1 {segment.start:.3f} {segment.duration:.3f} <NA> <NA> {label} <NA> <NA>\n")
+
+
+def load_rttm(path: str) -> Dict[str, Annotation]:
+    """pyannote.database.util.load_rttm: {uri: Annotation}, one track per line (track id = line index)."""
+    out: Dict[str, Annotation] = {}
+    with open(path) as f:
+        for i, line in enumerate(f):
+            parts = line.split()
+            if not parts:
+                continue
+            if len(parts) < 8:
+                raise ValueError(f"{path}:{i + 1}: not an RTTM line")
+            uri, start, dur, spk = parts[1], float(parts[3]), float(parts[4]), parts[7]
+            out.setdefault(uri, Annotation(uri)).add(Segment(start, start + dur), i, spk)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ host stages
+def powerset_to_multilabel(logp: np.ndarray) -> np.ndarray:
+    """Powerset.to_multilabel(soft=False): argmax class -> 0/1 activity of the 3 local speakers."""
+    mapping = np.zeros((len(POWERSET), 3), np.float32)
+    for k, spk in enumerate(POWERSET):
+        mapping[k, list(spk)] = 1.0
+    return mapping[np.argmax(logp, axis=-1)]
+
+
+def closest_frame(t: float, start: float = 0.0) -> int:
+    """pyannote.core.SlidingWindow.closest_frame for the model's receptive field."""
+    return int(np.rint((t - start - 0.5 * FRAME_DURATION) / FRAME_STEP))
+
+
+def aggregate(scores: np.ndarray, chunk_step: float, chunk_duration: float, skip_average: bool = False,
+              missing: float = 0.0, epsilon: float = 1e-12) -> np.ndarray:
+    """pyannote.audio Inference.aggregate(hamming=False, warm_up=(0,0)): overlap-add of per-chunk scores
+    (num_chunks, frames, classes), NaN entries ignored, onto the file-level frame grid."""
+    num_chunks, nf, ncls = scores.shape
+    mask = 1.0 - np.isnan(scores)
+    data = np.nan_to_num(scores, copy=True, nan=0.0)
+    num_frames = closest_frame(chunk_duration + (num_chunks - 1) * chunk_step + 0.5 * FRAME_DURATION) + 1
+    total = max(num_frames, closest_frame((num_chunks - 1) * chunk_step + 0.5 * FRAME_DURATION) + nf)
+    agg = np.zeros((total, ncls), np.float64)
+    cnt = np.zeros((total, ncls), np.float64)
+    seen = np.zeros((total, ncls), np.float64)
+    for c in range(num_chunks):
+        s = closest_frame(c * chunk_step + 0.5 * FRAME_DURATION)
+        agg[s:s + nf] += data[c] * mask[c]
+        cnt[s:s + nf] += mask[c]
+        seen[s:s + nf] = np.maximum(seen[s:s + nf], mask[c])
+    avg = agg if skip_average else agg / np.maximum(cnt, epsilon)
+    avg[seen == 0.0] = missing
+    return avg[:num_frames]
+
+
+def speaker_count(binarized: np.ndarray, chunk_step: float, chunk_duration: float) -> np.ndarray:
+    """SpeakerDiarizationMixin.speaker_count: rounded average number of active speakers per frame."""
+    count = aggregate(np.sum(binarized, axis=-1, keepdims=True), chunk_step, chunk_duration)
+    return np.rint(count).astype(np.uint8)
+
+
+def embedding_masks(binarized: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
+                    window_samples: int = 160000) -> np.ndarray:
+    """SpeakerDiarization.get_embeddings mask choice: frames where the speaker talks alone, unless that
+    leaves too few frames, in which case all of the speaker's frames.  -> (chunks, speakers, frames)."""
+    num_chunks, nf, nspk = binarized.shape
+    masks = np.nan_to_num(binarized, nan=0.0).astype(np.float32)
+    if exclude_overlap:
+        min_num_frames = math.ceil(nf * min_num_samples / window_samples)
+        clean = masks * (np.sum(masks, axis=2, keepdims=True) < 2)
+        use_clean = np.sum(clean, axis=1, keepdims=True) > min_num_frames
+        masks = np.where(use_clean, clean, masks)
+    return np.ascontiguousarray(np.transpose(masks, (0, 2, 1)))
+
+
+def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold: float, min_cluster_size: int,
+                       method: str = "centroid", num_clusters: Optional[int] = None, min_clusters: Optional[int] = None,
+                       max_clusters: Optional[int] = None):
+    """pyannote.audio.pipelines.clustering.AgglomerativeClustering.__call__ (metric cosine):
+    embeddings (chunks, speakers, dim), binarized (chunks, frames, speakers) -> hard_clusters (chunks, speakers),
+    centroids (clusters, dim)."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.spatial.distance import cdist
+
+    num_chunks, nspk, dim = embeddings.shape
+    active = np.sum(binarized, axis=1) > 0
+    valid = ~np.any(np.isnan(embeddings), axis=2)
+    chunk_idx, speaker_idx = np.where(active * valid)
+    train = embeddings[chunk_idx, speaker_idx].astype(np.float64)
+    n = train.shape[0]
+    if n == 0:
+        return np.zeros((num_chunks, nspk), np.int64), np.zeros((1, dim))
+    lo = num_clusters or min_clusters or 1
+    lo = max(1, min(n, lo))
+    hi = num_clusters or max_clusters or n
+    hi = max(1, min(n, hi))
+    if hi < 2:
+        return np.zeros((num_chunks, nspk), np.int64), np.mean(train, axis=0, keepdims=True)
+
+    mcs = min(min_cluster_size, max(1, round(0.1 * n)))
+    if n == 1:
+        clusters = np.zeros((1,), np.int64)
+    else:
+        unit = train / np.linalg.norm(train, axis=-1, keepdims=True)
+        dendrogram = linkage(unit, method=method, metric="euclidean")
+        clusters = fcluster(dendrogram, threshold, criterion="distance") - 1
+        uniq, counts = np.unique(clusters, return_counts=True)
+        large = uniq[counts >= mcs]
+        target = num_clusters
+        if len(large) < lo:
+            target = lo
+        elif len(large) > hi:
+            target = hi
+        if target is not None and len(large) != target:
+            # walk the dendrogram away from the threshold until the number of large clusters fits
+            dd = np.copy(dendrogram)
+            dd[:, 2] = np.arange(n - 1)
+            best_it, best_large = n - 1, 1
+            for it in np.argsort(np.abs(dendrogram[:, 2] - threshold)):
+                if dd[it, 3] < mcs:
+                    continue
+                cl = fcluster(dd, it, criterion="distance") - 1
+                u, cts = np.unique(cl, return_counts=True)
+                nl = int(np.sum(cts >= mcs))
+                if abs(nl - target) < abs(best_large - target):
+                    best_it, best_large = it, nl
+                if nl == target:
+                    break
+            clusters = fcluster(dd, best_it, criterion="distance") - 1
+            uniq, counts = np.unique(clusters, return_counts=True)
+            large = uniq[counts >= mcs]
+        if len(large) == 0:
+            clusters[:] = 0
+        else:
+            small = uniq[counts < mcs]
+            if len(small):
+                large_c = np.vstack([np.mean(unit[clusters == k], axis=0) for k in large])
+                small_c = np.vstack([np.mean(unit[clusters == k], axis=0) for k in small])
+                nearest = np.argmin(cdist(large_c, small_c, metric="cosine"), axis=0)
+                for s_i, l_i in enumerate(nearest):
+                    clusters[clusters == small[s_i]] = large[l_i]
+                _, clusters = np.unique(clusters, return_inverse=True)
+
+    k = int(np.max(clusters)) + 1
+    centroids = np.vstack([np.mean(train[clusters == i], axis=0) for i in range(k)])
+    flat = embeddings.reshape(num_chunks * nspk, dim).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e2k = cdist(flat, centroids, metric="cosine").reshape(num_chunks, nspk, k)
+    soft = 2.0 - e2k
+    soft = np.where(np.isnan(soft), -np.inf, soft)
+    hard = np.argmax(soft, axis=2)
+    return hard, centroids
+
+
+def reconstruct(segmentations: np.ndarray, hard_clusters: np.ndarray, count: np.ndarray, chunk_step: float,
+                chunk_duration: float) -> np.ndarray:
+    """SpeakerDiarization.reconstruct + to_diarization: (frames, clusters) 0/1 matrix in which the `count[t]`
+    most active clusters of frame t are on."""
+    num_chunks, nf, _ = segmentations.shape
+    k = int(np.max(hard_clusters)) + 1
+    clustered = np.full((num_chunks, nf, max(k, 1)), np.nan)
+    for c in range(num_chunks):
+        for kk in np.unique(hard_clusters[c]):
+            if kk == -2:
+                continue
+            clustered[c, :, kk] = np.max(segmentations[c][:, hard_clusters[c] == kk], axis=1)
+    act = aggregate(clustered, chunk_step, chunk_duration, skip_average=True)
+    max_per_frame = int(np.max(count)) if count.size else 0
+    if act.shape[1] < max_per_frame:
+        act = np.pad(act, ((0, 0), (0, max_per_frame - act.shape[1])))
+    n = min(act.shape[0], count.shape[0])
+    act, cnt = act[:n], count[:n, 0].astype(np.int64)
+    order = np.argsort(-act, axis=-1, kind="stable")
+    binary = np.zeros_like(act)
+    ranks = np.arange(act.shape[1])[None, :] < cnt[:, None]
+    np.put_along_axis(binary, order, ranks.astype(act.dtype), axis=1)
+    return binary
+
+
+def to_annotation(binary: np.ndarray, min_duration_off: float = 0.0, uri: Optional[str] = None) -> Annotation:
+    """pyannote.audio.utils.signal.Binarize(onset=offset=0.5) on the 0/1 matrix: one track per speaker turn,
+    turn boundaries at frame middles."""
+    ann = Annotation(uri)
+    n = binary.shape[0]
+    if n == 0:
+        return ann
+    ts = np.arange(n) * FRAME_STEP + 0.5 * FRAME_DURATION
+    for k in range(binary.shape[1]):
+        col = binary[:, k]
+        regions = []
+        start, is_active = ts[0], col[0] > 0.5
+        t = ts[0]
+        for t, y in zip(ts[1:], col[1:]):
+            if is_active:
+                if y < 0.5:
+                    regions.append([start, t]); start = t; is_active = False
+            elif y > 0.5:
+                start = t; is_active = True
+        if is_active:
+            regions.append([start, t])
+        if min_duration_off > 0.0 and regions:       # Annotation.support(collar): bridge short same-speaker gaps
+            merged = [regions[0]]
+            for s, e in regions[1:]:
+                if s - merged[-1][1] <= min_duration_off:
+                    merged[-1][1] = max(merged[-1][1], e)
+                else:
+                    merged.append([s, e])
+            regions = merged
+        for i, (s, e) in enumerate(regions):
+            ann.add(Segment(float(s), float(e)), f"{k}_{i}", k)
+    return ann
+
+
+# ------------------------------------------------------------------------------------------------ pipeline
+class SpeakerDiarization:
+    """`pipeline(file)` -> Annotation.  Built by Pipeline.from_pretrained."""
+
+    def __init__(self, cfg: dict, segmentation_sd: dict, embedding_sd: dict, params: Optional[dict] = None, dtype: str = "bf16"):
+        self.cfg = dict(cfg)
+        self.params = {**DEFAULT_PARAMS, **(params or {})}
+        self._seg_sd, self._emb_sd = segmentation_sd, embedding_sd
+        self.dtype = dtype
+        self.device_index: Optional[int] = None
+        self._engine = None
+        self.timings: Dict[str, float] = {}
+
+    # pyannote API --------------------------------------------------------------------------------
+    def to(self, device):
+        """Accepts torch.device / "cuda" / "cuda:1" / int.  A CPU device is refused: the networks only exist as
+        HIP kernels (the reference falls back to CPU torch, infer_pyannote3.0.py:35; we do not)."""
+        idx = 0
+        if hasattr(device, "type"):
+            if device.type != "cuda":
+                raise RuntimeError("reverb_amd diarization runs on an MI355X only (no CPU fallback); got device " + str(device))
+            idx = device.index or 0
+        elif isinstance(device, str):
+            if not device.startswith("cuda"):
+                raise RuntimeError("reverb_amd diarization runs on an MI355X only (no CPU fallback); got device " + device)
+            idx = int(device.split(":")[1]) if ":" in device else 0
+        else:
+            idx = int(device)
+        if self._engine is not None and idx != self.device_index:
+            self._engine.close(); self._engine = None
+        self.device_index = idx
+        return self
+
+    def instantiate(self, params: dict):
+        self.params = {**self.params, **params}
+        return self
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .diar_engine import DiarEngine
+            self._engine = DiarEngine(self.cfg, self._seg_sd, self._emb_sd, dtype=self.dtype, device=self.device_index or 0)
+        return self._engine
+
+    @staticmethod
+    def _load(file) -> Tuple[np.ndarray, str]:
+        from . import wav as W
+        if isinstance(file, dict):
+            uri = file.get("uri")
+            if "waveform" in file:
+                w = file["waveform"]
+                w = w.detach().cpu().numpy() if hasattr(w, "detach") else np.asarray(w)
+                if int(file.get("sample_rate", 16000)) != 16000:
+                    raise ValueError("only 16 kHz audio is supported (resampling is listed under 'next' in DESIGN.md)")
+                w = w.mean(axis=0) if w.ndim == 2 else w          # pyannote Audio: downmix to mono
+                pcm = w if w.dtype == np.int16 else np.clip(np.rint(w * 32768.0), -32768, 32767).astype(np.int16)
+                return pcm, uri or "waveform"
+            file = file["audio"]
+        path = os.fspath(file)
+        pcm, sr = W.read_wav(path)
+        if sr != 16000:
+            raise ValueError(f"{path}: sample rate {sr}; only 16 kHz audio is supported")
+        if pcm.ndim == 2:                                          # (channels, samples) -> mono mean like pyannote Audio
+            pcm = np.clip(np.rint(pcm.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
+        return pcm, os.path.splitext(os.path.basename(path))[0]
+
+    def __call__(self, file, num_speakers: Optional[int] = None, min_speakers: Optional[int] = None,
+                 max_speakers: Optional[int] = None, return_embeddings: bool = False):
+        import time
+        t0 = time.perf_counter()
+        pcm, uri = self._load(file)
+        eng = self.engine
+        step = self.cfg["step_samples"] / self.cfg["sample_rate"]
+        dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
+        W = eng.upload(pcm)
+        t1 = time.perf_counter()
+        logp = eng.segment()
+        t2 = time.perf_counter()
+        binarized = powerset_to_multilabel(logp)                              # (W, frames, 3)
+        count = speaker_count(binarized, step, dur)
+        if np.max(count) == 0:
+            self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, total=time.perf_counter() - t0)
+            return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
+        masks = embedding_masks(binarized, bool(self.params["embedding_exclude_overlap"]), 400, self.cfg["window_samples"])
+        t3 = time.perf_counter()
+        nspk = binarized.shape[2]
+        active = masks.sum(axis=2) > 0                                        # inactive (window, speaker) pairs are never used downstream
+        wi, si = np.nonzero(active)
+        emb = np.full((W, nspk, self.cfg["emb_dim"]), np.nan, np.float32)
+        if wi.size:
+            emb[wi, si] = eng.embed(wi.astype(np.int64), masks[wi, si])
+        t4 = time.perf_counter()
+        cp = self.params["clustering"]
+        ms = max_speakers if max_speakers is not None else np.inf
+        hard, centroids = cluster_embeddings(emb, binarized, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
+                                             num_speakers, min_speakers, max_speakers)
+        t5 = time.perf_counter()
+        count = np.minimum(count, ms).astype(np.int8)
+        hard = hard.copy()
+        hard[np.sum(binarized, axis=1) == 0] = -2
+        binary = reconstruct(binarized, hard, count, step, dur)
+        ann = to_annotation(binary, float(self.params["segmentation"].get("min_duration_off", 0.0)), uri)
+        mapping = {label: f"SPEAKER_{i:02d}" for i, label in enumerate(ann.labels())}
+        ann = ann.rename_labels(mapping)
+        t6 = time.perf_counter()
+        self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, clustering=t5 - t4,
+                            reconstruction=t6 - t5, total=t6 - t0, windows=W, embeddings=int(wi.size))
+        if return_embeddings:
+            return ann, centroids
+        return ann
+
+    apply = __call__
+
+
+class Pipeline:
+    """`pyannote.audio.Pipeline` entry point used by the reference."""
+
+    @staticmethod
+    def from_pretrained(checkpoint_path, use_auth_token=None, hparams_file=None, cache_dir=None, dtype: str = "bf16") -> SpeakerDiarization:
+        """`checkpoint_path`: a directory holding `config.yaml` (pyannote pipeline config: params.clustering.*,
+        params.segmentation.*) and the two checkpoints `segmentation.pt` / `embedding.pt` (torch state dicts, or
+        pytorch-lightning checkpoints with a "state_dict" entry).  Hub names such as "Revai/reverb-diarization-v1"
+        need the files downloaded first (this process does no network I/O)."""
+        import yaml
+        path = os.fspath(checkpoint_path)
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"{path!r} is not a local pipeline directory.  Download the pipeline (config.yaml, segmentation and embedding "
+                "checkpoints) and pass the directory; reverb_amd does not fetch from the Hugging Face hub.")
+        with open(os.path.join(path, "config.yaml")) as f:
+            conf = yaml.safe_load(f) or {}
+        params = conf.get("params", {})
+        pp = conf.get("pipeline", {}).get("params", {})
+        if "embedding_exclude_overlap" in pp:
+            params["embedding_exclude_overlap"] = bool(pp["embedding_exclude_overlap"])
+        from .synth_diar import DIAR_DIMS
+        cfg = dict(DIAR_DIMS)
+        cfg.update(conf.get("reverb_amd", {}))
+
+        def load_sd(stem):
+            import torch
+            for ext in (".pt", ".bin", ".ckpt"):
+                p = os.path.join(path, stem + ext)
+                if os.path.exists(p):
+                    sd = torch.load(p, map_location="cpu", weights_only=False)
+                    sd = sd.get("state_dict", sd)
+                    return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+            raise FileNotFoundError(f"{path}: no {stem}.pt / .bin / .ckpt")
+
+        return SpeakerDiarization(cfg, load_sd("segmentation"), load_sd("embedding"), params, dtype=dtype)

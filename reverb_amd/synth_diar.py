@@ -129,3 +129,26 @@ def synth_conversation(seconds: float, seed: int = 4321, sample_rate: int = 1600
     out += 0.003 * rng.standard_normal(n)
     out = out / (np.abs(out).max() + 1e-9) * 0.7
     return np.round(out * 32767.0).astype(np.int16)
+
+
+def write_pipeline_dir(path: str, seed: int = 0, cfg: dict = None) -> str:
+    """A local pipeline directory in the layout `reverb_amd.diarization.Pipeline.from_pretrained` reads:
+    config.yaml (pyannote/speaker-diarization-3.1 hyper-parameters) + segmentation.pt + embedding.pt."""
+    import os
+    import torch
+    import yaml
+    cfg = cfg or DIAR_DIMS
+    os.makedirs(path, exist_ok=True)
+    conf = {
+        "version": "3.1.0",
+        "pipeline": {"name": "pyannote.audio.pipelines.SpeakerDiarization",
+                     "params": {"clustering": "AgglomerativeClustering", "embedding": "embedding.pt", "embedding_batch_size": 32,
+                                "embedding_exclude_overlap": True, "segmentation": "segmentation.pt", "segmentation_batch_size": 32}},
+        "params": {"clustering": {"method": "centroid", "min_cluster_size": 12, "threshold": 0.7045654963945799},
+                   "segmentation": {"min_duration_off": 0.0}},
+    }
+    with open(os.path.join(path, "config.yaml"), "w") as f:
+        yaml.safe_dump(conf, f)
+    torch.save({k: torch.from_numpy(v) for k, v in make_segmentation_sd(cfg, seed).items()}, os.path.join(path, "segmentation.pt"))
+    torch.save({k: torch.from_numpy(v) for k, v in make_embedding_sd(cfg, seed).items()}, os.path.join(path, "embedding.pt"))
+    return path

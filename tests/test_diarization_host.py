@@ -1,0 +1,166 @@
+"""Host logic of the diarization pipeline (reverb_amd/diarization.py) and of the word->speaker join
+(reverb_amd/bin/assign_words2speakers.py; reference diarization/assign_words2speakers.py:25-89) on
+hand-made inputs.  No GPU, no oracle: these are property / known-answer checks of pure numpy code."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from reverb_amd import diarization as D
+from reverb_amd.bin import assign_words2speakers as A
+
+
+def test_powerset_mapping():
+    logp = np.full((1, 7, 7), -10.0, np.float32)
+    for k in range(7):
+        logp[0, k, k] = -0.1
+    ml = D.powerset_to_multilabel(logp)[0]
+    want = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, 0, 1], [0, 1, 1]], np.float32)
+    assert np.array_equal(ml, want)
+
+
+def test_frame_grid_and_aggregate_average():
+    assert D.closest_frame(0.5 * D.FRAME_DURATION) == 0
+    assert D.closest_frame(1.0 + 0.5 * D.FRAME_DURATION) == 59          # 1 s hop = 59.26 frames
+    W, nf = 5, 589
+    scores = np.ones((W, nf, 1))
+    scores[2] = 3.0
+    avg = D.aggregate(scores, 1.0, 10.0)
+    assert avg.shape[0] == int(np.rint((10.0 + W - 1) / D.FRAME_STEP)) + 1
+    assert np.isclose(avg[0, 0], 1.0)                                    # only chunk 0 covers frame 0
+    s2 = D.closest_frame(2.0 + 0.5 * D.FRAME_DURATION)
+    assert np.isclose(avg[s2 + 10, 0], (1 + 1 + 3) / 3.0)               # chunks 0,1,2 overlap there
+    assert avg[-1, 0] == 0.0                                             # beyond the last chunk: `missing`
+    tot = D.aggregate(scores, 1.0, 10.0, skip_average=True)
+    assert np.isclose(tot[s2 + 10, 0], 5.0)
+    nan = scores.copy(); nan[2] = np.nan
+    avg2 = D.aggregate(nan, 1.0, 10.0)
+    assert np.isclose(avg2[s2 + 10, 0], 1.0)                             # NaN chunk ignored
+
+
+def test_speaker_count_rounds_mean_activity():
+    W, nf = 3, 589
+    b = np.zeros((W, nf, 3), np.float32)
+    b[:, :, 0] = 1.0
+    b[1, :, 1] = 1.0                                                     # one of the three chunks sees a 2nd speaker
+    c = D.speaker_count(b, 1.0, 10.0)
+    s1, s2 = D.closest_frame(1.0 + 0.5 * D.FRAME_DURATION), D.closest_frame(2.0 + 0.5 * D.FRAME_DURATION)
+    assert c[0, 0] == 1 and c[s1 + 5, 0] == 2 and c[s2 + 5, 0] == 1      # mean 1, 1.5 -> 2 (rint half-even), 1.33 -> 1
+
+
+def test_embedding_masks_exclude_overlap_with_fallback():
+    b = np.zeros((1, 589, 3), np.float32)
+    b[0, 100:200, 0] = 1; b[0, 150:300, 1] = 1                           # overlap in 150..200
+    b[0, 400:402, 2] = 1; b[0, 400:402, 0] = 1                           # speaker 2 only ever overlapped
+    m = D.embedding_masks(b, True)
+    assert m.shape == (1, 3, 589)
+    assert m[0, 0].sum() == 50 and m[0, 0, 150:200].sum() == 0
+    assert m[0, 1].sum() == 100
+    assert m[0, 2].sum() == 2                                            # clean mask empty -> falls back to the full mask
+    assert np.array_equal(D.embedding_masks(b, False)[0, 0], b[0, :, 0])
+
+
+def _toy_embeddings(seed=0):
+    rng = np.random.default_rng(seed)
+    W, dim = 40, 16
+    a, b_ = np.zeros(dim), np.zeros(dim)
+    a[0], b_[1] = 1.0, 1.0
+    emb = np.zeros((W, 3, dim), np.float32)
+    seg = np.zeros((W, 20, 3), np.float32)
+    truth = np.full((W, 3), -1)
+    for w in range(W):
+        emb[w, 0] = 5.0 * (a + 0.05 * rng.standard_normal(dim)); seg[w, :10, 0] = 1; truth[w, 0] = 0
+        if w % 2 == 0:
+            emb[w, 1] = 0.3 * (b_ + 0.05 * rng.standard_normal(dim)); seg[w, 10:, 1] = 1; truth[w, 1] = 1
+        emb[w, 2] = np.nan                                               # never active
+    c = (a + b_) / np.sqrt(2) + 0.05 * rng.standard_normal(dim)          # 2 stray embeddings between the groups
+    emb[1, 1] = c; seg[1, 10:, 1] = 1
+    emb[3, 1] = c + 0.01; seg[3, 10:, 1] = 1
+    return emb, seg, truth
+
+
+def test_clustering_two_speakers_small_cluster_reassigned():
+    emb, seg, truth = _toy_embeddings()
+    hard, cent = D.cluster_embeddings(emb, seg, threshold=0.7045654963945799, min_cluster_size=12)
+    assert cent.shape[0] == 2
+    k0 = hard[0, 0]
+    assert np.all(hard[:, 0] == k0)
+    assert np.all(hard[::2, 1] == 1 - k0)
+    forced = D.cluster_embeddings(emb, seg, 0.7045654963945799, 12, num_clusters=1)[0]
+    assert np.all(forced == 0)
+
+
+def test_reconstruct_and_rttm():
+    W, nf = 4, 589
+    seg = np.zeros((W, nf, 3), np.float32)
+    hard = np.full((W, 3), -2)
+    for w in range(W):
+        # global speaker 0 talks in file seconds [2, 6), speaker 1 in [5, 9): place them per chunk
+        t = (np.arange(nf) * D.FRAME_STEP + 0.5 * D.FRAME_DURATION) + w * 1.0
+        seg[w, :, w % 3] = ((t >= 2) & (t < 6))                          # local slot differs per chunk
+        seg[w, :, (w + 1) % 3] = ((t >= 5) & (t < 9))
+        hard[w, w % 3] = 0; hard[w, (w + 1) % 3] = 1
+    count = D.speaker_count(seg, 1.0, 10.0)
+    binary = D.reconstruct(seg, hard, count, 1.0, 10.0)
+    ann = D.to_annotation(binary, 0.0, uri="toy")
+    ann = ann.rename_labels({k: f"SPEAKER_{i:02d}" for i, k in enumerate(ann.labels())})
+    buf = io.StringIO(); ann.write_rttm(buf)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2
+    pat = re.compile(r"^SPEAKER toy 1 (\d+\.\d{3}) (\d+\.\d{3}) <NA> <NA> (SPEAKER_\d\d) <NA> <NA>$")
+    got = {m.group(3): (float(m.group(1)), float(m.group(2))) for m in map(pat.match, lines)}
+    assert abs(got["SPEAKER_00"][0] - 2.0) < 0.05 and abs(got["SPEAKER_00"][1] - 4.0) < 0.08
+    assert abs(got["SPEAKER_01"][0] - 5.0) < 0.05 and abs(got["SPEAKER_01"][1] - 4.0) < 0.08
+
+
+def test_rttm_roundtrip_and_label_with_space(tmp_path):
+    ann = D.Annotation("u1")
+    ann.add(D.Segment(1.0, 2.5), "a", "SPEAKER_01"); ann.add(D.Segment(0.25, 0.75), "b", "SPEAKER_00")
+    p = tmp_path / "x.rttm"
+    with open(p, "w") as f:
+        ann.write_rttm(f)
+    assert open(p).read().splitlines()[0] == "SPEAKER u1 1 0.250 0.500 <NA> <NA> SPEAKER_00 <NA> <NA>"
+    back = D.load_rttm(str(p))
+    assert list(back) == ["u1"]
+    assert [(round(s.start, 3), round(s.end, 3), l) for s, _, l in back["u1"].itertracks(yield_label=True)] == \
+        [(0.25, 0.75, "SPEAKER_00"), (1.0, 2.5, "SPEAKER_01")]
+    bad = D.Annotation("u 1"); bad.add(D.Segment(0, 1), 0, "x")
+    with pytest.raises(ValueError):
+        bad.write_rttm(io.StringIO())
+
+
+def test_speaker_for_segment_cases():
+    turns = [(0.0, 2.0, "A"), (1.5, 4.0, "B"), (6.0, 7.0, "A")]
+    assert A.speaker_for_segment(0.2, 0.5, turns) == "A"                 # exactly one turn
+    assert A.speaker_for_segment(1.6, 1.0, turns) == "B"                 # both overlap: B 1.0 s vs A 0.4 s
+    assert A.speaker_for_segment(1.4, 0.3, turns) == "A"                 # A 0.3 vs B 0.2
+    assert A.speaker_for_segment(4.5, 0.2, turns) == "B"                 # gap: nearest is B (0.5 s) not A (1.3 s)
+    assert A.speaker_for_segment(5.5, 0.2, turns) == "A"
+    assert A.speaker_for_segment(2.0, 0.0, turns) == "A"                 # empty query -> nearest; both at distance 0 -> earliest
+    assert A.speaker_for_segment(1.0, 1.0, []) == ""
+    assert A.speaker_for_segment(2.0, 0.5, turns) == "B"                 # half-open: A ends at 2.0
+
+
+def test_assign_words_cli(tmp_path):
+    rttm, ctm, stm = tmp_path / "d.rttm", tmp_path / "w.ctm", tmp_path / "o.stm"
+    rttm.write_text("SPEAKER rec 1 0.000 2.000 <NA> <NA> SPEAKER_00 <NA> <NA>\nSPEAKER rec 1 2.000 3.000 <NA> <NA> SPEAKER_01 <NA> <NA>\n")
+    ctm.write_text("rec 0 0.10 0.30 hello 0.99\nrec 0 1.90 0.40 there 0.50\nrec 0 9.00 0.20 bye 1.00\n")
+    A.main([str(rttm), str(ctm), str(stm)])
+    assert stm.read_text().splitlines() == ["rec 1 SPEAKER_00 0.100 0.400 hello", "rec 1 SPEAKER_01 1.900 2.300 there",
+                                            "rec 1 SPEAKER_01 9.000 9.200 bye"]
+
+
+def test_pipeline_loading_errors(tmp_path):
+    with pytest.raises(FileNotFoundError, match="not a local pipeline directory"):
+        D.Pipeline.from_pretrained("Revai/reverb-diarization-v1", use_auth_token="x")
+    from reverb_amd import synth_diar
+    d = synth_diar.write_pipeline_dir(str(tmp_path / "pipe"))
+    pipe = D.Pipeline.from_pretrained(d)
+    assert pipe.params["clustering"]["min_cluster_size"] == 12
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pipe.to("cpu")
+    import torch
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pipe.to(torch.device("cpu"))
