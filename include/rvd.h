@@ -72,6 +72,11 @@ int rvd_embed(rvd_engine* e, const int64_t* win, const float* mask, int n, float
 /* debug: the 80-bin log-mel features of one window as fed to the ResNet, [frames][80]; returns frames in *n */
 int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_frames);
 
+/* clustering step of the pipeline: the dendrogram scipy.cluster.hierarchy.linkage(X, method="centroid",
+ * metric="euclidean") returns for X host fp64 [n][d] -- Z host fp64 [n-1][4] (id_a, id_b, distance, size),
+ * rows in merge order, cluster n+k created by row k.  fp64 throughout. */
+int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z);
+
 int rvd_set_profiling(rvd_engine* e, int enabled);
 int rvd_reset_timings(rvd_engine* e);
 int rvd_get_timing(rvd_engine* e, const char* name, double* ms, double* flops, int64_t* launches);

@@ -707,6 +707,42 @@ int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_fram
   return OK;
 }
 
+int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z) {
+  if (!e || !X || !Z || n < 1 || d < 1) { set_error("rvd_centroid_linkage: bad argument"); return E_ARG; }
+  if (n > 46000) { set_error("rvd_centroid_linkage: more than 46000 points"); return E_UNSUPPORTED; }
+  if (n == 1) return OK;
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  DevBuf dX, dD, dI, dM, dZ;
+  int rc = OK;
+  do {
+    if ((rc = dX.ensure((size_t)n * d * 8)) != OK) break;
+    if ((rc = dD.ensure((size_t)n * n * 8)) != OK) break;
+    if ((rc = dI.ensure((size_t)3 * n * 4)) != OK) break;
+    if ((rc = dM.ensure((size_t)n * 8)) != OK) break;
+    if ((rc = dZ.ensure((size_t)(n - 1) * 4 * 8)) != OK) break;
+    std::vector<int> init((size_t)3 * n);
+    for (int i = 0; i < n; ++i) { init[i] = 1; init[n + i] = i; init[2 * n + i] = -1; }
+    std::vector<double> inf(n, INFINITY);
+    hipMemcpyAsync(dX.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, e->stream);
+    hipMemcpyAsync(dI.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, e->stream);
+    hipMemcpyAsync(dM.p, inf.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream);
+    hipStreamSynchronize(e->stream);
+    {
+      DScope sc(e, "linkage");
+      rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), dI.as<int>(), dI.as<int>() + n, dI.as<int>() + 2 * n,
+                            dM.as<double>(), dZ.as<double>());
+    }
+    if (rc != OK) break;
+    if (hipMemcpyAsync(Z, dZ.p, (size_t)(n - 1) * 4 * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) {
+      set_error(std::string("rvd_centroid_linkage: ") + hipGetErrorString(hipGetLastError()));
+      rc = E_HIP;
+    }
+  } while (0);
+  dX.release(); dD.release(); dI.release(); dM.release(); dZ.release();
+  return rc;
+}
+
 int rvd_set_profiling(rvd_engine* e, int enabled) { if (!e) return E_ARG; drain(e); e->profiling = enabled != 0; return OK; }
 int rvd_reset_timings(rvd_engine* e) { if (!e) return E_ARG; drain(e); e->prof.clear(); return OK; }
 int rvd_get_timing(rvd_engine* e, const char* name, double* ms, double* flops, int64_t* launches) {

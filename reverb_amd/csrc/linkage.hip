@@ -1,0 +1,173 @@
+// Centroid-linkage agglomerative clustering of the speaker embeddings on the GPU.
+//
+// pyannote's AgglomerativeClustering (the clustering step of the pipeline the reference runs,
+// diarization/infer_pyannote3.0.py:40) calls scipy.cluster.hierarchy.linkage(X, "centroid", "euclidean")
+// on up to 3 embeddings per 1 s hop: ~10^4 points for an hour of audio, where scipy needs ~7 s for pdist
+// and ~3 s for the merge loop on one host core.  Here the fp64 distance matrix is built by a tiled kernel
+// and the merge loop -- scipy's `fast_linkage` (Muellner's generic algorithm: nearest-neighbour
+// candidates with lazy validation, Lance-Williams centroid update) restated step for step so that the
+// dendrogram is the same -- runs as ONE persistent 1024-thread workgroup: every merge is a block-wide
+// argmin over the candidate distances plus one fused pass over the two merged rows.
+#include "kernels.h"
+
+namespace rvb {
+
+// ------------------------------------------------------------------------------------ pairwise distances (fp64)
+// D[i][j] = sqrt(sum_k (X[i][k] - X[j][k])^2), full symmetric n x n.  64x64 tile per block, 4x4 per thread.
+__global__ __launch_bounds__(256) void pdist_kernel(const double* __restrict__ X, int n, int d, double* __restrict__ D) {
+  __shared__ double sa[16][65], sb[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (j0 + 63 < i0) return;     // strictly-lower tiles are filled by symmetry
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int k0 = 0; k0 < d; k0 += 16) {
+    for (int v = threadIdx.x; v < 64 * 16; v += 256) {
+      const int r = v >> 4, kk = v & 15;
+      const int gi = i0 + r, gj = j0 + r, gk = k0 + kk;
+      sa[kk][r] = (gi < n && gk < d) ? X[(size_t)gi * d + gk] : 0.0;
+      sb[kk][r] = (gj < n && gk < d) ? X[(size_t)gj * d + gk] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sa[kk][ty * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tx * 4 + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const double df = av[a] - bv[b]; acc[a][b] = fma(df, df, acc[a][b]); }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+      if (i < n && j < n && i <= j) {
+        const double v = i == j ? 0.0 : sqrt(acc[a][b]);
+        D[(size_t)i * n + j] = v;
+        D[(size_t)j * n + i] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------ block-wide (value, index) argmin
+struct MinPair { double v; int i; };
+__device__ inline MinPair min_pair(MinPair a, MinPair b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MinPair q;
+    q.v = __shfl_xor(p.v, o, 64);
+    q.i = __shfl_xor(p.i, o, 64);
+    p = min_pair(p, q);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = p;
+  __syncthreads();
+  MinPair r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = min_pair(r, red[w]);
+  return r;
+}
+
+// nearest neighbour of every x among y > x (scipy find_min_dist: first index on ties); one block per row
+__global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__ D, int n, int* __restrict__ neighbor,
+                                                      double* __restrict__ min_dist) {
+  __shared__ MinPair red[4];
+  const int x = blockIdx.x;
+  MinPair p{INFINITY, 0x7fffffff};
+  for (int j = x + 1 + threadIdx.x; j < n; j += 256) p = min_pair(p, MinPair{D[(size_t)x * n + j], j});
+  p = block_argmin(p, red);
+  if (threadIdx.x == 0) { neighbor[x] = p.v < INFINITY ? p.i : -1; min_dist[x] = p.v; }
+}
+
+// ------------------------------------------------------------------------------------ merge loop (one workgroup)
+__global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, int n, int* __restrict__ size,
+                                                       int* __restrict__ cluster_id, int* __restrict__ neighbor,
+                                                       double* __restrict__ min_dist, double* __restrict__ Z) {
+  __shared__ MinPair red[16];
+  __shared__ int s_x, s_y, s_ok;
+  __shared__ double s_dist;
+  const int tid = threadIdx.x;
+  for (int k = 0; k < n - 1; ++k) {
+    // ---- closest valid candidate pair (lazy validation of the nearest-neighbour guesses) ----
+    for (int it = 0; it < n - k; ++it) {
+      MinPair p{INFINITY, 0x7fffffff};
+      for (int z = tid; z < n - 1; z += 1024)
+        if (size[z] > 0) p = min_pair(p, MinPair{min_dist[z], z});
+      p = block_argmin(p, red);
+      if (tid == 0) {
+        const int x = p.i, y = neighbor[x];
+        s_x = x; s_y = y; s_dist = p.v;
+        s_ok = (y >= 0 && size[y] > 0 && p.v == D[(size_t)x * n + y]) ? 1 : 0;
+      }
+      __syncthreads();
+      if (s_ok) break;
+      const int x = s_x;
+      MinPair q{INFINITY, 0x7fffffff};
+      for (int j = x + 1 + tid; j < n; j += 1024)
+        if (size[j] > 0) q = min_pair(q, MinPair{D[(size_t)x * n + j], j});
+      q = block_argmin(q, red);
+      if (tid == 0) { neighbor[x] = q.v < INFINITY ? q.i : -1; min_dist[x] = q.v; }
+      __syncthreads();
+    }
+    const int x = s_x, y = s_y;
+    const double dist = s_dist;
+    const int nx = size[x], ny = size[y];
+    __syncthreads();
+    if (tid == 0) {
+      int ix = cluster_id[x], iy = cluster_id[y];
+      if (ix > iy) { const int t = ix; ix = iy; iy = t; }
+      Z[4 * (size_t)k + 0] = ix; Z[4 * (size_t)k + 1] = iy; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
+      size[x] = 0; size[y] = nx + ny; cluster_id[y] = n + k;
+      min_dist[x] = INFINITY;
+    }
+    __syncthreads();
+    // ---- one pass over the merged rows: Lance-Williams centroid update, candidate maintenance, and the
+    // new cluster's own nearest neighbour ----
+    const double* rx = D + (size_t)x * n;
+    double* ry = D + (size_t)y * n;
+    const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
+    MinPair best{INFINITY, 0x7fffffff};
+    for (int z = tid; z < n; z += 1024) {
+      if (z == y || size[z] == 0) continue;
+      const double dxi = rx[z], dyi = ry[z];
+      const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - (fx * fy * dist * dist) / fs) / fs);
+      ry[z] = nd;
+      D[(size_t)z * n + y] = nd;
+      if (z < y) {
+        if (z < x && neighbor[z] == x) neighbor[z] = y;
+        if (nd < min_dist[z]) { neighbor[z] = y; min_dist[z] = nd; }
+      } else {
+        best = min_pair(best, MinPair{nd, z});
+      }
+    }
+    best = block_argmin(best, red);
+    if (tid == 0 && y < n - 1) { neighbor[y] = best.v < INFINITY ? best.i : -1; min_dist[y] = best.v; }
+    __syncthreads();
+  }
+}
+
+int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, int* size, int* cluster_id, int* neighbor,
+                     double* min_dist, double* Z) {
+  if (n < 2) return OK;
+  const int t = cdiv(n, 64);
+  hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, s, X, n, d, D);
+  RVB_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
+  RVB_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(linkage_kernel, dim3(1), dim3(1024), 0, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace rvb

@@ -115,6 +115,15 @@ class DiarEngine:
         _check(self.lib.rvd_get_emb_fbank(self._h, int(window), fptr(out), C.byref(n)), "rvd_get_emb_fbank")
         return out[:n.value].copy()
 
+    def centroid_linkage(self, X: np.ndarray) -> np.ndarray:
+        """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") on the GPU (fp64)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        n, d = X.shape
+        Z = np.zeros((max(n - 1, 0), 4), np.float64)
+        f64 = C.POINTER(C.c_double)
+        _check(self.lib.rvd_centroid_linkage(self._h, X.ctypes.data_as(f64), n, d, Z.ctypes.data_as(f64)), "rvd_centroid_linkage")
+        return Z
+
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
         _check(self.lib.rvd_set_profiling(self._h, 1 if on else 0), "rvd_set_profiling")

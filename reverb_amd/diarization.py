@@ -169,10 +169,11 @@ def embedding_masks(binarized: np.ndarray, exclude_overlap: bool, min_num_sample
 
 def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold: float, min_cluster_size: int,
                        method: str = "centroid", num_clusters: Optional[int] = None, min_clusters: Optional[int] = None,
-                       max_clusters: Optional[int] = None):
+                       max_clusters: Optional[int] = None, linkage_fn=None):
     """pyannote.audio.pipelines.clustering.AgglomerativeClustering.__call__ (metric cosine):
     embeddings (chunks, speakers, dim), binarized (chunks, frames, speakers) -> hard_clusters (chunks, speakers),
-    centroids (clusters, dim)."""
+    centroids (clusters, dim).  `linkage_fn(unit_vectors) -> Z` replaces scipy's linkage (the pipeline passes the
+    GPU implementation, DiarEngine.centroid_linkage, which returns the same dendrogram)."""
     from scipy.cluster.hierarchy import fcluster, linkage
     from scipy.spatial.distance import cdist
 
@@ -195,8 +196,12 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
     if n == 1:
         clusters = np.zeros((1,), np.int64)
     else:
-        unit = train / np.linalg.norm(train, axis=-1, keepdims=True)
-        dendrogram = linkage(unit, method=method, metric="euclidean")
+        train32 = train.astype(np.float32)                        # pyannote normalises the float32 embeddings in place,
+        unit = (train32 / np.linalg.norm(train32, axis=-1, keepdims=True)).astype(np.float64)   # scipy then works in fp64
+        if linkage_fn is not None and method == "centroid":
+            dendrogram = linkage_fn(unit)
+        else:
+            dendrogram = linkage(unit, method=method, metric="euclidean")
         clusters = fcluster(dendrogram, threshold, criterion="distance") - 1
         uniq, counts = np.unique(clusters, return_counts=True)
         large = uniq[counts >= mcs]
@@ -400,7 +405,7 @@ class SpeakerDiarization:
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
         hard, centroids = cluster_embeddings(emb, binarized, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
-                                             num_speakers, min_speakers, max_speakers)
+                                             num_speakers, min_speakers, max_speakers, linkage_fn=eng.centroid_linkage)
         t5 = time.perf_counter()
         count = np.minimum(count, ms).astype(np.int8)
         hard = hard.copy()

@@ -178,3 +178,23 @@ def test_embedding_bf16_close_to_oracle(case, emb_case):
     cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
     assert cos[active].min() > 0.995, cos
     eng.close()
+
+
+# ------------------------------------------------------------------------------------ clustering on the GPU
+@pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3)])
+def test_centroid_linkage_matches_scipy(case, n, d, seed):
+    """scipy is what pyannote itself calls; it is installed on the GPU box, so the kernel is pinned to it."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from reverb_amd.diar_engine import DiarEngine
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((5, d))
+    X = centers[rng.integers(5, size=n)] + 0.35 * rng.standard_normal((n, d))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = linkage(X, method="centroid", metric="euclidean")
+    eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
+    got = eng.centroid_linkage(X)
+    eng.close()
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])          # same merges in the same order
+    assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
+    assert np.array_equal(fcluster(got, 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
