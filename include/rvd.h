@@ -61,8 +61,12 @@ int rvd_frames_per_window(const rvd_engine* e);
 /* 16-bit mono PCM at cfg.sample_rate -> HBM; evaluates the sinc filter bank once for all windows */
 int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n_samples);
 
-/* segmentation model on windows [first, first+n): logp_out host fp32 [n][frames][num_classes] */
+/* segmentation model on windows [first, first+n): logp_out host fp32 [n][frames][num_classes] (NULL: keep the
+ * result on the device only) */
 int rvd_segment(rvd_engine* e, int64_t first_window, int n_windows, float* logp_out);
+/* argmax powerset class of every frame of the last rvd_segment (what Powerset.to_multilabel(soft=False) needs):
+ * out host uint8 [n][frames] */
+int rvd_get_classes(rvd_engine* e, uint8_t* out);
 /* debug taps of the last rvd_segment: "sincnet" [n][frames][sinc_channels], "lstm" [n][frames][2*hidden] */
 int rvd_get_tap(rvd_engine* e, const char* name, float* out);
 

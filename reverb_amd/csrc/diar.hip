@@ -342,8 +342,8 @@ int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh
 // ------------------------------------------------------------------------------------ classifier + log-softmax
 template <typename T>
 __global__ __launch_bounds__(256) void classifier_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                         const float* __restrict__ b, float* __restrict__ logp, int64_t M,
-                                                         int in, int C) {
+                                                         const float* __restrict__ b, float* __restrict__ logp,
+                                                         uint8_t* __restrict__ cls, int64_t M, int in, int C) {
   __shared__ float sw[16 * 256];
   for (int i = threadIdx.x; i < C * in; i += 256) sw[i] = w[i];
   __syncthreads();
@@ -374,14 +374,20 @@ __global__ __launch_bounds__(256) void classifier_kernel(const T* __restrict__ x
   const float lse = mx + logf(se);
 #pragma unroll
   for (int c = 0; c < 16; ++c) if (c < C) logp[row * C + c] = acc[c] - lse;
+  if (cls) {                       // argmax class, first index on ties (torch.argmax / np.argmax)
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < 16; ++c) if (c < C && acc[c] > acc[best]) best = c;
+    cls[row] = (uint8_t)best;
+  }
 }
 
 int classifier_logsoftmax(hipStream_t s, int dtype, const void* x, int ldx, const float* w, const float* b, float* logp,
-                          int64_t M, int in, int C) {
+                          uint8_t* cls, int64_t M, int in, int C) {
   if (C > 16 || in > 256 || (in % 8) || (ldx % 8)) { set_error("classifier_logsoftmax: needs C <= 16, in <= 256, in and ldx multiples of 8"); return E_ARG; }
   if (M <= 0) return OK;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(classifier_kernel<bf16_t>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, logp, M, in, C);
-  else hipLaunchKernelGGL(classifier_kernel<float>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const float*)x, ldx, w, b, logp, M, in, C);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(classifier_kernel<bf16_t>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, logp, cls, M, in, C);
+  else hipLaunchKernelGGL(classifier_kernel<float>, dim3(cdiv(M, 256)), dim3(256), 0, s, (const float*)x, ldx, w, b, logp, cls, M, in, C);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -20,7 +20,7 @@ constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 struct ConvW { DevBuf w, b; int cin = 0, cout = 0, taps = 9, stride = 1; };
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
-constexpr int EMB_BATCH = 48;      // windows per trunk pass (activations ~36 MB per window in bf16)
+constexpr int EMB_BATCH = 96;      // windows per trunk pass (activations ~36 MB per window in bf16 -> 3.5 GB)
 }  // namespace
 
 struct rvd_engine {
@@ -48,7 +48,7 @@ struct rvd_engine {
   int64_t n_samples = 0, n_pad = 0, n_windows = 0, craw_frames = 0;
 
   // workspace of rvd_segment
-  DevBuf stats, a1, c2, a2, c3, a3, xproj, hA, hB, l0, l1, logp;
+  DevBuf stats, a1, c2, a2, c3, a3, xproj, hA, hB, l0, l1, logp, cls;
   int last_W = 0;
   const void* last_lstm = nullptr;
 
@@ -282,6 +282,7 @@ int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
   RVD_TRY(e->l0.ensure((size_t)R3 * c.linear_dim * ts));
   RVD_TRY(e->l1.ensure((size_t)R3 * c.linear_dim * ts));
   RVD_TRY(e->logp.ensure((size_t)R3 * c.num_classes * 4));
+  RVD_TRY(e->cls.ensure((size_t)R3));
 
   { DScope sc(e, "window_stats");
     RVD_TRY(window_stats(e->stream, e->wave.as<float>(), first, W, c.step_samples, c.window_samples, 1e-5f, e->stats.as<float>())); }
@@ -322,7 +323,7 @@ int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
   }
   { DScope sc(e, "classifier");
     RVD_TRY(classifier_logsoftmax(e->stream, e->dtype, x, ldx, e->cls_w.as<float>(), e->cls_b.as<float>(), e->logp.as<float>(),
-                                  R3, ldx, c.num_classes)); }
+                                  e->cls.as<uint8_t>(), R3, ldx, c.num_classes)); }
   e->last_W = W;
   if (logp_out) {
     DScope sc(e, "d2h");
@@ -459,7 +460,8 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
   a.in = in; a.w = c.w.p; a.bias = c.b.as<float>(); a.res = res; a.out = out;
   a.B = B; a.Fi = di.F; a.Ti = di.T; a.Cin = c.cin; a.Fo = dq.F; a.To = dq.T; a.Cout = c.cout;
   a.stride = c.stride; a.taps = c.taps; a.relu = relu;
-  DScope sc(e, "emb_conv", 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
+  const std::string nm = std::string(c.taps == 1 ? "emb_conv_sc" : (c.stride == 2 ? "emb_conv_s2_" : "emb_conv_")) + (c.taps == 1 ? "" : std::to_string(c.cout));
+  DScope sc(e, nm.c_str(), 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
   return conv2d(e->stream, e->dtype, a);
 }
 
@@ -467,8 +469,6 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
 int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
   const rvd_model_cfg& c = e->cfg;
   const int fps = c.step_samples / FB_SHIFT;
-  { DScope sc(e, "emb_cmn");
-    RVD_TRY(emb_window_mean(e->stream, e->emb_fb.as<float>(), e->e_win.as<int64_t>(), B, fps, e->nfr, e->e_mean.as<float>())); }
   const StageDims d0 = stage_dims(e, 0);
   { DScope sc(e, "emb_stem", 2.0 * (double)B * d0.F * d0.T * d0.C * 9);
     RVD_TRY(emb_conv1(e->stream, e->dtype, e->emb_fb.as<float>(), e->e_win.as<int64_t>(), e->e_mean.as<float>(), e->stem_w.as<float>(),
@@ -526,7 +526,6 @@ int embed_impl(rvd_engine* e, const int64_t* win, const float* mask, int n, floa
     const int B = (int)uniq.size(), ni = i1 - i0;
     RVD_TRY(ensure_emb_workspace(e, B));
     RVD_TRY(e->e_win.ensure((size_t)B * 8));
-    RVD_TRY(e->e_mean.ensure((size_t)B * FB_MEL * 4));
     RVD_TRY(e->e_item_b.ensure((size_t)ni * 4));
     RVD_TRY(e->e_mask.ensure((size_t)ni * frames * 4));
     RVD_TRY(e->e_stats.ensure((size_t)ni * stats * dt_size(e->dtype)));
@@ -604,7 +603,7 @@ void rvd_destroy(rvd_engine* e) {
   drain(e);
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   DevBuf* bufs[] = {&e->filt, &e->fsum, &e->cls_w, &e->cls_b, &e->stage, &e->pcm, &e->wave, &e->craw, &e->stats, &e->a1, &e->c2,
-                    &e->a2, &e->c3, &e->a3, &e->xproj, &e->hA, &e->hB, &e->l0, &e->l1, &e->logp, &e->conv2.w, &e->conv2.b,
+                    &e->a2, &e->c3, &e->a3, &e->xproj, &e->hA, &e->hB, &e->l0, &e->l1, &e->logp, &e->cls, &e->conv2.w, &e->conv2.b,
                     &e->conv3.w, &e->conv3.b};
   for (auto* b : bufs) b->release();
   for (auto& n : e->norm) { n.g.release(); n.b.release(); }
@@ -669,6 +668,9 @@ int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n) {
     DScope sc(e, "emb_fbank");
     FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};
     RVD_TRY(fbank(e->stream, e->pcm_pad.as<int16_t>(), e->emb_frames, e->emb_fb.as<float>(), t));
+    // per-window CMN means for every window of the file (one block each)
+    RVD_TRY(e->e_mean.ensure((size_t)e->n_windows * FB_MEL * 4));
+    RVD_TRY(emb_window_mean(e->stream, e->emb_fb.as<float>(), nullptr, (int)e->n_windows, c.step_samples / FB_SHIFT, e->nfr, e->e_mean.as<float>()));
   }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   return OK;
@@ -678,6 +680,14 @@ int rvd_segment(rvd_engine* e, int64_t first_window, int n_windows, float* logp_
   if (!e) { set_error("rvd_segment: null engine"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   return segment_impl(e, first_window, n_windows, logp_out);
+}
+
+int rvd_get_classes(rvd_engine* e, uint8_t* out) {
+  if (!e || !out) { set_error("rvd_get_classes: null argument"); return E_ARG; }
+  if (e->last_W <= 0) { set_error("rvd_get_classes: no rvd_segment call yet"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_HIP_CHECK(hipMemcpy(out, e->cls.p, (size_t)e->last_W * e->p3, hipMemcpyDeviceToHost));
+  return OK;
 }
 
 int rvd_get_tap(rvd_engine* e, const char* name, float* out) {

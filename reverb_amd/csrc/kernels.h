@@ -143,9 +143,9 @@ int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a);
 // (forward | reverse) gates i,f,g,o; whh T [2][4H][H]; out T [W*T, 2H].
 int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh, void* out, int W, int T);
 
-// logp[r][:] = log_softmax(x[r].Wc^T + bc)   x T [M, ldx], Wc fp32 [C][in], C <= 16
+// logp[r][:] = log_softmax(x[r].Wc^T + bc)   x T [M, ldx], Wc fp32 [C][in], C <= 16; cls[r] = argmax (nullable)
 int classifier_logsoftmax(hipStream_t s, int dtype, const void* x, int ldx, const float* w, const float* b,
-                          float* logp, int64_t M, int in, int C);
+                          float* logp, uint8_t* cls, int64_t M, int in, int C);
 
 // ---------------------------------------------------------------- resnet.hip (speaker-embedding ResNet34)
 // mean[b][bin] over the nfr fbank frames of window win[b] (frames start at win*frames_per_step)

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void emb_mean_kernel(const float* __restrict__
   __shared__ float red[3][80];
   const int b = blockIdx.x;
   const int bin = threadIdx.x % 80, slot = threadIdx.x / 80;
-  const float* x = fb + (size_t)win[b] * frames_per_step * 80;
+  const float* x = fb + (size_t)(win ? win[b] : (int64_t)b) * frames_per_step * 80;
   float s = 0.f;
   if (slot < 3)
     for (int t = slot; t < nfr; t += 3) s += x[(size_t)t * 80 + bin];
@@ -39,53 +39,80 @@ int emb_window_mean(hipStream_t s, const float* fb, const int64_t* win, int B, i
 
 // ------------------------------------------------------------------------------------ stem: Conv2d(1, C, 3, pad 1) + BN + ReLU
 // input plane x[f][t] = fbank[win*step + t][f] - mean[f] (the (B,T,F) -> (B,1,F,T) permute of the reference is
-// just this indexing); one thread per output pixel, all C (<= 32) channels.
+// just this indexing).  A block owns all F mel bins x 16 frames: the 18 fbank rows it needs are read as
+// contiguous 320-byte rows into LDS (f fastest), the outputs are written t fastest, i.e. 16 pixels x C
+// channels = 1 KiB contiguous runs of the NHWC plane.
+static constexpr int ST_TT = 16, ST_F = 80;
 template <typename T>
 __global__ __launch_bounds__(256) void emb_conv1_kernel(const float* __restrict__ fb, const int64_t* __restrict__ win,
                                                         const float* __restrict__ mean, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ out, int B, int F, int NT_,
                                                         int frames_per_step, int C) {
   __shared__ float sw[32 * 9 + 32];
+  __shared__ float sx[ST_TT + 2][ST_F + 2];
   for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
   for (int i = threadIdx.x; i < C; i += 256) sw[32 * 9 + i] = bias[i];
-  __syncthreads();
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t per = (int64_t)F * NT_;
-  if (idx >= per * B) return;
-  const int b = (int)(idx / per);
-  const int rem = (int)(idx - (int64_t)b * per);
-  const int f = rem / NT_, t = rem - f * NT_;
+  const int tiles_t = (NT_ + ST_TT - 1) / ST_TT;
+  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x - b * tiles_t) * ST_TT;
   const float* x = fb + (size_t)win[b] * frames_per_step * 80;
-  const float* mu = mean + b * 80;
-  float in[9];
+  const float* mu = mean + win[b] * 80;            // per-window CMN means of the whole file (computed at upload)
+  for (int i = threadIdx.x; i < (ST_TT + 2) * (ST_F + 2); i += 256) {
+    const int r = i / (ST_F + 2), cf = i - r * (ST_F + 2);
+    const int tt = t0 + r - 1, ff = cf - 1;
+    sx[r][cf] = (tt >= 0 && tt < NT_ && ff >= 0 && ff < F) ? x[(size_t)tt * 80 + ff] - mu[ff] : 0.f;
+  }
+  __syncthreads();
+  // thread = (8-channel group cg, pixel lane): its 72 weights live in registers for all of its pixels, and the
+  // four threads of a pixel write the four 16-byte pieces of its 64-byte channel run
+  constexpr int CG = 8;
+  const int ngrp = C / CG;                       // 1..4
+  const int cg = threadIdx.x % ngrp, pl = threadIdx.x / ngrp;
+  const int npl = 256 / ngrp;
+  float wr[CG][9], br_[CG];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+  for (int e = 0; e < CG; ++e) {
+    br_[e] = sw[32 * 9 + cg * CG + e];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int ff = f + kh - 1, tt = t + kw - 1;
-      in[kh * 3 + kw] = (ff >= 0 && ff < F && tt >= 0 && tt < NT_) ? x[(size_t)tt * 80 + ff] - mu[ff] : 0.f;
+    for (int k = 0; k < 9; ++k) wr[e][k] = sw[(cg * CG + e) * 9 + k];
+  }
+  for (int pidx = pl; pidx < F * ST_TT; pidx += npl) {
+    const int f = pidx / ST_TT, tl = pidx - f * ST_TT;
+    const int t = t0 + tl;
+    if (t >= NT_) continue;
+    float in[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) in[kh * 3 + kw] = sx[tl + kw][f + kh];
+    float v[CG];
+#pragma unroll
+    for (int e = 0; e < CG; ++e) {
+      float a = br_[e];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = fmaf(in[k], wr[e][k], a);
+      v[e] = fmaxf(a, 0.f);
     }
-  T* o = out + (((size_t)b * (F + 2) + f + 1) * (NT_ + 2) + t + 1) * C;
-  constexpr int VE = 16 / (int)sizeof(T);
-  for (int c0 = 0; c0 < C; c0 += VE) {
-    T v[VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float a = sw[32 * 9 + c0 + e];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) a = fmaf(in[k], sw[(c0 + e) * 9 + k], a);
-      v[e] = Cvt<T>::from_f32(fmaxf(a, 0.f));
+    T* o = out + (((size_t)b * (F + 2) + f + 1) * (NT_ + 2) + t + 1) * C + cg * CG;
+    if constexpr (sizeof(T) == 2) {
+      uint4 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+      pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+      *(uint4*)o = pk;
+    } else {
+      ((float4*)o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      ((float4*)o)[1] = make_float4(v[4], v[5], v[6], v[7]);
     }
-    *(uint4*)(o + c0) = *(const uint4*)v;
   }
 }
 int emb_conv1(hipStream_t s, int dtype, const float* fb, const int64_t* win, const float* mean, const float* w, const float* bias,
               void* out, int B, int F, int NT_, int frames_per_step, int C) {
-  if (C > 32 || C % 8) { set_error("emb_conv1: stem channels must be a multiple of 8, <= 32"); return E_UNSUPPORTED; }
+  if ((C != 8 && C != 16 && C != 32) || F > ST_F) { set_error("emb_conv1: stem channels must be 8, 16 or 32, and at most 80 mel bins"); return E_UNSUPPORTED; }
   if (B <= 0) return OK;
-  const int64_t n = (int64_t)B * F * NT_;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(emb_conv1_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, s, fb, win, mean, w, bias, (bf16_t*)out, B, F, NT_, frames_per_step, C);
-  else hipLaunchKernelGGL(emb_conv1_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, s, fb, win, mean, w, bias, (float*)out, B, F, NT_, frames_per_step, C);
+  const int blocks = B * cdiv(NT_, ST_TT);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(emb_conv1_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, fb, win, mean, w, bias, (bf16_t*)out, B, F, NT_, frames_per_step, C);
+  else hipLaunchKernelGGL(emb_conv1_kernel<float>, dim3(blocks), dim3(256), 0, s, fb, win, mean, w, bias, (float*)out, B, F, NT_, frames_per_step, C);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -93,16 +120,20 @@ int emb_conv1(hipStream_t s, int dtype, const float* fb, const int64_t* win, con
 // ------------------------------------------------------------------------------------ 3x3 / 1x1 convolution on MFMA
 static constexpr int CV_TF = 4, CV_TT = 64, CV_MI = 4;
 
-template <typename T, int NT>
+template <typename T, int NT, int STRIDE>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cv_smem[];
   constexpr int CK = 64 / (int)sizeof(T);     // input channels per 64-byte chunk
   constexpr int VE = Mma16<T>::VE;
   constexpr int NJ = NT / 16;
+  constexpr int s = STRIDE;
+  constexpr int PF = s * (CV_TF - 1) + 3, PT = s * (CV_TT - 1) + 3;
+  constexpr int NPV = PF * PT * 4;                 // 16-byte vectors of the input patch
+  constexpr int PV = (NPV + 255) / 256;            // ... per thread
+  constexpr int BV = (9 * NT * 4 + 255) / 256;     // 16-byte vectors of the 9 taps' weights per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int s = p.stride, taps = p.taps;
-  const int PF = s * (CV_TF - 1) + 3, PT = s * (CV_TT - 1) + 3;
+  const int taps = p.taps;
   char* sP = cv_smem;
   char* sB = cv_smem + ((PF * PT * 64 + 127) & ~127);
 
@@ -114,9 +145,42 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   const int b = bid / tiles_f;
   const int f0 = tf * CV_TF, t0 = tt * CV_TT, n0 = tn * NT;
   const int FiP = p.Fi + 2, TiP = p.Ti + 2;
+  const int nchunks = p.Cin / CK;
 
-  const T* __restrict__ in = (const T*)p.in;
+  const T* __restrict__ in = (const T*)p.in + (size_t)b * FiP * TiP * p.Cin;
   const T* __restrict__ w = (const T*)p.w;
+
+  // per-thread staging coordinates (the same for every channel chunk): global element offset, -1 = zero fill
+  int poff[PV], boff[BV];
+  const int nbvec = taps * NT * 4;
+#pragma unroll
+  for (int i = 0; i < PV; ++i) {
+    const int v = tid + i * 256;
+    const int px = v >> 2, piece = v & 3;
+    const int pf = px / PT, pt = px - pf * PT;
+    const int gf = f0 * s + pf, gt = t0 * s + pt;
+    poff[i] = (v < NPV && gf < FiP && gt < TiP) ? (gf * TiP + gt) * p.Cin + piece * VE : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int v = tid + i * 256;
+    const int row = v >> 2, piece = v & 3;
+    const int tap = row / NT, n = row - tap * NT;
+    boff[i] = v < nbvec ? (tap * nchunks * p.Cout + n0 + n) * CK + piece * VE : -1;
+  }
+  uint4 pr[PV], br[BV];
+  auto load_regs = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < PV; ++i) pr[i] = poff[i] >= 0 ? *(const uint4*)(in + poff[i] + ch * CK) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) br[i] = boff[i] >= 0 ? *(const uint4*)(w + boff[i] + (size_t)ch * p.Cout * CK) : make_uint4(0, 0, 0, 0);
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < PV; ++i) { const int v = tid + i * 256; if (v < NPV) *(uint4*)(sP + v * 16) = pr[i]; }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) { const int v = tid + i * 256; if (v < nbvec) *(uint4*)(sB + v * 16) = br[i]; }
+  };
 
   f32x4_t acc[CV_MI][NJ];
 #pragma unroll
@@ -124,24 +188,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nchunks = p.Cin / CK;
-  const int npvec = PF * PT * 4, nbvec = taps * NT * 4;
+  load_regs(0);
+  store_lds();
+  __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch) __syncthreads();
-    for (int v = tid; v < npvec; v += 256) {
-      const int px = v >> 2, piece = v & 3;
-      const int pf = px / PT, pt = px - pf * PT;
-      const int gf = f0 * s + pf, gt = t0 * s + pt;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (gf < FiP && gt < TiP) val = *(const uint4*)(in + (((size_t)b * FiP + gf) * TiP + gt) * p.Cin + ch * CK + piece * VE);
-      *(uint4*)(sP + px * 64 + piece * 16) = val;
-    }
-    for (int v = tid; v < nbvec; v += 256) {
-      const int row = v >> 2, piece = v & 3;
-      const int tap = row / NT, n = row - tap * NT;
-      *(uint4*)(sB + row * 64 + piece * 16) = *(const uint4*)(w + (((size_t)tap * nchunks + ch) * p.Cout + n0 + n) * CK + piece * VE);
-    }
-    __syncthreads();
+    if (ch + 1 < nchunks) load_regs(ch + 1);      // next chunk's global loads fly under this chunk's MFMAs
     for (int tap = 0; tap < taps; ++tap) {
       const int kh = taps == 9 ? tap / 3 : 1, kw = taps == 9 ? tap - (tap / 3) * 3 : 1;
       uint4 bf[NJ];
@@ -154,6 +205,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) Mma16<T>::run(a, bf[j], acc[mi][j]);
       }
+    }
+    if (ch + 1 < nchunks) {
+      __syncthreads();
+      store_lds();
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -213,14 +269,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int NT>
-static int launch_conv(hipStream_t st, const ConvArgs& p) {
-  const int s = p.stride;
+template <typename T, int NT, int STRIDE>
+static int launch_conv_s(hipStream_t st, const ConvArgs& p) {
+  constexpr int s = STRIDE;
   const int PF = s * (CV_TF - 1) + 3, PT = s * (CV_TT - 1) + 3;
   size_t lds = (size_t)((PF * PT * 64 + 127) & ~127) + (size_t)p.taps * NT * 64;
   const size_t slab = (size_t)4 * 16 * (NT * 4 + 16);
   if (lds < slab) lds = slab;
-  auto kern = conv_kernel<T, NT>;
+  auto kern = conv_kernel<T, NT, STRIDE>;
   static size_t attr = 0;
   if (lds > attr) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -230,6 +286,11 @@ static int launch_conv(hipStream_t st, const ConvArgs& p) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
+}
+
+template <typename T, int NT>
+static int launch_conv(hipStream_t st, const ConvArgs& p) {
+  return p.stride == 2 ? launch_conv_s<T, NT, 2>(st, p) : launch_conv_s<T, NT, 1>(st, p);
 }
 
 int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
@@ -260,8 +321,8 @@ __global__ __launch_bounds__(256) void tstp_kernel(const T* __restrict__ x, cons
                                                    const float* __restrict__ mask, int mask_len, int F, int TT, int C,
                                                    T* __restrict__ stats) {
   __shared__ float sw[256];
-  __shared__ float sv[2];
-  const int it = blockIdx.x;
+  __shared__ float sv[3];
+  const int it = blockIdx.x, f = blockIdx.y;
   const int b = item_b[it];
   const float scale = (float)mask_len / (float)TT;
   for (int t = threadIdx.x; t < TT; t += 256) {
@@ -271,33 +332,37 @@ __global__ __launch_bounds__(256) void tstp_kernel(const T* __restrict__ x, cons
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float v1 = 0.f, v2 = 0.f;
-    for (int t = 0; t < TT; ++t) { v1 += sw[t]; v2 += sw[t] * sw[t]; }
-    v1 += 1e-8f;
-    sv[0] = v1; sv[1] = v1 - v2 / v1 + 1e-8f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < TT; ++t) { s1 += sw[t]; s2 += sw[t] * sw[t]; }
+    const float v1 = s1 + 1e-8f;
+    sv[0] = v1; sv[1] = v1 - s2 / v1 + 1e-8f; sv[2] = s1;
   }
   __syncthreads();
-  const float v1 = sv[0], den = sv[1];
+  const float v1 = sv[0], den = sv[1], s1 = sv[2];
   for (int c = threadIdx.x; c < C; c += 256) {
-    for (int f = 0; f < F; ++f) {
-      const T* xp = x + (((size_t)b * (F + 2) + f + 1) * (TT + 2) + 1) * C + c;
-      float m = 0.f;
-      for (int t = 0; t < TT; ++t) m = fmaf(Cvt<T>::to_f32(xp[(size_t)t * C]), sw[t], m);
-      m /= v1;
-      float q = 0.f;
-      for (int t = 0; t < TT; ++t) { const float d = Cvt<T>::to_f32(xp[(size_t)t * C]) - m; q = fmaf(d * d, sw[t], q); }
-      T* o = stats + (size_t)it * 2 * C * F;
-      o[c * F + f] = Cvt<T>::from_f32(m);
-      o[C * F + c * F + f] = Cvt<T>::from_f32(sqrtf(q / den));
+    const T* xp = x + (((size_t)b * (F + 2) + f + 1) * (TT + 2) + 1) * C + c;
+    double a1 = 0.0, a2 = 0.0;          // sum w x, sum w x^2 (one pass; fp64 keeps the variance exact enough)
+#pragma unroll 5
+    for (int t = 0; t < TT; ++t) {
+      const float v = Cvt<T>::to_f32(xp[(size_t)t * C]);
+      const double wv = (double)sw[t] * v;
+      a1 += wv; a2 += wv * v;
     }
+    const double m = a1 / (double)v1;
+    double q = a2 - 2.0 * m * a1 + m * m * (double)s1;      // = sum w (x - m)^2
+    if (q < 0.0) q = 0.0;
+    T* o = stats + (size_t)it * 2 * C * F;
+    o[c * F + f] = Cvt<T>::from_f32((float)m);
+    o[C * F + c * F + f] = Cvt<T>::from_f32(sqrtf((float)(q / (double)den)));
   }
 }
 int tstp_pool(hipStream_t s, int dtype, const void* x, const int* item_b, const float* mask, int mask_len, int n_items, int F,
               int TT, int C, void* stats) {
   if (TT > 256) { set_error("tstp_pool: more than 256 trunk frames per window"); return E_UNSUPPORTED; }
   if (n_items <= 0) return OK;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(tstp_kernel<bf16_t>, dim3(n_items), dim3(256), 0, s, (const bf16_t*)x, item_b, mask, mask_len, F, TT, C, (bf16_t*)stats);
-  else hipLaunchKernelGGL(tstp_kernel<float>, dim3(n_items), dim3(256), 0, s, (const float*)x, item_b, mask, mask_len, F, TT, C, (float*)stats);
+  const dim3 grid(n_items, F);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(tstp_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, item_b, mask, mask_len, F, TT, C, (bf16_t*)stats);
+  else hipLaunchKernelGGL(tstp_kernel<float>, grid, dim3(256), 0, s, (const float*)x, item_b, mask, mask_len, F, TT, C, (float*)stats);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

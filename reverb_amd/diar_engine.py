@@ -90,13 +90,23 @@ class DiarEngine:
             _check(self.lib.rvd_segment(self._h, first + b0, nb, fptr(out[b0:b0 + nb])), "rvd_segment")
         return out
 
+    def segment_classes(self, first: int = 0, n: Optional[int] = None, batch: int = 4096) -> np.ndarray:
+        """argmax powerset class per frame, uint8 [n, frames] (the log-probabilities stay on the device)."""
+        n = self.n_windows - first if n is None else n
+        out = np.empty((n, self.frames), np.uint8)
+        for b0 in range(0, n, batch):
+            nb = min(batch, n - b0)
+            _check(self.lib.rvd_segment(self._h, first + b0, nb, None), "rvd_segment")
+            _check(self.lib.rvd_get_classes(self._h, out[b0:b0 + nb].ctypes.data_as(C.POINTER(C.c_uint8))), "rvd_get_classes")
+        return out
+
     def tap(self, name: str, n: int) -> np.ndarray:
         width = {"sincnet": self.cfg["sinc_channels"], "lstm": 2 * self.cfg["lstm_hidden"]}[name]
         out = np.empty((n, self.frames, width), np.float32)
         _check(self.lib.rvd_get_tap(self._h, name.encode(), fptr(out)), "rvd_get_tap")
         return out
 
-    def embed(self, windows: np.ndarray, masks: np.ndarray, batch: int = 256) -> np.ndarray:
+    def embed(self, windows: np.ndarray, masks: np.ndarray, batch: int = 1 << 20) -> np.ndarray:
         """one embedding per (window, mask) item: windows int64 [n], masks float32 [n, frames] -> [n, emb_dim]."""
         windows = np.ascontiguousarray(windows, dtype=np.int64)
         masks = np.ascontiguousarray(masks, dtype=np.float32)

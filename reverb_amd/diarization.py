@@ -120,6 +120,14 @@ def powerset_to_multilabel(logp: np.ndarray) -> np.ndarray:
     return mapping[np.argmax(logp, axis=-1)]
 
 
+def classes_to_multilabel(classes: np.ndarray) -> np.ndarray:
+    """Same as powerset_to_multilabel for already-argmaxed class indices (uint8 [chunks, frames])."""
+    mapping = np.zeros((len(POWERSET), 3), np.float32)
+    for k, spk in enumerate(POWERSET):
+        mapping[k, list(spk)] = 1.0
+    return mapping[classes]
+
+
 def closest_frame(t: float, start: float = 0.0) -> int:
     """pyannote.core.SlidingWindow.closest_frame for the model's receptive field."""
     return int(np.rint((t - start - 0.5 * FRAME_DURATION) / FRAME_STEP))
@@ -128,22 +136,26 @@ def closest_frame(t: float, start: float = 0.0) -> int:
 def aggregate(scores: np.ndarray, chunk_step: float, chunk_duration: float, skip_average: bool = False,
               missing: float = 0.0, epsilon: float = 1e-12) -> np.ndarray:
     """pyannote.audio Inference.aggregate(hamming=False, warm_up=(0,0)): overlap-add of per-chunk scores
-    (num_chunks, frames, classes), NaN entries ignored, onto the file-level frame grid."""
+    (num_chunks, frames, classes), NaN entries ignored, onto the file-level frame grid.  The per-chunk
+    `+=` loop of the original is done as one weighted bincount per class (same sums, fp64)."""
     num_chunks, nf, ncls = scores.shape
-    mask = 1.0 - np.isnan(scores)
-    data = np.nan_to_num(scores, copy=True, nan=0.0)
     num_frames = closest_frame(chunk_duration + (num_chunks - 1) * chunk_step + 0.5 * FRAME_DURATION) + 1
-    total = max(num_frames, closest_frame((num_chunks - 1) * chunk_step + 0.5 * FRAME_DURATION) + nf)
+    starts = np.rint((np.arange(num_chunks) * chunk_step) / FRAME_STEP).astype(np.int64)     # closest_frame(c*step + dur/2)
+    total = int(max(num_frames, starts[-1] + nf))
+    idx = (starts[:, None] + np.arange(nf)[None, :]).ravel()
     agg = np.zeros((total, ncls), np.float64)
     cnt = np.zeros((total, ncls), np.float64)
-    seen = np.zeros((total, ncls), np.float64)
-    for c in range(num_chunks):
-        s = closest_frame(c * chunk_step + 0.5 * FRAME_DURATION)
-        agg[s:s + nf] += data[c] * mask[c]
-        cnt[s:s + nf] += mask[c]
-        seen[s:s + nf] = np.maximum(seen[s:s + nf], mask[c])
+    for k in range(ncls):
+        col = scores[:, :, k].ravel()
+        ok = ~np.isnan(col)
+        if ok.all():
+            agg[:, k] = np.bincount(idx, weights=col, minlength=total)
+            cnt[:, k] = np.bincount(idx, minlength=total)
+        else:
+            agg[:, k] = np.bincount(idx[ok], weights=col[ok], minlength=total)
+            cnt[:, k] = np.bincount(idx[ok], minlength=total)
     avg = agg if skip_average else agg / np.maximum(cnt, epsilon)
-    avg[seen == 0.0] = missing
+    avg[cnt == 0.0] = missing
     return avg[:num_frames]
 
 
@@ -151,6 +163,40 @@ def speaker_count(binarized: np.ndarray, chunk_step: float, chunk_duration: floa
     """SpeakerDiarizationMixin.speaker_count: rounded average number of active speakers per frame."""
     count = aggregate(np.sum(binarized, axis=-1, keepdims=True), chunk_step, chunk_duration)
     return np.rint(count).astype(np.uint8)
+
+
+_NSPK = np.array([len(p) for p in POWERSET], np.float64)
+
+
+def speaker_count_from_classes(classes: np.ndarray, chunk_step: float, chunk_duration: float) -> np.ndarray:
+    """speaker_count(classes_to_multilabel(classes)) without materialising the multilabel tensor."""
+    return np.rint(aggregate(_NSPK[classes][:, :, None], chunk_step, chunk_duration)).astype(np.uint8)
+
+
+def embedding_items_from_classes(classes: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
+                                 window_samples: int = 160000):
+    """The (chunk, local speaker) pairs that are active at all, and their pooling masks as
+    embedding_masks() would build them: -> (chunk_idx, speaker_idx, masks float32 [n, frames])."""
+    num_chunks, nf = classes.shape
+    lut = np.zeros((len(POWERSET), 3), bool)
+    for k, spk in enumerate(POWERSET):
+        lut[k, list(spk)] = True
+    counts = np.stack([np.bincount(row, minlength=len(POWERSET)) for row in classes]) if num_chunks < 64 else None
+    if counts is None:
+        flat = classes.astype(np.int64) + len(POWERSET) * np.arange(num_chunks)[:, None]
+        counts = np.bincount(flat.ravel(), minlength=num_chunks * len(POWERSET)).reshape(num_chunks, len(POWERSET))
+    total = counts @ lut.astype(np.int64)                         # frames each local speaker is active in
+    alone = counts[:, 1:4]                                        # ... active alone (classes {s} are 1..3)
+    wi, si = np.nonzero(total > 0)
+    rows = classes[wi]
+    full = lut[rows, si[:, None]]
+    if exclude_overlap:
+        min_num_frames = math.ceil(nf * min_num_samples / window_samples)
+        clean = rows == (si + 1)[:, None].astype(classes.dtype)
+        masks = np.where((alone[wi, si] > min_num_frames)[:, None], clean, full)
+    else:
+        masks = full
+    return wi, si, masks.astype(np.float32)
 
 
 def embedding_masks(binarized: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
@@ -178,8 +224,8 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
     from scipy.spatial.distance import cdist
 
     num_chunks, nspk, dim = embeddings.shape
-    active = np.sum(binarized, axis=1) > 0
-    valid = ~np.any(np.isnan(embeddings), axis=2)
+    active = np.any(binarized > 0, axis=1)
+    valid = ~np.isnan(embeddings[:, :, 0]) & ~np.any(np.isnan(embeddings), axis=2)
     chunk_idx, speaker_idx = np.where(active * valid)
     train = embeddings[chunk_idx, speaker_idx].astype(np.float64)
     n = train.shape[0]
@@ -242,12 +288,18 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
 
     k = int(np.max(clusters)) + 1
     centroids = np.vstack([np.mean(train[clusters == i], axis=0) for i in range(k)])
-    flat = embeddings.reshape(num_chunks * nspk, dim).astype(np.float64)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        e2k = cdist(flat, centroids, metric="cosine").reshape(num_chunks, nspk, k)
-    soft = 2.0 - e2k
-    soft = np.where(np.isnan(soft), -np.inf, soft)
-    hard = np.argmax(soft, axis=2)
+    # assign every (chunk, speaker) embedding to the most similar centroid: soft = 2 - cosine distance; only the
+    # trained pairs have embeddings here (the others are NaN and are marked inactive by the caller)
+    cn = centroids / np.linalg.norm(centroids, axis=1, keepdims=True)
+    sim = (train / np.linalg.norm(train, axis=1, keepdims=True)) @ cn.T          # = 1 - cdist(.., "cosine")
+    hard = np.zeros((num_chunks, nspk), np.int64)
+    hard[chunk_idx, speaker_idx] = np.argmax(sim, axis=1)
+    rest = valid & ~active
+    if rest.any():                                              # valid embeddings of inactive speakers (never trained on)
+        ri, rs = np.nonzero(rest)
+        e = embeddings[ri, rs].astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            hard[ri, rs] = np.argmax(np.nan_to_num((e / np.linalg.norm(e, axis=1, keepdims=True)) @ cn.T, nan=-np.inf), axis=1)
     return hard, centroids
 
 
@@ -257,12 +309,12 @@ def reconstruct(segmentations: np.ndarray, hard_clusters: np.ndarray, count: np.
     most active clusters of frame t are on."""
     num_chunks, nf, _ = segmentations.shape
     k = int(np.max(hard_clusters)) + 1
-    clustered = np.full((num_chunks, nf, max(k, 1)), np.nan)
-    for c in range(num_chunks):
-        for kk in np.unique(hard_clusters[c]):
-            if kk == -2:
-                continue
-            clustered[c, :, kk] = np.max(segmentations[c][:, hard_clusters[c] == kk], axis=1)
+    clustered = np.full((num_chunks, nf, max(k, 1)), np.nan, np.float32)
+    for kk in range(k):                              # max over the local speakers of a chunk mapped to cluster kk
+        for sp in range(segmentations.shape[2]):
+            sel = hard_clusters[:, sp] == kk
+            if sel.any():
+                clustered[sel, :, kk] = np.fmax(clustered[sel, :, kk], segmentations[sel, :, sp])
     act = aggregate(clustered, chunk_step, chunk_duration, skip_average=True)
     max_per_frame = int(np.max(count)) if count.size else 0
     if act.shape[1] < max_per_frame:
@@ -278,35 +330,33 @@ def reconstruct(segmentations: np.ndarray, hard_clusters: np.ndarray, count: np.
 
 def to_annotation(binary: np.ndarray, min_duration_off: float = 0.0, uri: Optional[str] = None) -> Annotation:
     """pyannote.audio.utils.signal.Binarize(onset=offset=0.5) on the 0/1 matrix: one track per speaker turn,
-    turn boundaries at frame middles."""
+    turn boundaries at frame middles (a turn ends at the middle of the first inactive frame, or of the last
+    frame when still active there)."""
     ann = Annotation(uri)
     n = binary.shape[0]
     if n == 0:
         return ann
     ts = np.arange(n) * FRAME_STEP + 0.5 * FRAME_DURATION
     for k in range(binary.shape[1]):
-        col = binary[:, k]
-        regions = []
-        start, is_active = ts[0], col[0] > 0.5
-        t = ts[0]
-        for t, y in zip(ts[1:], col[1:]):
-            if is_active:
-                if y < 0.5:
-                    regions.append([start, t]); start = t; is_active = False
-            elif y > 0.5:
-                start = t; is_active = True
-        if is_active:
-            regions.append([start, t])
+        on = binary[:, k] > 0.5
+        d = np.diff(on.astype(np.int8))
+        starts = list(np.nonzero(d == 1)[0] + 1)
+        ends = list(np.nonzero(d == -1)[0] + 1)
+        if on[0]:
+            starts.insert(0, 0)
+        if on[-1]:
+            ends.append(n - 1)
+        regions = [[ts[a], ts[b]] for a, b in zip(starts, ends)]
         if min_duration_off > 0.0 and regions:       # Annotation.support(collar): bridge short same-speaker gaps
             merged = [regions[0]]
-            for s, e in regions[1:]:
-                if s - merged[-1][1] <= min_duration_off:
-                    merged[-1][1] = max(merged[-1][1], e)
+            for s_, e_ in regions[1:]:
+                if s_ - merged[-1][1] <= min_duration_off:
+                    merged[-1][1] = max(merged[-1][1], e_)
                 else:
-                    merged.append([s, e])
+                    merged.append([s_, e_])
             regions = merged
-        for i, (s, e) in enumerate(regions):
-            ann.add(Segment(float(s), float(e)), f"{k}_{i}", k)
+        for i, (s_, e_) in enumerate(regions):
+            ann.add(Segment(float(s_), float(e_)), f"{k}_{i}", k)
     return ann
 
 
@@ -386,22 +436,21 @@ class SpeakerDiarization:
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
         W = eng.upload(pcm)
         t1 = time.perf_counter()
-        logp = eng.segment()
+        classes = eng.segment_classes()                                       # argmax powerset class, on the GPU
         t2 = time.perf_counter()
-        binarized = powerset_to_multilabel(logp)                              # (W, frames, 3)
-        count = speaker_count(binarized, step, dur)
+        count = speaker_count_from_classes(classes, step, dur)
         if np.max(count) == 0:
             self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, total=time.perf_counter() - t0)
             return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
-        masks = embedding_masks(binarized, bool(self.params["embedding_exclude_overlap"]), 400, self.cfg["window_samples"])
+        # inactive (window, speaker) pairs are never used downstream: only the active ones are embedded
+        wi, si, masks = embedding_items_from_classes(classes, bool(self.params["embedding_exclude_overlap"]), 400, self.cfg["window_samples"])
         t3 = time.perf_counter()
-        nspk = binarized.shape[2]
-        active = masks.sum(axis=2) > 0                                        # inactive (window, speaker) pairs are never used downstream
-        wi, si = np.nonzero(active)
+        nspk = 3
         emb = np.full((W, nspk, self.cfg["emb_dim"]), np.nan, np.float32)
         if wi.size:
-            emb[wi, si] = eng.embed(wi.astype(np.int64), masks[wi, si])
+            emb[wi, si] = eng.embed(wi.astype(np.int64), masks)
         t4 = time.perf_counter()
+        binarized = classes_to_multilabel(classes)                            # (W, frames, 3)
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
         hard, centroids = cluster_embeddings(emb, binarized, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),

@@ -17,6 +17,6 @@ for rep in range(2):
     t0 = time.time(); ann = pipe(wave); dt = time.time() - t0
     print(f"rep {rep}: {hours} h in {dt:.3f} s  RTFx {hours*3600/dt:.0f}  turns {len(ann)} speakers {len(ann.labels())}")
     print("   ", json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()}))
-for k in ("sinc_conv", "pool_norm", "sincnet_conv", "lstm_inproj", "lstm_recurrence", "linear", "classifier", "d2h", "emb_fbank", "emb_cmn", "emb_stem", "emb_conv", "emb_pool", "emb_linear"):
+for k in ("sinc_conv", "pool_norm", "sincnet_conv", "lstm_inproj", "lstm_recurrence", "linear", "classifier", "d2h", "emb_fbank", "emb_cmn", "emb_stem", "emb_conv_32", "emb_conv_64", "emb_conv_128", "emb_conv_256", "emb_conv_s2_64", "emb_conv_s2_128", "emb_conv_s2_256", "emb_conv_sc", "emb_pool", "emb_linear"):
     ms, fl, n = pipe.engine.timing(k)
     print(f"  {k:16s} {ms:9.2f} ms  {n:5d} launches  {fl/ms/1e9 if ms else 0:8.1f} TFLOP/s")

@@ -21,7 +21,7 @@ for rep in range(2):
     emb = eng.embed(wins, masks)
     dt = time.time() - t0
     print(f"rep {rep}: {W} windows, {3*W} embeddings in {1e3*dt:.1f} ms = {1e3*dt/W:.3f} ms/window -> 1 h (3591 windows): {dt/W*3591:.2f} s")
-for k in ("emb_cmn", "emb_stem", "emb_conv", "emb_pool", "emb_linear"):
+for k in ("emb_cmn", "emb_stem", "emb_conv_32", "emb_conv_64", "emb_conv_128", "emb_conv_256", "emb_conv_s2_64", "emb_conv_s2_128", "emb_conv_s2_256", "emb_conv_sc", "emb_pool", "emb_linear"):
     ms, fl, n = eng.timing(k)
     print(f"  {k:12s} {ms:9.2f} ms  {n:5d} launches  {fl/ms/1e9 if ms else 0:8.1f} TFLOP/s")
 print("emb mean abs", float(np.abs(emb).mean()))
