@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[3]: the diarization pipeline (pyannote SincNet+LSTM segmentation, ResNet34
+speaker embeddings, clustering, RTTM turns) on long-form synthetic 16 kHz audio.  Same output contract as
+bench.py; the headline metric of the repo stays bench.py's ASR RTFx -- this is the second workload.
+
+A "step" is one full `pipeline(audio)` call on `--hours` of audio held in host memory (PCM upload
+included): sinc bank + segmentation of every 10 s window (1 s hop) -> powerset classes -> masked ResNet34
+embeddings of every active (window, speaker) -> GPU centroid-linkage clustering -> reconstruction.
+With N > 1 (torchrun, one process per GPU) the windows are sharded in contiguous ranges and ONE RCCL
+all-gather moves classes + embeddings (reverb_amd/dist.py:diarize_sharded); strong scaling (one file).
+
+  python bench_diar.py --steps 3 --warmup 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+CONV_KEYS = ("emb_conv_32", "emb_conv_64", "emb_conv_128", "emb_conv_256", "emb_conv_s2_64", "emb_conv_s2_128",
+             "emb_conv_s2_256", "emb_conv_sc")
+STAGE_KEYS = ("h2d", "sinc_conv", "window_stats", "pool_norm", "sincnet_conv", "lstm_inproj", "lstm_recurrence", "linear",
+              "classifier", "emb_fbank", "emb_stem") + CONV_KEYS + ("emb_pool", "emb_linear", "linkage")
+
+
+def cpu_baseline(cfg, seg_sd, emb_sd, pcm, n_windows):
+    """The oracle (oracle/diar_ref.py: torch restatement of PyanNet + WeSpeaker ResNet34, i.e. what pyannote runs on
+    CPU) on the first windows, the ResNet once per (window, local speaker) as pyannote does."""
+    import torch
+    from oracle import diar_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    win, step = cfg["window_samples"], cfg["step_samples"]
+    wav = torch.from_numpy(pcm[: (n_windows - 1) * step + win].astype(np.float32) / 32768.0)
+    x = torch.stack([wav[w * step:w * step + win] for w in range(n_windows)])[:, None]
+    ssd, esd = R.to_torch_sd(seg_sd), R.to_torch_sd(emb_sd)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        logp = R.pyannet(ssd, x)
+        ml = torch.from_numpy(R.powerset_to_multilabel(logp))
+        for w in range(n_windows):
+            feats = torch.from_numpy(R.hamming_fbank(x[w, 0].numpy()))[None].repeat(3, 1, 1)
+            R.wespeaker_embed(esd, feats, ml[w].T.contiguous())
+    dt = time.perf_counter() - t0
+    return {"value": round(n_windows * (step / cfg["sample_rate"]) / dt, 3), "unit": "audio-sec/wall-sec", "cores": cores,
+            "kind": "port", "sample": f"{n_windows} windows of 10 s (1 s hop = {n_windows} s of new audio): segmentation + 3 ResNet34 "
+                                      f"passes per window, torch fp32, {dt:.1f} s; clustering not included"}
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--hours", type=float, default=1.0)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--cpu-baseline-windows", type=int, default=6)
+    args = p.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_diar.py needs an MI355X: the networks have no CPU fallback")
+    device = torch.device("cuda", local_rank)
+
+    from reverb_amd import diarization as D, synth_diar as SD
+    from reverb_amd.dist import diarize_sharded
+    cfg = SD.make_diar_config()
+    seg_sd, emb_sd = SD.make_segmentation_sd(cfg, 0), SD.make_embedding_sd(cfg, 0)
+    pipe = D.SpeakerDiarization(cfg, seg_sd, emb_sd, None, dtype=args.dtype).to(device)
+    base = SD.synth_conversation(120.0)
+    n = int(args.hours * 3600 * 16000)
+    pcm = np.tile(base, n // len(base) + 1)[:n]
+    # de-duplicate the tiles: +-3 LSB of noise, so that no two windows (and no two embeddings) are bit-identical
+    pcm = (pcm.astype(np.int32) + np.random.default_rng(7 + rank).integers(-3, 4, size=n)).clip(-32768, 32767).astype(np.int16)
+
+    def step():
+        if world > 1:
+            return diarize_sharded(pipe, pcm, device, uri="bench")
+        return pipe({"waveform": pcm, "sample_rate": 16000, "uri": "bench"})
+
+    for _ in range(args.warmup):
+        step()
+    eng = pipe.engine
+    eng.reset_timings(); eng.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ann = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profiling(False)
+    if rank == 0:
+        conv = [eng.timing(k) for k in CONV_KEYS]
+        ms, fl, launches = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
+        ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+        out = {
+            "metric": "RTFx (audio-sec/wall-sec) diarization pipeline (pyannote segmentation + ResNet34 embeddings + clustering)",
+            "value": round(args.hours * 3600 * args.steps / dt, 2), "unit": "audio-sec/wall-sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"diarization of one {args.hours:g} h 16 kHz recording: {eng.num_windows(n)} windows of 10 s / 1 s hop, "
+                                   "PyanNet segmentation (SincNet + 4xBiLSTM128), WeSpeaker ResNet34 embeddings, centroid linkage, "
+                                   "synthetic weights", "parallelism": f"window-shard x{world}",
+                       "turns": len(ann), "speakers": len(ann.labels())},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                         "kernel": "rvb::conv_kernel (all ResNet34 3x3/1x1 convolutions of the timed steps, rank 0)",
+                         "launches": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
+                         "flops_per_launch": round(fl / max(launches, 1), 1)},
+            "stage_ms_per_step": {k: round(eng.timing(k)[0] / args.steps, 3) for k in STAGE_KEYS},
+            "host_s_last_step": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()},
+        }
+        out["cpu_baseline"] = cpu_baseline(cfg, seg_sd, emb_sd, pcm, args.cpu_baseline_windows) if (world == 1 and args.cpu_baseline_windows > 0) else None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

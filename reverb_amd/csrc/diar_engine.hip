@@ -719,7 +719,7 @@ int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_fram
 
 int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z) {
   if (!e || !X || !Z || n < 1 || d < 1) { set_error("rvd_centroid_linkage: bad argument"); return E_ARG; }
-  if (n > 46000) { set_error("rvd_centroid_linkage: more than 46000 points"); return E_UNSUPPORTED; }
+  if (n > 46000) { set_error("rvd_centroid_linkage: more than 46000 points"); return E_UNSUPPORTED; }   // n^2 index and uint16 sizes
   if (n == 1) return OK;
   RVB_HIP_CHECK(hipSetDevice(e->device));
   DevBuf dX, dD, dI, dM, dZ;
@@ -730,8 +730,8 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     if ((rc = dI.ensure((size_t)3 * n * 4)) != OK) break;
     if ((rc = dM.ensure((size_t)n * 8)) != OK) break;
     if ((rc = dZ.ensure((size_t)(n - 1) * 4 * 8)) != OK) break;
-    std::vector<int> init((size_t)3 * n);
-    for (int i = 0; i < n; ++i) { init[i] = 1; init[n + i] = i; init[2 * n + i] = -1; }
+    std::vector<int> init((size_t)3 * n);     // [cluster_id | neighbor | size as uint16]
+    for (int i = 0; i < n; ++i) { init[i] = i; init[n + i] = -1; ((uint16_t*)&init[2 * (size_t)n])[i] = 1; }
     std::vector<double> inf(n, INFINITY);
     hipMemcpyAsync(dX.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, e->stream);
     hipMemcpyAsync(dI.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, e->stream);
@@ -739,14 +739,28 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     hipStreamSynchronize(e->stream);
     {
       DScope sc(e, "linkage");
-      rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), dI.as<int>(), dI.as<int>() + n, dI.as<int>() + 2 * n,
-                            dM.as<double>(), dZ.as<double>());
+      rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), (uint16_t*)(dI.as<int>() + 2 * n), dI.as<int>(),
+                            dI.as<int>() + n, dM.as<double>(), dZ.as<double>());
     }
     if (rc != OK) break;
     if (hipMemcpyAsync(Z, dZ.p, (size_t)(n - 1) * 4 * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess) {
       set_error(std::string("rvd_centroid_linkage: ") + hipGetErrorString(hipGetLastError()));
       rc = E_HIP;
+      break;
+    }
+    { double retries = 0.0;
+      hipMemcpy(&retries, dM.as<double>() + (n - 1), 8, hipMemcpyDeviceToHost);
+      e->prof["linkage"].flops += retries; }      // reported through rvd_get_timing("linkage").flops
+    // slots -> scipy cluster ids: the merged cluster lives on in slot y under the new id n + k
+    std::vector<int> cid(n);
+    for (int i = 0; i < n; ++i) cid[i] = i;
+    for (int k = 0; k < n - 1; ++k) {
+      const int x = (int)Z[4 * (size_t)k], y = (int)Z[4 * (size_t)k + 1];
+      const int ix = cid[x], iy = cid[y];
+      Z[4 * (size_t)k] = ix < iy ? ix : iy;
+      Z[4 * (size_t)k + 1] = ix < iy ? iy : ix;
+      cid[y] = n + k;
     }
   } while (0);
   dX.release(); dD.release(); dI.release(); dM.release(); dZ.release();

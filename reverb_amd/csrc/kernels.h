@@ -176,9 +176,9 @@ int tstp_pool(hipStream_t s, int dtype, const void* x, const int* item_b, const 
 
 // ---------------------------------------------------------------- linkage.hip
 // scipy.cluster.hierarchy.linkage(X, "centroid", "euclidean") for X fp64 [n][d] (device): Z fp64 [n-1][4] in merge
-// order.  Scratch (device): D [n*n] doubles, size/cluster_id (initialised to 1 / arange) and neighbor [n] ints,
-// min_dist [n] doubles.
-int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, int* size, int* cluster_id, int* neighbor,
+// order.  Scratch (device): D [n*n] doubles, size [n] uint16 (initialised to 1), cluster_id [n] (arange) and
+// neighbor [n] ints, min_dist [n] doubles.
+int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
                      double* min_dist, double* Z);
 
 }  // namespace rvb

@@ -91,45 +91,62 @@ __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------ merge loop (one workgroup)
-__global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, int n, int* __restrict__ size,
-                                                       int* __restrict__ cluster_id, int* __restrict__ neighbor,
-                                                       double* __restrict__ min_dist, double* __restrict__ Z) {
+// LDS_STATE: the per-cluster state (candidate distance fp64, candidate neighbour, cluster size) lives in LDS
+// (14 bytes per point: up to ~11 500 points = one hour of audio at 3 speakers per hop), so an iteration
+// touches HBM/L2 only for the validity check D[x][y] and for the two merged rows.
+template <bool LDS_STATE>
+__global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
+                                                       int* __restrict__ cluster_id, int* __restrict__ g_neighbor,
+                                                       double* __restrict__ g_min_dist, double* __restrict__ Z) {
+  extern __shared__ __attribute__((aligned(16))) char lk_smem[];
   __shared__ MinPair red[16];
   __shared__ int s_x, s_y, s_ok;
   __shared__ double s_dist;
+  double* s_md = (double*)lk_smem;
+  int* s_nb = (int*)(s_md + (LDS_STATE ? n : 0));
+  uint16_t* s_sz = (uint16_t*)(s_nb + (LDS_STATE ? n : 0));
+  auto MD = [&](int i) -> double& { if constexpr (LDS_STATE) return s_md[i]; else return g_min_dist[i]; };
+  auto NB = [&](int i) -> int& { if constexpr (LDS_STATE) return s_nb[i]; else return g_neighbor[i]; };
+  auto SZ = [&](int i) -> uint16_t& { if constexpr (LDS_STATE) return s_sz[i]; else return g_size[i]; };
   const int tid = threadIdx.x;
+  long long retries = 0;
+  if (LDS_STATE) {
+    for (int i = tid; i < n; i += 1024) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }
+    __syncthreads();
+  }
   for (int k = 0; k < n - 1; ++k) {
     // ---- closest valid candidate pair (lazy validation of the nearest-neighbour guesses) ----
     for (int it = 0; it < n - k; ++it) {
       MinPair p{INFINITY, 0x7fffffff};
       for (int z = tid; z < n - 1; z += 1024)
-        if (size[z] > 0) p = min_pair(p, MinPair{min_dist[z], z});
+        if (SZ(z) > 0) p = min_pair(p, MinPair{MD(z), z});
       p = block_argmin(p, red);
       if (tid == 0) {
-        const int x = p.i, y = neighbor[x];
+        const int x = p.i, y = NB(x);
         s_x = x; s_y = y; s_dist = p.v;
-        s_ok = (y >= 0 && size[y] > 0 && p.v == D[(size_t)x * n + y]) ? 1 : 0;
+        s_ok = (y >= 0 && SZ(y) > 0 && p.v == D[(size_t)x * n + y]) ? 1 : 0;
       }
       __syncthreads();
       if (s_ok) break;
+      ++retries;
       const int x = s_x;
       MinPair q{INFINITY, 0x7fffffff};
       for (int j = x + 1 + tid; j < n; j += 1024)
-        if (size[j] > 0) q = min_pair(q, MinPair{D[(size_t)x * n + j], j});
+        if (SZ(j) > 0) q = min_pair(q, MinPair{D[(size_t)x * n + j], j});
       q = block_argmin(q, red);
-      if (tid == 0) { neighbor[x] = q.v < INFINITY ? q.i : -1; min_dist[x] = q.v; }
+      if (tid == 0) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; }
       __syncthreads();
     }
     const int x = s_x, y = s_y;
     const double dist = s_dist;
-    const int nx = size[x], ny = size[y];
+    const int nx = SZ(x), ny = SZ(y);
     __syncthreads();
     if (tid == 0) {
-      int ix = cluster_id[x], iy = cluster_id[y];
-      if (ix > iy) { const int t = ix; ix = iy; iy = t; }
-      Z[4 * (size_t)k + 0] = ix; Z[4 * (size_t)k + 1] = iy; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
-      size[x] = 0; size[y] = nx + ny; cluster_id[y] = n + k;
-      min_dist[x] = INFINITY;
+      SZ(x) = 0; SZ(y) = (uint16_t)(nx + ny);
+      MD(x) = INFINITY;
+    }
+    if (tid == 64) {      // dendrogram row as (slot x, slot y): stores only; the host turns slots into cluster ids
+      Z[4 * (size_t)k + 0] = x; Z[4 * (size_t)k + 1] = y; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
     }
     __syncthreads();
     // ---- one pass over the merged rows: Lance-Williams centroid update, candidate maintenance, and the
@@ -137,27 +154,29 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
     const double* rx = D + (size_t)x * n;
     double* ry = D + (size_t)y * n;
     const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
+    const double sub = (fx * fy * dist * dist) / fs;
     MinPair best{INFINITY, 0x7fffffff};
     for (int z = tid; z < n; z += 1024) {
-      if (z == y || size[z] == 0) continue;
+      if (z == y || SZ(z) == 0) continue;
       const double dxi = rx[z], dyi = ry[z];
-      const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - (fx * fy * dist * dist) / fs) / fs);
+      const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) / fs);
       ry[z] = nd;
       D[(size_t)z * n + y] = nd;
       if (z < y) {
-        if (z < x && neighbor[z] == x) neighbor[z] = y;
-        if (nd < min_dist[z]) { neighbor[z] = y; min_dist[z] = nd; }
+        if (z < x && NB(z) == x) NB(z) = y;
+        if (nd < MD(z)) { NB(z) = y; MD(z) = nd; }
       } else {
         best = min_pair(best, MinPair{nd, z});
       }
     }
     best = block_argmin(best, red);
-    if (tid == 0 && y < n - 1) { neighbor[y] = best.v < INFINITY ? best.i : -1; min_dist[y] = best.v; }
+    if (tid == 0 && y < n - 1) { NB(y) = best.v < INFINITY ? best.i : -1; MD(y) = best.v; }
     __syncthreads();
   }
+  if (tid == 0) g_min_dist[n - 1] = (double)retries;     // statistics: invalid candidates re-evaluated (slot n-1 is unused)
 }
 
-int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, int* size, int* cluster_id, int* neighbor,
+int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
                      double* min_dist, double* Z) {
   if (n < 2) return OK;
   const int t = cdiv(n, 64);
@@ -165,7 +184,17 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, in
   RVB_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
   RVB_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(linkage_kernel, dim3(1), dim3(1024), 0, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+  const size_t lds = (size_t)n * 14 + 16;
+  if (lds <= 158 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(linkage_kernel<true>, dim3(1), dim3(1024), lds, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+  } else {
+    hipLaunchKernelGGL(linkage_kernel<false>, dim3(1), dim3(1024), 0, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+  }
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

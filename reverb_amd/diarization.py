@@ -426,36 +426,43 @@ class SpeakerDiarization:
             pcm = np.clip(np.rint(pcm.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
         return pcm, os.path.splitext(os.path.basename(path))[0]
 
-    def __call__(self, file, num_speakers: Optional[int] = None, min_speakers: Optional[int] = None,
-                 max_speakers: Optional[int] = None, return_embeddings: bool = False):
+    def networks(self, pcm: np.ndarray):
+        """The GPU part on one recording (or one rank's slice of it): argmax powerset classes per window frame
+        (uint8 [W, frames]) and one embedding per active (window, local speaker) pair (float32 [W, 3, dim], NaN
+        where the speaker is inactive)."""
         import time
-        t0 = time.perf_counter()
-        pcm, uri = self._load(file)
         eng = self.engine
-        step = self.cfg["step_samples"] / self.cfg["sample_rate"]
-        dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
+        t0 = time.perf_counter()
         W = eng.upload(pcm)
         t1 = time.perf_counter()
-        classes = eng.segment_classes()                                       # argmax powerset class, on the GPU
+        classes = eng.segment_classes()                                       # argmax on the GPU
         t2 = time.perf_counter()
-        count = speaker_count_from_classes(classes, step, dur)
-        if np.max(count) == 0:
-            self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, total=time.perf_counter() - t0)
-            return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
         # inactive (window, speaker) pairs are never used downstream: only the active ones are embedded
         wi, si, masks = embedding_items_from_classes(classes, bool(self.params["embedding_exclude_overlap"]), 400, self.cfg["window_samples"])
         t3 = time.perf_counter()
-        nspk = 3
-        emb = np.full((W, nspk, self.cfg["emb_dim"]), np.nan, np.float32)
+        emb = np.full((W, 3, self.cfg["emb_dim"]), np.nan, np.float32)
         if wi.size:
             emb[wi, si] = eng.embed(wi.astype(np.int64), masks)
         t4 = time.perf_counter()
+        self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, windows=W, embeddings=int(wi.size))
+        return classes, emb
+
+    def finish(self, classes: np.ndarray, emb: np.ndarray, uri: Optional[str], num_speakers: Optional[int] = None,
+               min_speakers: Optional[int] = None, max_speakers: Optional[int] = None, return_embeddings: bool = False):
+        """The host part: speaker count, clustering (linkage on the GPU), reconstruction, RTTM turns."""
+        import time
+        t0 = time.perf_counter()
+        step = self.cfg["step_samples"] / self.cfg["sample_rate"]
+        dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
+        count = speaker_count_from_classes(classes, step, dur)
+        if np.max(count) == 0:
+            return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
         binarized = classes_to_multilabel(classes)                            # (W, frames, 3)
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
         hard, centroids = cluster_embeddings(emb, binarized, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
-                                             num_speakers, min_speakers, max_speakers, linkage_fn=eng.centroid_linkage)
-        t5 = time.perf_counter()
+                                             num_speakers, min_speakers, max_speakers, linkage_fn=self.engine.centroid_linkage)
+        t1 = time.perf_counter()
         count = np.minimum(count, ms).astype(np.int8)
         hard = hard.copy()
         hard[np.sum(binarized, axis=1) == 0] = -2
@@ -463,12 +470,21 @@ class SpeakerDiarization:
         ann = to_annotation(binary, float(self.params["segmentation"].get("min_duration_off", 0.0)), uri)
         mapping = {label: f"SPEAKER_{i:02d}" for i, label in enumerate(ann.labels())}
         ann = ann.rename_labels(mapping)
-        t6 = time.perf_counter()
-        self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, clustering=t5 - t4,
-                            reconstruction=t6 - t5, total=t6 - t0, windows=W, embeddings=int(wi.size))
+        t2 = time.perf_counter()
+        self.timings.update(clustering=t1 - t0, reconstruction=t2 - t1)
         if return_embeddings:
             return ann, centroids
         return ann
+
+    def __call__(self, file, num_speakers: Optional[int] = None, min_speakers: Optional[int] = None,
+                 max_speakers: Optional[int] = None, return_embeddings: bool = False):
+        import time
+        t0 = time.perf_counter()
+        pcm, uri = self._load(file)
+        classes, emb = self.networks(pcm)
+        out = self.finish(classes, emb, uri, num_speakers, min_speakers, max_speakers, return_embeddings)
+        self.timings["total"] = time.perf_counter() - t0
+        return out
 
     apply = __call__
 

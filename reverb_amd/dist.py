@@ -110,3 +110,53 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
         nf = engine.fbank()
         local = engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
     return {m: all_gather_results(local[m], device) for m in modes}
+
+
+# ------------------------------------------------------------------------------------------------ diarization
+def window_sample_range(n_samples: int, window: int, step: int, w0: int, w1: int) -> Tuple[int, int]:
+    """Samples a rank needs for diarization windows [w0, w1): window w covers [w*step, w*step + window); the
+    slice ends where the last window ends, or at the end of the file (the zero-padded tail window)."""
+    if w1 <= w0:
+        return 0, 0
+    return w0 * step, min(n_samples, (w1 - 1) * step + window)
+
+
+def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
+    """Diarize one long recording with the 10 s windows of pyannote's sliding inference split into contiguous
+    ranges, one per rank (one process per GPU).  Both networks run on the rank's own windows with no data-path
+    collective; one all-gather then brings the per-window powerset classes (uint8, 589 B per window) and the
+    speaker embeddings (3 x 256 fp32 per window) to every rank, and the global part -- speaker count,
+    clustering, reconstruction -- runs identically everywhere.  Returns the Annotation on every rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cfg = pipeline.cfg
+    win, step = int(cfg["window_samples"]), int(cfg["step_samples"])
+    n = len(pcm)
+    full = (n - win) // step + 1 if n >= win else 0
+    n_windows = full + (1 if (n < win or (n - win) % step > 0) else 0)
+    ranges = chunk_ranges(n_windows, world)
+    w0, w1 = ranges[rank]
+    frames = None
+    if w1 > w0:
+        s0, s1 = window_sample_range(n, win, step, w0, w1)
+        classes, emb = pipeline.networks(pcm[s0:s1])
+        assert classes.shape[0] == w1 - w0, (classes.shape, w0, w1)
+        frames = classes.shape[1]
+    fr = torch.tensor([frames or 0], device=device, dtype=torch.int64)
+    dist.all_reduce(fr, op=dist.ReduceOp.MAX)
+    frames = int(fr.item())
+    dim = int(cfg["emb_dim"])
+    kmax = max(b - a for a, b in ranges)
+    pc = np.zeros((kmax, frames), np.uint8)
+    pe = np.full((kmax, 3, dim), np.nan, np.float32)
+    if w1 > w0:
+        pc[:w1 - w0], pe[:w1 - w0] = classes, emb
+    tc, te = torch.from_numpy(pc).to(device), torch.from_numpy(pe).to(device)
+    gc = [torch.empty_like(tc) for _ in range(world)]
+    ge = [torch.empty_like(te) for _ in range(world)]
+    dist.all_gather(gc, tc)
+    dist.all_gather(ge, te)
+    all_c = np.concatenate([gc[r].cpu().numpy()[:b - a] for r, (a, b) in enumerate(ranges)])
+    all_e = np.concatenate([ge[r].cpu().numpy()[:b - a] for r, (a, b) in enumerate(ranges)])
+    return pipeline.finish(all_c, all_e, uri, **kwargs)
