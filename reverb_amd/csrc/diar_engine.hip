@@ -609,6 +609,12 @@ void rvd_destroy(rvd_engine* e) {
   for (auto& n : e->norm) { n.g.release(); n.b.release(); }
   for (auto& l : e->lstm) { l.ih.w.release(); l.ih.b.release(); l.whh.release(); }
   for (auto& l : e->lin) { l.w.release(); l.b.release(); }
+  DevBuf* ebufs[] = {&e->stem_w, &e->stem_b, &e->seg1.w, &e->seg1.b, &e->fb_window, &e->fb_twiddle, &e->fb_melw, &e->fb_lo, &e->fb_hi,
+                     &e->pcm_pad, &e->emb_fb, &e->e_win, &e->e_mean, &e->e_item_b, &e->e_mask, &e->e_stats, &e->e_out};
+  for (auto* b : ebufs) b->release();
+  for (auto& st : e->stages)
+    for (auto& blk : st) { blk.c1.w.release(); blk.c1.b.release(); blk.c2.w.release(); blk.c2.b.release(); blk.sc.w.release(); blk.sc.b.release(); }
+  for (auto& row : e->act) for (auto& b : row) b.release();
   hipStreamDestroy(e->stream);
   delete e;
 }
