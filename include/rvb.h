@@ -106,6 +106,13 @@ int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int3
  * Per chunk: index of the winning hypothesis, its score (fp32 accumulation as the reference),
  * confidence, and per-token confidences [max_len] of the winner. */
 int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight);
+/* `attention` mode (asr/wenet/transformer/search.py:251-360): autoregressive beam search with the left decoder on
+ * the chunks of the last rvb_encode; per-hypothesis K/V caches on the device, beam bookkeeping on the host in float32
+ * as the reference does.  Runs until every beam ended with <eos> or for encoder-frames steps. */
+int rvb_attention_decode(rvb_engine* e, int beam, float length_penalty);
+/* best hypothesis of one chunk without <sos>/<eos>; `tokens` needs room for rvb_encoder_frames() entries */
+int rvb_get_attention_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* n_tokens, float* score);
+
 int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence,
                      double* tokens_confidence /* [len of best] */);
 /* all chunks of the batch at once: the winning hypothesis of each chunk, arrays padded to [B][T]

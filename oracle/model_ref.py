@@ -222,6 +222,45 @@ def decoder_forward(sd: SD, cfg: dict, side: str, memory, memory_mask, ys_in, ys
     return _lin(sd, p + ".output_layer", x)
 
 
+def decoder_step(sd: SD, cfg: dict, side: str, memory, memory_mask, tok, pos: int, cache, cat_embs):
+    """One autoregressive position of decoder_forward for every row (decoder.py:191-234 computes the same thing
+    from cached layer outputs; here the cache holds each layer's self-attention keys/values, which is the same
+    function of the prefix).  tok (R,) int64, cache: list of [k, v] per layer or None.  -> logits (R, V), cache."""
+    dc = cfg["decoder_conf"]
+    h = dc["attention_heads"]
+    p = f"decoder.{side}"
+    d = sd[p + ".embed.0.weight"].shape[1]
+    dk = d // h
+    R = tok.shape[0]
+    x = F.embedding(tok, sd[p + ".embed.0.weight"]) * math.sqrt(d) + sinusoid_pe(pos + 1, d)[pos].unsqueeze(0)   # (R, d)
+    new_cache = []
+    j = 0
+    while (p + f".decoders.{j}.norm1.weight") in sd:
+        q = p + f".decoders.{j}"
+        is_lsl = (q + ".language_layers.0.weight") in sd
+        eps = 1e-12 if is_lsl else 1e-5
+        t = _ln(sd, q + ".norm1", x, eps)
+        k_new = _lin(sd, q + ".self_attn.linear_k", t).view(R, h, 1, dk)
+        v_new = _lin(sd, q + ".self_attn.linear_v", t).view(R, h, 1, dk)
+        if cache is not None:
+            k_all, v_all = torch.cat([cache[j][0], k_new], 2), torch.cat([cache[j][1], v_new], 2)
+        else:
+            k_all, v_all = k_new, v_new
+        new_cache.append([k_all, v_all])
+        qq = _lin(sd, q + ".self_attn.linear_q", t).view(R, h, 1, dk)
+        att = torch.softmax(torch.matmul(qq, k_all.transpose(-2, -1)) / math.sqrt(dk), dim=-1)
+        o = torch.matmul(att, v_all).transpose(1, 2).reshape(R, d)
+        x = x + _lin(sd, q + ".self_attn.linear_out", o)
+        x = x + mha(sd, q + ".src_attn", _ln(sd, q + ".norm2", x, eps).unsqueeze(1), memory, memory_mask, h).squeeze(1)
+        z = _ln(sd, q + ".norm3", x, eps)
+        if is_lsl:
+            z = lsl_mix(sd, q, z, cat_embs)
+        x = x + ffn(sd, q + ".feed_forward", z, F.relu)
+        j += 1
+    x = _ln(sd, p + ".after_norm", x, 1e-5)
+    return _lin(sd, p + ".output_layer", x), new_cache
+
+
 def reverse_hyps(hyps: torch.Tensor, hyps_lens: torch.Tensor, eos: int) -> torch.Tensor:
     """asr_model.py:896-953: right-to-left decoder input built from sos-prefixed hyps."""
     r_lens = hyps_lens - 1

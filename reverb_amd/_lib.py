@@ -57,6 +57,8 @@ SIGNATURES = {
     "rvb_get_nbest_count": (C.c_int, [_eng, C.c_int, _i32p, _i32p]),
     "rvb_get_nbest": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "rvb_attention_rescore": (C.c_int, [_eng, C.c_double, C.c_double]),
+    "rvb_attention_decode": (C.c_int, [_eng, C.c_int, C.c_float]),
+    "rvb_get_attention_result": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _f32p]),
     "rvb_get_rescored": (C.c_int, [_eng, C.c_int, _i32p, _f32p, _f64p, _f64p]),
     "rvb_get_rescored_batch": (C.c_int, [_eng, _i32p, _i32p, _i32p, _i32p, _f32p, _f64p, _f64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),

@@ -280,4 +280,25 @@ int convert_f32(hipStream_t s, int dtype, const float* src, void* dst, size_t n)
   return OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// beam reorder of a per-hypothesis cache: dst[r][t][:] = src[parent[r]][t][:] for t < rows
+// (search.py:307-312 `torch.index_select(c, dim=0, index=cache_index)`); row_bytes % 16 == 0
+__global__ __launch_bounds__(256) void gather_cache_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                           const int* __restrict__ parent, int L, int rows, int row_bytes) {
+  const int r = blockIdx.y;
+  const size_t so = (size_t)parent[r] * L * row_bytes, dof = (size_t)r * L * row_bytes;
+  const int nvec = rows * (row_bytes / 16);
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nvec; v += gridDim.x * 256)
+    ((uint4*)(dst + dof))[v] = ((const uint4*)(src + so))[v];
+}
+int gather_cache(hipStream_t s, const void* src, void* dst, const int* parent, int R, int L, int rows, int row_bytes) {
+  if (R <= 0 || rows <= 0) return OK;
+  if (row_bytes % 16) { set_error("gather_cache: rows must be multiples of 16 bytes"); return E_ARG; }
+  const int nvec = rows * (row_bytes / 16);
+  dim3 grid(cdiv(nvec, 256) < 8 ? cdiv(nvec, 256) : 8, R);
+  hipLaunchKernelGGL(gather_cache_kernel, grid, dim3(256), 0, s, (const char*)src, (char*)dst, parent, L, rows, row_bytes);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 }  // namespace rvb

@@ -102,6 +102,10 @@ struct rvb_engine {
   const int* cur_lens = nullptr;   // device pointer: valid encoder frames of the slice being encoded
   std::vector<rvb::PrefixResult> nbest;
   std::vector<rvb::RescoreResult> rescored;
+  std::vector<std::vector<int>> attn_tokens;     // rvb_attention_decode: best hypothesis per chunk
+  std::vector<float> attn_scores;
+  rvb::DevBuf atopv, atopi;                       // per-step top-k of the decoder output
+  std::vector<rvb::DevBuf> kcache, vcache, kcache2, vcache2, memkv;   // per decoder layer
   // decoder workspace
   rvb::DevBuf dx, dxn, dy, dh, dqkv, dq, dao, kvmem, d_tok, d_pos, d_tgt, d_logp;
   rvb::DevBuf d_hq_start, d_hq_len, d_hkv_start, d_hkv_len;

@@ -778,6 +778,187 @@ static int rescore_impl(rvb_engine* e, double ctc_weight, double reverse_weight)
   return OK;
 }
 
+
+// ------------------------------------------------------------------------------------ attention beam search
+// `attention` mode (search.py:251-360): autoregressive beam search with the left decoder.  The reference's
+// forward_one_step (decoder.py:191-234) recomputes the keys/values of the whole prefix at every step; here every
+// decoder layer keeps a K/V cache per hypothesis ([R][L][d], reordered by the beam's parent index after each step),
+// the memory K/V of each chunk is projected once, and one step is one decoder row per hypothesis.  The beam
+// bookkeeping follows the reference line by line in float32.
+static int attention_decode_impl(rvb_engine* e, int N, float length_penalty) {
+  const rvb_model_cfg& c = e->cfg;
+  if (e->B <= 0) { set_error("rvb_attention_decode before rvb_encode"); return E_STATE; }
+  if (!e->dec_l.present) { set_error("model has no attention decoder"); return E_STATE; }
+  if (N < 1 || N > 64) { set_error("rvb_attention_decode: beam must be in 1..64"); return E_ARG; }
+  RVB_TRY(wait_slices(e, -1));
+  Decoder& D = e->dec_l;
+  const int B = e->B, T2 = e->T2, d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
+  const int eos = c.eos_id, sos = c.sos_id;
+  const int R = B * N, L = T2, M = B * T2, NL = (int)D.layers.size();
+  const size_t es = dt_size(e->dtype);
+  if (L > e->pe_rows) { set_error("rvb_attention_decode: more steps than positional-table rows"); return E_UNSUPPORTED; }
+  if (N > V) { set_error("rvb_attention_decode: beam larger than the vocabulary"); return E_ARG; }
+  const int Vld = (V + 3) & ~3;
+
+  e->kcache.resize(NL); e->vcache.resize(NL); e->kcache2.resize(NL); e->vcache2.resize(NL); e->memkv.resize(NL);
+  const size_t cbytes = (size_t)R * L * d * es;
+  for (int l = 0; l < NL; ++l) {
+    RVB_TRY(e->kcache[l].ensure(cbytes)); RVB_TRY(e->vcache[l].ensure(cbytes));
+    RVB_TRY(e->kcache2[l].ensure(cbytes)); RVB_TRY(e->vcache2[l].ensure(cbytes));
+    RVB_TRY(e->memkv[l].ensure((size_t)M * 2 * d * es));
+    RVB_TRY(run_gemm(e, e->enc_out.p, d, D.layers[l].src_kv, e->memkv[l].p, 2 * d, M, false));   // once per chunk, not per step
+  }
+  RVB_TRY(e->dx.ensure((size_t)R * d * 4));
+  RVB_TRY(e->dxn.ensure((size_t)R * d * es));
+  RVB_TRY(e->dy.ensure((size_t)R * d * es));
+  RVB_TRY(e->dao.ensure((size_t)R * d * es));
+  RVB_TRY(e->dq.ensure((size_t)R * d * es));
+  RVB_TRY(e->dqkv.ensure((size_t)R * 3 * d * es));
+  RVB_TRY(e->dh.ensure((size_t)R * ff * es));
+  RVB_TRY(e->logits.ensure((size_t)std::min(R, LOGIT_SLAB) * Vld * 4));
+  RVB_TRY(e->atopv.ensure((size_t)R * N * 4));
+  RVB_TRY(e->atopi.ensure((size_t)R * N * 4));
+
+  // sequence descriptors: self-attention = one query row per hypothesis against its cache rows [r*L, r*L + s];
+  // cross-attention = the N hypotheses of a chunk form one query sequence against the chunk's valid frames
+  std::vector<int32_t> q1(R), one(R, 1), kv0(R), kvl(R), cq(B), cn(B, N), ckv(2 * (size_t)B);
+  for (int r = 0; r < R; ++r) { q1[r] = r; kv0[r] = r * L; }
+  for (int b = 0; b < B; ++b) { cq[b] = b * N; ckv[b] = b * T2; ckv[B + b] = e->enc_lens[b]; }
+  RVB_TRY(upload_i32(e, e->d_hq_start, q1.data(), R));
+  RVB_TRY(upload_i32(e, e->d_hq_len, one.data(), R));
+  RVB_TRY(upload_i32(e, e->d_seq_start, kv0.data(), R));
+  RVB_TRY(upload_i32(e, e->d_hkv_start, cq.data(), B));
+  RVB_TRY(upload_i32(e, e->d_hkv_len, cn.data(), B));
+  RVB_TRY(upload_i32(e, e->d_aux_i32, ckv.data(), ckv.size()));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+
+  std::vector<std::vector<int>> hyps(R, std::vector<int>(1, sos));
+  std::vector<float> scores(R, -INFINITY);
+  for (int b = 0; b < B; ++b) scores[(size_t)b * N] = 0.f;            // search.py:289-292
+  std::vector<char> end_flag(R, 0);
+  std::vector<int32_t> tok(R), pos(R), parent(R);
+  std::vector<float> topv((size_t)R * N);
+  std::vector<int32_t> topi((size_t)R * N);
+  float* x = e->dx.as<float>();
+
+  for (int s = 0; s < L; ++s) {                                        // i = s + 1 in search.py:296
+    int n_end = 0;
+    for (int r = 0; r < R; ++r) n_end += end_flag[r];
+    if (n_end == R) break;
+    for (int r = 0; r < R; ++r) { tok[r] = hyps[r].back(); pos[r] = s; kvl[r] = s + 1; }
+    RVB_TRY(upload_i32(e, e->d_tok, tok.data(), R));
+    RVB_TRY(upload_i32(e, e->d_pos, pos.data(), R));
+    RVB_TRY(upload_i32(e, e->d_seq_len, kvl.data(), R));
+    {
+      Scope sc(e, "embed");
+      RVB_TRY(embed_tokens(e->stream, D.embed.as<float>(), e->pe_f32.as<float>(), e->d_tok.as<int>(), e->d_pos.as<int>(), x, R, d,
+                           std::sqrt((float)d)));
+    }
+    for (int l = 0; l < NL; ++l) {
+      DecLayer& Ly = D.layers[l];
+      RVB_TRY(run_norm(e, x, Ly.n1, e->dxn.p, false, R, d));
+      RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.self_qkv, e->dqkv.p, 3 * d, R, false));
+      RVB_HIP_CHECK(hipMemcpy2DAsync((char*)e->kcache[l].p + (size_t)s * d * es, (size_t)L * d * es, (const char*)e->dqkv.p + (size_t)d * es,
+                                     (size_t)3 * d * es, (size_t)d * es, R, hipMemcpyDeviceToDevice, e->stream));
+      RVB_HIP_CHECK(hipMemcpy2DAsync((char*)e->vcache[l].p + (size_t)s * d * es, (size_t)L * d * es, (const char*)e->dqkv.p + (size_t)2 * d * es,
+                                     (size_t)3 * d * es, (size_t)d * es, R, hipMemcpyDeviceToDevice, e->stream));
+      AttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = e->dqkv.p; a.k = e->kcache[l].p; a.v = e->vcache[l].p;
+      a.q_stride = 3 * d; a.k_stride = a.v_stride = d; a.o_stride = d; a.out = e->dao.p;
+      a.q_start = e->d_hq_start.as<int>(); a.q_len = e->d_hq_len.as<int>();
+      a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->d_seq_len.as<int>();
+      a.nseq = R; a.heads = heads; a.dk = dk; a.max_q = 1; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
+      { Scope sc(e, "attention"); RVB_TRY(attention(e->stream, e->dtype, a)); }
+      RVB_TRY(run_gemm(e, e->dao.p, d, Ly.self_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+      RVB_TRY(run_norm(e, x, Ly.n2, e->dxn.p, false, R, d));
+      RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.src_q, e->dq.p, d, R, false));
+      a.q = e->dq.p; a.k = e->memkv[l].p; a.v = (const char*)e->memkv[l].p + (size_t)d * es;
+      a.q_stride = d; a.k_stride = a.v_stride = 2 * d;
+      a.q_start = e->d_hkv_start.as<int>(); a.q_len = e->d_hkv_len.as<int>();
+      a.kv_start = e->d_aux_i32.as<int>(); a.kv_len = e->d_aux_i32.as<int>() + B;
+      a.nseq = B; a.max_q = N;
+      { Scope sc(e, "attention"); RVB_TRY(attention(e->stream, e->dtype, a)); }
+      RVB_TRY(run_gemm(e, e->dao.p, d, Ly.src_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+      RVB_TRY(run_norm(e, x, Ly.n3, e->dxn.p, false, R, d));
+      const void* ffin = e->dxn.p;
+      if (Ly.is_lsl) { RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.lsl, e->dy.p, d, R, false)); ffin = e->dy.p; }
+      RVB_TRY(run_gemm(e, ffin, d, Ly.ff1, e->dh.p, ff, R, false, 1.f, ACT_RELU));
+      RVB_TRY(run_gemm(e, e->dh.p, ff, Ly.ff2, x, d, R, true, 1.f, ACT_NONE, x, d));
+    }
+    RVB_TRY(run_norm(e, x, D.after, e->dxn.p, false, R, d));
+    for (int r0 = 0; r0 < R; r0 += LOGIT_SLAB) {
+      const int rows = std::min(LOGIT_SLAB, R - r0);
+      RVB_TRY(run_gemm(e, (const char*)e->dxn.p + (size_t)r0 * d * es, d, D.out, e->logits.p, Vld, rows, true));
+      Scope sc(e, "ctc_topk");
+      RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), rows, V, Vld, N, 0.f, 0, e->atopv.as<float>() + (size_t)r0 * N,
+                              e->atopi.as<int>() + (size_t)r0 * N, nullptr));
+    }
+    RVB_HIP_CHECK(hipMemcpyAsync(topv.data(), e->atopv.p, (size_t)R * N * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipMemcpyAsync(topi.data(), e->atopi.p, (size_t)R * N * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+
+    // ---- beam update, search.py:300-345 ----
+    bool moved = false;
+    std::vector<std::vector<int>> nh(R);
+    std::vector<float> ns(R);
+    std::vector<std::pair<float, int>> cand((size_t)N * N);
+    for (int b = 0; b < B; ++b) {
+      for (int n = 0; n < N; ++n) {
+        const int r = b * N + n;
+        for (int k = 0; k < N; ++k) {
+          float lp = topv[(size_t)r * N + k];
+          if (end_flag[r]) lp = k == 0 ? 0.f : -INFINITY;             // mask_finished_scores
+          cand[(size_t)n * N + k] = {scores[r] + lp, n * N + k};
+        }
+      }
+      // torch.topk: descending; equal values keep the lower index first
+      std::stable_sort(cand.begin(), cand.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b2) { return a.first > b2.first; });
+      for (int n = 0; n < N; ++n) {
+        const int off = cand[n].second, pn = off / N, pk = off % N;
+        const int pr = b * N + pn, r = b * N + n;
+        const int pred = end_flag[pr] ? eos : topi[(size_t)pr * N + pk];   // mask_finished_preds
+        nh[r] = hyps[pr];
+        nh[r].push_back(pred);
+        ns[r] = cand[n].first;
+        parent[r] = pr;
+        moved |= pr != r;
+      }
+    }
+    hyps.swap(nh);
+    scores.swap(ns);
+    for (int r = 0; r < R; ++r) end_flag[r] = hyps[r].back() == eos;
+    if (moved && s + 1 < L) {
+      RVB_TRY(upload_i32(e, e->d_tgt, parent.data(), R));
+      for (int l = 0; l < NL; ++l) {
+        RVB_TRY(gather_cache(e->stream, e->kcache[l].p, e->kcache2[l].p, e->d_tgt.as<int>(), R, L, s + 1, (int)(d * es)));
+        RVB_TRY(gather_cache(e->stream, e->vcache[l].p, e->vcache2[l].p, e->d_tgt.as<int>(), R, L, s + 1, (int)(d * es)));
+        std::swap(e->kcache[l], e->kcache2[l]);
+        std::swap(e->vcache[l], e->vcache2[l]);
+      }
+    }
+  }
+  // ---- best of the beam, search.py:347-360 (float32 like the tensors there) ----
+  e->attn_tokens.assign(B, {});
+  e->attn_scores.assign(B, 0.f);
+  for (int b = 0; b < B; ++b) {
+    float best = -INFINITY;
+    int bi = 0;
+    for (int n = 0; n < N; ++n) {
+      const std::vector<int>& h = hyps[(size_t)b * N + n];
+      int len = 0;
+      for (int t : h) len += t != eos;
+      const float sc = scores[(size_t)b * N + n] / std::pow((float)len, length_penalty);
+      if (n == 0 || sc > best) { best = sc; bi = n; }
+    }
+    const std::vector<int>& h = hyps[(size_t)b * N + bi];
+    for (size_t j = 1; j < h.size(); ++j) if (h[j] != eos) e->attn_tokens[b].push_back(h[j]);
+    e->attn_scores[b] = best;
+  }
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
 }  // namespace rvb
 
 // ================================================================================================
@@ -827,6 +1008,8 @@ void rvb_destroy(rvb_engine* e) {
                     &e->conv2.w, &e->conv2.b, &e->embed_out.w, &e->embed_out.b, &e->ctc.w, &e->ctc.b,
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
+  e->atopv.release(); e->atopi.release();
+  for (auto* v : {&e->kcache, &e->vcache, &e->kcache2, &e->vcache2, &e->memkv}) for (auto& b : *v) b.release();
   auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); };
   auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };
   for (auto& L : e->enc) {
@@ -1003,6 +1186,21 @@ int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weigh
   if (!e) { set_error("null engine"); return E_ARG; }
   return rescore_impl(e, ctc_weight, reverse_weight);
 }
+int rvb_attention_decode(rvb_engine* e, int beam, float length_penalty) {
+  if (!e) { set_error("rvb_attention_decode: null engine"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return attention_decode_impl(e, beam, length_penalty);
+}
+int rvb_get_attention_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* n_tokens, float* score) {
+  if (!e || !n_tokens) { set_error("rvb_get_attention_result: null argument"); return E_ARG; }
+  if (chunk < 0 || chunk >= (int)e->attn_tokens.size()) { set_error("rvb_get_attention_result: no attention result for this chunk"); return E_STATE; }
+  const std::vector<int>& t = e->attn_tokens[chunk];
+  if (tokens) for (size_t i = 0; i < t.size(); ++i) tokens[i] = t[i];     // capacity: rvb_encoder_frames() entries
+  *n_tokens = (int32_t)t.size();
+  if (score) *score = e->attn_scores[chunk];
+  return OK;
+}
+
 int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence, double* tokens_confidence) {
   if (!e || chunk < 0 || chunk >= (int)e->rescored.size()) { set_error("rvb_get_rescored: bad chunk / no rescoring results"); return E_STATE; }
   const RescoreResult& r = e->rescored[chunk];

@@ -88,6 +88,9 @@ int logsoftmax_topk(hipStream_t s, const float* logits, int M, int V, int ld, in
 // out[r] = logits[r][target[r]] - logsumexp(logits[r][:V])
 int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out);
 
+// dst[r][t][:] = src[parent[r]][t][:], t < rows: caches [R][L][row_bytes]
+int gather_cache(hipStream_t s, const void* src, void* dst, const int* parent, int R, int L, int rows, int row_bytes);
+
 // fp32 -> T conversion copy (weight packing), n elements
 int convert_f32(hipStream_t s, int dtype, const float* src, void* dst, size_t n);
 

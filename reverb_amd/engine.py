@@ -15,7 +15,7 @@ from .search import DecodeResult
 
 DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32,
           "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16}
-SUPPORTED_MODES = ("ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring")
+SUPPORTED_MODES = ("attention", "ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring")
 
 
 def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_frames: int) -> ModelCfg:
@@ -236,12 +236,26 @@ class Engine:
         check(self.lib.rvb_get_rescore_logp(self.handle, chunk, hyp, 1 if right else 0, fptr(out)))
         return out
 
-    def search(self, methods: Sequence[str], ctc_weight: float, reverse_weight: float) -> Dict[str, List[DecodeResult]]:
-        """Search stages of ASRModel.decode (asr_model.py:399-425) on the last encoded batch."""
+    def attention_beam(self, length_penalty: float = 0.0) -> List[DecodeResult]:
+        """`attention` mode (search.py:251-360): tokens only, like the reference's DecodeResult(hyp.tolist())."""
+        check(self.lib.rvb_attention_decode(self.handle, self.beam, float(length_penalty)), "rvb_attention_decode")
+        tok = np.empty(max(self.enc_frames, 1), np.int32)
+        res = []
+        for b in range(self.batch):
+            n, sc = C.c_int32(0), C.c_float(0)
+            check(self.lib.rvb_get_attention_result(self.handle, b, iptr(tok), C.byref(n), C.byref(sc)), "rvb_get_attention_result")
+            res.append(DecodeResult(tok[:n.value].tolist()))
+        return res
+
+    def search(self, methods: Sequence[str], ctc_weight: float, reverse_weight: float, length_penalty: float = 0.0
+               ) -> Dict[str, List[DecodeResult]]:
+        """Search stages of ASRModel.decode (asr_model.py:391-425) on the last encoded batch."""
         results: Dict[str, List[DecodeResult]] = {}
         for m in methods:
             if m not in SUPPORTED_MODES:
                 raise RvbError(f"decoding mode {m!r} is not built yet (supported: {', '.join(SUPPORTED_MODES)})")
+        if "attention" in methods:
+            results["attention"] = self.attention_beam(length_penalty)
         if "ctc_greedy_search" in methods:
             results["ctc_greedy_search"] = self.greedy()
         if "attention_rescoring" in methods and "ctc_prefix_beam_search" not in methods:
@@ -257,7 +271,8 @@ class Engine:
         return results
 
     def decode_resident(self, n_frames: int, modes, chunk_size: int, beam_size: int, ctc_weight: float,
-                        reverse_weight: float, blank_penalty: float = 0.0) -> Dict[str, List[DecodeResult]]:
+                        reverse_weight: float, blank_penalty: float = 0.0, length_penalty: float = 0.0
+                        ) -> Dict[str, List[DecodeResult]]:
         """Decode the device-resident features of the last fbank() call: fixed, non-overlapping
         chunks with a length-masked zero-padded tail (feats_batcher, cli/reverb.py:148-180),
         `max_chunks` chunks per launch, results concatenated in chunk order."""
@@ -271,7 +286,7 @@ class Engine:
         for s in range(0, n_chunks, self.cfg.max_chunks):
             e = min(n_chunks, s + self.cfg.max_chunks)
             self.encode(None, lens[s:e], beam_size, blank_penalty, first_chunk=s, T0=chunk_size)
-            part = self.search(modes, ctc_weight, reverse_weight)
+            part = self.search(modes, ctc_weight, reverse_weight, length_penalty)
             for m in modes:
                 out[m].extend(part[m])
         return out

@@ -78,7 +78,7 @@ class RvbASRModel:
         mc = self.engine.cfg.max_chunks
         for s in range(0, feats.shape[0], mc):
             self.engine.encode(feats[s:s + mc], lens[s:s + mc], beam_size, blank_penalty)
-            part = self.engine.search(methods, ctc_weight, reverse_weight)
+            part = self.engine.search(methods, ctc_weight, reverse_weight, length_penalty)
             for k, v in part.items():
                 results.setdefault(k, []).extend(v)
         return results
@@ -197,14 +197,14 @@ class ReverbASR:
         eng.upload_pcm(self._load_pcm(audio_file, 16000))
         n_frames = eng.fbank()
         eng.set_cat_embs([verbatimicity, 1.0 - verbatimicity])
-        hyps = self.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
+        hyps = self.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, length_penalty)
         return [get_output(format, self.tokenizer, Path(audio_file).name, hyps[mode], timings_adjustment, chunk_size,
                            self.input_frame_length, self.output_frame_length) for mode in modes]
 
     def decode_resident(self, n_frames: int, modes, chunk_size: int, beam_size: int, ctc_weight: float,
-                        reverse_weight: float, blank_penalty: float = 0.0):
+                        reverse_weight: float, blank_penalty: float = 0.0, length_penalty: float = 0.0):
         return self.engine.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight,
-                                           blank_penalty)
+                                           blank_penalty, length_penalty)
 
     def transcribe(self, audio_file, mode: str = "ctc_prefix_beam_search", format: str = "txt",
                    verbatimicity: float = 1.0, chunk_size: int = 2051, batch_size: int = 1, beam_size: int = 10,
@@ -256,6 +256,12 @@ def get_output(format: str, tokenizer, audio_name: str, hyps: List[DecodeResult]
     lines, shift_ms = [], 0
     for hyp in hyps:
         times = hyp.times if hyp.times is not None else hyp.ctc_frames
+        if times is None:
+            # `attention` mode carries no timestamps (search.py:357-360: DecodeResult(hyp.tolist())); the reference's
+            # get_output then fails in ctc_align on len(None).  Text output does not need times; CTM cannot be written.
+            if format != "txt":
+                raise ValueError("this decoding mode produces no timestamps: use format='txt'")
+            times = [0] * len(hyp.tokens)
         words = ctc_align(hyp.tokens, times, hyp.tokens_confidence, tokenizer, output_frame_length, shift_ms)
         words = adjust_model_time_offset(words, timings_adjustment_ms)
         shift_ms += chunk_size * input_frame_length

@@ -216,3 +216,40 @@ def test_slice_pipeline_and_bulk_results_equal_plain_path():
             for a, b in zip(part[m], full[m][s:s + 10]):
                 assert list(a.tokens) == list(b.tokens)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------ `attention` mode
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_ln_r2l", "tiny_bn", "small_ln"])
+def test_attention_mode_f32_matches_reference_golden(name):
+    """search.py:251-360 on the engine (K/V caches on the device, beam bookkeeping on the host) against the tokens
+    the unmodified reference produced (oracle/gen_golden_attention.py); covers beams that never emit <eos>
+    (tiny_ln_r2l: 145 / 249 steps), immediate <eos> (tiny_ln: empty result) and a length penalty."""
+    import json
+    from golden_util import GOLDEN
+    case = Case(name)
+    with open(os.path.join(GOLDEN, name + "_attention.json")) as f:
+        gold = json.load(f)
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "f32")
+    eng.encode(x, lens, case.beam)
+    for run in gold["runs"]:
+        got = eng.search(["attention"], 0.0, 0.0, length_penalty=run["length_penalty"])["attention"]
+        assert [list(r.tokens) for r in got] == run["tokens"], (name, run["length_penalty"])
+        assert all(r.times is None for r in got)
+    # the other modes still work on the same encoded batch afterwards
+    res = eng.search(["attention_rescoring"], case.ctc_weight, case.reverse_weight)["attention_rescoring"]
+    assert [list(r.tokens) for r in res] == [g["tokens"] for g in case.golden("attention_rescoring")]
+    eng.close()
+
+
+def test_attention_mode_bf16_runs_and_batches_consistently():
+    case = Case("tiny_bn")
+    x, lens = case.chunked_feats()
+    eng = _engine(case, "bf16")
+    eng.encode(x, lens, case.beam)
+    a = [list(r.tokens) for r in eng.search(["attention"], 0.0, 0.0)["attention"]]
+    eng.encode(x[:1], lens[:1], case.beam)
+    b = [list(r.tokens) for r in eng.search(["attention"], 0.0, 0.0)["attention"]]
+    assert b[0] == a[0]
+    assert all(0 <= t < case.cfg["output_dim"] - 1 for h in a for t in h)
+    eng.close()

@@ -64,3 +64,20 @@ def test_fbank_edges():
     assert fbank_ref.fbank(np.zeros(560, np.int16)).shape == (2, 80)
     # silence -> log of the floor
     np.testing.assert_allclose(fbank_ref.fbank(np.zeros(400, np.int16)), np.log(np.float32(1.1920929e-07)), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_ln_r2l", "tiny_bn", "small_ln"])
+def test_attention_mode_oracle_matches_reference_golden(name):
+    """`attention` mode (search.py:251-360): the oracle's K/V-cached restatement reproduces the tokens the
+    unmodified reference (cached forward_one_step) produced -- oracle/gen_golden_attention.py."""
+    import json
+    case = Case(name)
+    with open(GOLDEN + f"/{name}_attention.json") as f:
+        gold = json.load(f)
+    x, lens = case.chunked_feats()
+    sd = M.to_torch_sd(case.sd)
+    with torch.no_grad():
+        enc, mask = M.encoder_forward(sd, case.cfg, torch.from_numpy(x), torch.from_numpy(lens), torch.tensor(case.cat))
+        for run in gold["runs"]:
+            res = S.attention_beam_search(sd, case.cfg, enc, mask, case.beam, run["length_penalty"], torch.tensor(case.cat))
+            assert [list(r.tokens) for r in res] == run["tokens"], (name, run["length_penalty"])
