@@ -71,6 +71,13 @@ int rvb_load_tensor(rvb_engine* e, const char* name, const float* host, const in
  * cat_embs.  Fails listing the first missing tensor. */
 int rvb_finalize(rvb_engine* e, const float* cat_embs, int n_cat);
 
+/* Same for PCM at another sample rate: resampled on the device to 16 kHz the way the reference does
+ * (asr/wenet/cli/reverb.py:128-134: `torchaudio.transforms.Resample(sr, 16000)` on the float waveform =
+ * sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99); the fbank then reads the un-rounded float result. */
+int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n_samples, int sample_rate);
+/* the waveform the fbank will read (after resampling, int16 scale); out may be NULL to query the length */
+int rvb_get_waveform(rvb_engine* e, float* out, int64_t* n_samples);
+
 /* ReverbASR.compute_feats (cli/reverb.py:119-146): Kaldi fbank of 16 kHz mono int16 PCM.
  * rvb_upload_pcm copies the samples to HBM; rvb_fbank computes [n_frames,80] log-mel on the
  * device (kept resident, zero-padded to whole chunks) and optionally copies it to feats_out. */

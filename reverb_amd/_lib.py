@@ -45,6 +45,8 @@ SIGNATURES = {
     "rvb_finalize": (C.c_int, [_eng, _f32p, C.c_int]),
     "rvb_num_frames": (C.c_int64, [C.c_int64]),
     "rvb_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvb_upload_pcm_rate": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int]),
+    "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_encode": (C.c_int, [_eng, _f32p, C.c_int64, _i32p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rvb_encoder_frames": (C.c_int, [_eng, _i32p]),

@@ -1058,6 +1058,63 @@ int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n) {
   if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   e->n_samples = n;
+  e->pcm_is_float = false;
+  return OK;
+}
+
+int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample_rate) {
+  const int target = 16000;
+  if (sample_rate == target) return rvb_upload_pcm(e, pcm, n);
+  if (!e || (!pcm && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_pcm_rate: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  // torchaudio.functional.resample kernel (sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99), built in fp64
+  int a = sample_rate, b = target;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int orig = sample_rate / a, nw = target / a;
+  const double lpw = 6.0, rolloff = 0.99;
+  const double base_freq = std::min(orig, nw) * rolloff;
+  const int width = (int)std::ceil(lpw * orig / base_freq);
+  const int K = 2 * width + orig;
+  std::vector<float> ker((size_t)nw * K);
+  const double PI = 3.14159265358979323846;
+  for (int p = 0; p < nw; ++p)
+    for (int k = 0; k < K; ++k) {
+      double t = (-(double)p / nw + (double)(k - width) / orig) * base_freq;
+      t = std::max(-lpw, std::min(lpw, t));
+      const double c = std::cos(t * PI / lpw / 2.0);
+      const double window = c * c;
+      t *= PI;
+      const double sinc = t == 0.0 ? 1.0 : std::sin(t) / t;
+      ker[(size_t)p * K + k] = (float)(sinc * window * (base_freq / orig));
+    }
+  const int64_t n_out = (nw * n + orig - 1) / orig;          // ceil(new * length / orig)
+  RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
+  RVB_TRY(e->rs_kernel.ensure(ker.size() * 4));
+  RVB_TRY(e->wave_f32.ensure((size_t)std::max<int64_t>(n_out, 1) * 4));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+  RVB_HIP_CHECK(hipMemcpyAsync(e->rs_kernel.p, ker.data(), ker.size() * 4, hipMemcpyHostToDevice, e->stream));
+  {
+    Scope sc(e, "resample");
+    RVB_TRY(resample(e->stream, e->pcm.as<int16_t>(), n, e->rs_kernel.as<float>(), orig, nw, width, K, e->wave_f32.as<float>(), n_out));
+  }
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->n_samples = n_out;
+  e->pcm_is_float = true;
+  return OK;
+}
+
+int rvb_get_waveform(rvb_engine* e, float* out, int64_t* n) {
+  if (!e) { set_error("rvb_get_waveform: null engine"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  if (n) *n = e->n_samples;
+  if (!out || e->n_samples == 0) return OK;
+  if (e->pcm_is_float) {
+    RVB_HIP_CHECK(hipMemcpy(out, e->wave_f32.p, (size_t)e->n_samples * 4, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<int16_t> tmp(e->n_samples);
+    RVB_HIP_CHECK(hipMemcpy(tmp.data(), e->pcm.p, (size_t)e->n_samples * 2, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < e->n_samples; ++i) out[i] = (float)tmp[i];
+  }
   return OK;
 }
 
@@ -1073,7 +1130,8 @@ int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
   FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};
   {
     Scope sc(e, "fbank");
-    RVB_TRY(fbank(e->stream, e->pcm.as<int16_t>(), nf, e->feats.as<float>(), t));
+    if (e->pcm_is_float) RVB_TRY(fbank_f32(e->stream, e->wave_f32.as<float>(), nf, e->feats.as<float>(), t));
+    else RVB_TRY(fbank(e->stream, e->pcm.as<int16_t>(), nf, e->feats.as<float>(), t));
   }
   if (feats_out && nf) RVB_HIP_CHECK(hipMemcpyAsync(feats_out, e->feats.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost, e->stream));
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));

@@ -16,7 +16,8 @@ namespace rvb {
 
 static constexpr int WIN = 400, SHIFT = 160, NFFT = 512, NBIN = 257, NMEL = 80;
 
-__global__ __launch_bounds__(256) void fbank_kernel(const int16_t* __restrict__ pcm, int64_t n_frames,
+template <typename In>
+__global__ __launch_bounds__(256) void fbank_kernel(const In* __restrict__ pcm, int64_t n_frames,
                                                     float* __restrict__ feats, FbankTables t) {
   __shared__ float s_re[4][NFFT];
   __shared__ float s_im[4][NFFT];
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const int16_t* __restrict__ 
   // 1. load window, remove DC
   float x[7];
   float sum = 0.f;
-  const int16_t* src = pcm + frame * SHIFT;
+  const In* src = pcm + frame * SHIFT;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int j = lane + 64 * i;
@@ -117,7 +118,44 @@ __global__ __launch_bounds__(256) void fbank_kernel(const int16_t* __restrict__ 
 
 int fbank(hipStream_t s, const int16_t* pcm, int64_t n_frames, float* feats, const FbankTables& t) {
   if (n_frames <= 0) return OK;
-  hipLaunchKernelGGL(fbank_kernel, dim3(cdiv(n_frames, 4)), dim3(256), 0, s, pcm, n_frames, feats, t);
+  hipLaunchKernelGGL(fbank_kernel<int16_t>, dim3(cdiv(n_frames, 4)), dim3(256), 0, s, pcm, n_frames, feats, t);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// same on a float waveform at int16 scale (the output of the resampler: reverb.py:128-134 resamples the
+// `.to(float)` waveform and hands the un-rounded result to kaldi.fbank)
+int fbank_f32(hipStream_t s, const float* wave, int64_t n_frames, float* feats, const FbankTables& t) {
+  if (n_frames <= 0) return OK;
+  hipLaunchKernelGGL(fbank_kernel<float>, dim3(cdiv(n_frames, 4)), dim3(256), 0, s, wave, n_frames, feats, t);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// torchaudio.transforms.Resample(orig, new) (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) as a
+// polyphase FIR: out[j*new + p] = sum_k ker[p][k] * x[j*orig + k - width], x zero outside [0, n_in).
+// One thread per output sample; the K-tap windows of neighbouring outputs overlap almost entirely (L1/L2).
+__global__ __launch_bounds__(256) void resample_kernel(const int16_t* __restrict__ pcm, int64_t n_in, const float* __restrict__ ker,
+                                                       int orig, int new_, int width, int K, float* __restrict__ out,
+                                                       int64_t n_out) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_out) return;
+  const int64_t j = n / new_;
+  const int p = (int)(n - j * new_);
+  const int64_t base = j * orig - width;
+  const float* kr = ker + (size_t)p * K;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t i = base + k;
+    if (i >= 0 && i < n_in) acc = fmaf(kr[k], (float)pcm[i], acc);
+  }
+  out[n] = acc;
+}
+int resample(hipStream_t s, const int16_t* pcm, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
+             int64_t n_out) {
+  if (n_out <= 0) return OK;
+  hipLaunchKernelGGL(resample_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pcm, n_in, ker, orig, new_, width, K, out, n_out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

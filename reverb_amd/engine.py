@@ -122,10 +122,25 @@ class Engine:
         self._cat = cat
 
     # -------------------------------------------------------------------------------- front end
-    def upload_pcm(self, pcm: np.ndarray):
+    def upload_pcm(self, pcm: np.ndarray, sample_rate: int = 16000):
+        """int16 mono PCM -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134)."""
         pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
-        check(self.lib.rvb_upload_pcm(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm)), "rvb_upload_pcm")
-        self._n_samples = len(pcm)
+        if sample_rate == 16000:
+            check(self.lib.rvb_upload_pcm(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm)), "rvb_upload_pcm")
+            self._n_samples = len(pcm)
+        else:
+            check(self.lib.rvb_upload_pcm_rate(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm), int(sample_rate)),
+                  "rvb_upload_pcm_rate")
+            n = C.c_int64(0)
+            check(self.lib.rvb_get_waveform(self.handle, None, C.byref(n)), "rvb_get_waveform")
+            self._n_samples = int(n.value)
+
+    def waveform(self) -> np.ndarray:
+        """The waveform the fbank reads (float32, int16 scale; after resampling if any)."""
+        out = np.empty(max(self._n_samples, 1), np.float32)
+        n = C.c_int64(0)
+        check(self.lib.rvb_get_waveform(self.handle, fptr(out), C.byref(n)), "rvb_get_waveform")
+        return out[:int(n.value)]
 
     def fbank(self, return_feats: bool = False):
         """Kaldi fbank of the uploaded PCM; features stay resident in HBM.  Returns n_frames

@@ -147,20 +147,20 @@ class ReverbASR:
         return p.as_posix()
 
     # ------------------------------------------------------------------ front end
-    def _load_pcm(self, audio_file: str, resample_rate: int) -> np.ndarray:
+    def _load_pcm(self, audio_file: str, resample_rate: int):
+        """-> (int16 channel 0, its sample rate); the engine resamples to 16 kHz on the device when needed."""
         wave, rate = read_wav(audio_file)
         logging.info(f"detected sample rate: {rate}")
-        if rate != resample_rate:
-            raise NotImplementedError(f"{audio_file}: {rate} Hz input needs resampling to {resample_rate} Hz, "
-                                      "which is not built yet (SURVEY.md 8f-2)")
-        return wave[0]                                    # kaldi.fbank uses channel 0 (Appendix A8)
+        if resample_rate != 16000:
+            raise NotImplementedError("the device front end is built for a 16 kHz model (resample_rate=16000)")
+        return wave[0], rate                              # kaldi.fbank uses channel 0 (Appendix A8)
 
     def compute_feats(self, audio_file: str, resample_rate: int = 16000, num_mel_bins=23, frame_length=25,
                       frame_shift=10, dither=0.0):
         """(1, frames, num_mel_bins) float32 tensor; the same features stay resident in HBM."""
         if (num_mel_bins, frame_length, frame_shift, dither) != (80, 25, 10, 0.0):
             raise NotImplementedError("the device fbank is built for 80 bins / 25 ms / 10 ms / no dither")
-        self.engine.upload_pcm(self._load_pcm(audio_file, resample_rate))
+        self.engine.upload_pcm(*self._load_pcm(audio_file, resample_rate))
         _, feats = self.engine.fbank(return_feats=True)
         return _torch().from_numpy(feats).unsqueeze(0)
 
@@ -194,7 +194,7 @@ class ReverbASR:
         eng = self.engine
         if chunk_size > eng.cfg.chunk_frames:
             raise ValueError(f"chunk_size {chunk_size} exceeds the engine's chunk_frames {eng.cfg.chunk_frames}")
-        eng.upload_pcm(self._load_pcm(audio_file, 16000))
+        eng.upload_pcm(*self._load_pcm(audio_file, 16000))
         n_frames = eng.fbank()
         eng.set_cat_embs([verbatimicity, 1.0 - verbatimicity])
         hyps = self.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, length_penalty)
