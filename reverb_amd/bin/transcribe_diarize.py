@@ -1,0 +1,101 @@
+#!/usr/bin/env python
+"""Joint ASR + diarization of one recording (BASELINE config 5; the reference does it in three commands:
+`recognize_wav.py --output_format ctm`, `infer_pyannote3.0.py`, `assign_words2speakers.py rttm ctm stm`):
+
+    python -m reverb_amd.bin.transcribe_diarize a.wav --asr-model DIR --pipeline-model DIR --out-dir out
+
+writes out/a.ctm, out/a.rttm and out/a.stm (one `<uri> 1 <speaker> <start> <end> <word>` line per word).
+With torchrun (one process per GPU) the ASR chunks and the diarization windows are sharded across the ranks
+(reverb_amd/dist.py) and rank 0 writes the files.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+
+def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, **decode_kw):
+    from reverb_amd.bin.assign_words2speakers import make_turns, speaker_for_segment
+    from reverb_amd.reverb import get_output
+    from reverb_amd.wav import read_wav
+    stem = os.path.splitext(os.path.basename(audio))[0]
+    wave, rate = read_wav(audio)
+    timings = {}
+    t0 = time.perf_counter()
+    chunk = asr.engine.cfg.chunk_frames
+    kw = dict(beam_size=10, ctc_weight=0.1, reverse_weight=0.0)
+    kw.update(decode_kw)
+    if world > 1:
+        from reverb_amd.dist import decode_sharded, diarize_sharded
+        if rate != 16000:
+            raise NotImplementedError("sharded decoding slices 16 kHz PCM; resample the file first")
+        hyps = decode_sharded(asr.engine, wave[0], [mode], chunk, kw["beam_size"], kw["ctc_weight"], kw["reverse_weight"], device)[mode]
+    else:
+        asr.engine.upload_pcm(wave[0], rate)
+        nf = asr.engine.fbank()
+        hyps = asr.decode_resident(nf, [mode], chunk, kw["beam_size"], kw["ctc_weight"], kw["reverse_weight"])[mode]
+    ctm = get_output("ctm", asr.tokenizer, stem, hyps, 230, chunk, asr.input_frame_length, asr.output_frame_length)
+    timings["asr"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    if world > 1:
+        mono = np.clip(np.rint(wave.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
+        ann = diarize_sharded(pipe, mono, device, uri=stem)
+    else:
+        ann = pipe(audio)
+    timings["diarization"] = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    turns = make_turns(ann) if len(ann) else []
+    stm_lines = []
+    for line in ctm.splitlines():
+        parts = line.split(" ")
+        if len(parts) < 6:
+            continue
+        start, dur, token = float(parts[2]), float(parts[3]), parts[4]
+        stm_lines.append(f"{stem} 1 {speaker_for_segment(start, dur, turns)} {start:.3f} {(start + dur):.3f} {token}")
+    timings["join"] = time.perf_counter() - t2
+    if rank == 0 and out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, stem + ".ctm"), "w") as f:
+            f.write(ctm + ("\n" if ctm else ""))
+        with open(os.path.join(out_dir, stem + ".rttm"), "w") as f:
+            ann.write_rttm(f)
+        with open(os.path.join(out_dir, stem + ".stm"), "w") as f:
+            f.write("\n".join(stm_lines) + ("\n" if stm_lines else ""))
+    timings["total"] = time.perf_counter() - t0
+    return ctm, ann, stm_lines, timings
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="ASR + diarization + word->speaker assignment")
+    p.add_argument("audios", nargs="+")
+    p.add_argument("--asr-model", required=True, help="Reverb-ASR model directory (config.yaml, *.pt, tk.units.txt, ...)")
+    p.add_argument("--pipeline-model", required=True, help="diarization pipeline directory (config.yaml, segmentation.pt, embedding.pt)")
+    p.add_argument("--out-dir", required=True)
+    p.add_argument("--mode", default="attention_rescoring")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = p.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=device)
+    from reverb_amd.diarization import Pipeline
+    from reverb_amd.reverb import load_model
+    asr = load_model(args.asr_model, gpu=local, dtype=args.dtype, max_chunks=256)
+    pipe = Pipeline.from_pretrained(args.pipeline_model, dtype=args.dtype).to(f"cuda:{local}")
+    for audio in args.audios:
+        _, ann, stm, t = run(audio, asr, pipe, args.out_dir, args.mode, device, world, rank)
+        if rank == 0:
+            print(f"{audio}: {len(stm)} words, {len(ann.labels())} speakers, asr {t['asr']:.3f} s, diarization {t['diarization']:.3f} s")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

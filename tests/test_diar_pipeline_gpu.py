@@ -75,3 +75,20 @@ def test_cli_script(setup, tmp_path):
     infer_pyannote3.main([wav, "--out-dir", str(tmp_path / "out"), "--pipeline-model", model])
     text = (tmp_path / "out" / "talk.rttm").read_text()
     assert text.startswith("SPEAKER talk 1 ")
+
+
+def test_joint_transcribe_diarize_writes_ctm_rttm_stm(setup, tmp_path):
+    """BASELINE config 5 shape on one GPU: ASR CTM + diarization RTTM + word->speaker STM for one file."""
+    model, wav, pcm = setup
+    from reverb_amd.bin import transcribe_diarize
+    asr_dir = synth.write_model_dir(str(tmp_path / "asr"), "tiny")
+    transcribe_diarize.main([wav, "--asr-model", asr_dir, "--pipeline-model", model, "--out-dir", str(tmp_path / "o"), "--dtype", "f32"])
+    ctm = (tmp_path / "o" / "talk.ctm").read_text().splitlines()
+    rttm = (tmp_path / "o" / "talk.rttm").read_text().splitlines()
+    stm = (tmp_path / "o" / "talk.stm").read_text().splitlines()
+    assert len(ctm) == len(stm) > 0 and len(rttm) > 0
+    speakers = {l.split()[7] for l in rttm}
+    for c, s in zip(ctm, stm):
+        cp, sp = c.split(" "), s.split(" ")
+        assert sp[0] == "talk" and sp[1] == "1" and sp[2] in speakers
+        assert abs(float(sp[3]) - float(cp[2])) < 1e-3 and sp[5] == cp[4]
