@@ -85,6 +85,12 @@ int64_t rvb_num_frames(int64_t n_samples);
 int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
 int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int64_t* n_frames);
 
+/* Chunk-masked encoder attention for the following rvb_encode calls: query frame i attends the encoder frames
+ * [max((i/chunk - left)*chunk, 0), (i/chunk + 1)*chunk) -- what `decoding_chunk_size` / `num_decoding_left_chunks`
+ * select in BaseEncoder.forward via add_optional_chunk_mask (encoder.py:140-145, utils/mask.py:86-197) for models
+ * trained with use_dynamic_chunk / static_chunk_size.  chunk_size <= 0: full context (default); left < 0: all. */
+int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks);
+
 /* ASRModel._forward_encoder + ctc_logprobs + per-frame top-`beam` (asr_model.py:288-329,378-389,
  * search.py:155): encode a batch of B chunks of T0 frames.  feats: host fp32 [B,T0,80], or NULL
  * to read chunk rows [first_chunk, first_chunk+B) of the device-resident rvb_fbank output.

@@ -147,10 +147,21 @@ def conformer_layer(sd: SD, p: str, x, mask, pos_emb, mask_pad, h, norm, cat_emb
     return _ln(sd, p + ".norm_final", x, 1e-5)
 
 
+def subsequent_chunk_mask(size: int, chunk_size: int, num_left_chunks: int = -1) -> torch.Tensor:
+    """utils/mask.py:86-123."""
+    ret = torch.zeros(size, size, dtype=torch.bool)
+    for i in range(size):
+        start = 0 if num_left_chunks < 0 else max((i // chunk_size - num_left_chunks) * chunk_size, 0)
+        ret[i, start:min((i // chunk_size + 1) * chunk_size, size)] = True
+    return ret
+
+
 def encoder_forward(sd: SD, cfg: dict, feats: torch.Tensor, feats_lens: torch.Tensor,
-                    cat_embs: torch.Tensor, taps: Optional[dict] = None):
-    """transformer/encoder.py:117-149 (full-context, decoding_chunk_size<0).
-    feats (B,T0,80) raw log-mel; returns (B,T',d), mask (B,1,T')."""
+                    cat_embs: torch.Tensor, taps: Optional[dict] = None, decoding_chunk_size: int = -1,
+                    num_decoding_left_chunks: int = -1):
+    """transformer/encoder.py:117-149; the attention mask is add_optional_chunk_mask's (utils/mask.py:126-197,
+    decoding branches): full context unless the model has use_dynamic_chunk and decoding_chunk_size > 0, or a
+    static_chunk_size.  feats (B,T0,80) raw log-mel; returns (B,T',d), mask (B,1,T')."""
     ec = cfg["encoder_conf"]
     h, nb, norm = ec["attention_heads"], ec["num_blocks"], ec.get("cnn_module_norm", "batch_norm")
     T0 = feats.shape[1]
@@ -160,9 +171,16 @@ def encoder_forward(sd: SD, cfg: dict, feats: torch.Tensor, feats_lens: torch.Te
     if taps is not None:
         taps["embed"] = x.clone()
     has_lsl = "encoder.encoders.0.language_layers.0.weight" in sd
+    att_mask = masks
+    L = x.shape[1]
+    if ec.get("use_dynamic_chunk", False):
+        if decoding_chunk_size > 0:
+            att_mask = masks & subsequent_chunk_mask(L, decoding_chunk_size, num_decoding_left_chunks).unsqueeze(0)
+    elif int(ec.get("static_chunk_size", 0)) > 0:
+        att_mask = masks & subsequent_chunk_mask(L, int(ec["static_chunk_size"]), num_decoding_left_chunks).unsqueeze(0)
     for i in range(nb):
         is_lsl = has_lsl and i in (0, nb - 1)
-        x = conformer_layer(sd, f"encoder.encoders.{i}", x, masks, pos_emb, masks, h, norm, cat_embs, is_lsl)
+        x = conformer_layer(sd, f"encoder.encoders.{i}", x, att_mask, pos_emb, masks, h, norm, cat_embs, is_lsl)
         if taps is not None:
             taps[f"layer{i}"] = x.clone()
     x = _ln(sd, "encoder.after_norm", x, 1e-5)

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rvb_finalize": (C.c_int, [_eng, _f32p, C.c_int]),
     "rvb_num_frames": (C.c_int64, [C.c_int64]),
     "rvb_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvb_set_decoding_chunk": (C.c_int, [_eng, C.c_int, C.c_int]),
     "rvb_upload_pcm_rate": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int]),
     "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),

@@ -109,8 +109,16 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   char* sP = smem + L::OFF_P;
   char* sV = smem + L::OFF_V;
 
-  int kend = kvlen;
+  int kend = kvlen, kbeg = 0;
   if (a.causal) kend = min(kvlen, q0 + QT);
+  // streaming-style chunk mask (utils/mask.py:86-123 subsequent_chunk_mask): query i sees keys
+  // [max((i/cs - left)*cs, 0), (i/cs + 1)*cs); the tile loop covers the union over this block's queries
+  const int cs = a.chunk;
+  if (cs > 0) {
+    const int qlast = min(q0 + QT, qlen) - 1;
+    kend = min(kend, (qlast / cs + 1) * cs);
+    if (a.left >= 0) kbeg = (max((q0 / cs - a.left) * cs, 0) / KT) * KT;
+  }
   // Staging: every thread fetches one 16-byte vector of K, P and V per tile (coalesced: 8 lanes per
   // 128-byte row), holds tile t+1 in VGPRs while tile t is multiplied, and writes it to LDS at the
   // top of the next iteration.  K and P rows are stored as they come.  V is stored TRANSPOSED
@@ -150,8 +158,8 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       }
     }
   };
-  if (kend > 0) gload(0);
-  for (int kt0 = 0; kt0 < kend; kt0 += KT) {
+  if (kend > kbeg) gload(kbeg);
+  for (int kt0 = kbeg; kt0 < kend; kt0 += KT) {
     lstore();
     __syncthreads();
     if (kt0 + KT < kend) gload(kt0 + KT);       // in flight under the MFMAs / softmax below
@@ -178,13 +186,19 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[nf][r] = s[nf][r] / a.sqrt_dk;
     }
-    if (a.causal || kt0 + KT > kvlen) {          // block-uniform
+    if (a.causal || cs > 0 || kt0 + KT > kvlen) {          // block-uniform
+      int lo = 0, hi = kvlen;
+      if (cs > 0) {
+        const int ci = my_q / cs;
+        hi = min(kvlen, (ci + 1) * cs);
+        if (a.left >= 0) lo = max((ci - a.left) * cs, 0);
+      }
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt0 + nf * 16 + lgrp * 4 + r;
-          if (key >= kvlen || (a.causal && key > my_q)) s[nf][r] = -INFINITY;
+          if (key >= hi || key < lo || (a.causal && key > my_q)) s[nf][r] = -INFINITY;
         }
     }
     float mx = -INFINITY;

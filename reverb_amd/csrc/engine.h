@@ -87,6 +87,7 @@ struct rvb_engine {
   rvb::DevBuf pcm, feats;        // int16 [n], fp32 [chunks*T0pad][80]
   rvb::DevBuf wave_f32, rs_kernel; // resampled waveform (fp32, int16 scale) when the input rate is not 16 kHz
   bool pcm_is_float = false;
+  int dec_chunk = 0, dec_left = -1;   // encoder chunk mask (decoding_chunk_size / num_decoding_left_chunks), 0 = full context
   int64_t n_samples = 0, n_frames = 0, feat_rows = 0;
 
   // ---- batch state ----

@@ -410,6 +410,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
     a.q_start = e->d_seq_start.as<int>(); a.q_len = e->d_seq_len.as<int>();
     a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->cur_lens;
     a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
+    a.chunk = e->dec_chunk; a.left = e->dec_left;          // add_optional_chunk_mask, encoder.py:140-145
     Scope sc(e, "attention", 6.0 * B * (double)T * T * d);
     RVB_TRY(attention(e->stream, e->dtype, a));
   }
@@ -1059,6 +1060,14 @@ int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n) {
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   e->n_samples = n;
   e->pcm_is_float = false;
+  return OK;
+}
+
+int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks) {
+  if (!e) { set_error("rvb_set_decoding_chunk: null engine"); return E_ARG; }
+  if (chunk_size > 4095 || num_left_chunks > 4094) { set_error("rvb_set_decoding_chunk: value too large"); return E_ARG; }
+  e->dec_chunk = chunk_size > 0 ? chunk_size : 0;
+  e->dec_left = num_left_chunks < 0 ? -1 : num_left_chunks;
   return OK;
 }
 

@@ -109,6 +109,7 @@ struct AttnArgs {
   const int* kv_start; const int* kv_len;        // per sequence
   int nseq, heads, dk, max_q;
   int causal;
+  int chunk, left;   // chunk > 0: streaming chunk mask (utils/mask.py:86-123), left < 0 = all left chunks
   float sqrt_dk;   // scores are divided by this (attention.py:384,395: `/ math.sqrt(self.d_k)`)
 };
 int attention(hipStream_t s, int dtype, const AttnArgs& a);

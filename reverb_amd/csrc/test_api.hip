@@ -158,7 +158,9 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
   a.q_stride = a.k_stride = a.v_stride = a.p_stride = a.o_stride = d;
   a.bias_u = (const float*)du.p; a.bias_v = (const float*)dvv.p; a.out = dout.p;
   a.q_start = (const int*)qs.p; a.q_len = (const int*)ql.p; a.kv_start = (const int*)ks.p; a.kv_len = (const int*)kl.p;
-  a.nseq = nseq; a.heads = heads; a.dk = dk; a.causal = causal; a.sqrt_dk = sqrtf((float)dk);
+  // `causal`: bit 0 = causal mask; bits 8..19 = streaming chunk size (0 = off); bits 20..31 = left chunks + 1 (0 = all)
+  a.nseq = nseq; a.heads = heads; a.dk = dk; a.causal = causal & 1; a.sqrt_dk = sqrtf((float)dk);
+  a.chunk = (causal >> 8) & 0xfff; a.left = ((causal >> 20) & 0xfff) - 1;
   int mq = 0;
   for (int i = 0; i < nseq; ++i) mq = q_len[i] > mq ? q_len[i] : mq;
   a.max_q = mq;

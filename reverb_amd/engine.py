@@ -135,6 +135,25 @@ class Engine:
             check(self.lib.rvb_get_waveform(self.handle, None, C.byref(n)), "rvb_get_waveform")
             self._n_samples = int(n.value)
 
+    def set_decoding_chunk(self, chunk_size: int = -1, num_left_chunks: int = -1):
+        """Chunk mask of the encoder self-attention for the next encode() calls (<= 0: full context)."""
+        check(self.lib.rvb_set_decoding_chunk(self.handle, int(chunk_size), int(num_left_chunks)), "rvb_set_decoding_chunk")
+
+    def apply_decoding_chunk(self, decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1):
+        """What BaseEncoder.forward does with these two arguments (encoder.py:140-145 -> add_optional_chunk_mask,
+        utils/mask.py:126-197): they select a chunk mask only for models configured with use_dynamic_chunk, a
+        static_chunk_size model is always chunk-masked, any other model ignores them."""
+        ec = self.configs.get("encoder_conf", {})
+        if ec.get("use_dynamic_chunk", False):
+            if decoding_chunk_size > 0:
+                self.set_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
+            else:
+                self.set_decoding_chunk(-1, -1)
+        elif int(ec.get("static_chunk_size", 0)) > 0:
+            self.set_decoding_chunk(int(ec["static_chunk_size"]), num_decoding_left_chunks)
+        else:
+            self.set_decoding_chunk(-1, -1)
+
     def waveform(self) -> np.ndarray:
         """The waveform the fbank reads (float32, int16 scale; after resampling if any)."""
         out = np.empty(max(self._n_samples, 1), np.float32)

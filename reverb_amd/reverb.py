@@ -64,8 +64,9 @@ class RvbASRModel:
                length_penalty: float = 0.0, infos=None, cat_embs=None, cv=None, cv_lengths=None):
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
-        if simulate_streaming or decoding_chunk_size > 0:
-            raise NotImplementedError("streaming / chunked-attention decoding is not built yet (SURVEY.md 8f-3)")
+        if simulate_streaming:
+            raise NotImplementedError("simulate_streaming (forward_chunk_by_chunk with caches) is not built yet (SURVEY.md 8f-3)")
+        self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         if context_graph is not None:
             raise NotImplementedError("context biasing is out of scope")
         if blank_id != self.engine.cfg.blank_id:
@@ -186,8 +187,9 @@ class ReverbASR:
                          decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1, ctc_weight: float = 0.1,
                          simulate_streaming: bool = False, reverse_weight: float = 0.0, blank_penalty: float = 0.0,
                          length_penalty: float = 0.0, timings_adjustment: float = 230) -> list[str]:
-        if simulate_streaming or decoding_chunk_size > 0:
-            raise NotImplementedError("streaming / chunked-attention decoding is not built yet (SURVEY.md 8f-3)")
+        if simulate_streaming:
+            raise NotImplementedError("simulate_streaming (forward_chunk_by_chunk with caches) is not built yet (SURVEY.md 8f-3)")
+        self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         fc = self.test_conf["fbank_conf"]
         if (fc["num_mel_bins"], fc["frame_length"], fc["frame_shift"]) != (80, 25, 10):
             raise NotImplementedError("the device fbank is built for 80 bins / 25 ms / 10 ms")

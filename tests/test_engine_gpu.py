@@ -253,3 +253,40 @@ def test_attention_mode_bf16_runs_and_batches_consistently():
     assert b[0] == a[0]
     assert all(0 <= t < case.cfg["output_dim"] - 1 for h in a for t in h)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------ chunk-masked decoding
+def test_chunk_masked_decoding_f32_matches_reference_golden():
+    """--decoding_chunk_size / --num_decoding_left_chunks (recognize_wav.py:95-112) on a use_dynamic_chunk model."""
+    import json
+    from golden_util import GOLDEN
+    case = Case("tiny_ln")
+    with open(os.path.join(GOLDEN, "tiny_ln_chunkmask.json")) as f:
+        gold = json.load(f)
+    arrays = np.load(os.path.join(GOLDEN, "tiny_ln_chunkmask.npz"))
+    cfg = dict(case.cfg)
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], use_dynamic_chunk=True)
+    x, lens = case.chunked_feats()
+    eng = Engine(cfg, case.sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    for run in gold["runs"]:
+        cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+        eng.apply_decoding_chunk(cs, left)
+        eng.encode(x, lens, case.beam)
+        enc = eng.encoder_out()[:, ::4]
+        want = arrays[f"enc_{cs}_{left}".replace("-", "m")]
+        for b, n in enumerate(eng.encoder_lens()):
+            nn = len(range(0, n, 4))
+            np.testing.assert_allclose(enc[b, :nn], want[b, :nn], rtol=2e-3, atol=2e-3)
+        res = eng.search(["ctc_greedy_search", "attention_rescoring"], case.ctc_weight, 0.0)
+        assert [list(r.tokens) for r in res["ctc_greedy_search"]] == run["greedy"], (cs, left)
+        assert [list(r.tokens) for r in res["attention_rescoring"]] == run["rescoring"], (cs, left)
+    eng.close()
+    # a model that was not trained for it ignores the flags, as the reference does
+    eng2 = _engine(case, "f32")
+    eng2.apply_decoding_chunk(16, 2)
+    eng2.encode(x[:1], lens[:1], case.beam)
+    a = eng2.encoder_out().copy()
+    eng2.apply_decoding_chunk(-1, -1)
+    eng2.encode(x[:1], lens[:1], case.beam)
+    assert np.array_equal(a, eng2.encoder_out())
+    eng2.close()

@@ -269,3 +269,35 @@ def test_fbank_vs_oracle(lib):
     quiet = (pcm // 4000).astype(np.int16)
     _lib.check(lib.rvb_test_fbank(quiet.ctypes.data_as(_lib._i16p), len(quiet), fptr(feats)))
     np.testing.assert_allclose(feats, fbank_ref.fbank(quiet), rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("chunk,left", [(16, -1), (16, 2), (7, 1), (64, 0), (200, 3)])
+def test_attention_chunk_mask(lib, dtype, chunk, left):
+    """subsequent_chunk_mask (utils/mask.py:86-123) inside the kernel: query i sees keys
+    [max((i/cs - left)*cs, 0), (i/cs + 1)*cs) of its own sequence; tiles outside the range are skipped."""
+    rng = np.random.default_rng(chunk * 31 + left + dtype)
+    lens = i32([300, 77, 1])
+    heads, dk = 2, 64
+    d = heads * dk
+    starts = i32(np.concatenate([[0], np.cumsum(lens)[:-1]]))
+    rows = int(lens.sum())
+    q, k, v = (rnd(dtype, rng.standard_normal((rows, d))) for _ in range(3))
+    out = np.empty((rows, d), np.float32)
+    code = ((left + 1) << 20) | (chunk << 8)          # test-API packing of (chunk, left) into the `causal` argument
+    _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), None, None, None, fptr(out), rows, rows, 0, heads, dk,
+                                      iptr(starts), iptr(lens), iptr(starts), iptr(lens), 3, code))
+    ref = np.zeros((rows, d))
+    for s0, L in zip(starts, lens):
+        idx = np.arange(L)
+        lo = np.zeros(L, int) if left < 0 else np.maximum((idx // chunk - left) * chunk, 0)
+        hi = np.minimum((idx // chunk + 1) * chunk, L)
+        mask = (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
+        for h in range(heads):
+            sl = slice(h * dk, (h + 1) * dk)
+            sc = q[s0:s0 + L, sl].astype(np.float64) @ k[s0:s0 + L, sl].astype(np.float64).T / math.sqrt(dk)
+            sc = np.where(mask, sc, -np.inf)
+            pr = np.exp(sc - sc.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+            ref[s0:s0 + L, sl] = pr @ v[s0:s0 + L, sl].astype(np.float64)
+    tol = 2e-5 if dtype == F32 else 3e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)

@@ -81,3 +81,31 @@ def test_attention_mode_oracle_matches_reference_golden(name):
         for run in gold["runs"]:
             res = S.attention_beam_search(sd, case.cfg, enc, mask, case.beam, run["length_penalty"], torch.tensor(case.cat))
             assert [list(r.tokens) for r in res] == run["tokens"], (name, run["length_penalty"])
+
+
+def test_chunk_masked_encoder_oracle_matches_reference_golden():
+    """decoding_chunk_size / num_decoding_left_chunks on a use_dynamic_chunk model (utils/mask.py:86-197): the oracle's
+    encoder reproduces the unmodified reference bit for bit (oracle/gen_golden_chunkmask.py)."""
+    import json
+    case = Case("tiny_ln")
+    with open(GOLDEN + "/tiny_ln_chunkmask.json") as f:
+        gold = json.load(f)
+    arrays = np.load(GOLDEN + "/tiny_ln_chunkmask.npz")
+    cfg = dict(case.cfg)
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], use_dynamic_chunk=True)
+    x, lens = case.chunked_feats()
+    sd = M.to_torch_sd(case.sd)
+    with torch.no_grad():
+        for run in gold["runs"]:
+            cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+            enc, mask = M.encoder_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(lens), torch.tensor(case.cat),
+                                          decoding_chunk_size=cs, num_decoding_left_chunks=left)
+            np.testing.assert_array_equal(enc.numpy()[:, ::4], arrays[f"enc_{cs}_{left}".replace("-", "m")])
+            probs = M.ctc_logprobs(sd, enc)
+            got = S.ctc_greedy_search(probs, mask.squeeze(1).sum(1), 0)
+            assert [list(r.tokens) for r in got] == run["greedy"], (cs, left)
+    # a model without use_dynamic_chunk ignores the arguments (full context)
+    with torch.no_grad():
+        a, _ = M.encoder_forward(sd, case.cfg, torch.from_numpy(x[:1]), torch.from_numpy(lens[:1]), torch.tensor(case.cat), decoding_chunk_size=16)
+        b, _ = M.encoder_forward(sd, case.cfg, torch.from_numpy(x[:1]), torch.from_numpy(lens[:1]), torch.tensor(case.cat))
+    assert torch.equal(a, b)
