@@ -176,11 +176,12 @@ template <> struct Pair<float> {
   }
 };
 
-// block = 64 time steps x 128 channels; a lane owns 2 adjacent channels (4-/8-byte loads, 8-byte stores)
+// block = 64 time steps x 128 channels.  Staging: one thread per (row, 16-byte channel group) -- the two GLU halves
+// are read as 16-byte vectors (many bytes in flight per lane), gated, and written to LDS as fp32.  Compute: a lane
+// owns 2 adjacent channels and 16 consecutive frames (8-byte stores).
 template <typename T>
 __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
-  __shared__ float2 s_g[DW_TT + DW_KMAX - 1][DW_CT / 2];
-  __shared__ float2 s_w[DW_KMAX][DW_CT / 2];
+  __shared__ __attribute__((aligned(16))) float2 s_g[DW_TT + DW_KMAX - 1][DW_CT / 2];
   const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
   const int ch = c0 + 2 * c;
@@ -188,50 +189,81 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
   const int K = a.K, pad = (K - 1) / 2;
   const int len = a.lens[b];
   const T* G = (const T*)a.G;
-  float2 gpad = make_float2(0.f, 0.f);  // GLU of the pointwise-conv1 bias: what a zero-masked (padded) frame yields
-  if (cok) {
-    gpad.x = a.pw1_bias[ch] / (1.0f + expf(-a.pw1_bias[a.d + ch]));
-    gpad.y = a.pw1_bias[ch + 1] / (1.0f + expf(-a.pw1_bias[a.d + ch + 1]));
-  }
-  for (int k = slot; k < K; k += 4)
-    s_w[k][c] = cok ? make_float2(a.dw_w[(size_t)ch * K + k], a.dw_w[(size_t)(ch + 1) * K + k]) : make_float2(0.f, 0.f);
-  const int rows = DW_TT + K - 1;
+  constexpr int VE = 16 / (int)sizeof(T);          // channels per 16-byte vector
+  constexpr int NG = DW_CT / VE;                   // vector groups per row
+  constexpr int rows = DW_TT + DW_KMAX - 1;        // always the full window: rows past DW_TT + K - 1 are zero-filled
+  const bool vec_ok = (a.d % VE) == 0;
 #pragma unroll 4
-  for (int r = slot; r < rows; r += 4) {
+  for (int v = threadIdx.x; v < rows * NG; v += 256) {
+    const int r = v / NG, grp = v - r * NG;
     const int t = t0 - pad + r;
-    float2 g = make_float2(0.f, 0.f);
-    if (cok && t >= 0 && t < a.T) {
+    const int cg = c0 + grp * VE;                  // first channel of the group
+    float g[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] = 0.f;
+    if (cg < a.d && t >= 0 && t < a.T && r < DW_TT + K - 1) {
       if (t < len) {
         const T* gr = G + ((size_t)b * a.T + t) * 2 * a.d;
-        float a0, a1, b0, b1;
-        Pair<T>::load(gr + ch, a0, a1);
-        Pair<T>::load(gr + a.d + ch, b0, b1);
-        g.x = a0 / (1.0f + expf(-b0));
-        g.y = a1 / (1.0f + expf(-b1));
+        T av[VE], bvv[VE];
+        if (vec_ok) {
+          *(uint4*)av = *(const uint4*)(gr + cg);
+          *(uint4*)bvv = *(const uint4*)(gr + a.d + cg);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            av[e] = cg + e < a.d ? gr[cg + e] : Cvt<T>::from_f32(0.f);
+            bvv[e] = cg + e < a.d ? gr[a.d + cg + e] : Cvt<T>::from_f32(0.f);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float a0 = Cvt<T>::to_f32(av[e]), b0 = Cvt<T>::to_f32(bvv[e]);
+          if constexpr (sizeof(T) == 2)   // bf16 mode: hardware exp2/rcp (the gate is rounded to bf16 precision anyway)
+            g[e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b0));
+          else
+            g[e] = a0 / (1.0f + expf(-b0));
+        }
       } else {
-        g = gpad;
+        // GLU of the pointwise-conv1 bias: what a zero-masked (padded) frame yields (convolution.py:107-118)
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          if (cg + e < a.d) g[e] = a.pw1_bias[cg + e] / (1.0f + expf(-a.pw1_bias[a.d + cg + e]));
       }
     }
-    s_g[r][c] = g;
+    float* dst = (float*)&s_g[r][0] + grp * VE;
+#pragma unroll
+    for (int q = 0; q < VE / 4; ++q) ((float4*)dst)[q] = make_float4(g[q * 4], g[q * 4 + 1], g[q * 4 + 2], g[q * 4 + 3]);
   }
   __syncthreads();
   if (!cok) return;
-  float2 acc[DW_TT / 4];
+  // Each thread owns 16 CONSECUTIVE output frames of its channel pair: the 46 input rows they touch are read from
+  // LDS once each and fanned out to the (up to 16) outputs they contribute to, taps in registers -- 46 LDS reads
+  // per thread instead of one per FMA pair (the strided version was LDS-bandwidth bound).
+  constexpr int OPT = DW_TT / 4;                 // outputs per thread
+  float2 wk[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k)
+    wk[k] = k < K ? make_float2(a.dw_w[(size_t)ch * K + k], a.dw_w[(size_t)(ch + 1) * K + k]) : make_float2(0.f, 0.f);
+  float2 acc[OPT];
   const float2 bv = make_float2(a.dw_b[ch], a.dw_b[ch + 1]);
 #pragma unroll
-  for (int i = 0; i < DW_TT / 4; ++i) acc[i] = bv;
-  for (int k = 0; k < K; ++k) {
-    const float2 wk = s_w[k][c];
+  for (int i = 0; i < OPT; ++i) acc[i] = bv;
+  const int rbase = slot * OPT;
 #pragma unroll
-    for (int i = 0; i < DW_TT / 4; ++i) {
-      const float2 g = s_g[slot + 4 * i + k][c];
-      acc[i].x += wk.x * g.x;
-      acc[i].y += wk.y * g.y;
+  for (int r = 0; r < OPT + DW_KMAX - 1; ++r) {
+    const float2 g = s_g[rbase + r][c];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+      const int k = r - i;                        // compile-time after unrolling
+      if (k >= 0 && k < DW_KMAX) {
+        acc[i].x = fmaf(wk[k].x, g.x, acc[i].x);
+        acc[i].y = fmaf(wk[k].y, g.y, acc[i].y);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < DW_TT / 4; ++i) {
-    const int t = t0 + slot + 4 * i;
+  for (int i = 0; i < OPT; ++i) {
+    const int t = t0 + rbase + i;
     if (t < a.T) *(float2*)(a.out + ((size_t)b * a.T + t) * a.d + ch) = acc[i];
   }
 }
