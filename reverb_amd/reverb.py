@@ -65,7 +65,8 @@ class RvbASRModel:
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
         if simulate_streaming:
-            raise NotImplementedError("simulate_streaming (forward_chunk_by_chunk with caches) is not built yet (SURVEY.md 8f-3)")
+            raise NotImplementedError("simulate_streaming is not built: the reference's forward_chunk_by_chunk path drops cat_embs "
+                                      "(asr_model.py:301-306) and asserts in the language-specific layers for Reverb models")
         self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         if context_graph is not None:
             raise NotImplementedError("context biasing is out of scope")
@@ -188,7 +189,8 @@ class ReverbASR:
                          simulate_streaming: bool = False, reverse_weight: float = 0.0, blank_penalty: float = 0.0,
                          length_penalty: float = 0.0, timings_adjustment: float = 230) -> list[str]:
         if simulate_streaming:
-            raise NotImplementedError("simulate_streaming (forward_chunk_by_chunk with caches) is not built yet (SURVEY.md 8f-3)")
+            raise NotImplementedError("simulate_streaming is not built: the reference's forward_chunk_by_chunk path drops cat_embs "
+                                      "(asr_model.py:301-306) and asserts in the language-specific layers for Reverb models")
         self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         fc = self.test_conf["fbank_conf"]
         if (fc["num_mel_bins"], fc["frame_length"], fc["frame_shift"]) != (80, 25, 10):
