@@ -120,7 +120,7 @@ int emb_conv1(hipStream_t s, int dtype, const float* fb, const int64_t* win, con
 // ------------------------------------------------------------------------------------ 3x3 / 1x1 convolution on MFMA
 static constexpr int CV_TF = 4, CV_TT = 64, CV_MI = 4;
 
-template <typename T, int NT, int STRIDE>
+template <typename T, int NT, int STRIDE, int TAPS>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cv_smem[];
   constexpr int CK = 64 / (int)sizeof(T);     // input channels per 64-byte chunk
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   constexpr int BV = (9 * NT * 4 + 255) / 256;     // 16-byte vectors of the 9 taps' weights per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int taps = p.taps;
+  constexpr int taps = TAPS;
   char* sP = cv_smem;
   char* sB = cv_smem + ((PF * PT * 64 + 127) & ~127);
 
@@ -193,18 +193,26 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch + 1 < nchunks) load_regs(ch + 1);      // next chunk's global loads fly under this chunk's MFMAs
-    for (int tap = 0; tap < taps; ++tap) {
+    // taps fully unrolled with the NEXT tap's fragments read from LDS before the current tap's MFMAs are issued:
+    // with one wave per SIMD nothing else hides the LDS latency
+    uint4 bf[2][NJ], af[2][CV_MI];
+    auto read_frags = [&](int tap, int buf) {
       const int kh = taps == 9 ? tap / 3 : 1, kw = taps == 9 ? tap - (tap / 3) * 3 : 1;
-      uint4 bf[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = *(const uint4*)(sB + (tap * NT + j * 16 + li) * 64 + lg * 16);
+      for (int j = 0; j < NJ; ++j) bf[buf][j] = *(const uint4*)(sB + (tap * NT + j * 16 + li) * 64 + lg * 16);
       const char* arow = sP + ((s * wave + kh) * PT + kw) * 64 + lg * 16;
 #pragma unroll
-      for (int mi = 0; mi < CV_MI; ++mi) {
-        const uint4 a = *(const uint4*)(arow + (s * (mi * 16 + li)) * 64);
+      for (int mi = 0; mi < CV_MI; ++mi) af[buf][mi] = *(const uint4*)(arow + (s * (mi * 16 + li)) * 64);
+    };
+    read_frags(0, 0);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) Mma16<T>::run(a, bf[j], acc[mi][j]);
-      }
+    for (int tap = 0; tap < taps; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < taps) read_frags(tap + 1, cur ^ 1);
+#pragma unroll
+      for (int mi = 0; mi < CV_MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mma16<T>::run(af[cur][mi], bf[cur][j], acc[mi][j]);
     }
     if (ch + 1 < nchunks) {
       __syncthreads();
@@ -269,14 +277,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   }
 }
 
-template <typename T, int NT, int STRIDE>
-static int launch_conv_s(hipStream_t st, const ConvArgs& p) {
+template <typename T, int NT, int STRIDE, int TAPS>
+static int launch_conv_st(hipStream_t st, const ConvArgs& p) {
   constexpr int s = STRIDE;
   const int PF = s * (CV_TF - 1) + 3, PT = s * (CV_TT - 1) + 3;
   size_t lds = (size_t)((PF * PT * 64 + 127) & ~127) + (size_t)p.taps * NT * 64;
   const size_t slab = (size_t)4 * 16 * (NT * 4 + 16);
   if (lds < slab) lds = slab;
-  auto kern = conv_kernel<T, NT, STRIDE>;
+  auto kern = conv_kernel<T, NT, STRIDE, TAPS>;
   static size_t attr = 0;
   if (lds > attr) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -290,7 +298,8 @@ static int launch_conv_s(hipStream_t st, const ConvArgs& p) {
 
 template <typename T, int NT>
 static int launch_conv(hipStream_t st, const ConvArgs& p) {
-  return p.stride == 2 ? launch_conv_s<T, NT, 2>(st, p) : launch_conv_s<T, NT, 1>(st, p);
+  if (p.taps == 1) return p.stride == 2 ? launch_conv_st<T, NT, 2, 1>(st, p) : launch_conv_st<T, NT, 1, 1>(st, p);
+  return p.stride == 2 ? launch_conv_st<T, NT, 2, 9>(st, p) : launch_conv_st<T, NT, 1, 9>(st, p);
 }
 
 int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
