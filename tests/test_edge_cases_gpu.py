@@ -1,0 +1,83 @@
+"""Edge cases of the front door (ReverbASR.transcribe / Engine.decode_resident / diarization pipeline): empty and
+sub-frame audio, inputs that subsample to zero or one encoder frame, a chunk boundary straddled by one frame."""
+import numpy as np
+import pytest
+
+from reverb_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 400
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from reverb_amd.engine import Engine
+    cfg = synth.make_config("tiny")
+    e = Engine(cfg, synth.make_state_dict(cfg, 0, synth.CTC_GAMMA, 12.33), dtype="f32", device=0, max_chunks=3, chunk_frames=CHUNK)
+    yield e
+    e.close()
+
+
+def _decode(eng, pcm, modes=("ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring", "attention")):
+    eng.upload_pcm(pcm)
+    nf = eng.fbank()
+    return nf, eng.decode_resident(nf, list(modes), CHUNK, 4, 0.1, 0.0)
+
+
+@pytest.mark.parametrize("n_samples", [0, 1, 399])
+def test_audio_shorter_than_one_frame_gives_no_chunks(eng, n_samples):
+    nf, res = _decode(eng, np.zeros(n_samples, np.int16))
+    assert nf == 0
+    assert all(res[m] == [] for m in res)
+
+
+@pytest.mark.parametrize("frames,enc", [(1, 0), (6, 0), (7, 1), (10, 1), (11, 2)])
+def test_inputs_that_subsample_to_zero_or_one_encoder_frame(eng, frames, enc):
+    """(n - 7)//4 + 1 valid encoder frames (subsampling.py:226): 0 for fewer than 7 input frames -- the searches must
+    return empty hypotheses, not crash (the reference's conv2d raises on such inputs; an empty result is the useful answer)."""
+    pcm = synth.synth_audio(1.0, seed=2)[: 400 + 160 * (frames - 1)]
+    nf, res = _decode(eng, pcm)
+    assert nf == frames
+    assert eng.encoder_lens().tolist() == [enc]
+    for m in res:
+        assert len(res[m]) == 1
+        if enc == 0:
+            assert list(res[m][0].tokens) == []
+
+
+def test_one_frame_past_a_chunk_boundary(eng):
+    pcm = synth.synth_audio(5.0, seed=4)[: 400 + 160 * CHUNK]          # CHUNK + 1 frames -> chunks of CHUNK and 1 frames
+    nf, res = _decode(eng, pcm, ("ctc_greedy_search", "attention_rescoring"))
+    assert nf == CHUNK + 1
+    assert eng.encoder_lens().tolist() == [(CHUNK - 7) // 4 + 1, 0]
+    assert len(res["attention_rescoring"]) == 2 and list(res["attention_rescoring"][1].tokens) == []
+    # the first chunk is unaffected by the presence of the tail chunk
+    nf1, res1 = _decode(eng, pcm[: 400 + 160 * (CHUNK - 1)], ("ctc_greedy_search", "attention_rescoring"))
+    assert nf1 == CHUNK
+    assert list(res1["attention_rescoring"][0].tokens) == list(res["attention_rescoring"][0].tokens)
+
+
+def test_more_chunks_than_one_launch_holds(eng):
+    pcm = synth.synth_audio(4.0 * 7 + 1.3, seed=6)                      # 8 chunks of 4 s with max_chunks = 3
+    nf, res = _decode(eng, pcm, ("attention_rescoring",))
+    assert len(res["attention_rescoring"]) == -(-nf // CHUNK) == 8
+    from reverb_amd.engine import Engine
+    big = Engine(eng.configs, synth.make_state_dict(eng.configs, 0, synth.CTC_GAMMA, 12.33), dtype="f32", device=0, max_chunks=16,
+                 chunk_frames=CHUNK)
+    big.upload_pcm(pcm)
+    want = big.decode_resident(big.fbank(), ["attention_rescoring"], CHUNK, 4, 0.1, 0.0)["attention_rescoring"]
+    big.close()
+    assert [list(r.tokens) for r in res["attention_rescoring"]] == [list(r.tokens) for r in want]
+
+
+def test_diarization_rejects_empty_audio_and_handles_silence(tmp_path):
+    from reverb_amd import diarization as D, synth_diar
+    from reverb_amd._lib import RvbError
+    pipe = D.Pipeline.from_pretrained(synth_diar.write_pipeline_dir(str(tmp_path / "p")), dtype="f32").to("cuda")
+    with pytest.raises(RvbError):
+        pipe({"waveform": np.zeros(0, np.int16), "sample_rate": 16000})
+    ann = pipe({"waveform": np.zeros(16000 * 3, np.int16), "sample_rate": 16000, "uri": "silence"})   # 3 s of digital silence
+    assert ann.uri == "silence"
+    for seg, _, label in ann.itertracks(yield_label=True):
+        assert 0.0 <= seg.start < seg.end <= 10.1 and label.startswith("SPEAKER_")
