@@ -489,8 +489,13 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   // GPU is still encoding slice i+1.  Workspaces are sized for one slice.
   // two slices: with 256x256 GEMM tiles a finer split leaves the N=1024 GEMMs with <2 waves of tiles per CU
   // (measured: 4 slices 818 TFLOP/s vs 923 un-sliced)
-  const int nsplit = B >= 16 ? 2 : 1;
-  const int SB = (B + nsplit - 1) / nsplit;
+  // uneven split: the host search of the LAST slice is the part nothing overlaps, so that slice is the small one;
+  // the first slice's search hides under the GPU time of the second.  For large batches the tail is exactly 32
+  // chunks (32 x 512 frames = 64 row tiles = one full wave of 256x256 tiles over the 256 CUs for the N = 1024 GEMMs);
+  // measured on the 176-chunk bench batch: first slice 96/112/128/144/160 -> 201.1/199.8/198.6/197.4/198.9 ms
+  int SB = B >= 16 ? (B * 7 + 9) / 10 : B;            // chunks in the first (largest) slice
+  if (B >= 64) SB = B - 32;
+  if (const char* ov = getenv("RVB_SLICE0")) { const int v = atoi(ov); if (v > 0 && v <= B) SB = v; }   // tuning override
   const int Ms = SB * T2;
   RVB_TRY(e->X1.ensure((size_t)SB * T1 * F1 * d * es));
   RVB_TRY(e->X2.ensure((size_t)SB * T2 * F2 * d * es));
@@ -515,7 +520,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   }
   e->slices.clear();
   for (int c0 = 0; c0 < B; c0 += SB) {
-    const int nb = std::min(SB, B - c0);
+    const int nb = std::min(SB, B - c0);               // first slice SB chunks, second slice the rest (<= SB)
     const int m = nb * T2;
     const int row0 = c0 * T2;
     e->cur_lens = e->d_enc_lens.as<int>() + c0;       // per-chunk arrays of this slice (starts are slice-relative)
