@@ -8,6 +8,8 @@
 // candidates with lazy validation, Lance-Williams centroid update) restated step for step so that the
 // dendrogram is the same -- runs as ONE persistent 1024-thread workgroup: every merge is a block-wide
 // argmin over the candidate distances plus one fused pass over the two merged rows.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace rvb {
@@ -185,7 +187,8 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
   RVB_HIP_CHECK(hipGetLastError());
   const size_t lds = (size_t)n * 14 + 16;
-  if (lds <= 158 * 1024) {
+  const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
+  if (lds <= 158 * 1024 && !force_global) {
     static bool attr_set = false;
     if (!attr_set) {
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));

@@ -198,3 +198,20 @@ def test_centroid_linkage_matches_scipy(case, n, d, seed):
     assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])          # same merges in the same order
     assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
     assert np.array_equal(fcluster(got, 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
+
+
+def test_centroid_linkage_large_n_variant_matches_scipy(case, monkeypatch):
+    """More than ~11 500 points (3 h of audio) do not fit the LDS-resident state: the same loop then keeps its state in
+    global memory.  RVD_LINKAGE_GLOBAL forces that variant on a small input so that it is checked against scipy too."""
+    from scipy.cluster.hierarchy import linkage
+    from reverb_amd.diar_engine import DiarEngine
+    monkeypatch.setenv("RVD_LINKAGE_GLOBAL", "1")
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((3, 32))[rng.integers(3, size=700)] + 0.3 * rng.standard_normal((700, 32))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
+    got = eng.centroid_linkage(X)
+    eng.close()
+    want = linkage(X, method="centroid", metric="euclidean")
+    assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])
+    assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
