@@ -842,9 +842,9 @@ static int attention_decode_impl(rvb_engine* e, int N, float length_penalty) {
   std::vector<float> scores(R, -INFINITY);
   for (int b = 0; b < B; ++b) scores[(size_t)b * N] = 0.f;            // search.py:289-292
   std::vector<char> end_flag(R, 0);
-  for (int b = 0; b < B; ++b)                                          // a chunk without a single valid encoder frame has nothing to attend to:
-    if (e->enc_lens[b] <= 0)                                            // its beams start finished and the result is empty (the reference cannot
-      for (int n = 0; n < N; ++n) end_flag[(size_t)b * N + n] = 1;     // reach this state: its subsampling conv rejects inputs shorter than 7 frames)
+  // (a chunk without a single valid encoder frame is NOT special-cased: the reference decodes it against a fully masked
+  // memory -- attention output zero, attention.py:112-114 -- and emits whatever the decoder's prior produces; the golden
+  // case tiny_bn has such a 5-frame tail chunk)
   std::vector<int32_t> tok(R), pos(R), parent(R);
   std::vector<float> topv((size_t)R * N);
   std::vector<int32_t> topi((size_t)R * N);
