@@ -124,9 +124,12 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
         if (SZ(z) > 0) p = min_pair(p, MinPair{MD(z), z});
       p = block_argmin(p, red);
       if (tid == 0) {
+        // scipy validates the candidate lazily with `dist == D[x, neighbor[x]]`; here that predicate is kept up to
+        // date where D changes (the merge pass below), encoded in the sign of the neighbour: nb >= 0 valid,
+        // nb <= -2 stale (neighbour -2-nb), -1 none -- no global read on the critical path
         const int x = p.i, y = NB(x);
         s_x = x; s_y = y; s_dist = p.v;
-        s_ok = (y >= 0 && SZ(y) > 0 && p.v == D[(size_t)x * n + y]) ? 1 : 0;
+        s_ok = y >= 0 ? 1 : 0;
       }
       __syncthreads();
       if (s_ok) break;
@@ -165,8 +168,13 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
       ry[z] = nd;
       D[(size_t)z * n + y] = nd;
       if (z < y) {
-        if (z < x && NB(z) == x) NB(z) = y;
-        if (nd < MD(z)) { NB(z) = y; MD(z) = nd; }
+        const int nb0 = NB(z);
+        int nb = nb0;
+        int dec = nb <= -2 ? -2 - nb : nb;                 // neighbour whatever the validity
+        if (z < x && dec == x) dec = y;                    // scipy: "reassign neighbor candidates from x to y"
+        if (dec == y) nb = (MD(z) == nd) ? y : -2 - y;     // D[z][y] just changed: re-evaluate `dist == D[z, neighbor]`
+        if (nd < MD(z)) { nb = y; MD(z) = nd; }            // lower-bound update
+        if (nb != nb0) NB(z) = nb;
       } else {
         best = min_pair(best, MinPair{nd, z});
       }
