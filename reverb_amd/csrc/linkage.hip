@@ -81,6 +81,26 @@ __device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
   return r;
 }
 
+// one-barrier variant for back-to-back reductions: the caller alternates between two result buffers, so the writes of
+// reduction k+1 cannot race with the reads of reduction k (those are separated by reduction k+1's own barrier from k+2)
+__device__ inline MinPair block_argmin_alt(MinPair p, MinPair (*red)[16], int& phase) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MinPair q;
+    q.v = __shfl_xor(p.v, o, 64);
+    q.i = __shfl_xor(p.i, o, 64);
+    p = min_pair(p, q);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  MinPair* buf = red[phase & 1];
+  ++phase;
+  if (lane == 0) buf[wv] = p;
+  __syncthreads();
+  MinPair r = buf[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = min_pair(r, buf[w]);
+  return r;
+}
+
 // nearest neighbour of every x among y > x (scipy find_min_dist: first index on ties); one block per row
 __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__ D, int n, int* __restrict__ neighbor,
                                                       double* __restrict__ min_dist) {
@@ -97,11 +117,12 @@ __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__
 // (14 bytes per point: up to ~11 500 points = one hour of audio at 3 speakers per hop), so an iteration
 // touches HBM/L2 only for the validity check D[x][y] and for the two merged rows.
 template <bool LDS_STATE>
-__global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
+__global__ __launch_bounds__(1024) void linkage_kernel(int getenv_prof, double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
                                                        int* __restrict__ cluster_id, int* __restrict__ g_neighbor,
                                                        double* __restrict__ g_min_dist, double* __restrict__ Z) {
   extern __shared__ __attribute__((aligned(16))) char lk_smem[];
-  __shared__ MinPair red[16];
+  __shared__ MinPair red[2][16];
+  int rphase = 0;
   __shared__ int s_x, s_y, s_ok;
   __shared__ double s_dist;
   double* s_md = (double*)lk_smem;
@@ -112,6 +133,8 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
   auto SZ = [&](int i) -> uint16_t& { if constexpr (LDS_STATE) return s_sz[i]; else return g_size[i]; };
   const int tid = threadIdx.x;
   long long retries = 0;
+  long long t_arg = 0, t_scan = 0, t_merge = 0, t_misc = 0, t0c = 0;
+  const bool prof = getenv_prof;
   if (LDS_STATE) {
     for (int i = tid; i < n; i += 1024) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }
     __syncthreads();
@@ -119,10 +142,10 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
   for (int k = 0; k < n - 1; ++k) {
     // ---- closest valid candidate pair (lazy validation of the nearest-neighbour guesses) ----
     for (int it = 0; it < n - k; ++it) {
+      if (prof) t0c = wall_clock64();
       MinPair p{INFINITY, 0x7fffffff};
-      for (int z = tid; z < n - 1; z += 1024)
-        if (SZ(z) > 0) p = min_pair(p, MinPair{MD(z), z});
-      p = block_argmin(p, red);
+      for (int z = tid; z < n - 1; z += 1024) p = min_pair(p, MinPair{MD(z), z});      // dropped rows hold +inf
+      p = block_argmin_alt(p, red, rphase);
       if (tid == 0) {
         // scipy validates the candidate lazily with `dist == D[x, neighbor[x]]`; here that predicate is kept up to
         // date where D changes (the merge pass below), encoded in the sign of the neighbour: nb >= 0 valid,
@@ -132,16 +155,19 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
         s_ok = y >= 0 ? 1 : 0;
       }
       __syncthreads();
+      if (prof) { const long long t1 = wall_clock64(); t_arg += t1 - t0c; t0c = t1; }
       if (s_ok) break;
       ++retries;
       const int x = s_x;
       MinPair q{INFINITY, 0x7fffffff};
       for (int j = x + 1 + tid; j < n; j += 1024)
         if (SZ(j) > 0) q = min_pair(q, MinPair{D[(size_t)x * n + j], j});
-      q = block_argmin(q, red);
+      q = block_argmin_alt(q, red, rphase);
       if (tid == 0) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; }
       __syncthreads();
+      if (prof) { const long long t1 = wall_clock64(); t_scan += t1 - t0c; }
     }
+    if (prof) t0c = wall_clock64();
     const int x = s_x, y = s_y;
     const double dist = s_dist;
     const int nx = SZ(x), ny = SZ(y);
@@ -179,10 +205,12 @@ __global__ __launch_bounds__(1024) void linkage_kernel(double* __restrict__ D, i
         best = min_pair(best, MinPair{nd, z});
       }
     }
-    best = block_argmin(best, red);
+    best = block_argmin_alt(best, red, rphase);
     if (tid == 0 && y < n - 1) { NB(y) = best.v < INFINITY ? best.i : -1; MD(y) = best.v; }
     __syncthreads();
+    if (prof) t_merge += wall_clock64() - t0c;
   }
+  if (tid == 0 && prof) printf("linkage n=%d: argmin+validate %.1f ms, row rescans %.1f ms, merge pass %.1f ms (100 MHz wall clock), retries %lld\n", n, t_arg * 1e-5, t_scan * 1e-5, t_merge * 1e-5, retries);
   if (tid == 0) g_min_dist[n - 1] = (double)retries;     // statistics: invalid candidates re-evaluated (slot n-1 is unused)
 }
 
@@ -202,9 +230,9 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(linkage_kernel<true>, dim3(1), dim3(1024), lds, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+    hipLaunchKernelGGL(linkage_kernel<true>, dim3(1), dim3(1024), lds, s, getenv("RVD_LINKAGE_PROF") ? 1 : 0, D, n, size, cluster_id, neighbor, min_dist, Z);
   } else {
-    hipLaunchKernelGGL(linkage_kernel<false>, dim3(1), dim3(1024), 0, s, D, n, size, cluster_id, neighbor, min_dist, Z);
+    hipLaunchKernelGGL(linkage_kernel<false>, dim3(1), dim3(1024), 0, s, getenv("RVD_LINKAGE_PROF") ? 1 : 0, D, n, size, cluster_id, neighbor, min_dist, Z);
   }
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
