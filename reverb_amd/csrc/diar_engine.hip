@@ -1,6 +1,7 @@
 // rvd_* : diarization engine (segmentation + embedding networks of the pyannote pipeline the reference
 // runs in diarization/infer_pyannote3.0.py:33-42) on one MI355X.  Kernels: diar.hip, resnet.hip, gemm*.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -20,7 +21,11 @@ constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 struct ConvW { DevBuf w, b; int cin = 0, cout = 0, taps = 9, stride = 1; };
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
-constexpr int EMB_BATCH = 96;      // windows per trunk pass (activations ~36 MB per window in bf16 -> 3.5 GB)
+static int emb_batch() {            // windows per trunk pass; RVD_EMB_BATCH overrides (tuning)
+  static int v = [] { const char* e = getenv("RVD_EMB_BATCH"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
+  return v;
+}
+#define EMB_BATCH (emb_batch())      // windows per trunk pass (activations ~36 MB per window in bf16 -> 3.5 GB)
 }  // namespace
 
 struct rvd_engine {
