@@ -173,18 +173,32 @@ def speaker_count_from_classes(classes: np.ndarray, chunk_step: float, chunk_dur
     return np.rint(aggregate(_NSPK[classes][:, :, None], chunk_step, chunk_duration)).astype(np.uint8)
 
 
+def _lut() -> np.ndarray:
+    lut = np.zeros((len(POWERSET), 3), bool)
+    for k, spk in enumerate(POWERSET):
+        lut[k, list(spk)] = True
+    return lut
+
+
+def class_histogram(classes: np.ndarray) -> np.ndarray:
+    """frames per powerset class of every chunk: int64 (chunks, 7)."""
+    num_chunks = classes.shape[0]
+    flat = classes.astype(np.int64) + len(POWERSET) * np.arange(num_chunks)[:, None]
+    return np.bincount(flat.ravel(), minlength=num_chunks * len(POWERSET)).reshape(num_chunks, len(POWERSET))
+
+
+def active_from_classes(classes: np.ndarray) -> np.ndarray:
+    """bool (chunks, 3): the local speaker is active in at least one frame (= np.sum(binarized, axis=1) > 0)."""
+    return (class_histogram(classes) @ _lut().astype(np.int64)) > 0
+
+
 def embedding_items_from_classes(classes: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
                                  window_samples: int = 160000):
     """The (chunk, local speaker) pairs that are active at all, and their pooling masks as
     embedding_masks() would build them: -> (chunk_idx, speaker_idx, masks float32 [n, frames])."""
     num_chunks, nf = classes.shape
-    lut = np.zeros((len(POWERSET), 3), bool)
-    for k, spk in enumerate(POWERSET):
-        lut[k, list(spk)] = True
-    counts = np.stack([np.bincount(row, minlength=len(POWERSET)) for row in classes]) if num_chunks < 64 else None
-    if counts is None:
-        flat = classes.astype(np.int64) + len(POWERSET) * np.arange(num_chunks)[:, None]
-        counts = np.bincount(flat.ravel(), minlength=num_chunks * len(POWERSET)).reshape(num_chunks, len(POWERSET))
+    lut = _lut()
+    counts = class_histogram(classes)
     total = counts @ lut.astype(np.int64)                         # frames each local speaker is active in
     alone = counts[:, 1:4]                                        # ... active alone (classes {s} are 1..3)
     wi, si = np.nonzero(total > 0)
@@ -215,7 +229,7 @@ def embedding_masks(binarized: np.ndarray, exclude_overlap: bool, min_num_sample
 
 def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold: float, min_cluster_size: int,
                        method: str = "centroid", num_clusters: Optional[int] = None, min_clusters: Optional[int] = None,
-                       max_clusters: Optional[int] = None, linkage_fn=None):
+                       max_clusters: Optional[int] = None, linkage_fn=None, active: Optional[np.ndarray] = None):
     """pyannote.audio.pipelines.clustering.AgglomerativeClustering.__call__ (metric cosine):
     embeddings (chunks, speakers, dim), binarized (chunks, frames, speakers) -> hard_clusters (chunks, speakers),
     centroids (clusters, dim).  `linkage_fn(unit_vectors) -> Z` replaces scipy's linkage (the pipeline passes the
@@ -224,10 +238,11 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
     from scipy.spatial.distance import cdist
 
     num_chunks, nspk, dim = embeddings.shape
-    active = np.any(binarized > 0, axis=1)
-    valid = ~np.isnan(embeddings[:, :, 0]) & ~np.any(np.isnan(embeddings), axis=2)
+    if active is None:                                   # (chunks, speakers): speaker active in at least one frame
+        active = np.any(binarized > 0, axis=1)
+    valid = ~np.isnan(embeddings.sum(axis=2))            # an embedding is valid iff none of its entries is NaN
     chunk_idx, speaker_idx = np.where(active * valid)
-    train = embeddings[chunk_idx, speaker_idx].astype(np.float64)
+    train = np.ascontiguousarray(embeddings[chunk_idx, speaker_idx], dtype=np.float32)     # float32, as pyannote holds them
     n = train.shape[0]
     if n == 0:
         return np.zeros((num_chunks, nspk), np.int64), np.zeros((1, dim))
@@ -242,8 +257,8 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
     if n == 1:
         clusters = np.zeros((1,), np.int64)
     else:
-        train32 = train.astype(np.float32)                        # pyannote normalises the float32 embeddings in place,
-        unit = (train32 / np.linalg.norm(train32, axis=-1, keepdims=True)).astype(np.float64)   # scipy then works in fp64
+        # pyannote normalises the float32 embeddings in place, scipy then works in fp64
+        unit = (train / np.linalg.norm(train, axis=-1, keepdims=True)).astype(np.float64)
         if linkage_fn is not None and method == "centroid":
             dendrogram = linkage_fn(unit)
         else:
@@ -287,11 +302,12 @@ def cluster_embeddings(embeddings: np.ndarray, binarized: np.ndarray, threshold:
                 _, clusters = np.unique(clusters, return_inverse=True)
 
     k = int(np.max(clusters)) + 1
-    centroids = np.vstack([np.mean(train[clusters == i], axis=0) for i in range(k)])
+    centroids = np.vstack([np.mean(train[clusters == i], axis=0) for i in range(k)]).astype(np.float64)
     # assign every (chunk, speaker) embedding to the most similar centroid: soft = 2 - cosine distance; only the
     # trained pairs have embeddings here (the others are NaN and are marked inactive by the caller)
     cn = centroids / np.linalg.norm(centroids, axis=1, keepdims=True)
-    sim = (train / np.linalg.norm(train, axis=1, keepdims=True)) @ cn.T          # = 1 - cdist(.., "cosine")
+    tn = unit if n > 1 else (train / np.linalg.norm(train, axis=1, keepdims=True)).astype(np.float64)
+    sim = tn @ cn.T                                                              # = 1 - cdist(.., "cosine")
     hard = np.zeros((num_chunks, nspk), np.int64)
     hard[chunk_idx, speaker_idx] = np.argmax(sim, axis=1)
     rest = valid & ~active
@@ -457,15 +473,17 @@ class SpeakerDiarization:
         count = speaker_count_from_classes(classes, step, dur)
         if np.max(count) == 0:
             return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
-        binarized = classes_to_multilabel(classes)                            # (W, frames, 3)
+        active = active_from_classes(classes)
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
-        hard, centroids = cluster_embeddings(emb, binarized, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
-                                             num_speakers, min_speakers, max_speakers, linkage_fn=self.engine.centroid_linkage)
+        hard, centroids = cluster_embeddings(emb, None, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
+                                             num_speakers, min_speakers, max_speakers, linkage_fn=self.engine.centroid_linkage,
+                                             active=active)
         t1 = time.perf_counter()
+        binarized = classes_to_multilabel(classes)                            # (W, frames, 3)
         count = np.minimum(count, ms).astype(np.int8)
         hard = hard.copy()
-        hard[np.sum(binarized, axis=1) == 0] = -2
+        hard[~active] = -2
         binary = reconstruct(binarized, hard, count, step, dur)
         ann = to_annotation(binary, float(self.params["segmentation"].get("min_duration_off", 0.0)), uri)
         mapping = {label: f"SPEAKER_{i:02d}" for i, label in enumerate(ann.labels())}
