@@ -133,30 +133,38 @@ def closest_frame(t: float, start: float = 0.0) -> int:
     return int(np.rint((t - start - 0.5 * FRAME_DURATION) / FRAME_STEP))
 
 
-def aggregate(scores: np.ndarray, chunk_step: float, chunk_duration: float, skip_average: bool = False,
-              missing: float = 0.0, epsilon: float = 1e-12) -> np.ndarray:
-    """pyannote.audio Inference.aggregate(hamming=False, warm_up=(0,0)): overlap-add of per-chunk scores
-    (num_chunks, frames, classes), NaN entries ignored, onto the file-level frame grid.  The per-chunk
-    `+=` loop of the original is done as one weighted bincount per class (same sums, fp64)."""
-    num_chunks, nf, ncls = scores.shape
+def _aggregate_cols(cols, chunk_step: float, chunk_duration: float, skip_average: bool, missing: float, epsilon: float) -> np.ndarray:
+    """overlap-add of per-class (num_chunks, frames) score planes onto the file-level frame grid -> (num_frames, classes)."""
+    num_chunks, nf = cols[0].shape
     num_frames = closest_frame(chunk_duration + (num_chunks - 1) * chunk_step + 0.5 * FRAME_DURATION) + 1
     starts = np.rint((np.arange(num_chunks) * chunk_step) / FRAME_STEP).astype(np.int64)     # closest_frame(c*step + dur/2)
     total = int(max(num_frames, starts[-1] + nf))
     idx = (starts[:, None] + np.arange(nf)[None, :]).ravel()
-    agg = np.zeros((total, ncls), np.float64)
-    cnt = np.zeros((total, ncls), np.float64)
-    for k in range(ncls):
-        col = scores[:, :, k].ravel()
+    agg = np.zeros((total, len(cols)), np.float64)
+    cnt = np.zeros((total, len(cols)), np.float64)
+    full_cnt = None
+    for k, plane in enumerate(cols):
+        col = plane.ravel()
         ok = ~np.isnan(col)
         if ok.all():
             agg[:, k] = np.bincount(idx, weights=col, minlength=total)
-            cnt[:, k] = np.bincount(idx, minlength=total)
+            if full_cnt is None:
+                full_cnt = np.bincount(idx, minlength=total)
+            cnt[:, k] = full_cnt
         else:
             agg[:, k] = np.bincount(idx[ok], weights=col[ok], minlength=total)
             cnt[:, k] = np.bincount(idx[ok], minlength=total)
     avg = agg if skip_average else agg / np.maximum(cnt, epsilon)
     avg[cnt == 0.0] = missing
     return avg[:num_frames]
+
+
+def aggregate(scores: np.ndarray, chunk_step: float, chunk_duration: float, skip_average: bool = False,
+              missing: float = 0.0, epsilon: float = 1e-12) -> np.ndarray:
+    """pyannote.audio Inference.aggregate(hamming=False, warm_up=(0,0)): overlap-add of per-chunk scores
+    (num_chunks, frames, classes), NaN entries ignored, onto the file-level frame grid.  The per-chunk
+    `+=` loop of the original is done as one weighted bincount per class (same sums, fp64)."""
+    return _aggregate_cols([scores[:, :, k] for k in range(scores.shape[2])], chunk_step, chunk_duration, skip_average, missing, epsilon)
 
 
 def speaker_count(binarized: np.ndarray, chunk_step: float, chunk_duration: float) -> np.ndarray:
@@ -325,13 +333,15 @@ def reconstruct(segmentations: np.ndarray, hard_clusters: np.ndarray, count: np.
     most active clusters of frame t are on."""
     num_chunks, nf, _ = segmentations.shape
     k = int(np.max(hard_clusters)) + 1
-    clustered = np.full((num_chunks, nf, max(k, 1)), np.nan, np.float32)
+    # one contiguous plane per cluster.  pyannote fills absent (chunk, cluster) pairs with NaN and its aggregation skips
+    # them; with skip_average=True that is the same as adding zeros (activities are >= 0), which keeps the fast path
+    planes = [np.zeros((num_chunks, nf), np.float32) for _ in range(max(k, 1))]
     for kk in range(k):                              # max over the local speakers of a chunk mapped to cluster kk
         for sp in range(segmentations.shape[2]):
-            sel = hard_clusters[:, sp] == kk
-            if sel.any():
-                clustered[sel, :, kk] = np.fmax(clustered[sel, :, kk], segmentations[sel, :, sp])
-    act = aggregate(clustered, chunk_step, chunk_duration, skip_average=True)
+            sel = np.nonzero(hard_clusters[:, sp] == kk)[0]
+            if sel.size:
+                planes[kk][sel] = np.maximum(planes[kk][sel], segmentations[sel, :, sp])
+    act = _aggregate_cols(planes, chunk_step, chunk_duration, True, 0.0, 1e-12)
     max_per_frame = int(np.max(count)) if count.size else 0
     if act.shape[1] < max_per_frame:
         act = np.pad(act, ((0, 0), (0, max_per_frame - act.shape[1])))
