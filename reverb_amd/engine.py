@@ -286,6 +286,9 @@ class Engine:
         """Search stages of ASRModel.decode (asr_model.py:391-425) on the last encoded batch."""
         results: Dict[str, List[DecodeResult]] = {}
         for m in methods:
+            if m == "joint_decoding":
+                raise RvbError("joint_decoding is not built: the reference's own decode(['joint_decoding']) raises a mask size "
+                               "mismatch for every model (search.py:474-489 / beam_search_timesync.py:150-154), see DESIGN.md section 7")
             if m not in SUPPORTED_MODES:
                 raise RvbError(f"decoding mode {m!r} is not built yet (supported: {', '.join(SUPPORTED_MODES)})")
         if "attention" in methods:
