@@ -23,10 +23,12 @@ int pcm_to_float(hipStream_t s, const int16_t* pcm, int64_t n, float* out, int64
 }
 
 // ------------------------------------------------------------------------------------ sinc filter bank
-// 64 frames x 80 filters per block; filters (80 KB) and the 881 samples they cover live in LDS.  Thread
+// 192 frames x 80 filters per block; filters (80 KB) and the 2161 samples they cover live in LDS.  Thread
 // (filter f, slot) walks its 16 frames four at a time: per tap one conflict-free LDS read of the weight
 // (row stride 251 words is odd) and four broadcast reads of samples feed four FMAs.
-static constexpr int SC_FT = 64, SC_NF = 80, SC_KS = 251, SC_THREADS = 320;
+// 12 slots x 80 filters = 960 threads (15 waves) per workgroup: the 80 KB of filters allow one workgroup per CU, so the
+// waves that hide the LDS latency have to come from inside it (320 threads: 16.5 ms per hour of audio)
+static constexpr int SC_SLOTS = 24, SC_FT = 8 * SC_SLOTS, SC_NF = 80, SC_KS = 251, SC_THREADS = (SC_NF / 2) * SC_SLOTS;
 
 __global__ __launch_bounds__(SC_THREADS) void sinc_conv_kernel(const float* __restrict__ wave, const float* __restrict__ filt,
                                                                float* __restrict__ craw, int64_t n_frames, int nf,
@@ -44,26 +46,33 @@ __global__ __launch_bounds__(SC_THREADS) void sinc_conv_kernel(const float* __re
     sx[i] = g < last ? wave[g] : 0.0f;
   }
   __syncthreads();
-  const int f = tid % SC_NF, slot = tid / SC_NF;
+  // thread = (filter pair f / f + 40, slot of 8 frames): per tap two weight reads and four broadcast sample reads feed
+  // eight FMAs
+  constexpr int HALF = SC_NF / 2;
+  const int f = tid % HALF, slot = tid / HALF;
   if (f >= nf) return;
-  const float* wf = sf + f * ksize;
+  const bool two = f + HALF < nf;
+  const float* wf0 = sf + f * ksize;
+  const float* wf1 = sf + (two ? f + HALF : f) * ksize;
 #pragma unroll 1
-  for (int g = 0; g < 4; ++g) {
-    const int fr = slot * 16 + g * 4;
+  for (int g = 0; g < 2; ++g) {
+    const int fr = slot * 8 + g * 4;
     const float* x0 = sx + fr * stride;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     for (int k = 0; k < ksize; ++k) {
-      const float w = wf[k];
-      a0 = fmaf(x0[k], w, a0);
-      a1 = fmaf(x0[k + stride], w, a1);
-      a2 = fmaf(x0[k + 2 * stride], w, a2);
-      a3 = fmaf(x0[k + 3 * stride], w, a3);
+      const float w0 = wf0[k], w1 = wf1[k];
+      const float v0 = x0[k], v1 = x0[k + stride], v2 = x0[k + 2 * stride], v3 = x0[k + 3 * stride];
+      a0 = fmaf(v0, w0, a0); a1 = fmaf(v1, w0, a1); a2 = fmaf(v2, w0, a2); a3 = fmaf(v3, w0, a3);
+      b0 = fmaf(v0, w1, b0); b1 = fmaf(v1, w1, b1); b2 = fmaf(v2, w1, b2); b3 = fmaf(v3, w1, b3);
     }
     const int64_t t = t0 + fr;
-    if (t < n_frames) craw[t * nf + f] = a0;
-    if (t + 1 < n_frames) craw[(t + 1) * nf + f] = a1;
-    if (t + 2 < n_frames) craw[(t + 2) * nf + f] = a2;
-    if (t + 3 < n_frames) craw[(t + 3) * nf + f] = a3;
+    const float av[4] = {a0, a1, a2, a3}, bv[4] = {b0, b1, b2, b3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (t + i < n_frames) {
+        craw[(t + i) * nf + f] = av[i];
+        if (two) craw[(t + i) * nf + f + HALF] = bv[i];
+      }
   }
 }
 
