@@ -4,8 +4,11 @@
 // asr/wenet/cli/reverb.py:220-253).  Reference structure followed per stage is cited inline.
 #include "engine.h"
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -576,27 +579,45 @@ static int wait_slices(rvb_engine* e, int i) {
 }
 
 // ------------------------------------------------------------------------------------ search
+// Host threads one engine may use for the search: RVB_SEARCH_THREADS, else this process's share of the cores when
+// several ranks run on the node (LOCAL_WORLD_SIZE is set by torchrun), at most 32.
+static unsigned search_threads() {
+  if (const char* s = getenv("RVB_SEARCH_THREADS")) {
+    const int v = atoi(s);
+    if (v > 0) return (unsigned)v;
+  }
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  if (const char* s = getenv("LOCAL_WORLD_SIZE")) {
+    const int v = atoi(s);
+    if (v > 1) hw = std::max(1u, hw / (unsigned)v);
+  }
+  return std::min(hw, 32u);
+}
+
 static int prefix_beam_impl(rvb_engine* e, int beam) {
   if (e->B <= 0) { set_error("rvb_ctc_prefix_beam before rvb_encode"); return E_STATE; }
   if (beam != e->beam) { set_error("rvb_ctc_prefix_beam: beam differs from the one given to rvb_encode"); return E_ARG; }
   const int B = e->B, T = e->T2;
   e->nbest.assign(B, PrefixResult());
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 4;
+  const unsigned hw = search_threads();
   double busy_ms = 0.0;
   for (size_t si = 0; si < e->slices.size(); ++si) {
     RVB_TRY(wait_slices(e, (int)si));            // GPU keeps encoding the later slices meanwhile
     const auto t0 = std::chrono::steady_clock::now();
     const int c0 = e->slices[si].c0, nb = e->slices[si].nb;
-    const unsigned nthr = std::min<unsigned>(std::min<unsigned>(hw, 256), (unsigned)nb);
+    // ~0.5 ms of work per full chunk: two or more chunks per thread amortise the thread start; chunks are handed
+    // out one at a time because their lengths (and so their cost) differ
+    const unsigned nthr = std::max(1u, std::min<unsigned>(hw, (unsigned)(nb + 1) / 2));
+    std::atomic<int> next_chunk(c0);
     std::vector<std::thread> pool;
-    for (unsigned w = 0; w < nthr; ++w) {
-      pool.emplace_back([=]() {
-        for (int b = c0 + (int)w; b < c0 + nb; b += (int)nthr)
-          prefix_beam_search(e->h_topv + (size_t)b * T * beam, e->h_topi + (size_t)b * T * beam, e->enc_lens[b], beam,
-                             beam, e->cfg.blank_id, &e->nbest[b]);
-      });
-    }
+    auto work = [&, c0, nb]() {
+      for (int b = next_chunk.fetch_add(1); b < c0 + nb; b = next_chunk.fetch_add(1))
+        prefix_beam_search(e->h_topv + (size_t)b * T * beam, e->h_topi + (size_t)b * T * beam, e->enc_lens[b], beam,
+                           beam, e->cfg.blank_id, &e->nbest[b]);
+    };
+    for (unsigned w = 1; w < nthr; ++w) pool.emplace_back(work);
+    work();                                      // the calling thread is worker 0
     for (auto& t : pool) t.join();
     busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }

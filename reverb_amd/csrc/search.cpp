@@ -5,11 +5,14 @@
 //   greedy_collapse     <- ctc_greedy_search :106-121 + remove_duplicates_and_blank
 //                          asr/wenet/utils/ctc_utils.py:22-32
 //
-// The reference walks Python dicts/tuples; here a prefix is a node id in a per-utterance trie
-// (parent id + last token) so dictionary lookups become array indexing, while the iteration
-// order (top-k tokens outer, current beam inner), the insertion order of new prefixes, the stable
-// descending sort and every float64 operation are kept identical -- including the `vs_ns` typo at
-// search.py:178 that leaves the Viterbi non-blank score of a repeated token un-updated.
+// The reference walks Python dicts keyed by token tuples; here a prefix is a node id in a per-utterance
+// trie (parent id + last token) and the candidates of a frame need no dictionary at all: the pair
+// (beam entry, top-k token) is visited exactly once per frame, so an extension is a fresh candidate
+// unless the extended prefix is itself in the beam (checked against the <= beam children that are).
+// Trie nodes are only created for the candidates that survive the pruning.  The iteration order
+// (top-k tokens outer, current beam inner), the insertion order of new prefixes, the stable descending
+// sort and every float64 operation are kept identical -- including the `vs_ns` typo at search.py:178
+// that leaves the Viterbi non-blank score of a repeated token un-updated.
 #include "search.h"
 
 #include <algorithm>
@@ -21,11 +24,11 @@ namespace rvb {
 static const double NEG_INF = -std::numeric_limits<double>::infinity();
 
 static inline double log_add2(double a, double b) {
-  // exact shortcuts: with one operand at -inf the reference computes max + log(0 + 1) = max + 0.0
+  // exact shortcuts: with one operand at -inf the reference computes max + log(0 + 1) = max + 0.0;
+  // otherwise one of its two exponentials is exp(0.0) == 1.0 exactly
   if (a == NEG_INF) return b;
   if (b == NEG_INF) return a;
-  const double mx = a > b ? a : b;
-  return mx + std::log(std::exp(a - mx) + std::exp(b - mx));
+  return a > b ? a + std::log(1.0 + std::exp(b - a)) : b + std::log(std::exp(a - b) + 1.0);
 }
 
 namespace {
@@ -40,18 +43,19 @@ struct PS {
   int times() const { return v_s > v_ns ? times_s : times_ns; }
 };
 struct Hyp {
-  int id;
+  int id;        // trie node of the prefix, -1 while it is a candidate that has no node yet
+  int par, tok;  // ... in which case it is `par` extended by `tok`
   PS ps;
   double score_cache;  // ps.score(), computed once per frame (pure function of ps)
 };
+struct Kid { int tok, hj; };
 }  // namespace
 
 void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int beam, int blank,
                         PrefixResult* out) {
-  // trie of prefixes: node 0 = empty prefix
-  // children of a node form a singly linked sibling list (a prefix has few live extensions)
+  // trie of the prefixes that have been in the beam: node 0 = empty prefix; the children of a node
+  // form a singly linked sibling list (short: only survivors get nodes)
   std::vector<int> parent(1, -1), last(1, -1), first_child(1, -1), next_sib(1, -1);
-  parent.reserve(16384); last.reserve(16384); first_child.reserve(16384); next_sib.reserve(16384);
   auto extend = [&](int id, int tok) -> int {
     for (int c = first_child[id]; c >= 0; c = next_sib[c])
       if (last[c] == tok) return c;
@@ -70,56 +74,71 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
     tn_parent.push_back(list); tn_val.push_back(v);
     return (int)tn_parent.size() - 1;
   };
-  std::vector<int> sel;
-  std::vector<char> taken;
-  std::vector<Hyp> cur(1), nxt;
-  cur[0].id = 0;
+
+  const size_t cap = (size_t)beam * (beam + 1);      // every beam entry itself + one extension per top-k token
+  std::vector<Hyp> cur, nxt;
+  cur.reserve(beam); nxt.reserve(cap);                // no reallocation: references into nxt stay valid
+  std::vector<int> self_slot(beam), order;
+  std::vector<std::vector<Kid>> kids(beam);
+  order.reserve(cap);
+  cur.emplace_back();
+  cur[0].id = 0; cur[0].par = -1; cur[0].tok = -1;
   cur[0].ps.s = 0.0; cur[0].ps.ns = NEG_INF; cur[0].ps.v_s = 0.0; cur[0].ps.v_ns = 0.0;
-  std::vector<int> slot;        // node id -> index in nxt for the current frame
-  std::vector<int> slot_frame;  // frame stamp validating `slot`
-  auto next_of = [&](int id, int t) -> PS& {
-    if ((int)slot.size() <= id) { slot.resize(id + 64, -1); slot_frame.resize(id + 64, -1); }
-    if (slot_frame[id] != t) {
-      slot_frame[id] = t;
-      slot[id] = (int)nxt.size();
-      nxt.emplace_back();
-      nxt.back().id = id;
-    }
-    return nxt[slot[id]].ps;
-  };
 
   for (int t = 0; t < T; ++t) {
+    const int nc = (int)cur.size();
     nxt.clear();
-    for (auto& h : cur) h.score_cache = h.ps.score();
+    for (int hi = 0; hi < nc; ++hi) {
+      cur[hi].score_cache = cur[hi].ps.score();
+      self_slot[hi] = -1;
+      kids[hi].clear();
+    }
+    for (int hj = 0; hj < nc; ++hj) {                 // which beam entries extend another beam entry by one token
+      const int pj = parent[cur[hj].id];
+      if (pj < 0) continue;
+      for (int hi = 0; hi < nc; ++hi)
+        if (cur[hi].id == pj) { kids[hi].push_back({last[cur[hj].id], hj}); break; }
+    }
+    auto self_of = [&](int hi) -> PS& {               // next_hyps[prefix]
+      if (self_slot[hi] < 0) {
+        self_slot[hi] = (int)nxt.size();
+        nxt.emplace_back();
+        nxt.back().id = cur[hi].id;
+      }
+      return nxt[self_slot[hi]].ps;
+    };
+    auto child_of = [&](int hi, int u) -> PS& {       // next_hyps[prefix + (u,)]
+      for (const Kid& k : kids[hi])
+        if (k.tok == u) return self_of(k.hj);
+      nxt.emplace_back();
+      Hyp& h = nxt.back();
+      h.id = -1; h.par = cur[hi].id; h.tok = u;
+      return h.ps;
+    };
+
     for (int kk = 0; kk < beam; ++kk) {
       const int u = ti[(size_t)t * kstride + kk];
       const double prob = (double)tv[(size_t)t * kstride + kk];
-      for (size_t hi = 0; hi < cur.size(); ++hi) {
-        const int pid = cur[hi].id;
+      for (int hi = 0; hi < nc; ++hi) {
+        const PS& ps = cur[hi].ps;
         const double sc = cur[hi].score_cache;
         if (u == blank) {
-          const PS& ps = cur[hi].ps;
-          PS& n = next_of(pid, t);
+          PS& n = self_of(hi);
           n.s = log_add2(n.s, sc + prob);
           n.v_s = ps.viterbi() + prob;
           n.times_s = ps.times();
-        } else if (u == last[pid]) {
-          {
-            const PS& ps = cur[hi].ps;
-            PS& n1 = next_of(pid, t);
-            n1.ns = log_add2(n1.ns, ps.ns + prob);
-            if (n1.v_ns < ps.v_ns + prob) {
-              // reference assigns a misspelled attribute here (`vs_ns`): v_ns stays as it was
-              if (n1.cur_token_prob < prob) {
-                n1.cur_token_prob = prob;
-                // copy of the list with its last element replaced by t
-                n1.times_ns = ps.times_ns >= 0 ? t_push(tn_parent[ps.times_ns], t) : -1;
-              }
+        } else if (u == last[cur[hi].id]) {
+          PS& n1 = self_of(hi);
+          n1.ns = log_add2(n1.ns, ps.ns + prob);
+          if (n1.v_ns < ps.v_ns + prob) {
+            // reference assigns a misspelled attribute here (`vs_ns`): v_ns stays as it was
+            if (n1.cur_token_prob < prob) {
+              n1.cur_token_prob = prob;
+              // copy of the list with its last element replaced by t
+              n1.times_ns = ps.times_ns >= 0 ? t_push(tn_parent[ps.times_ns], t) : -1;
             }
           }
-          const int nid = extend(pid, u);
-          PS& n2 = next_of(nid, t);          // may reallocate nxt: re-read ps afterwards
-          const PS& ps = cur[hi].ps;
+          PS& n2 = child_of(hi, u);
           n2.ns = log_add2(n2.ns, ps.s + prob);
           if (n2.v_ns < ps.v_s + prob) {
             n2.v_ns = ps.v_s + prob;
@@ -127,9 +146,7 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
             n2.times_ns = t_push(ps.times_s, t);
           }
         } else {
-          const int nid = extend(pid, u);
-          PS& n = next_of(nid, t);
-          const PS& ps = cur[hi].ps;
+          PS& n = child_of(hi, u);
           n.ns = log_add2(n.ns, sc + prob);
           const double vit = ps.viterbi() + prob;
           if (n.v_ns < vit) {
@@ -140,22 +157,22 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
         }
       }
     }
-    for (auto& h : nxt) h.score_cache = h.ps.score();
     // sorted(..., reverse=True)[:beam] of the reference: descending score, equal scores keep their
-    // insertion order.  Only the first `beam` are needed: repeated selection of the first maximum.
-    const int keep = std::min<int>(beam, (int)nxt.size());
-    sel.clear();
-    taken.assign(nxt.size(), 0);
-    for (int k = 0; k < keep; ++k) {
-      int best = -1;
-      for (int i = 0; i < (int)nxt.size(); ++i)
-        if (!taken[i] && (best < 0 || nxt[i].score_cache > nxt[best].score_cache)) best = i;
-      if (best < 0) break;
-      taken[best] = 1;
-      sel.push_back(best);
-    }
+    // insertion order (= index in nxt).
+    const int nn = (int)nxt.size();
+    order.resize(nn);
+    for (int i = 0; i < nn; ++i) { nxt[i].score_cache = nxt[i].ps.score(); order[i] = i; }
+    const int keep = std::min<int>(beam, nn);
+    std::partial_sort(order.begin(), order.begin() + keep, order.end(), [&](int a, int b) {
+      const double sa = nxt[a].score_cache, sb = nxt[b].score_cache;
+      return sa > sb || (sa == sb && a < b);
+    });
     cur.clear();
-    for (int i : sel) cur.push_back(nxt[i]);
+    for (int k = 0; k < keep; ++k) {
+      cur.push_back(nxt[order[k]]);
+      Hyp& h = cur.back();
+      if (h.id < 0) h.id = extend(h.par, h.tok);      // survivors get (or find again) their trie node
+    }
   }
 
   out->nbest.clear(); out->scores.clear(); out->times.clear();

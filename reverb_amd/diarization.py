@@ -176,11 +176,6 @@ def speaker_count(binarized: np.ndarray, chunk_step: float, chunk_duration: floa
 _NSPK = np.array([len(p) for p in POWERSET], np.float64)
 
 
-def speaker_count_from_classes(classes: np.ndarray, chunk_step: float, chunk_duration: float) -> np.ndarray:
-    """speaker_count(classes_to_multilabel(classes)) without materialising the multilabel tensor."""
-    return np.rint(aggregate(_NSPK[classes][:, :, None], chunk_step, chunk_duration)).astype(np.uint8)
-
-
 def _lut() -> np.ndarray:
     lut = np.zeros((len(POWERSET), 3), bool)
     for k, spk in enumerate(POWERSET):
@@ -188,37 +183,146 @@ def _lut() -> np.ndarray:
     return lut
 
 
-def class_histogram(classes: np.ndarray) -> np.ndarray:
+class ClassRuns:
+    """Run-length view of the argmax powerset classes (uint8 [chunks, frames]): the class of a window is
+    piecewise constant (a handful of runs per 589 frames), so every per-frame overlap-add of the host stages
+    becomes a difference array over run boundaries + one cumulative sum.  Sums of 0/1 activities are small
+    integers, exact in float64 either way, so the results are identical to the per-frame formulation."""
+
+    def __init__(self, classes: np.ndarray, chunk_step: float, chunk_duration: float):
+        classes = np.ascontiguousarray(classes)
+        W, nf = classes.shape
+        self.num_chunks, self.nf = W, nf
+        edge = np.empty((W, nf), bool)
+        edge[:, 0] = True
+        np.not_equal(classes[:, 1:], classes[:, :-1], out=edge[:, 1:])
+        self.w, self.a = np.nonzero(edge)                       # run r: frames [a, b) of chunk w, class c
+        self.c = classes[self.w, self.a]
+        self.b = np.empty_like(self.a)
+        if self.a.size:
+            self.b[:-1] = self.a[1:]
+            self.b[-1] = nf
+            self.b[:-1][self.w[1:] != self.w[:-1]] = nf
+        # file-level frame grid, as Inference.aggregate lays it out (see _aggregate_cols)
+        self.num_frames = closest_frame(chunk_duration + (W - 1) * chunk_step + 0.5 * FRAME_DURATION) + 1 if W else 0
+        self.starts = np.rint((np.arange(W) * chunk_step) / FRAME_STEP).astype(np.int64)
+        self.total = int(max(self.num_frames, self.starts[-1] + nf)) if W else 0
+        self.lo = self.starts[self.w] + self.a                  # file-level frame range [lo, hi) of every run
+        self.hi = self.starts[self.w] + self.b
+
+    def overlap_add(self, sel: np.ndarray, col: np.ndarray, ncol: int, weights: Optional[np.ndarray] = None) -> np.ndarray:
+        """sum over the runs `sel` of weights * [lo <= t < hi] into column `col` -> float64 (total, ncol)."""
+        n = (self.total + 1) * ncol
+        up = np.bincount(self.lo[sel] * ncol + col, weights=weights, minlength=n)
+        dn = np.bincount(self.hi[sel] * ncol + col, weights=weights, minlength=n)
+        return np.cumsum((up - dn).reshape(self.total + 1, ncol), axis=0)[:self.total].astype(np.float64, copy=False)
+
+    def coverage(self) -> np.ndarray:
+        """number of chunks that cover each file-level frame: float64 (total,)."""
+        d = np.bincount(self.starts, minlength=self.total + 1) - np.bincount(self.starts + self.nf, minlength=self.total + 1)
+        return np.cumsum(d)[:self.total].astype(np.float64)
+
+    def histogram(self) -> np.ndarray:
+        """frames per powerset class of every chunk: int64 (chunks, 7)."""
+        k = len(POWERSET)
+        return np.bincount(self.w * k + self.c, weights=self.b - self.a, minlength=self.num_chunks * k) \
+            .astype(np.int64).reshape(self.num_chunks, k)
+
+
+def speaker_count_from_classes(classes: np.ndarray, chunk_step: float, chunk_duration: float, runs: Optional[ClassRuns] = None) -> np.ndarray:
+    """speaker_count(classes_to_multilabel(classes)) without materialising the multilabel tensor."""
+    r = runs or ClassRuns(classes, chunk_step, chunk_duration)
+    if r.num_chunks == 0:
+        return np.zeros((0, 1), np.uint8)
+    spk = np.nonzero(r.c > 0)[0]
+    agg = r.overlap_add(spk, 0, 1, _NSPK[r.c[spk]])
+    cnt = r.coverage()[:, None]
+    avg = agg / np.maximum(cnt, 1e-12)
+    avg[cnt == 0.0] = 0.0
+    return np.rint(avg[:r.num_frames]).astype(np.uint8)
+
+
+def class_histogram(classes: np.ndarray, runs: Optional[ClassRuns] = None) -> np.ndarray:
     """frames per powerset class of every chunk: int64 (chunks, 7)."""
-    num_chunks = classes.shape[0]
-    flat = classes.astype(np.int64) + len(POWERSET) * np.arange(num_chunks)[:, None]
-    return np.bincount(flat.ravel(), minlength=num_chunks * len(POWERSET)).reshape(num_chunks, len(POWERSET))
+    return (runs or ClassRuns(classes, 1.0, 10.0)).histogram()
 
 
-def active_from_classes(classes: np.ndarray) -> np.ndarray:
+def active_from_classes(classes: np.ndarray, runs: Optional[ClassRuns] = None) -> np.ndarray:
     """bool (chunks, 3): the local speaker is active in at least one frame (= np.sum(binarized, axis=1) > 0)."""
-    return (class_histogram(classes) @ _lut().astype(np.int64)) > 0
+    return (class_histogram(classes, runs) @ _lut().astype(np.int64)) > 0
 
 
 def embedding_items_from_classes(classes: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
-                                 window_samples: int = 160000):
+                                 window_samples: int = 160000, runs: Optional[ClassRuns] = None):
     """The (chunk, local speaker) pairs that are active at all, and their pooling masks as
     embedding_masks() would build them: -> (chunk_idx, speaker_idx, masks float32 [n, frames])."""
     num_chunks, nf = classes.shape
     lut = _lut()
-    counts = class_histogram(classes)
+    counts = class_histogram(classes, runs)
     total = counts @ lut.astype(np.int64)                         # frames each local speaker is active in
     alone = counts[:, 1:4]                                        # ... active alone (classes {s} are 1..3)
     wi, si = np.nonzero(total > 0)
-    rows = classes[wi]
-    full = lut[rows, si[:, None]]
+    use_clean = np.zeros(wi.shape, bool)
     if exclude_overlap:
         min_num_frames = math.ceil(nf * min_num_samples / window_samples)
-        clean = rows == (si + 1)[:, None].astype(classes.dtype)
-        masks = np.where((alone[wi, si] > min_num_frames)[:, None], clean, full)
-    else:
-        masks = full
-    return wi, si, masks.astype(np.float32)
+        use_clean = alone[wi, si] > min_num_frames
+    masks = np.empty((wi.size, nf), np.float32)
+    for s in range(3):                                            # per (speaker, mask kind): OR of <= 3 class comparisons
+        for clean in (False, True):
+            grp = np.nonzero((si == s) & (use_clean == clean))[0]
+            if grp.size:
+                rows = classes[wi[grp]]
+                on = rows == (s + 1)
+                if not clean:
+                    for k in np.nonzero(lut[:, s])[0]:
+                        if k != s + 1:
+                            on |= rows == k
+                masks[grp] = on
+    return wi, si, masks
+
+
+def reconstruct_from_classes(classes: np.ndarray, hard_clusters: np.ndarray, count: np.ndarray, chunk_step: float,
+                             chunk_duration: float, runs: Optional[ClassRuns] = None) -> np.ndarray:
+    """reconstruct(classes_to_multilabel(classes), hard_clusters, count, ...) on the run-length view: a run of class c
+    in chunk w adds 1 to every cluster that one of the speakers of c is mapped to (once per cluster: the original takes
+    the max over the local speakers of a chunk that share a cluster)."""
+    r = runs or ClassRuns(classes, chunk_step, chunk_duration)
+    k = max(int(np.max(hard_clusters)) + 1, 1) if hard_clusters.size else 1
+    lut = _lut()
+    hw = hard_clusters[r.w]                                       # (runs, 3) cluster of each local speaker of the run's chunk
+    on = lut[r.c] & (hw >= 0)                                     # (runs, 3) speaker talks in the run and has a cluster
+    on[:, 1] &= ~(on[:, 0] & (hw[:, 0] == hw[:, 1]))
+    on[:, 2] &= ~((on[:, 0] & (hw[:, 0] == hw[:, 2])) | (on[:, 1] & (hw[:, 1] == hw[:, 2])))
+    ri, sp = np.nonzero(on)
+    act = r.overlap_add(ri, hw[ri, sp], k)[:r.num_frames]
+    return _top_count(act, count)
+
+
+def _top_count(act: np.ndarray, count: np.ndarray) -> np.ndarray:
+    """to_diarization: per frame, the `count[t]` most active clusters (ties: lowest cluster index first) are on."""
+    max_per_frame = int(np.max(count)) if count.size else 0
+    if act.shape[1] < max_per_frame:
+        act = np.pad(act, ((0, 0), (0, max_per_frame - act.shape[1])))
+    n = min(act.shape[0], count.shape[0])
+    act, cnt = act[:n], count[:n, 0].astype(np.int64)
+    ncl = act.shape[1]
+    if ncl <= 8:
+        # rank of cluster k in the stable descending order = clusters that beat it + equal ones with a lower index
+        cols = np.ascontiguousarray(act.T)                         # (clusters, frames): contiguous per cluster
+        cnt16 = cnt.astype(np.int16)
+        out = np.empty(cols.shape, act.dtype)
+        for k in range(ncl):
+            rank = np.zeros(n, np.int16)
+            for j in range(ncl):
+                if j != k:
+                    rank += (cols[j] >= cols[k]) if j < k else (cols[j] > cols[k])
+            out[k] = rank < cnt16
+        return np.ascontiguousarray(out.T)
+    order = np.argsort(-act, axis=-1, kind="stable")
+    binary = np.zeros_like(act)
+    ranks = np.arange(ncl)[None, :] < cnt[:, None]
+    np.put_along_axis(binary, order, ranks.astype(act.dtype), axis=1)
+    return binary
 
 
 def embedding_masks(binarized: np.ndarray, exclude_overlap: bool, min_num_samples: int = 400,
@@ -341,17 +445,7 @@ def reconstruct(segmentations: np.ndarray, hard_clusters: np.ndarray, count: np.
             sel = np.nonzero(hard_clusters[:, sp] == kk)[0]
             if sel.size:
                 planes[kk][sel] = np.maximum(planes[kk][sel], segmentations[sel, :, sp])
-    act = _aggregate_cols(planes, chunk_step, chunk_duration, True, 0.0, 1e-12)
-    max_per_frame = int(np.max(count)) if count.size else 0
-    if act.shape[1] < max_per_frame:
-        act = np.pad(act, ((0, 0), (0, max_per_frame - act.shape[1])))
-    n = min(act.shape[0], count.shape[0])
-    act, cnt = act[:n], count[:n, 0].astype(np.int64)
-    order = np.argsort(-act, axis=-1, kind="stable")
-    binary = np.zeros_like(act)
-    ranks = np.arange(act.shape[1])[None, :] < cnt[:, None]
-    np.put_along_axis(binary, order, ranks.astype(act.dtype), axis=1)
-    return binary
+    return _top_count(_aggregate_cols(planes, chunk_step, chunk_duration, True, 0.0, 1e-12), count)
 
 
 def to_annotation(binary: np.ndarray, min_duration_off: float = 0.0, uri: Optional[str] = None) -> Annotation:
@@ -398,6 +492,7 @@ class SpeakerDiarization:
         self.device_index: Optional[int] = None
         self._engine = None
         self.timings: Dict[str, float] = {}
+        self._runs_of, self._runs_val = None, None
 
     # pyannote API --------------------------------------------------------------------------------
     def to(self, device):
@@ -452,6 +547,13 @@ class SpeakerDiarization:
             pcm = np.clip(np.rint(pcm.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
         return pcm, os.path.splitext(os.path.basename(path))[0]
 
+    def _runs(self, classes: np.ndarray) -> ClassRuns:
+        """run-length view of `classes`, shared by networks() and finish() when they see the same array"""
+        if self._runs_of is not classes:
+            self._runs_of, self._runs_val = classes, ClassRuns(classes, self.cfg["step_samples"] / self.cfg["sample_rate"],
+                                                               self.cfg["window_samples"] / self.cfg["sample_rate"])
+        return self._runs_val
+
     def networks(self, pcm: np.ndarray):
         """The GPU part on one recording (or one rank's slice of it): argmax powerset classes per window frame
         (uint8 [W, frames]) and one embedding per active (window, local speaker) pair (float32 [W, 3, dim], NaN
@@ -464,7 +566,9 @@ class SpeakerDiarization:
         classes = eng.segment_classes()                                       # argmax on the GPU
         t2 = time.perf_counter()
         # inactive (window, speaker) pairs are never used downstream: only the active ones are embedded
-        wi, si, masks = embedding_items_from_classes(classes, bool(self.params["embedding_exclude_overlap"]), 400, self.cfg["window_samples"])
+        runs = self._runs(classes)
+        wi, si, masks = embedding_items_from_classes(classes, bool(self.params["embedding_exclude_overlap"]), 400,
+                                                     self.cfg["window_samples"], runs)
         t3 = time.perf_counter()
         emb = np.full((W, 3, self.cfg["emb_dim"]), np.nan, np.float32)
         if wi.size:
@@ -480,21 +584,22 @@ class SpeakerDiarization:
         t0 = time.perf_counter()
         step = self.cfg["step_samples"] / self.cfg["sample_rate"]
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
-        count = speaker_count_from_classes(classes, step, dur)
-        if np.max(count) == 0:
+        runs = self._runs(classes)
+        self._runs_of = self._runs_val = None                                 # one recording at a time: do not keep it alive
+        count = speaker_count_from_classes(classes, step, dur, runs)
+        if count.size == 0 or np.max(count) == 0:
             return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
-        active = active_from_classes(classes)
+        active = active_from_classes(classes, runs)
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
         hard, centroids = cluster_embeddings(emb, None, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),
                                              num_speakers, min_speakers, max_speakers, linkage_fn=self.engine.centroid_linkage,
                                              active=active)
         t1 = time.perf_counter()
-        binarized = classes_to_multilabel(classes)                            # (W, frames, 3)
         count = np.minimum(count, ms).astype(np.int8)
         hard = hard.copy()
         hard[~active] = -2
-        binary = reconstruct(binarized, hard, count, step, dur)
+        binary = reconstruct_from_classes(classes, hard, count, step, dur, runs)
         ann = to_annotation(binary, float(self.params["segmentation"].get("min_duration_off", 0.0)), uri)
         mapping = {label: f"SPEAKER_{i:02d}" for i, label in enumerate(ann.labels())}
         ann = ann.rename_labels(mapping)

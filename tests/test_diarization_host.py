@@ -115,6 +115,74 @@ def test_reconstruct_and_rttm():
     assert abs(got["SPEAKER_01"][0] - 5.0) < 0.05 and abs(got["SPEAKER_01"][1] - 4.0) < 0.08
 
 
+def _random_classes(rng, W, nf, min_run, max_run):
+    """Powerset classes cut from one file-level timeline (overlapping chunks agree where they overlap) plus a
+    local-speaker -> cluster map in which two local speakers of a chunk sometimes share a cluster."""
+    n_file = int((W - 1) / D.FRAME_STEP) + nf + 10
+    line = np.zeros(n_file, np.int64)
+    t = 0
+    while t < n_file:
+        run = int(rng.integers(min_run, max_run))
+        line[t:t + run] = rng.integers(0, 8)                              # 0 silence, 1..5 one speaker, 6..7 two at once
+        t += run
+    classes = np.zeros((W, nf), np.uint8)
+    hard = np.full((W, 3), -2, np.int64)
+    pair = {(0, 1): 4, (0, 2): 5, (1, 2): 6}
+    for w in range(W):
+        seg = line[int(np.rint(w / D.FRAME_STEP)):][:nf]
+        ids = [g for g in np.unique(seg) if 0 < g <= 5][:3]
+        for i, g in enumerate(ids):
+            classes[w][seg == g] = i + 1
+            hard[w, i] = rng.integers(0, 4) if rng.random() < 0.2 else g - 1
+        if len(ids) >= 2:
+            classes[w][seg == 6] = pair[(0, 1)]
+            classes[w][seg == 7] = pair[(0, 2)] if len(ids) == 3 else pair[(0, 1)]
+    return classes, hard
+
+
+@pytest.mark.parametrize("W,nf,min_run,max_run", [(1, 589, 30, 400), (9, 589, 1, 8), (60, 589, 5, 90), (3, 50, 1, 5), (2, 1, 1, 2)])
+def test_run_length_host_path_equals_per_frame_path(W, nf, min_run, max_run):
+    """The pipeline works on run-length views of the argmax classes (ClassRuns); the per-frame functions that follow
+    pyannote's formulation (speaker_count / embedding_masks / reconstruct on the multilabel tensor) must agree exactly."""
+    rng = np.random.default_rng(W * 1000 + nf)
+    classes, hard = _random_classes(rng, W, nf, min_run, max_run)
+    ml = D.classes_to_multilabel(classes)
+    runs = D.ClassRuns(classes, 1.0, 10.0)
+    assert np.array_equal(runs.histogram(), np.stack([np.bincount(c, minlength=7) for c in classes]))
+    count = D.speaker_count_from_classes(classes, 1.0, 10.0, runs)
+    want_count = D.speaker_count(ml, 1.0, 10.0)
+    assert count.dtype == want_count.dtype and np.array_equal(count, want_count)
+    active = D.active_from_classes(classes, runs)
+    assert np.array_equal(active, ml.sum(axis=1) > 0)
+    for exclude in (True, False):
+        wi, si, masks = D.embedding_items_from_classes(classes, exclude, runs=runs)
+        full = D.embedding_masks(ml, exclude)
+        assert np.array_equal(np.stack([wi, si]), np.stack(np.nonzero(active)))
+        assert masks.dtype == np.float32 and np.array_equal(masks, full[wi, si])
+    hard[~active] = -2
+    if hard.max() < 0:
+        hard[0, 0] = 0
+    for cap in (np.inf, 1):
+        cnt = np.minimum(count, cap).astype(np.int8)
+        got = D.reconstruct_from_classes(classes, hard, cnt, 1.0, 10.0, runs)
+        want = D.reconstruct(ml, hard, cnt, 1.0, 10.0)
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_top_count_ties_and_many_clusters():
+    rng = np.random.default_rng(3)
+    for ncl in (1, 3, 8, 11):                                             # 11 takes the argsort branch
+        act = rng.integers(0, 3, (200, ncl)).astype(np.float64)            # many ties
+        count = rng.integers(0, 4, (200, 1)).astype(np.int8)
+        got = D._top_count(act, count)
+        width = max(ncl, int(count.max()))
+        assert got.shape == (200, width)
+        padded = np.pad(act, ((0, 0), (0, width - ncl)))
+        for t in range(200):
+            order = sorted(range(width), key=lambda k: (-padded[t, k], k))[:count[t, 0]]
+            assert sorted(np.nonzero(got[t])[0]) == sorted(order)
+
+
 def test_rttm_roundtrip_and_label_with_space(tmp_path):
     ann = D.Annotation("u1")
     ann.add(D.Segment(1.0, 2.5), "a", "SPEAKER_01"); ann.add(D.Segment(0.25, 0.75), "b", "SPEAKER_00")
