@@ -1,0 +1,360 @@
+// GEMM main-loop laboratory (gfx950, bf16): C[M][N] (fp32) = A[M][K] * W[N][K]^T with the 256x256 tile and the
+// LDS-DMA fill of reverb_amd/csrc/gemm2.hip, parametrised over the things DESIGN.md section 8 item 1 names as
+// the next steps, so that one run on an MI355X measures them side by side:
+//
+//   NWM x NWN   waves per workgroup and their layout: 2x4 = 8 waves of 128x64 (gemm2 today; 192 KiB of fragment
+//               reads per 64-element K step) or 2x2 = 4 waves of 128x128 (128 KiB: LDS reads + DMA writes drop
+//               from 100 % to 75 % of the MFMA time at peak rate; accumulators take 256 registers, one wave/SIMD)
+//   KSUBS       K step of 64 (128-byte rows, as gemm2) or 32 elements (64-byte rows: half-size stages)
+//   NST         LDS stages: 2 x 64 KiB, or 4 x 32 KiB = three K steps of fill in flight
+//   PIPE        0: wait - barrier - refill - read - MFMA (gemm2);  1: fragments double-buffered in registers, the
+//               barrier and the refill sit between two MFMA blocks, reads of the next k32 slice land under MFMAs
+//
+// Inputs are small integers stored as bf16, so every variant must reproduce the naive kernel EXACTLY.
+//   hipcc -O3 --offload-arch=gfx950 -o scripts/micro/gemm_lab scripts/micro/gemm_lab.hip && scripts/micro/gemm_lab
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ inline void mma(const uint4& a, const uint4& b, f32x4& c) {
+  union U { uint4 u; bf16x8 v; };
+  U ua, ub;
+  ua.u = a; ub.u = b;
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
+}
+
+// The same instruction with the accumulator pinned to AGPRs.  A 128x128 wave tile owns 64 accumulator tuples = all 256
+// AGPRs; left to itself the register allocator parks some of them in VGPRs and copies them in and out around every
+// MFMA.  Opaque to the scheduler and to the hazard recognizer: the caller orders instructions by hand, never touches
+// one accumulator twice within 16 MFMAs, and idles before reading the accumulators with VALU instructions.
+__device__ inline void mma_a(const uint4& a, const uint4& b, f32x4& c) {
+  union U { uint4 u; bf16x8 v; };
+  U ua, ub;
+  ua.u = a; ub.u = b;
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(ua.v), "v"(ub.v));
+}
+
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 bytes land at lds .. lds+1024 in lane order.  Inline asm on purpose: the
+// compiler's waitcnt pass must not see these loads (it would drain vmcnt(0) before every ds_read), the explicit
+// s_waitcnt below orders them.  M0 belongs to the compiler: saved and restored.
+__device__ inline void dma1(const void* g, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds)
+      : "memory");
+}
+
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// wait until at most `groups` of the most recent DMA groups (PPW pieces each) are still in flight
+template <int PPW> __device__ inline void wait_groups(int groups) {
+  if (groups <= 0) wait_vm<0>();
+  else if (groups == 1) wait_vm<PPW>();
+  else if (groups == 2) wait_vm<2 * PPW>();
+  else wait_vm<3 * PPW>();
+}
+
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA>
+__global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                           float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NWM * NWN;
+  constexpr int BKB = 64 * KSUBS;        // bytes of K per tile row and stage
+  constexpr int BKE = BKB / 2;           // bf16 elements
+  constexpr int CPR = BKB / 16;          // 16-byte columns per row: 8 or 4
+  constexpr int RPI = 64 / CPR;          // rows one DMA instruction covers: 8 or 16
+  constexpr int STAGE = 512 * BKB;       // 256 rows of A then 256 rows of W
+  constexpr int PPW = 512 / RPI / NW;    // DMA pieces per wave per stage
+  constexpr int TM = 256 / NWM, TN = 256 / NWN, FI = TM / 16, FJ = TN / 16;
+  static_assert(3 * PPW <= 63, "vmcnt is a 6-bit counter");
+  static_assert(NST >= 2 && NST <= 4, "stages");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWN, wc = wave % NWN;
+
+  const int tiles_n = N / 256;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {   // XCD-aware bijective tile order (as gemm2): consecutive tiles of one XCD share the A panel
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // swizzle: LDS[row][c] = G[row][c ^ swz(row)] (16-byte columns): the 16 lanes of a fragment read (16 consecutive
+  // rows, one logical column) then touch 16 distinct 16-byte slots of a 256-byte bank row
+  auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+  // ---- DMA sources: the first NW/2 waves stage A, the others W; piece i of a wave = image rows [first + i*RPI, +RPI)
+  const bool isA = wave < NW / 2;
+  const int first = (wave % (NW / 2)) * PPW * RPI;       // first tile row this wave stages (within A's or W's 256)
+  const int lr = lane / CPR, lc = lane % CPR;
+  const uint16_t* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = first + i * RPI + lr;
+    const uint16_t* base = isA ? A + (size_t)(m0 + row) * K : W + (size_t)(n0 + row) * K;
+    src[i] = base + (lc ^ swz(row)) * 8;
+  }
+  const unsigned lds_wave = lds_base + (isA ? 0 : 256 * BKB) + first * BKB;
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    const unsigned dst = lds_wave + (kt % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma1(src[i] + (size_t)kt * BKE, dst + i * 1024);
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, lgrp = lane >> 4;
+  int roff[KSUBS];
+#pragma unroll
+  for (int s = 0; s < KSUBS; ++s) roff[s] = ((s * 4 + lgrp) ^ swz(frow)) << 4;
+  const int a_off = (wr * TM + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * TN + frow) * BKB;
+  const int nk = K / BKE;
+
+  // Both loop shapes END with the wait-barrier-refill step, never with MFMAs: the register copies the allocator places
+  // on loop edges then never read an accumulator that an (opaque, inline-asm) MFMA is still writing.  Straight-line
+  // MFMA blocks after the loops carry trailing s_nops for the same reason.
+  uint4 fa[2][FI], fb[2][FJ];
+  auto st_of = [&](int q) __attribute__((always_inline)) { return smem + ((q / KSUBS) % NST) * STAGE; };
+  auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const char* st = st_of(q);
+    const int s = q % KSUBS;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * BKB + roff[s]);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * BKB + roff[s]);
+  };
+  auto settle = [&]() __attribute__((always_inline)) { if (AMMA) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"); };   // in-flight MFMAs retire
+  auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        if (AMMA) mma_a(fa[buf][i], fb[buf][j], acc[i][j]);
+        else mma(fa[buf][i], fb[buf][j], acc[i][j]);
+      }
+  };
+  // multiply slice `mbuf` while slice q is read into the other buffer: two MFMAs, one fragment read, ..., then the
+  // remaining MFMAs.  AMMA: written in exactly that order (asm volatile MFMAs and loads keep their program order);
+  // otherwise sched_group_barriers ask the scheduler for it (left alone it sinks the reads to the end of the block to
+  // shorten live ranges, and the next block waits for them).
+  auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {
+    constexpr int mb = decltype(mbufc)::value, rb = 1 - mb;
+    if (AMMA) {
+      const char* st = st_of(q);
+      const int s = q % KSUBS;
+#pragma unroll
+      for (int m = 0; m < FI * FJ; ++m) {
+        mma_a(fa[mb][m / FJ], fb[mb][m % FJ], acc[m / FJ][m % FJ]);
+        if ((m & 1) && (m >> 1) < FI + FJ) {
+          const int r = m >> 1;
+          if (r < FJ) fb[rb][r] = *(const uint4*)(st + b_off + r * 16 * BKB + roff[s]);
+          else fa[rb][r - FJ] = *(const uint4*)(st + a_off + (r - FJ) * 16 * BKB + roff[s]);
+        }
+      }
+    } else {
+      read_slice(std::integral_constant<int, rb>(), q);
+      mma_slice(mbufc);
+#pragma unroll
+      for (int r = 0; r < FI + FJ; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA (first: they wait for the previous block's reads only)
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, FI * FJ - 2 * (FI + FJ), 0);
+    }
+  };
+  std::integral_constant<int, 0> b0;
+  std::integral_constant<int, 1> b1;
+
+  if (PIPE == 0) {
+    // stage kt: wait - barrier - refill the buffer of stage kt-1 - read all fragments - MFMAs          (gemm2's loop)
+    auto enter = [&](int kt) __attribute__((always_inline)) {
+      const int issued = kt + NST - 1 < nk ? kt + NST - 1 : nk;
+      wait_groups<PPW>(issued - kt - 1);           // this wave's pieces of stage kt have landed
+      __syncthreads();                             // ... and everybody else's; stage kt-1 is no longer read by anyone
+      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+    };
+    auto compute = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < KSUBS; ++s) {
+        read_slice(b0, kt * KSUBS + s);
+        mma_slice(b0);
+      }
+    };
+    for (int s = 0; s < NST - 1 && s < nk; ++s) issue(s);
+    enter(0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      compute(kt);
+      enter(kt + 1);
+    }
+    compute(nk - 1);
+    settle();
+  } else {
+    // k32 slices q = kt*KSUBS + s stream through the two register buffers; block u multiplies slice u and reads slice
+    // u+1.  A stage is "entered" (its DMA awaited, barrier, the buffer of the stage before it refilled with stage
+    // kt-1+NST) before its first slice is read.  Host guarantees nk >= 2 and an even number of slices.
+    auto enter_stage = [&](int kt) __attribute__((always_inline)) {               // kt >= 1
+      const int issued = kt - 1 + NST < nk ? kt - 1 + NST : nk;
+      wait_groups<PPW>(issued - kt - 1);
+      __syncthreads();
+      if (kt - 1 + NST < nk) issue(kt - 1 + NST);
+    };
+    const int nq = nk * KSUBS;
+    for (int s = 0; s < NST && s < nk; ++s) issue(s);
+    {
+      const int issued = NST < nk ? NST : nk;
+      wait_groups<PPW>(issued - 1);
+      __syncthreads();
+    }
+    read_slice(b0, 0);
+    if (KSUBS == 2) {
+      block(b0, 1);
+      enter_stage(1);
+      int u = 1;
+      for (; u <= nq - 5; u += 2) {                // slices u (sub 1 of a stage), u+1 (sub 0 of the next), then enter the one after
+        block(b1, u + 1);
+        block(b0, u + 2);
+        enter_stage((u + 3) / 2);
+      }
+      block(b1, nq - 2); settle();
+      block(b0, nq - 1); settle();
+      mma_slice(b1); settle();
+    } else {
+      enter_stage(1);
+      int u = 0;
+      for (; u <= nq - 4; u += 2) {
+        block(b0, u + 1);
+        enter_stage(u + 2);
+        block(b1, u + 2);
+        enter_stage(u + 3);
+      }
+      block(b0, nq - 1); settle();
+      mma_slice(b1); settle();
+    }
+  }
+
+  // ---- plain epilogue (the lab measures main loops; gemm2's LDS-transposed epilogue is not repeated here)
+  const int crow = (lane >> 4) * 4, ccol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* crow_p = C + (size_t)(m0 + wr * TM + i * 16 + crow + r) * N + n0 + wc * TN + ccol;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) crow_p[j * 16] = acc[i][j][r];
+    }
+}
+
+__global__ void fill_ints(uint16_t* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const int v = (int)(h % 5) - 2;                             // -2..2, exact in bf16; sums stay exact in fp32
+    const float f = (float)v;
+    p[i] = (uint16_t)(__float_as_uint(f) >> 16);
+  }
+}
+
+__global__ void naive_rows(const uint16_t* A, const uint16_t* W, float* C, int N, int K, int row0) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = row0 + blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k)
+    s += __uint_as_float((unsigned)A[(size_t)m * K + k] << 16) * __uint_as_float((unsigned)W[(size_t)n * K + k] << 16);
+  C[(size_t)blockIdx.y * N + n] = s;
+}
+
+struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int); int threads, lds; };
+
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0> Variant make(const char* name) {
+  auto k = gemm_lab<NWM, NWN, KSUBS, NST, PIPE, AMMA>;
+  const int lds = NST * 512 * 64 * KSUBS;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return {name, k, NWM * NWN * 64, lds};
+}
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 5;
+  std::vector<Variant> vs;
+  vs.push_back(make<2, 4, 2, 2, 0>("8w 128x64  BK64 2st simple (=gemm2)"));
+  vs.push_back(make<2, 4, 2, 2, 1>("8w 128x64  BK64 2st pipelined     "));
+  vs.push_back(make<2, 2, 2, 2, 0, 1>("4w 128x128 BK64 2st simple        "));
+  vs.push_back(make<2, 2, 2, 2, 1, 1>("4w 128x128 BK64 2st pipelined     "));
+  vs.push_back(make<2, 4, 1, 4, 0>("8w 128x64  BK32 4st simple        "));
+  vs.push_back(make<2, 4, 1, 4, 1>("8w 128x64  BK32 4st pipelined     "));
+  vs.push_back(make<2, 2, 1, 4, 0, 1>("4w 128x128 BK32 4st simple        "));
+  vs.push_back(make<2, 2, 1, 4, 1, 1>("4w 128x128 BK32 4st pipelined     "));
+  vs.push_back(make<2, 4, 1, 3, 1>("8w 128x64  BK32 3st pipelined     "));
+  vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
+
+  struct Shape { int M, N, K; };
+  const Shape shapes[] = {{90112, 1024, 1024}, {90112, 4096, 1024}, {90112, 1024, 4096}, {90112, 1024, 19456}};
+  const int CHK = 512;                                           // rows checked at the top and at the bottom of C
+  for (const Shape& sh : shapes) {
+    const int M = sh.M, N = sh.N, K = sh.K;
+    uint16_t *A, *W;
+    float *C, *R;
+    CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&W, (size_t)N * K * 2));
+    CHECK(hipMalloc(&C, (size_t)M * N * 4)); CHECK(hipMalloc(&R, (size_t)2 * CHK * N * 4));
+    hipLaunchKernelGGL(fill_ints, dim3(4096), dim3(256), 0, 0, A, (size_t)M * K, 17u);
+    hipLaunchKernelGGL(fill_ints, dim3(4096), dim3(256), 0, 0, W, (size_t)N * K, 91u);
+    hipLaunchKernelGGL(naive_rows, dim3((N + 255) / 256, CHK), dim3(256), 0, 0, A, W, R, N, K, 0);
+    hipLaunchKernelGGL(naive_rows, dim3((N + 255) / 256, CHK), dim3(256), 0, 0, A, W, R + (size_t)CHK * N, N, K, M - CHK);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ref((size_t)2 * CHK * N), got((size_t)2 * CHK * N);
+    CHECK(hipMemcpy(ref.data(), R, ref.size() * 4, hipMemcpyDeviceToHost));
+    printf("M=%d N=%d K=%d\n", M, N, K);
+    const int tiles = (M / 256) * (N / 256);
+    for (const Variant& v : vs) {
+      CHECK(hipMemset(C, 0xff, (size_t)M * N * 4));
+      hipLaunchKernelGGL(v.kern, dim3(tiles), dim3(v.threads), v.lds, 0, A, W, C, M, N, K);
+      CHECK(hipGetLastError());
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(got.data(), C, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(got.data() + (size_t)CHK * N, C + (size_t)(M - CHK) * N, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < ref.size(); ++i) bad += !(ref[i] == got[i]);
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(v.kern, dim3(tiles), dim3(v.threads), v.lds, 0, A, W, C, M, N, K);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("  %s  %8.3f ms  %7.1f TFLOP/s  %s\n", v.name, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12,
+             bad ? "WRONG" : "exact");
+      if (bad) printf("    (%zu of %zu checked elements differ)\n", bad, ref.size());
+      fflush(stdout);
+    }
+    CHECK(hipFree(A)); CHECK(hipFree(W)); CHECK(hipFree(C)); CHECK(hipFree(R));
+  }
+  return 0;
+}
