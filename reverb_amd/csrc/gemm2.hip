@@ -1,10 +1,12 @@
 // Large-shape MFMA GEMM for gfx950 (same contract as gemm.hip, used when K is a multiple of the
 // 128-byte K step):  256x256 output tile, 8 waves (2 along M x 4 along N, 128x64 per wave =
 // 8x4 MFMA 16x16 fragments), operands go HBM -> LDS directly with `global_load_lds_dwordx4`
-// (LDS-DMA, no VGPR round trip, no ds_write pass), two LDS stages of 64 KiB, one barrier per K step:
+// (LDS-DMA, no VGPR round trip, no ds_write pass), two LDS stages of 64 KiB, one barrier per K step,
+// fragments double-buffered in registers:
 //
-//     wait(own DMA of tile t) ; barrier ; ds_read fragments of tile t ; issue DMA of tile t+1 ;
-//     MFMAs of tile t   <- the DMA of t+1 lands underneath
+//     MFMAs of k32 slice 0 of tile t | ds_read slice 1 ;
+//     wait(own DMA of tile t+1) ; barrier ; issue DMA of tile t+2 into the stage tile t just left ;
+//     MFMAs of slice 1 of tile t | ds_read slice 0 of tile t+1      <- the DMA lands underneath both
 //
 // The LDS image is lane-linear (8 rows x 128 B per wave-instruction); bank conflicts of the
 // 128-byte rows are removed by an XOR swizzle applied to the SOURCE column and to the read:
@@ -14,6 +16,8 @@
 // (gemm.hip handles them).
 #include "common.h"
 #include "kernels.h"
+
+#include <type_traits>
 
 namespace rvb {
 
@@ -144,32 +148,101 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   roff[0] = ((0 * 4 + lgrp) ^ swz) << 4;
   roff[1] = ((1 * 4 + lgrp) ^ swz) << 4;
 
+  // ---- main loop: k32 slices q = 2*kt + s stream through two register buffers of fragments.  Block u multiplies
+  // slice u while slice u+1 is read (two MFMAs, one ds_read, ... so the reads leave early and land under the MFMAs);
+  // a stage is "entered" (own DMA awaited, barrier, the other buffer refilled with the stage after it) between two
+  // blocks, so there is MFMA work on both sides of every barrier.  Measured against the plain
+  // wait-barrier-refill-read-multiply loop in scripts/micro/gemm_lab.hip: +7..11 % on the engine's shapes.
   const int nk = p.K / BKE;
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt have landed
-    __syncthreads();                                   // ... and so have everybody else's
-    const char* sA = smem + cur * STAGE2 + (wr * 128 + frow) * ROW2;
-    const char* sB = smem + cur * STAGE2 + B2M * ROW2 + (wc * 64 + frow) * ROW2;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);   // other stage: last read one K step ago, every wave is past the barrier
-    uint4 a0[8], b0[4], a1[8], b1[4];
+  if constexpr (sizeof(T) == 2) {
+    const int nq = 2 * nk;
+    uint4 fa[2][8], fb[2][4];
+    const int a_off = (wr * 128 + frow) * ROW2;
+    const int b_off = B2M * ROW2 + (wc * 64 + frow) * ROW2;
+    auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      const char* st = smem + ((q >> 1) & 1) * STAGE2;
+      const int ro = roff[q & 1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a0[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[0]);
+      for (int i = 0; i < 8; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * ROW2 + ro);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[0]);
+      for (int j = 0; j < 4; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * ROW2 + ro);
+    };
+    auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a1[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[1]);
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[1]);
+        for (int j = 0; j < 4; ++j) Mma16<T>::run(fa[buf][i], fb[buf][j], acc[i][j]);
+    };
+    auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {     // multiply buffer mbuf, read slice q into the other
+      constexpr int mb = decltype(mbufc)::value;
+      read_slice(std::integral_constant<int, 1 - mb>(), q);
+      mma_slice(mbufc);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int r = 0; r < 12; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA first: they depend on the previous block's reads only
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one ds_read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    auto enter_stage = [&](int kt) __attribute__((always_inline)) {          // kt >= 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of stage kt have landed
+      __syncthreads();                                   // ... everybody's have; nobody reads stage kt-1 any more
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);      // into the buffer stage kt-1 just left
+    };
+    std::integral_constant<int, 0> b0;
+    std::integral_constant<int, 1> b1;
+    issue(0, 0);
+    if (nk > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 (the older group of 8 pieces)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    read_slice(b0, 0);
+    block(b0, 1);
+    if (nk > 1) {
+      enter_stage(1);
+      for (int u = 1; u <= nq - 5; u += 2) {
+        block(b1, u + 1);
+        block(b0, u + 2);
+        enter_stage((u + 3) >> 1);
+      }
+      block(b1, nq - 2);
+      block(b0, nq - 1);
+    }
+    mma_slice(b1);
+  } else {
+    // f32 (parity mode, four 16x16x4 MFMAs per fragment pair): the plain loop -- the double-buffered fragments do not
+    // fit next to 128 accumulator registers there
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt have landed
+      __syncthreads();                                   // ... and so have everybody else's
+      const char* sA = smem + cur * STAGE2 + (wr * 128 + frow) * ROW2;
+      const char* sB = smem + cur * STAGE2 + B2M * ROW2 + (wc * 64 + frow) * ROW2;
+      if (kt + 1 < nk) issue(kt + 1, cur ^ 1);   // other stage: last read one K step ago, every wave is past the barrier
+      uint4 a0[8], b0[4], a1[8], b1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Mma16<T>::run(a0[i], b0[j], acc[i][j]);
+      for (int i = 0; i < 8; ++i) a0[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[0]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) b0[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[0]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Mma16<T>::run(a1[i], b1[j], acc[i][j]);
+      for (int i = 0; i < 8; ++i) a1[i] = *(const uint4*)(sA + i * 16 * ROW2 + roff[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = *(const uint4*)(sB + j * 16 * ROW2 + roff[1]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma16<T>::run(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma16<T>::run(a1[i], b1[j], acc[i][j]);
+    }
   }
 
   // ---- epilogue ----
