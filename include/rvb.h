@@ -136,10 +136,12 @@ int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_
  * out[j] = log p(w_j | ...) for j < len and out[len] = log p(eos); right=1 for the r2l decoder */
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out);
 
-/* Stage timing (HIP events on the engine stream).  When enabled every kernel family is bracketed;
+/* Stage timing (HIP events on the engine stream).  level 1: every kernel family is bracketed;
  * names: "fbank","subsample","gemm","attention","rownorm","glu_dwconv","ctc_topk","embed",
- * "lse_gather","search_host".  flops: algorithmic FLOPs launched (gemm/attention only). */
-int rvb_set_profiling(rvb_engine* e, int enabled);
+ * "lse_gather","search_host".  level 2: only the GEMM launches (the dominant kernel; half the
+ * events, ~1 % less perturbation of the step).  level 0: off.
+ * flops: algorithmic FLOPs launched (gemm/attention only). */
+int rvb_set_profiling(rvb_engine* e, int level);
 int rvb_reset_timings(rvb_engine* e);
 int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, int64_t* launches);
 

@@ -114,7 +114,7 @@ struct rvb_engine {
   rvb::DevBuf d_hq_start, d_hq_len, d_hkv_start, d_hkv_len;
 
   // ---- profiling ----
-  bool profiling = false;
+  int profiling = 0;     // 0 off, 1 every stage, 2 GEMM launches only (what the roofline needs; half the events)
   std::map<std::string, rvb::ProfEntry> prof;
   struct Pending { hipEvent_t a, b; std::string name; };
   std::vector<Pending> pending;

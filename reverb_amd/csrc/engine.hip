@@ -41,7 +41,7 @@ struct Scope {
   Scope(rvb_engine* e_, const char* n, double flops = 0.0) : e(e_), name(n) {
     auto& pe = e->prof[name];
     pe.launches += 1; pe.flops += flops;
-    if (!e->profiling) return;
+    if (e->profiling == 0 || (e->profiling == 2 && name != "gemm")) return;
     auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else hipEventCreate(&ev); return ev; };
     a = get(); b = get();
     hipEventRecord(a, e->stream);
@@ -1336,7 +1336,7 @@ int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* ou
   return OK;
 }
 
-int rvb_set_profiling(rvb_engine* e, int enabled) { if (!e) return E_ARG; drain_prof(e); e->profiling = enabled != 0; return OK; }
+int rvb_set_profiling(rvb_engine* e, int level) { if (!e) return E_ARG; drain_prof(e); e->profiling = (level == 1 || level == 2) ? level : 0; return OK; }
 int rvb_reset_timings(rvb_engine* e) { if (!e) return E_ARG; drain_prof(e); e->prof.clear(); return OK; }
 int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, int64_t* launches) {
   if (!e || !name) return E_ARG;

@@ -329,8 +329,9 @@ class Engine:
         return out
 
     # -------------------------------------------------------------------------------- timings
-    def set_profiling(self, on: bool):
-        check(self.lib.rvb_set_profiling(self.handle, 1 if on else 0))
+    def set_profiling(self, on, gemm_only: bool = False):
+        """HIP-event stage timing: every stage, or (gemm_only) just the GEMM launches the roofline figure needs."""
+        check(self.lib.rvb_set_profiling(self.handle, 0 if not on else 2 if gemm_only else 1))
 
     def reset_timings(self):
         check(self.lib.rvb_reset_timings(self.handle))

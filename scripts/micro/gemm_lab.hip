@@ -68,9 +68,9 @@ template <int PPW> __device__ inline void wait_groups(int groups) {
   else wait_vm<3 * PPW>();
 }
 
-template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA>
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA, int STORE>
 __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                           float* __restrict__ C, int M, int N, int K) {
+                                                           float* __restrict__ C, int M, int N, int K, int phases) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NWM * NWN;
   constexpr int BKB = 64 * KSUBS;        // bytes of K per tile row and stage
@@ -88,6 +88,14 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / NWN, wc = wave % NWN;
 
+  // phases > 1: the workgroups of the first wave (one per CU) start `phase/phases` of a tile time apart.  Every CU runs
+  // equal tiles back to back, so without this all 256 CUs reach their epilogue at the same moment, the stores of a whole
+  // wave of tiles hit HBM as one burst, and nothing computes while it drains.
+  if (phases > 1 && blockIdx.x < 256) {
+    const int phase = (blockIdx.x >> 3) % phases;                 // bits above the XCD index: every XCD gets every phase
+    const int kilocycles = phase * (K / 64) * 1260 / phases / 1024;
+    for (int i = 0; i < kilocycles; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 clocks
+  }
   const int tiles_n = N / 256;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
@@ -267,9 +275,168 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* crow_p = C + (size_t)(m0 + wr * TM + i * 16 + crow + r) * N + n0 + wc * TN + ccol;
+      if (STORE) {
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) crow_p[j * 16] = acc[i][j][r];
+        for (int j = 0; j < FJ; ++j) crow_p[j * 16] = acc[i][j][r];
+      } else {                                                   // main loop only: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+          if (acc[i][j][r] == 12345.678f) crow_p[j * 16] = acc[i][j][r];
+      }
     }
+}
+
+// ---- persistent variant of "8w 128x64 BK64 2st pipelined": one workgroup per CU walks the tiles (same XCD-aware order);
+// the first two stages of the NEXT tile are requested before the epilogue of the current one (stage 0 into the buffer
+// that frees up at the last barrier of the K loop, stage 1 after one more barrier into the buffer of the last K step),
+// so the DMA start-up latency of a tile hides under the previous tile's stores.
+template <int STORE>
+__global__ __launch_bounds__(512) void gemm_persist(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                    float* __restrict__ C, int M, int N, int K, int store) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 128, BKE = 64, STAGE = 65536, PPW = 8, FI = 8, FJ = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = N / 256;
+  const int ntiles = (M / 256) * tiles_n;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const bool isA = wave < 4;
+  const int first = (wave & 3) * 64;                     // 8 pieces x 8 rows
+  const uint16_t* src[PPW];
+  auto tile_origin = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = vb & 7, idx = vb >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    m0 = tm * 256; n0 = tn * 256;
+  };
+  // lane id re-derived through volatile asm where it is needed outside the K loop: everything computed from it then
+  // stays out of the loop's live set (the K loop has no spare register: 128 acc + 96 fragment + 16 pointer VGPRs)
+  auto fresh_lane = [&]() __attribute__((always_inline)) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  auto set_src = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    const int lr = l >> 3, lc = l & 7;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = first + i * 8 + lr;
+      const uint16_t* base = isA ? A + (size_t)(m0 + row) * K : W + (size_t)(n0 + row) * K;
+      src[i] = base + (lc ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  const unsigned lds_wave = lds_base + (isA ? 0 : 256 * BKB) + first * BKB;
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {      // stage kt of the tile `src` points at
+    const unsigned dst = lds_wave + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma1(src[i] + (size_t)kt * BKE, dst + i * 1024);
+  };
+  const int frow = lane & 15, lgrp = lane >> 4;
+  int roff[2];
+  roff[0] = ((0 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  const int a_off = (wr * 128 + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+  const int nk = K / BKE, nq = 2 * nk;                   // host guarantees nk >= 2
+
+  int vb = blockIdx.x;
+  if (vb >= ntiles) return;
+  int m0, n0, par = 0;                                   // stage kt of the current tile lives in buffer (kt + par) & 1
+  tile_origin(vb, m0, n0);
+  set_src(m0, n0);
+  issue(0, 0);
+  issue(1, 1);
+  std::integral_constant<int, 0> b0;
+  std::integral_constant<int, 1> b1;
+  for (;;) {
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < ntiles;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) tile_origin(nvb, nm0, nn0);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fa[2][FI], fb[2][FJ];
+    auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      const char* st = smem + (((q >> 1) + par) & 1) * STAGE;
+      const int ro = roff[q & 1];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * BKB + ro);
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * BKB + ro);
+    };
+    auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma(fa[buf][i], fb[buf][j], acc[i][j]);
+    };
+    auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {
+      constexpr int mb = decltype(mbufc)::value;
+      read_slice(std::integral_constant<int, 1 - mb>(), q);
+      mma_slice(mbufc);
+#pragma unroll
+      for (int r = 0; r < FI + FJ; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, FI * FJ - 2 * (FI + FJ), 0);
+    };
+    auto enter_stage = [&](int kt) __attribute__((always_inline)) {        // kt >= 1
+      wait_vm<0>();
+      __syncthreads();
+      if (kt + 1 < nk) {
+        issue(kt + 1, (kt + 1 + par) & 1);
+      } else if (has_next) {                                               // last barrier of this tile's K loop:
+        set_src(nm0, nn0);                                                 // the buffer of stage nk-2 is free ->
+        issue(0, (nk + par) & 1);                                          // next tile's stage 0
+      }
+    };
+    wait_vm<0>();                 // stages 0 and 1 of this tile (and the previous tile's stores)
+    __syncthreads();
+    read_slice(b0, 0);
+    block(b0, 1);
+    enter_stage(1);
+    for (int u = 1; u <= nq - 5; u += 2) {
+      block(b1, u + 1);
+      block(b0, u + 2);
+      enter_stage((u + 3) >> 1);
+    }
+    block(b1, nq - 2);
+    block(b0, nq - 1);
+    mma_slice(b1);
+    if (has_next) {
+      __syncthreads();            // nobody reads the last stage any more
+      issue(1, (nk + 1 + par) & 1);
+    }
+    const int el = fresh_lane();
+    const int crow = (el >> 4) * 4, ccol = el & 15;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* crow_p = C + (size_t)(m0 + wr * 128 + i * 16 + crow + r) * N + n0 + wc * 64 + ccol;
+        if (STORE) {
+#pragma unroll
+          for (int j = 0; j < FJ; ++j) crow_p[j * 16] = acc[i][j][r];
+        } else {
+#pragma unroll
+          for (int j = 0; j < FJ; ++j)
+            if (acc[i][j][r] == 12345.678f) crow_p[j * 16] = acc[i][j][r];
+        }
+      }
+    if (!has_next) break;
+    par = (par + nk) & 1;
+    vb = nvb; m0 = nm0; n0 = nn0;
+  }
 }
 
 __global__ void fill_ints(uint16_t* p, size_t n, unsigned seed) {
@@ -291,17 +458,19 @@ __global__ void naive_rows(const uint16_t* A, const uint16_t* W, float* C, int N
   C[(size_t)blockIdx.y * N + n] = s;
 }
 
-struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int); int threads, lds; };
+struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int, int); int threads, lds, store, persistent, phases; };
 
-template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0> Variant make(const char* name) {
-  auto k = gemm_lab<NWM, NWN, KSUBS, NST, PIPE, AMMA>;
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0, int STORE = 1> Variant make(const char* name, int phases = 0) {
+  auto k = gemm_lab<NWM, NWN, KSUBS, NST, PIPE, AMMA, STORE>;
   const int lds = NST * 512 * 64 * KSUBS;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  return {name, k, NWM * NWN * 64, lds};
+  return {name, k, NWM * NWN * 64, lds, STORE, 0, phases};
 }
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 5;
+  int ncu = 256;
+  { hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount; }
   std::vector<Variant> vs;
   vs.push_back(make<2, 4, 2, 2, 0>("8w 128x64  BK64 2st simple (=gemm2)"));
   vs.push_back(make<2, 4, 2, 2, 1>("8w 128x64  BK64 2st pipelined     "));
@@ -312,6 +481,17 @@ int main(int argc, char** argv) {
   vs.push_back(make<2, 2, 1, 4, 0, 1>("4w 128x128 BK32 4st simple        "));
   vs.push_back(make<2, 2, 1, 4, 1, 1>("4w 128x128 BK32 4st pipelined     "));
   vs.push_back(make<2, 4, 1, 3, 1>("8w 128x64  BK32 3st pipelined     "));
+  CHECK(hipFuncSetAttribute((const void*)gemm_persist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  CHECK(hipFuncSetAttribute((const void*)gemm_persist<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  vs.push_back({"8w BK64 2st pipelined PERSISTENT  ", gemm_persist<1>, 512, 131072, 1, 1, 0});
+  vs.push_back(make<2, 4, 2, 2, 0, 0, 0>("8w simple     NO STORES          "));
+  vs.push_back(make<2, 4, 2, 2, 1, 0, 0>("8w pipelined  NO STORES          "));
+  vs.push_back({"8w pipelined PERSISTENT NO STORES ", gemm_persist<0>, 512, 131072, 0, 1, 0});
+  vs.push_back(make<2, 4, 2, 2, 1>("8w pipelined  first wave in 2 phases", 2));
+  vs.push_back(make<2, 4, 2, 2, 1>("8w pipelined  first wave in 4 phases", 4));
+  vs.push_back(make<2, 4, 2, 2, 1>("8w pipelined  first wave in 8 phases", 8));
+  vs.push_back(make<2, 4, 2, 2, 0>("8w simple     first wave in 4 phases", 4));
+  if (argc > 2) vs.erase(vs.begin() + 2, vs.begin() + 10);      // short run: skip the 4-wave / BK32 variants
   vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
 
   struct Shape { int M, N, K; };
@@ -334,23 +514,24 @@ int main(int argc, char** argv) {
     const int tiles = (M / 256) * (N / 256);
     for (const Variant& v : vs) {
       CHECK(hipMemset(C, 0xff, (size_t)M * N * 4));
-      hipLaunchKernelGGL(v.kern, dim3(tiles), dim3(v.threads), v.lds, 0, A, W, C, M, N, K);
+      const int grid = v.persistent ? (tiles < ncu ? tiles : ncu) : tiles;
+      hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), v.lds, 0, A, W, C, M, N, K, v.persistent ? v.store : v.phases);
       CHECK(hipGetLastError());
       CHECK(hipDeviceSynchronize());
       CHECK(hipMemcpy(got.data(), C, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
       CHECK(hipMemcpy(got.data() + (size_t)CHK * N, C + (size_t)(M - CHK) * N, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
       size_t bad = 0;
-      for (size_t i = 0; i < ref.size(); ++i) bad += !(ref[i] == got[i]);
+      if (v.store) for (size_t i = 0; i < ref.size(); ++i) bad += !(ref[i] == got[i]);
       hipEvent_t e0, e1;
       CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
       CHECK(hipEventRecord(e0));
-      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(v.kern, dim3(tiles), dim3(v.threads), v.lds, 0, A, W, C, M, N, K);
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), v.lds, 0, A, W, C, M, N, K, v.persistent ? v.store : v.phases);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms = 0;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
       printf("  %s  %8.3f ms  %7.1f TFLOP/s  %s\n", v.name, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12,
-             bad ? "WRONG" : "exact");
+             !v.store ? "(not checked)" : bad ? "WRONG" : "exact");
       if (bad) printf("    (%zu of %zu checked elements differ)\n", bad, ref.size());
       fflush(stdout);
     }
