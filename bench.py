@@ -110,9 +110,9 @@ def main():
         nf = eng.fbank()
         hyps = eng.decode_resident(nf, modes, chunk, args.beam, args.ctc_weight, args.reverse_weight)["attention_rescoring"]
         ntok = sum(len(h.tokens) for h in hyps)
-        if use_dist:      # one all-gather of the per-chunk results over RCCL/xGMI
-            hyps = all_gather_results(hyps, device)
-            ntok = sum(len(h.tokens) for h in hyps)
+        if use_dist:      # one all-gather of the per-chunk results over RCCL/xGMI; the other ranks'
+            hyps = all_gather_results(hyps, device)     # rows stay packed until somebody reads them (dist.GatheredResults)
+            ntok = hyps.total_tokens()
         return hyps, ntok
 
     for _ in range(args.warmup):

@@ -59,6 +59,10 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     merged = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"))
+    # the gathered sequence is lazy: length, token total, random access and negative / slice indexing all agree
+    assert merged.total_tokens() == sum(len(h.tokens) for h in merged)
+    assert len(merged) == sum(3 + 2 * r for r in range(world))
+    assert merged[-1].tokens == list(merged)[-1].tokens and [h.score for h in merged[1:4]] == [h.score for h in list(merged)[1:4]]
     q.put((rank, [(list(h.tokens), h.times, h.score, h.confidence, h.tokens_confidence) for h in merged]))
     dist.barrier()
     dist.destroy_process_group()
