@@ -60,3 +60,31 @@ def test_empty_utterance():
     lp = torch.randn(4, 9).log_softmax(-1)
     nbest, scores, times = native_prefix(lp, 0, 3)
     assert nbest == [()] and scores == [0.0] and times == [[]]
+
+
+def test_property_random_shapes_ties_and_tiny_beams():
+    """The native search keys a frame's candidates by (beam entry, top-k token) instead of by token tuple and only
+    creates trie nodes for survivors; prefixes that leave the beam and come back, exact score ties (quantised
+    logits: the stable sort order decides) and beams wider than the vocabulary minus one are where that could
+    differ from the reference's dictionary walk."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None, derandomize=True)
+    @given(st.integers(0, 2 ** 31 - 1), st.integers(1, 40), st.integers(2, 12), st.integers(1, 6), st.sampled_from([0.0, 0.5, 1.0]),
+           st.floats(-3.0, 6.0))
+    def check(seed, T, V, beam, quant, blank_bias):
+        beam = min(beam, V)
+        g = torch.Generator().manual_seed(seed)
+        logits = torch.randn(T, V, generator=g) * 2
+        logits[:, 0] += blank_bias
+        if quant:
+            logits = (logits / quant).round() * quant           # many exactly equal log-probs
+        lp = logits.log_softmax(-1)
+        n_t = T - (seed % 3 if T > 3 else 0)
+        o = S.ctc_prefix_beam_search(lp.unsqueeze(0), torch.tensor([n_t]), beam)[0]
+        nbest, scores, times = native_prefix(lp, n_t, beam)
+        assert nbest == [tuple(x) for x in o.nbest]
+        assert times == o.nbest_times
+        assert scores == o.nbest_scores
+
+    check()
