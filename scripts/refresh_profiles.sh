@@ -7,6 +7,8 @@ O=$R/gpurun_out/refresh
 mkdir -p $O
 export PYTHONPATH=$R TMPDIR=/tmp
 cd /tmp
+# GEMM main-loop laboratory (build it first, here or on the box: hipcc -O3 --offload-arch=gfx950 -o scripts/micro/gemm_lab scripts/micro/gemm_lab.hip)
+[ -x $R/scripts/micro/gemm_lab ] && timeout 120 $R/scripts/micro/gemm_lab 5 > $O/gemm_lab.txt 2>&1 < /dev/null
 timeout 300 python $R/bench.py --steps 3 --warmup 1 > $O/bench_r640.log 2>&1 < /dev/null
 timeout 300 python $R/bench.py --steps 3 --warmup 1 --model r268 > $O/bench_r268.log 2>&1 < /dev/null
 timeout 300 python $R/bench_diar.py --steps 3 --warmup 1 > $O/bench_diar.log 2>&1 < /dev/null
