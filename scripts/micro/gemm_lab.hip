@@ -12,10 +12,15 @@
 //
 // Inputs are small integers stored as bf16, so every variant must reproduce the naive kernel EXACTLY.
 //   hipcc -O3 --offload-arch=gfx950 -o scripts/micro/gemm_lab scripts/micro/gemm_lab.hip && scripts/micro/gemm_lab
+//   scripts/micro/gemm_lab 5 short   main-loop variants without the 4-wave / 64-byte-row ones
+//   scripts/micro/gemm_lab 5 real    pipelined loop + the engine's epilogue, one tile per workgroup vs persistent (NOT RUN YET:
+//                                    written after the round's GPU budget was spent; first thing to measure next round)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -458,6 +463,272 @@ __global__ void naive_rows(const uint16_t* A, const uint16_t* W, float* C, int N
   C[(size_t)blockIdx.y * N + n] = s;
 }
 
+// ---- the engine's epilogue (bias, optional fp32 residual, bf16 or fp32 output, full-line vector stores through an LDS
+// transposition slab) behind the pipelined main loop, one tile per workgroup (PERSIST = 0, = what gemm2.hip does) or
+// persistent with the next tile's two stages requested before the epilogue (PERSIST = 1).  The slab lives in the 32 KiB
+// of LDS above the two 64 KiB stages (8-row passes, 17 KiB), so the prefetch and the epilogue do not share a buffer.
+__device__ inline uint16_t f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <int PERSIST, int OUTBF>
+__global__ __launch_bounds__(512) void gemm_real(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, void* __restrict__ Cv,
+                                                 const float* __restrict__ bias, const float* __restrict__ res, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 128, BKE = 64, STAGE = 65536, PPW = 8, FI = 8, FJ = 4, SROW = 64 * 4 + 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = N / 256;
+  const int ntiles = (M / 256) * tiles_n;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const bool isA = wave < 4;
+  const int first = (wave & 3) * 64;
+  const uint16_t* src[PPW];
+  auto tile_origin = [&](int vb, int& m0, int& n0) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = vb & 7, idx = vb >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    m0 = tm * 256; n0 = tn * 256;
+  };
+  auto fresh_lane = [&]() __attribute__((always_inline)) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  auto set_src = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int l = fresh_lane();
+    const int lr = l >> 3, lc = l & 7;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = first + i * 8 + lr;
+      const uint16_t* base = isA ? A + (size_t)(m0 + row) * K : W + (size_t)(n0 + row) * K;
+      src[i] = base + (lc ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  const unsigned lds_wave = lds_base + (isA ? 0 : 256 * BKB) + first * BKB;
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    const unsigned dst = lds_wave + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) dma1(src[i] + (size_t)kt * BKE, dst + i * 1024);
+  };
+  const int frow = lane & 15, lgrp = lane >> 4;
+  int roff[2];
+  roff[0] = ((0 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  const int a_off = (wr * 128 + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+  const int nk = K / BKE, nq = 2 * nk;
+
+  int vb = blockIdx.x;
+  if (vb >= ntiles) return;
+  int m0, n0, par = 0;
+  tile_origin(vb, m0, n0);
+  set_src(m0, n0);
+  issue(0, 0);
+  issue(1, 1);
+  std::integral_constant<int, 0> b0;
+  std::integral_constant<int, 1> b1;
+  for (;;) {
+    const int nvb = vb + gridDim.x;
+    const bool has_next = PERSIST && nvb < ntiles;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) tile_origin(nvb, nm0, nn0);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fa[2][FI], fb[2][FJ];
+    auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      const char* st = smem + (((q >> 1) + par) & 1) * STAGE;
+      const int ro = roff[q & 1];
+#pragma unroll
+      for (int i = 0; i < FI; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * BKB + ro);
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * BKB + ro);
+    };
+    auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma(fa[buf][i], fb[buf][j], acc[i][j]);
+    };
+    auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {
+      constexpr int mb = decltype(mbufc)::value;
+      read_slice(std::integral_constant<int, 1 - mb>(), q);
+      mma_slice(mbufc);
+#pragma unroll
+      for (int r = 0; r < FI + FJ; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, FI * FJ - 2 * (FI + FJ), 0);
+    };
+    auto enter_stage = [&](int kt) __attribute__((always_inline)) {
+      wait_vm<0>();
+      __syncthreads();
+      if (kt + 1 < nk) {
+        issue(kt + 1, (kt + 1 + par) & 1);
+      } else if (has_next) {
+        set_src(nm0, nn0);
+        issue(0, (nk + par) & 1);
+      }
+    };
+    wait_vm<0>();
+    __syncthreads();
+    read_slice(b0, 0);
+    block(b0, 1);
+    enter_stage(1);
+    for (int u = 1; u <= nq - 5; u += 2) {
+      block(b1, u + 1);
+      block(b0, u + 2);
+      enter_stage((u + 3) >> 1);
+    }
+    block(b1, nq - 2);
+    block(b0, nq - 1);
+    mma_slice(b1);
+    if (has_next) {
+      __syncthreads();
+      issue(1, (nk + 1 + par) & 1);
+    }
+    // ---- epilogue: 8-row passes through the wave's private slab above the stages
+    {
+      char* slab = smem + 2 * STAGE + wave * (8 * SROW);
+      const int el = fresh_lane();
+      const int crow = ((el >> 4) & 1) * 4, ccol = el & 15, half = el >> 5;
+      const int orow = el >> 3, ocol = (el & 7) * 8;
+      const int col0 = n0 + wc * 64 + ocol;
+      float b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[e] = bias ? bias[col0 + e] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_wave_barrier();
+          if (half == h) {
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+          }
+          __builtin_amdgcn_wave_barrier();
+          const float4 x0 = *(const float4*)(slab + orow * SROW + ocol * 4);
+          const float4 x1 = *(const float4*)(slab + orow * SROW + ocol * 4 + 16);
+          float v[8] = {x0.x + b8[0], x0.y + b8[1], x0.z + b8[2], x0.w + b8[3], x1.x + b8[4], x1.y + b8[5], x1.z + b8[6], x1.w + b8[7]};
+          const size_t off = (size_t)(m0 + wr * 128 + i * 16 + h * 8 + orow) * N + col0;
+          if (res) {
+            const float4 r0 = *(const float4*)(res + off), r1 = *(const float4*)(res + off + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          }
+          if (OUTBF) {
+            uint4 o;
+            o.x = (unsigned)f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
+            o.z = (unsigned)f32_to_bf16_rne(v[4]) | ((unsigned)f32_to_bf16_rne(v[5]) << 16);
+            o.w = (unsigned)f32_to_bf16_rne(v[6]) | ((unsigned)f32_to_bf16_rne(v[7]) << 16);
+            *(uint4*)((uint16_t*)Cv + off) = o;
+          } else {
+            *(float4*)((float*)Cv + off) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)Cv + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
+    }
+    if (!has_next) break;
+    par = (par + nk) & 1;
+    vb = nvb; m0 = nm0; n0 = nn0;
+  }
+}
+
+__global__ void fill_small_f32(float* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2246822519u ^ (unsigned)(i >> 32) ^ seed;
+    h ^= h >> 13; h *= 2654435761u; h ^= h >> 16;
+    p[i] = (float)((int)(h % 9) - 4);
+  }
+}
+
+// second half of the program: `gemm_lab <reps> real`
+static int real_epilogue_run(int reps, int ncu) {
+  struct Shape { int M, N, K, outbf, use_res; const char* what; };
+  const Shape shapes[] = {{90112, 1024, 1024, 0, 1, "out-proj / pw2: f32 out + residual"}, {90112, 4096, 1024, 1, 0, "ff1: bf16 out"},
+                          {90112, 1024, 4096, 0, 1, "ff2: f32 out + residual"}, {90112, 3072, 1024, 1, 0, "qkv: bf16 out"}};
+  const int CHK = 512;
+  auto k00 = gemm_real<0, 0>; auto k01 = gemm_real<0, 1>; auto k10 = gemm_real<1, 0>; auto k11 = gemm_real<1, 1>;
+  const int LDS = 2 * 65536 + 8 * 8 * (64 * 4 + 16);
+  CHECK(hipFuncSetAttribute((const void*)k00, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  CHECK(hipFuncSetAttribute((const void*)k01, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  CHECK(hipFuncSetAttribute((const void*)k10, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  CHECK(hipFuncSetAttribute((const void*)k11, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  for (const Shape& sh : shapes) {
+    const int M = sh.M, N = sh.N, K = sh.K;
+    uint16_t *A, *W; float *R, *bias, *resid = nullptr; void* C;
+    const size_t esz = sh.outbf ? 2 : 4;
+    CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&W, (size_t)N * K * 2));
+    CHECK(hipMalloc(&C, (size_t)M * N * esz)); CHECK(hipMalloc(&R, (size_t)2 * CHK * N * 4)); CHECK(hipMalloc(&bias, (size_t)N * 4));
+    if (sh.use_res) { CHECK(hipMalloc(&resid, (size_t)M * N * 4)); hipLaunchKernelGGL(fill_small_f32, dim3(4096), dim3(256), 0, 0, resid, (size_t)M * N, 5u); }
+    hipLaunchKernelGGL(fill_ints, dim3(4096), dim3(256), 0, 0, A, (size_t)M * K, 17u);
+    hipLaunchKernelGGL(fill_ints, dim3(4096), dim3(256), 0, 0, W, (size_t)N * K, 91u);
+    hipLaunchKernelGGL(fill_small_f32, dim3(16), dim3(256), 0, 0, bias, (size_t)N, 3u);
+    hipLaunchKernelGGL(naive_rows, dim3((N + 255) / 256, CHK), dim3(256), 0, 0, A, W, R, N, K, 0);
+    hipLaunchKernelGGL(naive_rows, dim3((N + 255) / 256, CHK), dim3(256), 0, 0, A, W, R + (size_t)CHK * N, N, K, M - CHK);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ref((size_t)2 * CHK * N), hb(N), hres;
+    CHECK(hipMemcpy(ref.data(), R, ref.size() * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hb.data(), bias, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (sh.use_res) {
+      hres.resize((size_t)2 * CHK * N);
+      CHECK(hipMemcpy(hres.data(), resid, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(hres.data() + (size_t)CHK * N, resid + (size_t)(M - CHK) * N, (size_t)CHK * N * 4, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < ref.size(); ++i) ref[i] += hb[i % N] + (sh.use_res ? hres[i] : 0.f);      // small integers: exact
+    printf("M=%d N=%d K=%d  (%s)\n", M, N, K, sh.what);
+    const int tiles = (M / 256) * (N / 256);
+    for (int persist = 0; persist < 2; ++persist) {
+      auto kern = sh.outbf ? (persist ? k11 : k01) : (persist ? k10 : k00);
+      const int grid = persist ? (tiles < ncu ? tiles : ncu) : tiles;
+      CHECK(hipMemset(C, 0xff, (size_t)M * N * esz));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, A, W, C, bias, resid, M, N, K);
+      CHECK(hipGetLastError());
+      CHECK(hipDeviceSynchronize());
+      std::vector<char> got((size_t)2 * CHK * N * esz);
+      CHECK(hipMemcpy(got.data(), C, (size_t)CHK * N * esz, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(got.data() + (size_t)CHK * N * esz, (char*)C + (size_t)(M - CHK) * N * esz, (size_t)CHK * N * esz, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < ref.size(); ++i) {
+        if (sh.outbf) {
+          unsigned u; memcpy(&u, &ref[i], 4); u += 0x7fffu + ((u >> 16) & 1u);
+          bad += ((uint16_t*)got.data())[i] != (uint16_t)(u >> 16);
+        } else {
+          bad += !(((float*)got.data())[i] == ref[i]);
+        }
+      }
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, A, W, C, bias, resid, M, N, K);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("  pipelined loop + engine epilogue, %s  %8.3f ms  %7.1f TFLOP/s  %s\n", persist ? "persistent + next-tile prefetch" : "one tile per workgroup         ",
+             ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, bad ? "WRONG" : "exact");
+      if (bad) printf("    (%zu of %zu checked elements differ)\n", bad, ref.size());
+      fflush(stdout);
+    }
+    CHECK(hipFree(A)); CHECK(hipFree(W)); CHECK(hipFree(C)); CHECK(hipFree(R)); CHECK(hipFree(bias));
+    if (resid) CHECK(hipFree(resid));
+  }
+  return 0;
+}
+
 struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int, int); int threads, lds, store, persistent, phases; };
 
 template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0, int STORE = 1> Variant make(const char* name, int phases = 0) {
@@ -471,6 +742,7 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 5;
   int ncu = 256;
   { hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount; }
+  if (argc > 2 && std::string(argv[2]) == "real") return real_epilogue_run(reps, ncu);
   std::vector<Variant> vs;
   vs.push_back(make<2, 4, 2, 2, 0>("8w 128x64  BK64 2st simple (=gemm2)"));
   vs.push_back(make<2, 4, 2, 2, 1>("8w 128x64  BK64 2st pipelined     "));
