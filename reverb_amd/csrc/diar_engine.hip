@@ -86,18 +86,18 @@ struct DScope {
     auto& pe = e->prof[name];
     pe.launches += 1; pe.flops += flops;
     if (!e->profiling) return;
-    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else hipEventCreate(&ev); return ev; };
+    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
     a = get(); b = get();
-    hipEventRecord(a, e->stream);
+    (void)hipEventRecord(a, e->stream);
   }
-  ~DScope() { if (a) { hipEventRecord(b, e->stream); e->pending.push_back({a, b, name}); } }
+  ~DScope() { if (a) { (void)hipEventRecord(b, e->stream); e->pending.push_back({a, b, name}); } }
 };
 void drain(rvd_engine* e) {
   if (e->pending.empty()) return;
-  hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream);
   for (auto& p : e->pending) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, p.a, p.b);
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
     e->prof[p.name].ms += ms;
     e->event_pool.push_back(p.a); e->event_pool.push_back(p.b);
   }
@@ -603,10 +603,10 @@ int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
 
 void rvd_destroy(rvd_engine* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  hipStreamSynchronize(e->stream);
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
   drain(e);
-  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
   DevBuf* bufs[] = {&e->filt, &e->fsum, &e->cls_w, &e->cls_b, &e->stage, &e->pcm, &e->wave, &e->craw, &e->stats, &e->a1, &e->c2,
                     &e->a2, &e->c3, &e->a3, &e->xproj, &e->hA, &e->hB, &e->l0, &e->l1, &e->logp, &e->cls, &e->conv2.w, &e->conv2.b,
                     &e->conv3.w, &e->conv3.b};
@@ -620,7 +620,7 @@ void rvd_destroy(rvd_engine* e) {
   for (auto& st : e->stages)
     for (auto& blk : st) { blk.c1.w.release(); blk.c1.b.release(); blk.c2.w.release(); blk.c2.b.release(); blk.sc.w.release(); blk.sc.b.release(); }
   for (auto& row : e->act) for (auto& b : row) b.release();
-  hipStreamDestroy(e->stream);
+  (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -744,10 +744,10 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     std::vector<int> init((size_t)3 * n);     // [cluster_id | neighbor | size as uint16]
     for (int i = 0; i < n; ++i) { init[i] = i; init[n + i] = -1; ((uint16_t*)&init[2 * (size_t)n])[i] = 1; }
     std::vector<double> inf(n, INFINITY);
-    hipMemcpyAsync(dX.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, e->stream);
-    hipMemcpyAsync(dI.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, e->stream);
-    hipMemcpyAsync(dM.p, inf.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream);
-    hipStreamSynchronize(e->stream);
+    (void)hipMemcpyAsync(dX.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, e->stream);
+    (void)hipMemcpyAsync(dI.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, e->stream);
+    (void)hipMemcpyAsync(dM.p, inf.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream);
     {
       DScope sc(e, "linkage");
       rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), (uint16_t*)(dI.as<int>() + 2 * n), dI.as<int>(),
@@ -761,7 +761,7 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
       break;
     }
     { double retries = 0.0;
-      hipMemcpy(&retries, dM.as<double>() + (n - 1), 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&retries, dM.as<double>() + (n - 1), 8, hipMemcpyDeviceToHost);
       e->prof["linkage"].flops += retries; }      // reported through rvd_get_timing("linkage").flops
     // slots -> scipy cluster ids: the merged cluster lives on in slot y under the new id n + k
     std::vector<int> cid(n);

@@ -20,7 +20,7 @@ const char* last_error() { return g_err.c_str(); }
 
 int DevBuf::ensure(size_t n) {
   if (n <= bytes && p) return OK;
-  if (p) { hipFree(p); p = nullptr; bytes = 0; }
+  if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
   if (n == 0) n = 16;
   hipError_t err = hipMalloc(&p, n);
   if (err != hipSuccess) {
@@ -31,7 +31,7 @@ int DevBuf::ensure(size_t n) {
   bytes = n;
   return OK;
 }
-void DevBuf::release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 
 #define RVB_TRY(expr) do { int _r = (expr); if (_r != OK) return _r; } while (0)
 
@@ -42,22 +42,22 @@ struct Scope {
     auto& pe = e->prof[name];
     pe.launches += 1; pe.flops += flops;
     if (e->profiling == 0 || (e->profiling == 2 && name != "gemm")) return;
-    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else hipEventCreate(&ev); return ev; };
+    auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
     a = get(); b = get();
-    hipEventRecord(a, e->stream);
+    (void)hipEventRecord(a, e->stream);
   }
   ~Scope() {
     if (!a) return;
-    hipEventRecord(b, e->stream);
+    (void)hipEventRecord(b, e->stream);
     e->pending.push_back({a, b, name});
   }
 };
 static void drain_prof(rvb_engine* e) {
   if (e->pending.empty()) return;
-  hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream);
   for (auto& p : e->pending) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, p.a, p.b);
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
     e->prof[p.name].ms += ms;
     e->event_pool.push_back(p.a); e->event_pool.push_back(p.b);
   }
@@ -132,7 +132,7 @@ static int pack_concat(rvb_engine* e, Linear& L, const std::vector<std::string>&
     memcpy(b.data() + i * (size_t)out_each, tb->data.data(), (size_t)out_each * 4);
   }
   int r = pack_linear(e, L, w.data(), b.data(), (int)names.size() * out_each, in);
-  if (r == OK) hipStreamSynchronize(e->stream);   // w/b go out of scope
+  if (r == OK) (void)hipStreamSynchronize(e->stream);   // w/b go out of scope
   return r;
 }
 // language-specific layers folded with the category weights: W = sum_i c_i W_i, b = sum_i c_i b_i
@@ -154,7 +154,7 @@ static int pack_lsl(rvb_engine* e, Linear& L, const std::string& p, int d, const
     }
   }
   int r = pack_linear(e, L, w.data(), b.data(), d, d);
-  if (r == OK) hipStreamSynchronize(e->stream);
+  if (r == OK) (void)hipStreamSynchronize(e->stream);
   return r;
 }
 
@@ -260,7 +260,7 @@ static int pack_decoder(rvb_engine* e, Decoder& D, const std::string& p, int nbl
 
 static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
   const rvb_model_cfg& c = e->cfg;
-  const int d = c.d_model, h = c.heads, ff = c.ffn_dim, K = c.cnn_kernel, V = c.vocab, F0 = c.input_dim;
+  const int d = c.d_model, ff = c.ffn_dim, K = c.cnn_kernel, V = c.vocab, F0 = c.input_dim;
   const int F1 = (F0 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   if (c.num_langs > 0 && ncat != c.num_langs) { set_error("finalize: cat_embs length must equal num_langs"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
@@ -514,8 +514,8 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   RVB_TRY(e->topv.ensure((size_t)M * beam * 4));
   RVB_TRY(e->topi.ensure((size_t)M * beam * 4));
   if (e->h_top_cap < (size_t)M * beam) {
-    if (e->h_topv) hipHostFree(e->h_topv);
-    if (e->h_topi) hipHostFree(e->h_topi);
+    if (e->h_topv) (void)hipHostFree(e->h_topv);
+    if (e->h_topi) (void)hipHostFree(e->h_topi);
     e->h_topv = nullptr; e->h_topi = nullptr; e->h_top_cap = 0;
     RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topv, (size_t)M * beam * 4, hipHostMallocDefault));
     RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topi, (size_t)M * beam * 4, hipHostMallocDefault));
@@ -1026,8 +1026,8 @@ int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
 
 void rvb_destroy(rvb_engine* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  hipStreamSynchronize(e->stream);
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
   // DevBuf members are released explicitly: list the big ones, the rest die with the process
   DevBuf* bufs[] = {&e->cmvn_mean, &e->cmvn_istd, &e->conv1_w, &e->conv1_b, &e->pe_f32, &e->stage, &e->pcm, &e->feats,
                     &e->d_feats_in, &e->X1, &e->X2, &e->x, &e->xn, &e->y, &e->h, &e->ao, &e->dconv, &e->enc_out,
@@ -1054,13 +1054,13 @@ void rvb_destroy(rvb_engine* e) {
       for (LNorm* n : {&L.n1, &L.n2, &L.n3}) rel_n(*n);
     }
   }
-  if (e->h_topv) hipHostFree(e->h_topv);
-  if (e->h_topi) hipHostFree(e->h_topi);
-  for (auto& sl : e->slices) if (!sl.done) hipEventDestroy(sl.ev);
-  for (auto ev : e->slice_event_pool) hipEventDestroy(ev);
-  for (auto& p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto ev : e->event_pool) hipEventDestroy(ev);
-  hipStreamDestroy(e->stream);
+  if (e->h_topv) (void)hipHostFree(e->h_topv);
+  if (e->h_topi) (void)hipHostFree(e->h_topi);
+  for (auto& sl : e->slices) if (!sl.done) (void)hipEventDestroy(sl.ev);
+  for (auto ev : e->slice_event_pool) (void)hipEventDestroy(ev);
+  for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -1218,7 +1218,7 @@ int rvb_get_ctc_logprobs(rvb_engine* e, int chunk, float* out) {
   int r = run_gemm(e, (const char*)e->enc_out.p + (size_t)chunk * T * d * dt_size(e->dtype), d, e->ctc, e->logits.p, Vld, T, true);
   if (r == OK) r = logsoftmax_topk(e->stream, e->logits.as<float>(), T, V, Vld, 1, 0.f, e->cfg.blank_id, tv.as<float>(), ti.as<int>(), lp.as<float>());
   if (r == OK && hipMemcpyAsync(out, lp.p, (size_t)T * V * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) r = E_HIP;
-  hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream);
   lp.release(); tv.release(); ti.release();
   return r;
 }

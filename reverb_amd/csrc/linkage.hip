@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void linkage_kernel(int getenv_prof, double* 
   auto SZ = [&](int i) -> uint16_t& { if constexpr (LDS_STATE) return s_sz[i]; else return g_size[i]; };
   const int tid = threadIdx.x;
   long long retries = 0;
-  long long t_arg = 0, t_scan = 0, t_merge = 0, t_misc = 0, t0c = 0;
+  long long t_arg = 0, t_scan = 0, t_merge = 0, t0c = 0;
   const bool prof = getenv_prof;
   if (LDS_STATE) {
     for (int i = tid; i < n; i += 1024) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }

@@ -14,7 +14,7 @@ using namespace rvb;
 namespace {
 struct Dev {
   void* p = nullptr;
-  ~Dev() { if (p) hipFree(p); }
+  ~Dev() { if (p) (void)hipFree(p); }
   int alloc(size_t n) { if (n == 0) n = 16; if (hipMalloc(&p, n) != hipSuccess) { set_error("hipMalloc failed in test api"); return E_NOMEM; } return OK; }
 };
 int up_T(Dev& d, int dtype, const float* src, size_t n) {
@@ -263,16 +263,16 @@ extern "C" int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, 
   g_gemm_variant = variant;
   int r = gemm(nullptr, dtype, g);
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   if (r == OK) {
-    hipEventRecord(e0, nullptr);
+    (void)hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters && r == OK; ++i) r = gemm(nullptr, dtype, g);
-    hipEventRecord(e1, nullptr);
+    (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) { set_error("gemm bench kernel failed"); r = E_HIP; }
   }
   float ms = 0.f;
-  if (r == OK) hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (r == OK) (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (ms_out) *ms_out = iters > 0 ? ms / iters : 0.0;
   if (r == OK && max_abs_diff) {
     g_gemm_variant = 1;
