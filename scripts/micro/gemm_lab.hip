@@ -15,6 +15,7 @@
 //   scripts/micro/gemm_lab 5 short   main-loop variants without the 4-wave / 64-byte-row ones
 //   scripts/micro/gemm_lab 5 real    pipelined loop + the engine's epilogue, one tile per workgroup vs persistent (NOT RUN YET:
 //                                    written after the round's GPU budget was spent; first thing to measure next round)
+//   scripts/micro/gemm_lab 5 conv    3x3 convolution of the ResNet34 128/256-channel stages as an implicit GEMM on the same loop (NOT RUN YET)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -729,6 +730,218 @@ static int real_epilogue_run(int reps, int ncu) {
   return 0;
 }
 
+// ---- 3x3 stride-1 convolution as an implicit GEMM on the same pipelined LDS-DMA loop (candidate for the ResNet34 stages
+// with 128 / 256 channels): rows = output pixels of a bordered NHWC tensor
+// [B][F+2][T+2][Cin] (zero border), one K step = 64 channels of one tap gathered from the shifted pixels, weights
+// [Cout][9][Cin].  Tile 256 pixels x BN channels, 8 waves: 2x4 of 128x64 (BN = 256) or 4x2 of 64x64 (BN = 128).
+template <int BN>
+__global__ __launch_bounds__(512) void conv_igemm(const uint16_t* __restrict__ in, const uint16_t* __restrict__ w, float* __restrict__ out,
+                                                  int B, int F, int T, int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 128, BKE = 64;
+  constexpr int NWN = BN / 64, NWM = 8 / NWN;                 // 4 or 2 waves along N
+  constexpr int TM = 256 / NWM, FI = TM / 16, FJ = 4;         // wave tile TM x 64
+  constexpr int STAGE = (256 + BN) * BKB;
+  constexpr int WP = BN / 64;                                  // W pieces per wave (8 rows each)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWN, wc = wave % NWN;
+  const int TP = T + 2, FP = F + 2;
+  const int tiles_n = Cout / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int lr = lane >> 3, lc = lane & 7;
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[WP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    const int m = m0 + row;
+    const int b = m / (F * T), rem = m - b * (F * T);
+    const int fo = rem / T, to = rem - fo * T;
+    a_src[i] = in + ((size_t)(b * FP + fo) * TP + to) * Cin + (lc ^ ((row >> 1) & 7)) * 8;      // tap (0,0), channel 0
+  }
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int row = wave * (WP * 8) + i * 8 + lr;
+    w_src[i] = w + (size_t)(n0 + row) * 9 * Cin + (lc ^ ((row >> 1) & 7)) * 8;
+  }
+  const int cpt = Cin / BKE;                                   // K steps per tap
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKE;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const size_t aoff = (size_t)(kh * TP + kw) * Cin + c0;
+    const size_t woff = (size_t)tap * Cin + c0;
+    const unsigned dst = lds_base + (kt & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma1(a_src[i] + aoff, dst + (wave * 32 + i * 8) * BKB);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) dma1(w_src[i] + woff, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+  };
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, lgrp = lane >> 4;
+  int roff[2];
+  roff[0] = ((0 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  const int a_off = (wr * TM + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+  const int nk = 9 * cpt, nq = 2 * nk;
+  uint4 fa[2][FI], fb[2][FJ];
+  auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const char* st = smem + ((q >> 1) & 1) * STAGE;
+    const int ro = roff[q & 1];
+#pragma unroll
+    for (int i = 0; i < FI; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * BKB + ro);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * BKB + ro);
+  };
+  auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) mma(fa[buf][i], fb[buf][j], acc[i][j]);
+  };
+  auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {
+    constexpr int mb = decltype(mbufc)::value;
+    read_slice(std::integral_constant<int, 1 - mb>(), q);
+    mma_slice(mbufc);
+    constexpr int NR = FI + FJ, NM = FI * FJ, PER = NM / NR >= 2 ? 2 : 1;      // MFMAs between two reads
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (NM - PER * NR > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
+  };
+  auto enter_stage = [&](int kt) __attribute__((always_inline)) {
+    wait_vm<0>();
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1);
+  };
+  std::integral_constant<int, 0> b0;
+  std::integral_constant<int, 1> b1;
+  issue(0);
+  issue(1);
+  wait_vm<4 + WP>();                                           // stage 0 = the older group of 4 + WP pieces
+  __syncthreads();
+  read_slice(b0, 0);
+  block(b0, 1);
+  enter_stage(1);
+  for (int u = 1; u <= nq - 5; u += 2) {
+    block(b1, u + 1);
+    block(b0, u + 2);
+    enter_stage((u + 3) >> 1);
+  }
+  block(b1, nq - 2);
+  block(b0, nq - 1);
+  mma_slice(b1);
+  const int crow = (lane >> 4) * 4, ccol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* op = out + (size_t)(m0 + wr * TM + i * 16 + crow + r) * Cout + n0 + wc * 64 + ccol;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) op[j * 16] = acc[i][j][r];
+    }
+}
+
+__global__ void naive_conv_rows(const uint16_t* in, const uint16_t* w, float* out, int F, int T, int Cin, int Cout, int row0) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = row0 + blockIdx.y;
+  if (n >= Cout) return;
+  const int TP = T + 2, FP = F + 2;
+  const int b = m / (F * T), rem = m - b * (F * T), fo = rem / T, to = rem - fo * T;
+  float s = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const uint16_t* px = in + ((size_t)(b * FP + fo + kh) * TP + to + kw) * Cin;
+    const uint16_t* wr = w + ((size_t)n * 9 + tap) * Cin;
+    for (int c = 0; c < Cin; ++c) s += __uint_as_float((unsigned)px[c] << 16) * __uint_as_float((unsigned)wr[c] << 16);
+  }
+  out[(size_t)blockIdx.y * Cout + n] = s;
+}
+
+__global__ void zero_border(uint16_t* in, int B, int F, int T, int Cin) {
+  const int TP = T + 2, FP = F + 2;
+  const size_t npx = (size_t)B * FP * TP;
+  for (size_t px = blockIdx.x * (size_t)blockDim.x + threadIdx.x; px < npx; px += (size_t)gridDim.x * blockDim.x) {
+    const int t = px % TP, f = (px / TP) % FP;
+    if (t == 0 || t == TP - 1 || f == 0 || f == FP - 1)
+      for (int c = 0; c < Cin; ++c) in[px * Cin + c] = 0;
+  }
+}
+
+// `gemm_lab <reps> conv`
+static int conv_run(int reps) {
+  struct Shape { int B, F, T, C; const char* what; };
+  const Shape shapes[] = {{192, 20, 250, 128, "ResNet34 stage 3: 128 -> 128 channels, 192 windows"}, {192, 10, 128, 256, "ResNet34 stage 4: 256 -> 256 channels (T padded 125 -> 128)"}};
+  const int CHK = 512;
+  auto k128 = conv_igemm<128>; auto k256 = conv_igemm<256>;
+  CHECK(hipFuncSetAttribute((const void*)k128, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128));
+  CHECK(hipFuncSetAttribute((const void*)k256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
+  for (const Shape& sh : shapes) {
+    const int B = sh.B, F = sh.F, T = sh.T, C = sh.C;
+    const size_t M = (size_t)B * F * T;
+    if (M % 256) { printf("skip %s: pixels not a multiple of 256\n", sh.what); continue; }
+    const size_t nin = (size_t)B * (F + 2) * (T + 2) * C;
+    uint16_t *in, *w; float *out, *R;
+    CHECK(hipMalloc(&in, nin * 2)); CHECK(hipMalloc(&w, (size_t)C * 9 * C * 2));
+    CHECK(hipMalloc(&out, M * C * 4)); CHECK(hipMalloc(&R, (size_t)2 * CHK * C * 4));
+    hipLaunchKernelGGL(fill_ints, dim3(4096), dim3(256), 0, 0, in, nin, 23u);
+    hipLaunchKernelGGL(zero_border, dim3(4096), dim3(256), 0, 0, in, B, F, T, C);
+    hipLaunchKernelGGL(fill_ints, dim3(1024), dim3(256), 0, 0, w, (size_t)C * 9 * C, 77u);
+    hipLaunchKernelGGL(naive_conv_rows, dim3((C + 255) / 256, CHK), dim3(256), 0, 0, in, w, R, F, T, C, C, 0);
+    hipLaunchKernelGGL(naive_conv_rows, dim3((C + 255) / 256, CHK), dim3(256), 0, 0, in, w, R + (size_t)CHK * C, F, T, C, C, (int)(M - CHK));
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ref((size_t)2 * CHK * C), got((size_t)2 * CHK * C);
+    CHECK(hipMemcpy(ref.data(), R, ref.size() * 4, hipMemcpyDeviceToHost));
+    printf("%s: %zu pixels, K = %d\n", sh.what, M, 9 * C);
+    for (int bn : {128, 256}) {
+      if (C % bn) continue;
+      auto kern = bn == 128 ? k128 : k256;
+      const int lds = 2 * (256 + bn) * 128;
+      const int tiles = (int)(M / 256) * (C / bn);
+      CHECK(hipMemset(out, 0xff, M * C * 4));
+      hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, in, w, out, B, F, T, C, C);
+      CHECK(hipGetLastError());
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(got.data(), out, (size_t)CHK * C * 4, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(got.data() + (size_t)CHK * C, out + (M - CHK) * C, (size_t)CHK * C * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < ref.size(); ++i) bad += !(ref[i] == got[i]);
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, in, w, out, B, F, T, C, C);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("  implicit GEMM, 256 x %3d tile  %8.3f ms  %7.1f TFLOP/s  %s   (direct conv_kernel in the engine: 555-598 TFLOP/s on these stages)\n", bn, ms,
+             2.0 * M * C * 9.0 * C / (ms * 1e-3) / 1e12, bad ? "WRONG" : "exact");
+      if (bad) printf("    (%zu of %zu checked elements differ)\n", bad, ref.size());
+      fflush(stdout);
+    }
+    CHECK(hipFree(in)); CHECK(hipFree(w)); CHECK(hipFree(out)); CHECK(hipFree(R));
+  }
+  return 0;
+}
+
 struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int, int); int threads, lds, store, persistent, phases; };
 
 template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0, int STORE = 1> Variant make(const char* name, int phases = 0) {
@@ -743,6 +956,7 @@ int main(int argc, char** argv) {
   int ncu = 256;
   { hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount; }
   if (argc > 2 && std::string(argv[2]) == "real") return real_epilogue_run(reps, ncu);
+  if (argc > 2 && std::string(argv[2]) == "conv") return conv_run(reps);
   std::vector<Variant> vs;
   vs.push_back(make<2, 4, 2, 2, 0>("8w 128x64  BK64 2st simple (=gemm2)"));
   vs.push_back(make<2, 4, 2, 2, 1>("8w 128x64  BK64 2st pipelined     "));
