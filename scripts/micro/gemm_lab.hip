@@ -13,9 +13,10 @@
 // Inputs are small integers stored as bf16, so every variant must reproduce the naive kernel EXACTLY.
 //   hipcc -O3 --offload-arch=gfx950 -o scripts/micro/gemm_lab scripts/micro/gemm_lab.hip && scripts/micro/gemm_lab
 //   scripts/micro/gemm_lab 5 short   main-loop variants without the 4-wave / 64-byte-row ones
-//   scripts/micro/gemm_lab 5 real    pipelined loop + the engine's epilogue, one tile per workgroup vs persistent (NOT RUN YET:
-//                                    written after the round's GPU budget was spent; first thing to measure next round)
-//   scripts/micro/gemm_lab 5 conv    3x3 convolution of the ResNet34 128/256-channel stages as an implicit GEMM on the same loop (NOT RUN YET)
+//   scripts/micro/gemm_lab 5 real    pipelined loop + the engine's epilogue, one tile per workgroup vs persistent
+//                                    (profiles/r01_gemm_lab_real.txt: no gain)
+//   scripts/micro/gemm_lab 5 conv    3x3 convolution of the ResNet34 128/256-channel stages as an implicit GEMM on the same loop
+//                                    (profiles/r01_gemm_lab_conv.txt: 855 / 1193 TFLOP/s vs 555-598 for the direct kernel)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
