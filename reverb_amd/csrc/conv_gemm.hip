@@ -1,0 +1,256 @@
+// 3x3 stride-1 convolution of the ResNet34 trunk as an implicit GEMM on gemm2.hip's pipelined LDS-DMA loop (bf16).
+//
+//   rows    = output pixels (b, f, t) of the bordered NHWC tensor [B][F+2][T+2][Cin] (zero border = the padding)
+//   K steps = 64 input channels of one tap; the A operand of a step is gathered by LDS-DMA from the pixels shifted
+//             by (kh, kw): one 128-byte run per pixel, no im2col buffer, no register staging
+//   columns = output channels, weights [Cout][9][Cin] (BatchNorm folded), tile 256 pixels x 128 or 256 channels
+//
+// Main loop and gather measured in scripts/micro/gemm_lab.hip ("conv" mode, exact against a naive convolution):
+// 855 TFLOP/s for the 128-channel stage and 1193 for the 256-channel stage, against 555-598 for the direct
+// convolution (resnet.hip: conv_kernel), which stages a 6 x 66 pixel patch per block and runs one wave per SIMD.
+// The epilogue is conv_kernel's: 16-row slabs transposed through LDS, bias + residual + ReLU, full 128-byte runs of
+// channels per pixel into the bordered output.
+//
+// STATUS: written after the round's GPU budget was spent -- selected only with RVD_CONV_IGEMM=1 (diar_engine.hip packs
+// the second weight layout only then); resnet.hip's kernel stays the default until this one has passed tests/ on an
+// MI355X.
+#include "common.h"
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace rvb {
+
+namespace {
+
+__device__ inline void cg_mma(const uint4& a, const uint4& b, f32x4_t& c) {
+  union U { uint4 u; bf16x8_t v; };
+  U ua, ub;
+  ua.u = a; ub.u = b;
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
+}
+
+// one 1-KiB LDS-DMA piece (64 lanes x 16 bytes, lane order); inline asm so that hipcc's waitcnt pass does not see it
+// (it would drain vmcnt(0) before every ds_read); ordered by the explicit s_waitcnt in the loop.  M0 is saved/restored.
+__device__ inline void cg_dma(const void* g, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds)
+      : "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char cg_smem[];
+  constexpr int BKB = 128, BKE = 64;
+  constexpr int NWN = BN / 64, NWM = 8 / NWN;                 // waves along channels / pixels
+  constexpr int TM = 256 / NWM, FI = TM / 16, FJ = 4;         // wave tile TM pixels x 64 channels
+  constexpr int STAGE = (256 + BN) * BKB;
+  constexpr int WP = BN / 64;                                  // weight pieces (8 rows each) per wave
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWN, wc = wave % NWN;
+  const int F = p.Fo, T = p.To, Cin = p.Cin, Cout = p.Cout;
+  const int TP = T + 2, FP = F + 2;
+  const int M = p.B * F * T;
+  const int tiles_n = Cout / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {   // XCD-aware bijective tile order (as gemm2)
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const bf16_t* __restrict__ in = (const bf16_t*)p.in;
+  const bf16_t* __restrict__ w = (const bf16_t*)p.w_ig;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cg_smem;
+
+  // ---- DMA sources: wave w stages pixels [32w, 32w+32) and weight rows [8 WP w, +8 WP); source column swizzled
+  const int lr = lane >> 3, lc = lane & 7;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[WP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    int m = m0 + row;
+    if (m >= M) m = M - 1;                                     // clamped rows are computed and never stored
+    const int b = m / (F * T), rem = m - b * (F * T);
+    const int fo = rem / T, to = rem - fo * T;
+    a_src[i] = in + ((size_t)(b * FP + fo) * TP + to) * Cin + (lc ^ ((row >> 1) & 7)) * 8;      // tap (0,0), channel 0
+  }
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int row = wave * (WP * 8) + i * 8 + lr;
+    w_src[i] = w + (size_t)(n0 + row) * 9 * Cin + (lc ^ ((row >> 1) & 7)) * 8;
+  }
+  const int cpt = Cin / BKE;                                   // K steps per tap
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKE;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const size_t aoff = (size_t)(kh * TP + kw) * Cin + c0;
+    const size_t woff = (size_t)tap * Cin + c0;
+    const unsigned dst = lds_base + (kt & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cg_dma(a_src[i] + aoff, dst + (wave * 32 + i * 8) * BKB);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+  };
+
+  f32x4_t acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, lgrp = lane >> 4;
+  int roff[2];
+  roff[0] = ((0 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
+  const int a_off = (wr * TM + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+  const int nk = 9 * cpt, nq = 2 * nk;                         // nk >= 9
+  uint4 fa[2][FI], fb[2][FJ];
+  auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const char* st = cg_smem + ((q >> 1) & 1) * STAGE;
+    const int ro = roff[q & 1];
+#pragma unroll
+    for (int i = 0; i < FI; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * BKB + ro);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * BKB + ro);
+  };
+  auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) cg_mma(fa[buf][i], fb[buf][j], acc[i][j]);
+  };
+  auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {     // multiply buffer mbuf, read slice q into the other
+    constexpr int mb = decltype(mbufc)::value;
+    read_slice(std::integral_constant<int, 1 - mb>(), q);
+    mma_slice(mbufc);
+    constexpr int NR = FI + FJ, NM = FI * FJ, PER = NM / NR >= 2 ? 2 : 1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (NM - PER * NR > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * NR, 0);
+  };
+  auto enter_stage = [&](int kt) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1);
+  };
+  std::integral_constant<int, 0> b0;
+  std::integral_constant<int, 1> b1;
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + WP) : "memory");     // stage 0 = the older group of 4 + WP pieces
+  __syncthreads();
+  read_slice(b0, 0);
+  block(b0, 1);
+  enter_stage(1);
+  for (int u = 1; u <= nq - 5; u += 2) {
+    block(b1, u + 1);
+    block(b0, u + 2);
+    enter_stage((u + 3) >> 1);
+  }
+  block(b1, nq - 2);
+  block(b0, nq - 1);
+  mma_slice(b1);
+  __syncthreads();                                             // every wave is done with the stages: the slabs go there
+
+  // ---- epilogue (as conv_kernel): 16 x 64 slab per wave through LDS so that a lane owns 16 consecutive channels of
+  // one pixel; bias + residual + ReLU; 4 lanes write the 128-byte channel run of a pixel
+  constexpr int SROW = 64 * 4 + 16;
+  char* slab = cg_smem + wave * (16 * SROW);
+  const int crow = lgrp * 4, ccol = frow;
+  const int orow = lane >> 2, oseg = (lane & 3) * 16;
+  const int ch0 = n0 + wc * 64 + oseg;
+  float bias_r[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bias_r[e] = p.bias ? p.bias[ch0 + e] : 0.f;
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < FJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int m = m0 + wr * TM + i * 16 + orow;
+    if (m >= M) continue;
+    const int b = m / (F * T), rem = m - b * (F * T);
+    const int fo = rem / T, to = rem - fo * T;
+    const size_t pix = ((size_t)(b * FP + fo + 1) * TP + to + 1) * Cout + ch0;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = *(const float4*)(slab + orow * SROW + (oseg + q * 4) * 4);
+      v[q * 4 + 0] = x.x + bias_r[q * 4 + 0]; v[q * 4 + 1] = x.y + bias_r[q * 4 + 1];
+      v[q * 4 + 2] = x.z + bias_r[q * 4 + 2]; v[q * 4 + 3] = x.w + bias_r[q * 4 + 3];
+    }
+    if (p.res) {
+      const bf16_t* rp = (const bf16_t*)p.res + pix;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint4 raw = *(const uint4*)(rp + q * 8);
+        const bf16_t* re = (const bf16_t*)&raw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q * 8 + e] += bf16_to_f32(re[e]);
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    bf16_t* op = (bf16_t*)p.out + pix;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bf16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[q * 8 + e]);
+      *(uint4*)(op + q * 8) = *(const uint4*)o;
+    }
+  }
+}
+
+template <int BN>
+int launch_igemm(hipStream_t st, const ConvArgs& p) {
+  const int lds = 2 * (256 + BN) * 128;
+  auto kern = conv_igemm_kernel<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int64_t M = (int64_t)p.B * p.Fo * p.To;
+  const int64_t tiles = ((M + 255) / 256) * (p.Cout / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, p);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace
+
+bool conv_igemm_applicable(int dtype, const ConvArgs& p) {
+  return dtype == DT_BF16 && p.w_ig != nullptr && p.taps == 9 && p.stride == 1 && p.Cin % 64 == 0 && p.Cout % 128 == 0 &&
+         p.Fo == p.Fi && p.To == p.Ti && (int64_t)p.B * p.Fo * p.To < (int64_t)1 << 31;
+}
+
+int conv_igemm(hipStream_t s, const ConvArgs& p) {
+  if (p.B <= 0) return OK;
+  return p.Cout % 256 == 0 ? launch_igemm<256>(s, p) : launch_igemm<128>(s, p);
+}
+
+}  // namespace rvb

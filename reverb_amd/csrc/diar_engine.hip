@@ -18,7 +18,7 @@ namespace {
 struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
 constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 // ResNet34 trunk: conv weights packed [tap][Cin/CK][Cout][CK] with BatchNorm folded in
-struct ConvW { DevBuf w, b; int cin = 0, cout = 0, taps = 9, stride = 1; };
+struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1; };      // w_ig: conv_gemm.hip's layout (optional)
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
 static int emb_batch() {            // windows per trunk pass; RVD_EMB_BATCH overrides (tuning)
@@ -385,6 +385,16 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   }
   c.cin = cin; c.cout = cout; c.taps = taps; c.stride = stride;
   RVD_TRY(pack_T(e, c.w, pw.data(), pw.size()));
+  // experimental implicit-GEMM kernel (conv_gemm.hip): second weight layout [cout][tap][cin], only on request
+  if (getenv("RVD_CONV_IGEMM") && e->dtype == DT_BF16 && k == 3 && stride == 1 && cin % 64 == 0 && cout % 128 == 0) {
+    std::vector<float> pg((size_t)cout * taps * cin);
+    for (int o = 0; o < cout; ++o) {
+      const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f);
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < cin; ++ci) pg[((size_t)o * taps + t) * cin + ci] = w->data[((size_t)o * cin + ci) * taps + t] * sc;
+    }
+    RVD_TRY(pack_T(e, c.w_ig, pg.data(), pg.size()));
+  }
   return up_f32(e, c.b, pb.data(), pb.size());
 }
 
@@ -465,6 +475,7 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
   a.in = in; a.w = c.w.p; a.bias = c.b.as<float>(); a.res = res; a.out = out;
   a.B = B; a.Fi = di.F; a.Ti = di.T; a.Cin = c.cin; a.Fo = dq.F; a.To = dq.T; a.Cout = c.cout;
   a.stride = c.stride; a.taps = c.taps; a.relu = relu;
+  a.w_ig = c.w_ig.p;
   const std::string nm = std::string(c.taps == 1 ? "emb_conv_sc" : (c.stride == 2 ? "emb_conv_s2_" : "emb_conv_")) + (c.taps == 1 ? "" : std::to_string(c.cout));
   DScope sc(e, nm.c_str(), 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
   return conv2d(e->stream, e->dtype, a);
@@ -618,7 +629,8 @@ void rvd_destroy(rvd_engine* e) {
                      &e->pcm_pad, &e->emb_fb, &e->e_win, &e->e_mean, &e->e_item_b, &e->e_mask, &e->e_stats, &e->e_out};
   for (auto* b : ebufs) b->release();
   for (auto& st : e->stages)
-    for (auto& blk : st) { blk.c1.w.release(); blk.c1.b.release(); blk.c2.w.release(); blk.c2.b.release(); blk.sc.w.release(); blk.sc.b.release(); }
+    for (auto& blk : st)
+      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); }
   for (auto& row : e->act) for (auto& b : row) b.release();
   (void)hipStreamDestroy(e->stream);
   delete e;

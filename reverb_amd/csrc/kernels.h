@@ -174,8 +174,13 @@ struct ConvArgs {
   int stride;         // 1 | 2
   int taps;           // 9 (3x3, pad 1) | 1 (1x1)
   int relu;
+  const void* w_ig;   // bf16 [Cout][9][Cin] (BN folded) for conv_gemm.hip, or null (last: ConvArgs a{} leaves it null)
 };
 int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
+// conv_gemm.hip: 3x3 stride-1 convolution as an implicit GEMM on the LDS-DMA loop (bf16, Cin % 64 == 0, Cout % 128 == 0);
+// conv2d() routes to it when a.w_ig is set
+bool conv_igemm_applicable(int dtype, const ConvArgs& a);
+int conv_igemm(hipStream_t s, const ConvArgs& a);
 
 // weighted mean/std over time of the trunk output x T [B][F+2][TT+2][C] for each item (item_b = batch row,
 // mask [n_items][mask_len] resampled to TT by nearest); stats T [n_items][2*C*F]

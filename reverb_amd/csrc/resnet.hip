@@ -310,6 +310,7 @@ int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
     return E_UNSUPPORTED;
   }
   if (p.B <= 0) return OK;
+  if (conv_igemm_applicable(dtype, p)) return conv_igemm(s, p);     // only when the engine packed w_ig (RVD_CONV_IGEMM=1)
   const int nt = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
   if (dtype == DT_BF16) {
     if (nt == 128) return launch_conv<bf16_t, 128>(s, p);
