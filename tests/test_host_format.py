@@ -61,3 +61,25 @@ def test_tokenizer_detokenize():
     assert t.detokenize([1, 2])[1] == ["▁he", "llo"]
     assert t.detokenize([1, 2, 3, 4])[0] == "hello world"
     assert t.vocab_size() == 7
+
+
+@pytest.mark.parametrize("name", ["tiny_ln", "tiny_ln_r2l", "tiny_bn", "small_ln", "r268_chunk"])
+def test_formatter_reproduces_the_reference_strings_of_the_goldens(name):
+    """The reference's own DecodeResults (tests/golden/*.json, written by oracle/gen_golden.py from the unmodified
+    reference) through OUR get_output -> ctc_align -> adjust_model_time_offset -> hyps_to_ctm / hyps_to_txt must give
+    the strings the reference's get_output (cli/reverb.py:298-327) gave for them -- including the cases where the
+    reference raises because a result has fewer times than tokens."""
+    from reverb_amd import synth
+    from tests.golden_util import Case
+    case = Case(name)
+    units = synth.make_units(case.cfg["output_dim"])
+    t = RevBpeTokenizer(None, {u: i for i, u in enumerate(units)})
+    for mode in ("ctc_prefix_beam_search", "attention_rescoring"):
+        want = case.js["outputs"][mode]
+        hyps = [DecodeResult(g["tokens"], g["score"], g["confidence"], g["tokens_confidence"], g["times"]) for g in case.golden(mode)]
+        if "error" in want:
+            with pytest.raises(AssertionError):
+                get_output("ctm", t, "golden.wav", hyps, 230, case.chunk, 10, 40)
+            continue
+        for fmt in ("ctm", "txt"):
+            assert get_output(fmt, t, "golden.wav", hyps, 230, case.chunk, 10, 40) == want[fmt], (mode, fmt)

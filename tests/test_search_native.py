@@ -88,3 +88,31 @@ def test_property_random_shapes_ties_and_tiny_beams():
         assert scores == o.nbest_scores
 
     check()
+
+
+def test_native_search_on_the_reference_goldens():
+    """The native search fed with the reference's own per-frame top-k log-probs (tests/golden/*.npz) must give the
+    reference's n-best lists, float64 scores and peak frames of ctc_prefix_beam_search (tests/golden/*.json, both
+    written by the unmodified reference in oracle/gen_golden.py) -- no oracle in between."""
+    import pytest
+    from tests.golden_util import CASES, Case
+    lib = _lib.load()
+    checked = 0
+    for name in CASES:
+        case = Case(name)
+        tv_all, ti_all = case.arrays["topk_val"], case.arrays["topk_idx"]
+        beam = case.beam
+        for b, g in enumerate(case.golden("ctc_prefix_beam_search")):
+            T = int(case.js["encoder_lens"][b])
+            tv = np.ascontiguousarray(tv_all[b], np.float32); ti = np.ascontiguousarray(ti_all[b], np.int32)
+            ml = max(T, 1)
+            n = np.zeros(1, np.int32); toks = np.full((beam, ml), -1, np.int32); lens = np.zeros(beam, np.int32)
+            times = np.full((beam, ml), -1, np.int32); tl = np.zeros(beam, np.int32); sc = np.zeros(beam, np.float64)
+            _lib.check(lib.rvb_test_prefix_beam(fptr(tv), iptr(ti), T, beam, 0, iptr(n), iptr(toks), iptr(lens), iptr(times),
+                                                iptr(tl), dptr(sc)))
+            k = int(n[0])
+            assert [toks[i, :lens[i]].tolist() for i in range(k)] == g["nbest"], (name, b)
+            assert [times[i, :tl[i]].tolist() for i in range(k)] == g["nbest_times"], (name, b)
+            assert sc[:k].tolist() == pytest.approx(g["nbest_scores"], rel=0, abs=1e-9), (name, b)
+            checked += 1
+    assert checked >= 8
