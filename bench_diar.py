@@ -57,6 +57,74 @@ def cpu_baseline(cfg, seg_sd, emb_sd, pcm, n_windows):
                                       f"passes per window, torch fp32, {dt:.1f} s; clustering not included"}
 
 
+def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype="bf16", cpu_windows=3):
+    """Time `steps` diarization passes on `device`; returns the JSON record on rank 0 (None elsewhere).  bench.py calls
+    this for its `diarization` sub-record, main() below for the stand-alone line."""
+    import torch
+    from reverb_amd import diarization as D, synth_diar as SD
+    from reverb_amd.dist import diarize_sharded
+    use_dist = dist is not None
+    cfg = SD.make_diar_config()
+    seg_sd, emb_sd = SD.make_segmentation_sd(cfg, 0), SD.make_embedding_sd(cfg, 0)
+    pipe = D.SpeakerDiarization(cfg, seg_sd, emb_sd, None, dtype=dtype).to(device)
+    base = SD.synth_conversation(120.0)
+    n = int(hours * 3600 * 16000)
+    pcm = np.tile(base, n // len(base) + 1)[:n]
+    # de-duplicate the tiles: +-3 LSB of noise, so that no two windows (and no two embeddings) are bit-identical
+    pcm = (pcm.astype(np.int32) + np.random.default_rng(7 + rank).integers(-3, 4, size=n)).clip(-32768, 32767).astype(np.int16)
+
+    def step():
+        if use_dist:
+            return diarize_sharded(pipe, pcm, device, uri="bench")
+        return pipe({"waveform": pcm, "sample_rate": 16000, "uri": "bench"})
+
+    for _ in range(warmup):
+        step()
+    eng = pipe.engine
+    eng.reset_timings(); eng.set_profiling(True)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ann = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profiling(False)
+    out = None
+    if rank == 0:
+        conv = [eng.timing(k) for k in CONV_KEYS]
+        ms, fl, launches = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
+        ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+        out = {
+            "metric": "RTFx (audio-sec/wall-sec) diarization pipeline (pyannote segmentation + ResNet34 embeddings + clustering)",
+            "value": round(hours * 3600 * steps / dt, 2), "unit": "audio-sec/wall-sec",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"diarization of one {hours:g} h 16 kHz recording: {eng.num_windows(n)} windows of 10 s / 1 s hop, "
+                                   "PyanNet segmentation (SincNet + 4xBiLSTM128), WeSpeaker ResNet34 embeddings, centroid linkage, "
+                                   "synthetic weights", "parallelism": f"window-shard x{world}",
+                       "turns": len(ann), "speakers": len(ann.labels())},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                         "kernel": "rvb::conv_kernel / conv_igemm_kernel (all ResNet34 3x3/1x1 convolutions of the timed steps, rank 0)",
+                         "launches": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
+                         "flops_per_launch": round(fl / max(launches, 1), 1)},
+            "stage_ms_per_step": {k: round(eng.timing(k)[0] / steps, 3) for k in STAGE_KEYS},
+            "host_s_last_step": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()},
+        }
+        out["cpu_baseline"] = cpu_baseline(cfg, seg_sd, emb_sd, pcm, cpu_windows) if (world == 1 and cpu_windows > 0) else None
+    eng.close()
+    pipe._engine = None
+    return out
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -66,6 +134,9 @@ def main():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--cpu-baseline-windows", type=int, default=3)
     args = p.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # same self-launch as bench.py
+        import bench
+        sys.exit(bench.launch_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -77,67 +148,12 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()
     if not torch.cuda.is_available():
         raise SystemExit("bench_diar.py needs an MI355X: the networks have no CPU fallback")
     device = torch.device("cuda", local_rank)
-
-    from reverb_amd import diarization as D, synth_diar as SD
-    from reverb_amd.dist import diarize_sharded
-    cfg = SD.make_diar_config()
-    seg_sd, emb_sd = SD.make_segmentation_sd(cfg, 0), SD.make_embedding_sd(cfg, 0)
-    pipe = D.SpeakerDiarization(cfg, seg_sd, emb_sd, None, dtype=args.dtype).to(device)
-    base = SD.synth_conversation(120.0)
-    n = int(args.hours * 3600 * 16000)
-    pcm = np.tile(base, n // len(base) + 1)[:n]
-    # de-duplicate the tiles: +-3 LSB of noise, so that no two windows (and no two embeddings) are bit-identical
-    pcm = (pcm.astype(np.int32) + np.random.default_rng(7 + rank).integers(-3, 4, size=n)).clip(-32768, 32767).astype(np.int16)
-
-    def step():
-        if use_dist:
-            return diarize_sharded(pipe, pcm, device, uri="bench")
-        return pipe({"waveform": pcm, "sample_rate": 16000, "uri": "bench"})
-
-    for _ in range(args.warmup):
-        step()
-    eng = pipe.engine
-    eng.reset_timings(); eng.set_profiling(True)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ann = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    eng.set_profiling(False)
-    if rank == 0:
-        conv = [eng.timing(k) for k in CONV_KEYS]
-        ms, fl, launches = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
-        ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
-        out = {
-            "metric": "RTFx (audio-sec/wall-sec) diarization pipeline (pyannote segmentation + ResNet34 embeddings + clustering)",
-            "value": round(args.hours * 3600 * args.steps / dt, 2), "unit": "audio-sec/wall-sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"diarization of one {args.hours:g} h 16 kHz recording: {eng.num_windows(n)} windows of 10 s / 1 s hop, "
-                                   "PyanNet segmentation (SincNet + 4xBiLSTM128), WeSpeaker ResNet34 embeddings, centroid linkage, "
-                                   "synthetic weights", "parallelism": f"window-shard x{world}",
-                       "turns": len(ann), "speakers": len(ann.labels())},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                         "kernel": "rvb::conv_kernel (all ResNet34 3x3/1x1 convolutions of the timed steps, rank 0)",
-                         "launches": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
-                         "flops_per_launch": round(fl / max(launches, 1), 1)},
-            "stage_ms_per_step": {k: round(eng.timing(k)[0] / args.steps, 3) for k in STAGE_KEYS},
-            "host_s_last_step": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()},
-        }
-        out["cpu_baseline"] = cpu_baseline(cfg, seg_sd, emb_sd, pcm, args.cpu_baseline_windows) if (world == 1 and args.cpu_baseline_windows > 0) else None
+    out = run(device, rank, world, dist if use_dist else None, args.steps, args.warmup, args.hours, args.dtype,
+              args.cpu_baseline_windows)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

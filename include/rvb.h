@@ -83,6 +83,11 @@ int rvb_get_waveform(rvb_engine* e, float* out, int64_t* n_samples);
  * device (kept resident, zero-padded to whole chunks) and optionally copies it to feats_out. */
 int64_t rvb_num_frames(int64_t n_samples);
 int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
+/* Page-locked host memory for the audio reader (what `torchaudio.load` fills in the reference, cli/reverb.py:128):
+ * PCM decoded straight into such a buffer reaches HBM at the PCIe rate (115 MB per hour of audio in ~2 ms);
+ * pageable memory works with rvb_upload_pcm too, several times slower.  Free with rvb_host_free. */
+int rvb_host_alloc(void** out, int64_t bytes);
+int rvb_host_free(void* p);
 int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int64_t* n_frames);
 
 /* Chunk-masked encoder attention for the following rvb_encode calls: query frame i attends the encoder frames

@@ -1092,6 +1092,18 @@ int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n) {
   return OK;
 }
 
+int rvb_host_alloc(void** out, int64_t bytes) {
+  if (!out || bytes < 0) { set_error("rvb_host_alloc: bad argument"); return E_ARG; }
+  *out = nullptr;
+  hipError_t err = hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault);
+  if (err != hipSuccess) { *out = nullptr; set_error(std::string("hipHostMalloc: ") + hipGetErrorString(err)); return E_NOMEM; }
+  return OK;
+}
+int rvb_host_free(void* p) {
+  if (p) RVB_HIP_CHECK(hipHostFree(p));
+  return OK;
+}
+
 int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks) {
   if (!e) { set_error("rvb_set_decoding_chunk: null engine"); return E_ARG; }
   if (chunk_size > 4095 || num_left_chunks > 4094) { set_error("rvb_set_decoding_chunk: value too large"); return E_ARG; }

@@ -43,45 +43,82 @@ def sample_range(n_samples: int, chunk_frames: int, c0: int, c1: int) -> Tuple[i
     return f0 * FRAME_SHIFT, (f1 - 1) * FRAME_SHIFT + FRAME_LEN
 
 
-def pack_results(hyps: Sequence[DecodeResult], lmax: int):
-    n = len(hyps)
-    ints = np.full((n, 2 * lmax + 2), -1, np.int32)
-    flts = np.zeros((n, lmax + 2), np.float64)
-    for i, h in enumerate(hyps):
-        k, kt = len(h.tokens), len(h.times or [])
-        ints[i, 0], ints[i, 1] = k, kt
-        ints[i, 2:2 + k] = h.tokens
-        if kt:
-            ints[i, 2 + lmax:2 + lmax + kt] = h.times
-        flts[i, 0], flts[i, 1] = h.score, h.confidence
-        if h.tokens_confidence:
-            flts[i, 2:2 + k] = h.tokens_confidence
-    return ints, flts
+# ---- result exchange ------------------------------------------------------------------------------------------
+# One rank's results travel as ONE flat int32 buffer (ragged rows, no padding to a longest row):
+#   [MAGIC, count, n_int_words, n_doubles, total_tokens, 0, 0, 0]                      header (8 words)
+#   per row: k, kt, kf, kc, tokens[k], times[kt], ctc_frames[kf]                         (-1 = the field is None)
+#   (pad to an even word), then the doubles as int32 pairs: per row score, confidence, tokens_confidence[kc]
+# so that a single all-gather of a fixed-capacity buffer carries everything.  The capacity is
+# `max_count * _ROW_WORDS` words; a rank whose rows do not fit says so in its header (n_int_words / n_doubles are
+# the sizes it NEEDS), every rank sees that after the gather, raises the (process-sticky) row capacity by the same
+# rule and repeats -- the common case is one collective, an overflow costs one more, once.
+_MAGIC, _HDR = 0x52564231, 8
+_ROW_WORDS = 512                 # int32 words reserved per result row; grows on overflow (same on every rank)
 
 
-def unpack_results(ints: np.ndarray, flts: np.ndarray, n: int, lmax: int) -> List[DecodeResult]:
-    # one bulk conversion to Python scalars per array: every rank unpacks EVERY rank's chunks, so this runs
-    # world x chunks times per call (element-wise int()/float() cost 28 ms per step at 8 x 176 chunks)
-    rows_i, rows_f = ints[:n].tolist(), flts[:n].tolist()
-    out = []
-    for ri, rf in zip(rows_i, rows_f):
-        k, kt = ri[0], ri[1]
-        out.append(DecodeResult(tuple(ri[2:2 + k]), rf[0], confidence=rf[1], times=ri[2 + lmax:2 + lmax + kt],
-                                tokens_confidence=rf[2:2 + k]))
+def pack_results(hyps: Sequence[DecodeResult]) -> np.ndarray:
+    ints: List[int] = []
+    dbl: List[float] = []
+    total = 0
+    for h in hyps:
+        tok = list(h.tokens)
+        tim, frm, tc = h.times, getattr(h, "ctc_frames", None), h.tokens_confidence
+        ints += (len(tok), -1 if tim is None else len(tim), -1 if frm is None else len(frm), -1 if tc is None else len(tc))
+        ints += tok
+        if tim:
+            ints += tim
+        if frm:
+            ints += frm
+        dbl += (h.score, h.confidence)
+        if tc:
+            dbl += tc
+        total += len(tok)
+    if len(ints) & 1:
+        ints.append(0)
+    out = np.empty(_HDR + len(ints) + 2 * len(dbl), np.int32)
+    out[:_HDR] = (_MAGIC, len(hyps), len(ints), len(dbl), total, 0, 0, 0)
+    out[_HDR:_HDR + len(ints)] = ints
+    out[_HDR + len(ints):] = np.asarray(dbl, np.float64).view(np.int32)
+    return out
+
+
+def unpack_results(buf: np.ndarray) -> List[DecodeResult]:
+    # bulk conversion to Python scalars once per rank: every rank may unpack EVERY rank's chunks
+    if int(buf[0]) != _MAGIC:
+        raise ValueError("result buffer: bad magic")
+    n, ni, nd = int(buf[1]), int(buf[2]), int(buf[3])
+    ints = buf[_HDR:_HDR + ni].tolist()
+    dbl = np.ascontiguousarray(buf[_HDR + ni:_HDR + ni + 2 * nd]).view(np.float64).tolist()
+    out, p, q = [], 0, 0
+    for _ in range(n):
+        k, kt, kf, kc = ints[p:p + 4]
+        p += 4
+        tok = tuple(ints[p:p + k]); p += k
+        tim = frm = tc = None
+        if kt >= 0:
+            tim = ints[p:p + kt]; p += kt
+        if kf >= 0:
+            frm = ints[p:p + kf]; p += kf
+        score, conf = dbl[q], dbl[q + 1]
+        q += 2
+        if kc >= 0:
+            tc = dbl[q:q + kc]; q += kc
+        r = DecodeResult(tok, score, confidence=conf, times=tim, tokens_confidence=tc)
+        r.ctc_frames = frm
+        out.append(r)
     return out
 
 
 class GatheredResults(Sequence):
-    """Every rank's per-chunk results in rank (= chunk) order, as they arrived: packed integer / float rows per rank.
+    """Every rank's per-chunk results in rank (= chunk) order, as they arrived: one packed buffer per rank.
     Behaves like a list of DecodeResult; a rank's rows become Python objects the first time one of them is read
     (each rank already holds its own chunks as DecodeResults -- turning the other ranks' rows into 240 Python
     scalars per chunk on EVERY rank costs about 1.5 ms per 176 chunks per source rank, which only a consumer that
     actually reads them should pay)."""
 
-    def __init__(self, blocks, lmax: int):
-        self._blocks = blocks                      # [(ints, flts, count)] per rank, host arrays
-        self._lmax = lmax
-        self._starts = np.cumsum([0] + [b[2] for b in blocks])
+    def __init__(self, blocks):
+        self._blocks = blocks                      # per rank: packed int32 buffer (host)
+        self._starts = np.cumsum([0] + [int(b[1]) for b in blocks])
         self._cache = [None] * len(blocks)
 
     def __len__(self):
@@ -89,8 +126,7 @@ class GatheredResults(Sequence):
 
     def _rank(self, r: int) -> List[DecodeResult]:
         if self._cache[r] is None:
-            ints, flts, n = self._blocks[r]
-            self._cache[r] = unpack_results(ints, flts, n, self._lmax)
+            self._cache[r] = unpack_results(self._blocks[r])
         return self._cache[r]
 
     def __getitem__(self, i):
@@ -108,32 +144,38 @@ class GatheredResults(Sequence):
             yield from self._rank(r)
 
     def total_tokens(self) -> int:
-        return int(sum(int(b[0][:b[2], 0].sum()) for b in self._blocks))
+        return int(sum(int(b[4]) for b in self._blocks))
 
 
-def all_gather_results(hyps: Sequence[DecodeResult], device) -> "GatheredResults":
-    """All ranks end up with every rank's results in rank (= chunk) order.  Payload: tokens, CTC peak
-    frames, score, confidences -- about 1 KB per chunk, latency-bound on xGMI."""
+N_COLLECTIVES = 0        # all-gathers issued by all_gather_results so far (tests assert the common case is one per call)
+
+
+def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = None) -> "GatheredResults":
+    """All ranks end up with every rank's results in rank (= chunk) order after ONE all-gather.  Payload: tokens,
+    CTC peak frames, score, confidences -- about 1.3 KB per chunk, latency-bound on xGMI.
+    `max_count` = the largest number of results any rank contributes; it sizes the fixed-capacity buffer and must
+    be the same on every rank (default: len(hyps), i.e. every rank holds equally many)."""
     import torch
     import torch.distributed as dist
+    global _ROW_WORDS, N_COLLECTIVES
     world = dist.get_world_size()
-    lmax_local = max([len(h.tokens) for h in hyps] + [len(h.times or []) for h in hyps] + [1])
-    meta = torch.tensor([len(hyps), lmax_local], device=device, dtype=torch.int64)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    counts = [int(m[0]) for m in metas]
-    nmax, lmax = max(counts + [1]), max(int(m[1]) for m in metas)
-    ints, flts = pack_results(hyps, lmax)
-    pad_i = np.full((nmax, ints.shape[1]), -1, np.int32)
-    pad_f = np.zeros((nmax, flts.shape[1]), np.float64)
-    pad_i[:len(hyps)], pad_f[:len(hyps)] = ints, flts
-    ti, tf = torch.from_numpy(pad_i).to(device), torch.from_numpy(pad_f).to(device)
-    gi = [torch.empty_like(ti) for _ in range(world)]
-    gf = [torch.empty_like(tf) for _ in range(world)]
-    dist.all_gather(gi, ti)
-    dist.all_gather(gf, tf)
-    hi, hf = torch.stack(gi).cpu().numpy(), torch.stack(gf).cpu().numpy()    # two device-to-host copies, not 2 x world
-    return GatheredResults([(hi[r], hf[r], counts[r]) for r in range(world)], lmax)
+    buf = pack_results(hyps)
+    count = max(int(max_count if max_count is not None else len(hyps)), 1)
+    while True:
+        cap = _HDR + count * _ROW_WORDS
+        send = np.zeros(cap, np.int32)
+        m = min(cap, buf.size)
+        send[:m] = buf[:m]                         # the header always fits and states what this rank needs
+        t = torch.from_numpy(send).to(device)
+        g = torch.empty(world * cap, dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(g, t)
+        N_COLLECTIVES += 1
+        host = g.cpu().numpy().reshape(world, cap)  # one device-to-host copy
+        need = int((_HDR + host[:, 2].astype(np.int64) + 2 * host[:, 3].astype(np.int64)).max())
+        if need <= cap:
+            break
+        _ROW_WORDS = -(-(need - _HDR) // count) * 5 // 4 + 8       # same arithmetic on the same numbers on every rank
+    return GatheredResults([host[r, :_HDR + int(host[r, 2]) + 2 * int(host[r, 3])] for r in range(world)])
 
 
 def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: int, ctc_weight: float,
@@ -150,7 +192,16 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
         engine.upload_pcm(pcm[s0:s1])
         nf = engine.fbank()
         local = engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
-    return {m: all_gather_results(local[m], device) for m in modes}
+    # every mode's rows travel in the same single all-gather: rank block = [mode 0 rows | mode 1 rows | ...]
+    kmax = max(b - a for a, b in chunk_ranges(n_chunks, world))
+    merged = all_gather_results([h for m in modes for h in local[m]], device, max_count=kmax * len(modes))
+    out = {m: [] for m in modes}
+    for r, (a, b) in enumerate(chunk_ranges(n_chunks, world)):
+        rows = merged._rank(r)
+        assert len(rows) == (b - a) * len(modes), (len(rows), a, b)
+        for i, m in enumerate(modes):
+            out[m].extend(rows[i * (b - a):(i + 1) * (b - a)])
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ diarization

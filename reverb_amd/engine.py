@@ -97,9 +97,13 @@ class Engine:
         self.set_cat_embs(cat_embs)
         self.batch = 0
         self.enc_frames = 0
+        self._pinned = []
 
     # -------------------------------------------------------------------------------- lifecycle
     def close(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.rvb_host_free(p)
+        self._pinned = []
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.rvb_destroy(self.handle)
             self.handle = C.c_void_p()
@@ -122,6 +126,14 @@ class Engine:
         self._cat = cat
 
     # -------------------------------------------------------------------------------- front end
+    def pinned_pcm(self, n_samples: int) -> np.ndarray:
+        """int16 array of page-locked host memory (rvb_host_alloc) for the audio reader to fill: upload_pcm from it runs
+        at the PCIe rate.  The memory belongs to the engine and is released by close()."""
+        p = C.c_void_p()
+        check(self.lib.rvb_host_alloc(C.byref(p), int(n_samples) * 2), "rvb_host_alloc")
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_int16 * max(int(n_samples), 1)).from_address(p.value))[:int(n_samples)]
+
     def upload_pcm(self, pcm: np.ndarray, sample_rate: int = 16000):
         """int16 mono PCM -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134)."""
         pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)

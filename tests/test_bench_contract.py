@@ -29,6 +29,36 @@ def test_committed_bench_line_has_the_contract_fields(log):
     assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start two ranks, gather over the process group and
+    report n_gpus = 2 from the group itself.  RVB_BENCH_STUB swaps the engine for a host stub and RCCL for gloo, the
+    launcher, rendezvous, barrier / max-over-ranks timing and the one-collective result gather are the real code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["RVB_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--model", "tiny", "--hours", "0.02"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_reported_by_process_group"] == 2
+    assert d["config"]["results_gathered"] == 2 * 4 and d["config"]["parallelism"] == "chunk-shard x2"   # 72 s = 4 chunks per rank
+    assert d["data"].startswith("stub") and d["roofline"] is None       # can never be mistaken for a measurement
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+
+
+def test_bench_gpus_more_than_visible_is_refused():
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RVB_BENCH_STUB")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "only 0 GPU" in r.stderr
+
+
 def test_bench_scripts_parse_and_default_to_one_gpu():
     import ast
     for name in ("bench.py", "bench_diar.py"):

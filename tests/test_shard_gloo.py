@@ -48,43 +48,135 @@ def _fake_results(rank):
     for i in range(3 + 2 * rank):
         k = int(rng.integers(0, 9))
         toks = rng.integers(1, 40, k).tolist()
-        out.append(DecodeResult(tuple(toks), float(-rng.random() * 30), confidence=float(rng.random()),
-                                times=sorted(rng.integers(0, 512, k).tolist()),
-                                tokens_confidence=rng.random(k).tolist()))
+        if i % 3 == 2:      # greedy-style result: no times, no confidences, the ctc_frames extension instead (engine.greedy)
+            r = DecodeResult(toks)
+            r.ctc_frames = sorted(rng.integers(0, 512, k).tolist())
+        else:
+            r = DecodeResult(tuple(toks), float(-rng.random() * 30), confidence=float(rng.random()),
+                             times=sorted(rng.integers(0, 512, k).tolist()), tokens_confidence=rng.random(k).tolist())
+        out.append(r)
     return out
 
 
-def _worker(rank, world, port, q):
+def _row(h):
+    return (list(h.tokens), h.times, h.ctc_frames, h.score, h.confidence, h.tokens_confidence)
+
+
+def test_pack_unpack_roundtrip_keeps_none_and_empty_apart():
+    hyps = _fake_results(0) + _fake_results(3) + [DecodeResult((), 0.0, times=[], tokens_confidence=[])]
+    back = rdist.unpack_results(rdist.pack_results(hyps))
+    assert [_row(h) for h in back] == [_row(h) for h in hyps]
+    assert back[-1].times == [] and back[2].times is None and back[2].ctc_frames is not None
+
+
+def _worker(rank, world, port, q, row_words):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    merged = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"))
+    if row_words:
+        rdist._ROW_WORDS = row_words           # force the overflow path: the rows do not fit the first buffer
+    kmax = max(3 + 2 * r for r in range(world))
+    merged = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"), max_count=kmax)
+    first = rdist.N_COLLECTIVES
+    again = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"), max_count=kmax)
     # the gathered sequence is lazy: length, token total, random access and negative / slice indexing all agree
     assert merged.total_tokens() == sum(len(h.tokens) for h in merged)
     assert len(merged) == sum(3 + 2 * r for r in range(world))
     assert merged[-1].tokens == list(merged)[-1].tokens and [h.score for h in merged[1:4]] == [h.score for h in list(merged)[1:4]]
-    q.put((rank, [(list(h.tokens), h.times, h.score, h.confidence, h.tokens_confidence) for h in merged]))
+    assert [_row(h) for h in again] == [_row(h) for h in merged]
+    q.put((rank, [_row(h) for h in merged], first, rdist.N_COLLECTIVES - first))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_all_gather_results_world2_gloo():
+def _run_world2(target, args=()):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + tuple(args)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
+    got = [q.get(timeout=180) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = [(list(h.tokens), h.times, h.score, h.confidence, h.tokens_confidence)
-            for r in range(2) for h in _fake_results(r)]
-    assert got[0] == want and got[1] == want        # every rank holds all results, in chunk order
+    return {g[0]: g[1:] for g in got}
+
+
+@pytest.mark.parametrize("row_words", [0, 6])
+def test_all_gather_results_world2_gloo(row_words):
+    got = _run_world2(_worker, (row_words,))
+    want = [_row(h) for r in range(2) for h in _fake_results(r)]
+    for r in range(2):
+        rows, first, second = got[r]
+        assert rows == want                          # every rank holds all results, in chunk order
+        # ONE collective per call; a buffer that turns out too small costs exactly one more, once (the capacity is sticky)
+        assert first == (2 if row_words else 1) and second == 1
+
+
+# ------------------------------------------------------------------------------------------------ decode_sharded
+class _StubAsrEngine:
+    """Stands in for the GPU engine: the result of a chunk is a pure function of the samples its frames cover, so the
+    sharded run reproduces the single-process run exactly if (and only if) every rank decodes exactly its chunks from
+    exactly its samples (dist.sample_range with the 240-sample halo)."""
+
+    def upload_pcm(self, pcm):
+        self.pcm = np.asarray(pcm, np.int16)
+
+    def fbank(self):
+        return rdist.num_frames(len(self.pcm))
+
+    def decode_resident(self, n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty=0.0):
+        out = {m: [] for m in modes}
+        for c in range(-(-n_frames // chunk_size)):
+            f0, f1 = c * chunk_size, min((c + 1) * chunk_size, n_frames)
+            x = self.pcm[f0 * 160:(f1 - 1) * 160 + 400].astype(np.int64)
+            k = 2 + int(np.abs(x).sum() % 7)
+            toks = [int(abs(int(x[(j * 7919) % len(x)])) % 97) + 1 for j in range(k)]
+            for m in modes:
+                if m == "ctc_greedy_search":
+                    r = DecodeResult(toks)
+                    r.ctc_frames = list(range(k))
+                else:
+                    r = DecodeResult(tuple(toks), -float(k) - ctc_weight, confidence=1.0 / k, times=[3 * j for j in range(k)],
+                                     tokens_confidence=[float(t) / 100 for t in toks])
+                out[m].append(r)
+        return out
+
+
+_MODES = ["ctc_greedy_search", "attention_rescoring"]
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pcm = synth.synth_audio(37.3, seed=11)
+    res = rdist.decode_sharded(_StubAsrEngine(), pcm, _MODES, 500, 10, 0.1, 0.0, torch.device("cpu"))
+    q.put((rank, {m: [_row(h) for h in res[m]] for m in _MODES}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_decode_sharded_world2_gloo_matches_single_process():
+    pcm = synth.synth_audio(37.3, seed=11)
+    eng = _StubAsrEngine()
+    eng.upload_pcm(pcm)
+    want = eng.decode_resident(eng.fbank(), _MODES, 500, 10, 0.1, 0.0)
+    assert len(want[_MODES[0]]) == 8                 # 3729 frames -> 7 full chunks + a tail: ranks get 4 + 4
+    want = {m: [_row(h) for h in want[m]] for m in _MODES}
+    got = _run_world2(_sharded_worker)
+    assert got[0][0] == want and got[1][0] == want
+
+
+def test_greedy_results_survive_the_gather_for_get_output():
+    """a gathered greedy result must still carry ctc_frames (get_output falls back to them when times is None)."""
+    r = DecodeResult([5, 6, 7]); r.ctc_frames = [1, 4, 9]
+    back = rdist.unpack_results(rdist.pack_results([r]))[0]
+    assert back.times is None and back.ctc_frames == [1, 4, 9] and list(back.tokens) == [5, 6, 7]
 
 
 # ------------------------------------------------------------------------------------------------ diarization shard
