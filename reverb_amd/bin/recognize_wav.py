@@ -21,13 +21,13 @@ def get_args(argv=None):
     p.add_argument("--tokenizer-symbols", help="Path to tk.units.txt. Overrides the config path.")
     p.add_argument("--bpe-path", help="Path to tk.model. Overrides the config path.")
     p.add_argument("--cmvn-path", help="Path to cmvn. Overrides the config path.")
-    p.add_argument("--beam_size", type=int, default=10, help="beam size for search")
+    p.add_argument("--beam_size", type=int, default=10, help="beam size for search (CTC modes: at most 16, the device top-k width)")
     p.add_argument("--length_penalty", type=float, default=0.0, help="length penalty")
     p.add_argument("--blank_penalty", type=float, default=0.0, help="blank penalty")
     p.add_argument("--result_dir", required=True, help="asr result file")
     p.add_argument("--batch_size", type=int, default=1, help="batch size")
     p.add_argument("--chunk_size", type=int, default=2051, help="Chunk size")
-    p.add_argument("--modes", nargs="+", default=["ctc_prefix_beam_search", "attention_rescoring"], choices=MODES,
+    p.add_argument("--modes", nargs="+", default=["attention_rescoring"], choices=MODES,
                    help="One or more supported decoding mode.")
     p.add_argument("--ctc_weight", type=float, default=0.1, help="ctc weight for rescoring weight in attention rescoring")
     p.add_argument("--decoding_chunk_size", type=int, default=-1, help="decoding chunk size (<0: full chunk)")

@@ -1174,7 +1174,9 @@ int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
   RVB_HIP_CHECK(hipSetDevice(e->device));
   const int64_t nf = rvb_num_frames(e->n_samples);
   const int64_t T0 = e->cfg.chunk_frames;
-  const int64_t rows = ((nf + T0 - 1) / T0) * T0;    // zero padded to whole chunks (feats_batcher)
+  // zero padded so that ANY chunking with chunk_size <= chunk_frames finds whole chunks (feats_batcher pads the last
+  // chunk with zeros, cli/reverb.py:165-175): ceil(nf / c) * c < nf + c <= nf + chunk_frames
+  const int64_t rows = nf + T0;
   RVB_TRY(e->feats.ensure((size_t)std::max<int64_t>(rows, 1) * 80 * 4));
   RVB_HIP_CHECK(hipMemsetAsync(e->feats.p, 0, (size_t)std::max<int64_t>(rows, 1) * 80 * 4, e->stream));
   FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};

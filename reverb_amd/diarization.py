@@ -128,6 +128,9 @@ def classes_to_multilabel(classes: np.ndarray) -> np.ndarray:
     return mapping[classes]
 
 
+SEGMENT_PRECISION = 1e-6      # pyannote.core.segment.SEGMENT_PRECISION
+
+
 def closest_frame(t: float, start: float = 0.0) -> int:
     """pyannote.core.SlidingWindow.closest_frame for the model's receptive field."""
     return int(np.rint((t - start - 0.5 * FRAME_DURATION) / FRAME_STEP))
@@ -476,6 +479,8 @@ def to_annotation(binary: np.ndarray, min_duration_off: float = 0.0, uri: Option
                     merged.append([s_, e_])
             regions = merged
         for i, (s_, e_) in enumerate(regions):
+            if e_ - s_ <= SEGMENT_PRECISION:         # pyannote's Annotation.__setitem__ silently drops empty segments
+                continue                             # (a speaker active on the last frame only: start == end)
             ann.add(Segment(float(s_), float(e_)), f"{k}_{i}", k)
     return ann
 
@@ -657,4 +662,11 @@ class Pipeline:
                     return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
             raise FileNotFoundError(f"{path}: no {stem}.pt / .bin / .ckpt")
 
-        return SpeakerDiarization(cfg, load_sd("segmentation"), load_sd("embedding"), params, dtype=dtype)
+        seg_sd = load_sd("segmentation")
+        if not any(k.startswith("sincnet.") for k in seg_sd) or not any(k.startswith("lstm.") for k in seg_sd):
+            kinds = sorted({k.split(".")[0] for k in seg_sd})[:8]
+            raise NotImplementedError(
+                f"{path}: the segmentation checkpoint is not a PyanNet (SincNet + LSTM) model (top-level modules: {kinds}).  "
+                "Only the Revai/reverb-diarization-v1 architecture (pyannote/segmentation-3.0) is built; "
+                "reverb-diarization-v2 (WavLM-based segmentation) is not supported.")
+        return SpeakerDiarization(cfg, seg_sd, load_sd("embedding"), params, dtype=dtype)

@@ -325,8 +325,9 @@ class Engine:
         """Decode the device-resident features of the last fbank() call: fixed, non-overlapping
         chunks with a length-masked zero-padded tail (feats_batcher, cli/reverb.py:148-180),
         `max_chunks` chunks per launch, results concatenated in chunk order."""
-        if chunk_size != self.cfg.chunk_frames:
-            raise RvbError("resident decoding needs chunk_size == engine chunk_frames")
+        if not 7 <= chunk_size <= self.cfg.chunk_frames:
+            raise RvbError(f"resident decoding needs 7 <= chunk_size <= engine chunk_frames ({self.cfg.chunk_frames}); "
+                           "ReverbASR rebuilds the engine for larger chunks")
         n_chunks = -(-n_frames // chunk_size)
         lens = np.full(n_chunks, chunk_size, np.int32)
         if n_chunks:

@@ -118,6 +118,7 @@ class ReverbASR:
             sd = dict(sd)
             sd["encoder.global_cmvn.mean"] = torch.from_numpy(mean).float()
             sd["encoder.global_cmvn.istd"] = torch.from_numpy(istd).float()
+        self._sd, self._dtype, self._gpu, self._max_chunks = sd, dtype, max(gpu, 0), max_chunks
         self.engine = Engine(self.configs, sd, dtype=dtype, device=max(gpu, 0), max_chunks=max_chunks)
         self.model = RvbASRModel(self.engine)
         self.test_conf = self.configs["dataset_conf"]
@@ -195,15 +196,28 @@ class ReverbASR:
         fc = self.test_conf["fbank_conf"]
         if (fc["num_mel_bins"], fc["frame_length"], fc["frame_shift"]) != (80, 25, 10):
             raise NotImplementedError("the device fbank is built for 80 bins / 25 ms / 10 ms")
-        eng = self.engine
-        if chunk_size > eng.cfg.chunk_frames:
-            raise ValueError(f"chunk_size {chunk_size} exceeds the engine's chunk_frames {eng.cfg.chunk_frames}")
+        if chunk_size < 7:
+            raise ValueError("chunk_size must be at least 7 frames (Conv2dSubsampling4 needs 7 input frames, subsampling.py:201-226)")
+        eng = self._engine_for_chunk(chunk_size)
         eng.upload_pcm(*self._load_pcm(audio_file, 16000))
         n_frames = eng.fbank()
         eng.set_cat_embs([verbatimicity, 1.0 - verbatimicity])
         hyps = self.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, length_penalty)
         return [get_output(format, self.tokenizer, Path(audio_file).name, hyps[mode], timings_adjustment, chunk_size,
                            self.input_frame_length, self.output_frame_length) for mode in modes]
+
+    def _engine_for_chunk(self, chunk_size: int) -> Engine:
+        """The reference accepts any --chunk_size (cli/reverb.py:188, recognize_wav.py:66-70).  The engine sizes its
+        positional tables and workspace for `chunk_frames` input frames per chunk: smaller chunks run on the same
+        engine, a larger one rebuilds it once (weights are re-packed from the kept state dict)."""
+        if chunk_size > self.engine.cfg.chunk_frames:
+            cat = self.engine._cat
+            chunks = max(1, self._max_chunks * self.engine.cfg.chunk_frames // chunk_size)     # same workspace budget
+            self.engine.close()
+            self.engine = Engine(self.configs, self._sd, dtype=self._dtype, device=self._gpu, max_chunks=chunks,
+                                 chunk_frames=chunk_size, cat_embs=cat)
+            self.model = RvbASRModel(self.engine)
+        return self.engine
 
     def decode_resident(self, n_frames: int, modes, chunk_size: int, beam_size: int, ctc_weight: float,
                         reverse_weight: float, blank_penalty: float = 0.0, length_penalty: float = 0.0):

@@ -232,3 +232,27 @@ def test_pipeline_loading_errors(tmp_path):
     import torch
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pipe.to(torch.device("cpu"))
+
+
+def test_v2_segmentation_checkpoint_is_refused_with_a_clear_message(tmp_path):
+    """a non-PyanNet (e.g. WavLM-based reverb-diarization-v2) checkpoint must fail at load time, by name."""
+    import torch
+    from reverb_amd import synth_diar
+    d = synth_diar.write_pipeline_dir(str(tmp_path / "pipe"))
+    torch.save({"wavlm.encoder.layers.0.attention.k_proj.weight": torch.zeros(4, 4), "classifier.weight": torch.zeros(7, 4)},
+               os.path.join(d, "segmentation.pt"))
+    with pytest.raises(NotImplementedError, match="reverb-diarization-v2"):
+        D.Pipeline.from_pretrained(d)
+
+
+def test_speaker_active_on_the_last_frame_only_gives_no_empty_turn():
+    """ADVICE r1: start == end == ts[n-1] must not become a 0-duration RTTM line (pyannote drops empty segments;
+    make_turns / intervaltree would raise 'Null Interval' on it)."""
+    b = np.zeros((50, 2), np.float32)
+    b[10:20, 0] = 1
+    b[-1, 1] = 1                      # speaker 1: active on the final frame only
+    ann = D.to_annotation(b, uri="x")
+    segs = [(seg.start, seg.end, lab) for seg, _, lab in ann.itertracks(yield_label=True)]
+    assert len(segs) == 1 and segs[0][2] == 0 and segs[0][1] > segs[0][0]
+    b[-2:, 1] = 1                     # two frames: a real (one frame-step long) turn
+    assert len(list(D.to_annotation(b, uri="x").itertracks(yield_label=True))) == 2

@@ -188,6 +188,46 @@ def test_api_from_wav_file_matches_reference_ctm(name):
         asr.engine.close()
 
 
+@pytest.mark.parametrize("chunk_size", [1000, 2600])
+def test_transcribe_accepts_any_chunk_size(chunk_size):
+    """the reference takes any --chunk_size (cli/reverb.py:188); smaller chunks run on the resident features
+    of the same engine, a larger one rebuilds the engine.  Checked (a) against the feats_batcher -> model.decode path of
+    the same object (identical chunking, must be identical text) and (b) against the oracle on oracle features."""
+    import torch
+    import reverb_amd
+    from oracle import fbank_ref, model_ref as M, search_ref as S
+    from reverb_amd.reverb import get_output
+    case = Case("tiny_ln")
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_model_dir(os.path.join(d, "model"), "tiny_ln", sd=case.sd, cfg=case.cfg)
+        wav = os.path.join(d, "golden.wav")
+        synth.write_wav(wav, case.pcm)
+        asr = reverb_amd.load_model(os.path.join(d, "model"), dtype="f32", max_chunks=4)
+        mode = "attention_rescoring"
+        got = asr.transcribe(wav, mode=mode, format="ctm", verbatimicity=case.cat[0], chunk_size=chunk_size,
+                             beam_size=case.beam, ctc_weight=case.ctc_weight)
+        assert asr.engine.cfg.chunk_frames == max(chunk_size, 2051)
+        feats = asr.compute_feats(wav, num_mel_bins=80)
+        hyps = []
+        for x, lens in asr.feats_batcher(feats, chunk_size, 64):
+            hyps += asr.model.decode([mode], x, lens, case.beam, ctc_weight=case.ctc_weight, cat_embs=case.cat)[mode]
+        same_obj = get_output("ctm", asr.tokenizer, "golden.wav", hyps, 230, chunk_size, asr.input_frame_length,
+                              asr.output_frame_length)
+        assert got == same_obj and len(got.split("\n")) > 5
+        ofe = fbank_ref.fbank(case.pcm)
+        want = []
+        for i in range(0, ofe.shape[0], chunk_size):
+            part = ofe[i:i + chunk_size]
+            x = np.zeros((1, chunk_size, 80), np.float32); x[0, :len(part)] = part
+            want += S.decode(M.to_torch_sd(case.sd), case.cfg, [mode], torch.from_numpy(x), torch.tensor([len(part)], dtype=torch.int32),
+                             case.beam, ctc_weight=case.ctc_weight, reverse_weight=0.0, cat_embs=torch.tensor(case.cat))[mode]
+        wl = get_output("ctm", asr.tokenizer, "golden.wav", want, 230, chunk_size, 10, 40).split("\n")
+        gl = got.split("\n")
+        same = sum(1 for a, b in zip(gl, wl) if a.split()[:5] == b.split()[:5])
+        assert abs(len(gl) - len(wl)) <= max(1, len(wl) // 50) and same >= 0.9 * len(wl), f"{same}/{len(wl)} CTM lines equal"
+        asr.engine.close()
+
+
 def test_slice_pipeline_and_bulk_results_equal_plain_path():
     """>= 16 chunks are encoded in slices with the host search overlapped; results must not depend on it,
     and the rescoring-only fast path (bulk getter) must equal the per-chunk path."""
