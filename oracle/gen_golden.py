@@ -40,6 +40,20 @@ CASES = [
 ]
 
 
+# Long-form cases: the reference decodes chunk by chunk with batch 1 exactly as its CLI does (cli/reverb.py:220-253,
+# recognize_wav.py:60-64); only the winners are stored (tokens, times, scores) plus a strided encoder sample of the
+# first and the last chunk.  `r640_1h` IS the bench workload (bench.py: r640 weights, seed 0, beta frozen in
+# synth.CTC_BLANK_BIAS, 1 h of synth_audio(seed=1234), 176 chunks): what the 144 + 32 slice bf16 path is judged on.
+LONG_CASES = [
+    dict(name="small_66", dims="small", norm="layer_norm", seed=4, seconds=1340.0, chunk=2051, beam=10, ctc_weight=0.1,
+         reverse_weight=0.0, cat=[1.0, 0.0]),
+    dict(name="r640_chunk", dims="r640", norm="layer_norm", seed=0, seconds=20.6, chunk=2051, beam=10, ctc_weight=0.1,
+         reverse_weight=0.0, cat=[1.0, 0.0], frozen_beta=True),
+    dict(name="r640_1h", dims="r640", norm="layer_norm", seed=0, seconds=3600.0, chunk=2051, beam=10, ctc_weight=0.1,
+         reverse_weight=0.0, cat=[1.0, 0.0], frozen_beta=True),
+]
+
+
 class _Args:
     jit = False
 
@@ -136,6 +150,54 @@ def run_case(case):
     print(f"{case['name']}: beta={beta:.4f} chunks={len(lens)} enc_lens={js['encoder_lens']} rescored tokens/chunk={ntok}")
 
 
+def run_long_case(case):
+    import time
+    cfg = synth.make_config(case["dims"], case["norm"])
+    pcm = synth.synth_audio(case["seconds"], seed=1234 + case["seed"])
+    feats = fbank_ref.fbank(pcm)
+    x, lens = chunk_feats(feats, case["chunk"])
+    cat = torch.tensor(case["cat"])
+    if case.get("frozen_beta"):      # the weights bench.py runs: synth.calibrated_state_dict(dims, seed)
+        beta = synth.CTC_BLANK_BIAS[(case["dims"], case["seed"])]
+    else:
+        model, _ = build_reference_model(cfg, synth.make_state_dict(cfg, case["seed"], synth.CTC_GAMMA, 0.0))
+        beta = calibrate_beta(model, x, lens, cat)
+        del model
+    sd = synth.make_state_dict(cfg, case["seed"], synth.CTC_GAMMA, beta)
+    model, _ = build_reference_model(cfg, sd)
+    del sd
+    modes = ["ctc_greedy_search", "attention_rescoring"]
+    rows = {m: [] for m in modes}
+    enc_lens, arrays = [], {}
+    t0 = time.time()
+    for c in range(len(lens)):
+        xc, lc = torch.from_numpy(x[c:c + 1]), torch.from_numpy(lens[c:c + 1])
+        with torch.no_grad():
+            res = model.decode(modes, xc, lc, case["beam"], ctc_weight=case["ctc_weight"], reverse_weight=case["reverse_weight"],
+                               cat_embs=cat, blank_id=0, infos={"tasks": ["transcribe"], "langs": ["en"]})
+            if c in (0, len(lens) - 1):
+                enc, mask = model.encoder(xc, lc, -1, -1, cat_embs=cat)
+                probs = model.ctc_logprobs(enc)
+                n = int(mask.sum())
+                arrays[f"encoder_out_{c}"] = enc[0, :n:16, ::8].numpy().copy()
+                arrays[f"ctc_top1_{c}"] = probs[0, :n].max(-1).values.numpy().copy()
+                arrays[f"ctc_argmax_{c}"] = probs[0, :n].argmax(-1).numpy().astype(np.int32)
+        g, r = res["ctc_greedy_search"][0], res["attention_rescoring"][0]
+        rows["ctc_greedy_search"].append(dict(tokens=list(map(int, g.tokens))))
+        rows["attention_rescoring"].append(dict(tokens=list(map(int, r.tokens)), times=list(map(int, r.times)),
+                                                score=float(r.score), confidence=float(r.confidence)))
+        enc_lens.append(int(lc[0] > 6) * ((int(lc[0]) - 7) // 4 + 1))
+        if c % 8 == 0:
+            print(f"  {case['name']}: chunk {c + 1}/{len(lens)}  {time.time() - t0:.0f} s", flush=True)
+    js = dict(case=dict(case, long=True), beta=beta, gamma=synth.CTC_GAMMA, lens=lens.tolist(), encoder_lens=enc_lens, modes=rows)
+    os.makedirs(GOLDEN, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN, case["name"] + ".npz"), **arrays)
+    with open(os.path.join(GOLDEN, case["name"] + ".json"), "w") as f:
+        json.dump(js, f, separators=(",", ":"))
+    ntok = sum(len(r["tokens"]) for r in rows["attention_rescoring"])
+    print(f"{case['name']}: beta={beta:.4f} chunks={len(lens)} rescored tokens={ntok}  {time.time() - t0:.0f} s")
+
+
 def fbank_golden():
     """Pin the fbank restatement with the independent Kaldi-compatible implementation shipped in
     `transformers` (the reference's own torchaudio is not installable here: parity unpinned)."""
@@ -159,3 +221,6 @@ if __name__ == "__main__":
         if only and case["name"] not in only:
             continue
         run_case(case)
+    for case in LONG_CASES:          # long cases only on request: r640_1h takes ~20 min of CPU
+        if case["name"] in only:
+            run_long_case(case)

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace rvb {
@@ -25,6 +26,7 @@ static constexpr int B2M = 256, B2N = 256;
 static constexpr int ROW2 = 128;                         // bytes of K per tile row
 static constexpr int STAGE2 = (B2M + B2N) * ROW2;        // 64 KiB
 static constexpr int GEMM2_LDS = 2 * STAGE2;             // 128 KiB
+static constexpr int GEMM2_DEFAULT_FLAGS = 0, GEMM2_DEFAULT_GROUP_M = 0;
 
 __device__ inline float act_apply2(float v, int act) {
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
@@ -37,7 +39,12 @@ __device__ inline void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, typename OutT, bool CONV>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// MMA32 (bf16 only): v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_16x16x32_bf16 -- the same LDS bytes per flop (a lane's
+// 16-byte vector is 8 k-values of one of 32 rows instead of one of 16), half the MFMA instructions, and the shape whose
+// issue rate reaches the 2.5 PFLOP/s peak (16x16x32 tops out ~13 % lower, MI355X_MICROARCH.md / cdna_hip_programming.md 3).
+template <typename T, typename OutT, bool CONV, bool MMA32>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VE = Mma16<T>::VE;
@@ -55,7 +62,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  if (p.group_m > 1) {
+    // grouped order inside the XCD's contiguous run: walk `group_m` row tiles down, then the next column, so that the
+    // ~32 tiles an XCD runs at a time form a group_m x (32 / group_m) patch (for N = 4096: 8 + 4 operand panels per
+    // wave of tiles instead of 2 + 16) and successive patches keep their A panels in that XCD's L2
+    const int tiles_m = (p.M + B2M - 1) / B2M;
+    const int per_group = p.group_m * tiles_n;
+    const int g = bid / per_group;
+    const int first_m = g * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
+    const int in_g = bid - g * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  } else {
+    tm = bid / tiles_n; tn = bid - tm * tiles_n;
+  }
   const int m0 = tm * B2M, n0 = tn * B2N;
 
   const T* __restrict__ A = (const T*)p.A;
@@ -136,17 +158,38 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         : "memory", "scc");
   };
 
-  f32x4_t acc[8][4];
+  constexpr bool M32 = MMA32 && sizeof(T) == 2;
+  // 16x16 fragments: acc[i][j] = rows 16i.., cols 16j.. of the wave's 128x64 tile (C/D: col = lane&15, row = 4*(lane>>4)+r).
+  // 32x32 blocks (M32): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+  f32x4_t acc[M32 ? 1 : 8][M32 ? 1 : 4];
+  f32x16_t acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
-  const int frow = lane & 15, lgrp = lane >> 4;
+  // fragment addressing.  16x16x32: lane = (row 0..15, 16-byte column group 0..3 of the 64-byte k32 slice).
+  // 32x32x16: lane = (row 0..31, half g = lane>>5); MFMA t (0/1) of a k32 slice takes 16-byte columns 2t + g.  Which k a
+  // (lane group, element) slot carries is free as long as A and B agree (common.h), and the source swizzle
+  // (row>>1)&7 keeps either read pattern conflict-free: a ds_read_b128 lane group always holds every swizzle class twice,
+  // once on an even and once on an odd row.
+  const int frow = M32 ? (lane & 31) : (lane & 15), lgrp = M32 ? (lane >> 5) : (lane >> 4);
   const int swz = (frow >> 1) & 7;
   int roff[2];     // byte offset of this lane's 16-byte vector inside a row, per 64-byte chunk
   roff[0] = ((0 * 4 + lgrp) ^ swz) << 4;
   roff[1] = ((1 * 4 + lgrp) ^ swz) << 4;
+  int roff_t1[2];  // M32: second MFMA of the slice (columns 2 + g)
+  roff_t1[0] = ((0 * 4 + 2 + lgrp) ^ swz) << 4;
+  roff_t1[1] = ((1 * 4 + 2 + lgrp) ^ swz) << 4;
 
   // ---- main loop: k32 slices q = 2*kt + s stream through two register buffers of fragments.  Block u multiplies
   // slice u while slice u+1 is read (two MFMAs, one ds_read, ... so the reads leave early and land under the MFMAs);
@@ -163,28 +206,66 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
       constexpr int buf = decltype(bufc)::value;
       const char* st = smem + ((q >> 1) & 1) * STAGE2;
       const int ro = roff[q & 1];
+      if constexpr (M32) {
+        // fa[2*bi + t] = A rows 32bi + (lane&31), MFMA t of the slice; fb[2*bj + t] likewise for W rows (output columns)
+        const int r1 = roff_t1[q & 1];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * ROW2 + ro);
+        for (int bi = 0; bi < 4; ++bi) {
+          fa[buf][2 * bi] = *(const uint4*)(st + a_off + bi * 32 * ROW2 + ro);
+          fa[buf][2 * bi + 1] = *(const uint4*)(st + a_off + bi * 32 * ROW2 + r1);
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * ROW2 + ro);
+        for (int bj = 0; bj < 2; ++bj) {
+          fb[buf][2 * bj] = *(const uint4*)(st + b_off + bj * 32 * ROW2 + ro);
+          fb[buf][2 * bj + 1] = *(const uint4*)(st + b_off + bj * 32 * ROW2 + r1);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[buf][i] = *(const uint4*)(st + a_off + i * 16 * ROW2 + ro);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[buf][j] = *(const uint4*)(st + b_off + j * 16 * ROW2 + ro);
+      }
     };
     auto mma_slice = [&](auto bufc) __attribute__((always_inline)) {
       constexpr int buf = decltype(bufc)::value;
+      if constexpr (M32) {
+        union U { uint4 u; bf16x8_t v; };
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Mma16<T>::run(fa[buf][i], fb[buf][j], acc[i][j]);
+          for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj) {
+              U ua, ub;
+              ua.u = fa[buf][2 * bi + t]; ub.u = fb[buf][2 * bj + t];
+              acc32[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc32[bi][bj], 0, 0, 0);
+            }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma16<T>::run(fa[buf][i], fb[buf][j], acc[i][j]);
+      }
     };
     auto block = [&](auto mbufc, int q) __attribute__((always_inline)) {     // multiply buffer mbuf, read slice q into the other
       constexpr int mb = decltype(mbufc)::value;
       read_slice(std::integral_constant<int, 1 - mb>(), q);
       mma_slice(mbufc);
+      if constexpr (M32) {
 #pragma unroll
-      for (int r = 0; r < 12; ++r) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA first: they depend on the previous block's reads only
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one ds_read
+        for (int r = 0; r < 12; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 16 MFMAs of twice the length: one per fragment read
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA first: they depend on the previous block's reads only
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one ds_read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     };
     auto enter_stage = [&](int kt) __attribute__((always_inline)) {          // kt >= 1
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of stage kt have landed
@@ -193,6 +274,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     };
     std::integral_constant<int, 0> b0;
     std::integral_constant<int, 1> b1;
+    if (p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
     issue(0, 0);
     if (nk > 1) {
       issue(1, 1);
@@ -214,6 +296,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
       block(b0, nq - 1);
     }
     mma_slice(b1);
+    if (p.prio && wave >= 4) __builtin_amdgcn_s_setprio(0);
   } else {
     // f32 (parity mode, four 16x16x4 MFMAs per fragment pair): the plain loop -- the double-buffered fragments do not
     // fit next to 128 accumulator registers there
@@ -271,11 +354,24 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_wave_barrier();
+        if constexpr (M32) {
+          // rows [16i, 16i+16) of the wave tile = half h = i&1 of block row bi = i>>1: registers 8h .. 8h+7
+          const int bi = i >> 1, h = i & 1;
+          const int r32 = 4 * (lane >> 5), c32 = lane & 31;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(float*)(slab + (8 * qq + r32 + r) * SROW + (bj * 32 + c32) * 4) = acc32[bi][bj][8 * h + 4 * qq + r];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        }
         __builtin_amdgcn_wave_barrier();
         float v[16];
 #pragma unroll
@@ -335,6 +431,29 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     return;
   }
   // unaligned output / residual rows: element-wise stores
+  if constexpr (M32) {
+    auto finish32 = [&](auto actf) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const int col = n0 + wc * 64 + bj * 32 + (lane & 31);
+          const float bvv = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.M || col >= p.N) continue;
+            float v = actf(acc32[bi][bj][r] + bvv) * p.alpha;
+            if (p.res) v += p.res[(size_t)row * p.ldres + col];
+            C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
+          }
+        }
+    };
+    if (p.act == ACT_SILU) finish32([](float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); });
+    else if (p.act == ACT_RELU) finish32([](float v) { return fmaxf(v, 0.0f); });
+    else finish32([](float v) { return v; });
+    return;
+  }
   float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -371,10 +490,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   }
 }
 
-template <typename T, typename OutT, bool CONV>
+template <typename T, typename OutT, bool CONV, bool MMA32 = false>
 static int launch2(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
-  auto kern = gemm2_kernel<T, OutT, CONV>;
+  auto kern = gemm2_kernel<T, OutT, CONV, MMA32>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS));
     attr_set = true;
@@ -393,8 +512,24 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
   return true;
 }
 
-int gemm2(hipStream_t s, int dtype, const GemmArgs& p) {
+// tuning switches (tests / scripts/gemm_bench.py / environment; none changes results beyond fp32 summation order):
+//   bit 0  32x32x16 MFMAs        bit 1  s_setprio 1 for waves 4-7 in the K loop        group_m: tile order (0/1 = row-major)
+int g_gemm2_flags = -1, g_gemm2_group_m = -1;
+static void gemm2_opts_from_env() {
+  if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
+  if (g_gemm2_group_m < 0) { const char* e = getenv("RVB_GEMM2_GROUP_M"); g_gemm2_group_m = e ? atoi(e) : GEMM2_DEFAULT_GROUP_M; }
+}
+
+int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
+  gemm2_opts_from_env();
+  GemmArgs p = p0;
+  p.group_m = g_gemm2_group_m;
+  p.prio = (g_gemm2_flags >> 1) & 1;
   if (dtype == DT_BF16) {
+    if (g_gemm2_flags & 1) {
+      if (p.out_f32) return p.conv ? launch2<bf16_t, float, true, true>(s, p) : launch2<bf16_t, float, false, true>(s, p);
+      return p.conv ? launch2<bf16_t, bf16_t, true, true>(s, p) : launch2<bf16_t, bf16_t, false, true>(s, p);
+    }
     if (p.out_f32) return p.conv ? launch2<bf16_t, float, true>(s, p) : launch2<bf16_t, float, false>(s, p);
     return p.conv ? launch2<bf16_t, bf16_t, true>(s, p) : launch2<bf16_t, bf16_t, false>(s, p);
   }

@@ -24,12 +24,14 @@ struct GemmArgs {
   int out_f32;        // bf16 mode only: write fp32 instead of bf16
   int conv;           // implicit 3x3 stride-2 conv gather on A
   int cT1, cF1, cT2, cF2, cC;
+  int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
 // gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)
 bool gemm2_applicable(int dtype, const GemmArgs& a);
 int gemm2(hipStream_t s, int dtype, const GemmArgs& a);
 extern int g_gemm_variant;   // 0 = auto, 1 = always gemm.hip kernel, 2 = gemm2.hip whenever applicable
+extern int g_gemm2_flags, g_gemm2_group_m;   // gemm2.hip tuning switches (-1 = read RVB_GEMM2_FLAGS / RVB_GEMM2_GROUP_M or the defaults)
 
 // ---------------------------------------------------------------- fbank.hip
 struct FbankTables {

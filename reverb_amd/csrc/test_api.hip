@@ -238,6 +238,7 @@ template <typename T> void fill(void* p, size_t n, unsigned seed, float scale) {
 }  // namespace
 
 extern "C" int rvb_test_set_gemm_variant(int v) { g_gemm_variant = v; return OK; }
+extern "C" int rvb_test_set_gemm2_opts(int flags, int group_m) { g_gemm2_flags = flags; g_gemm2_group_m = group_m; return OK; }
 
 extern "C" int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, int iters, int act, int out_f32,
                                    int with_res, double* ms_out, double* max_abs_diff) {

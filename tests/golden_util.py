@@ -58,3 +58,36 @@ class Case:
 
     def golden(self, mode):
         return self.js["modes"][mode]
+
+
+LONG_CASES = ["small_66", "r640_chunk", "r640_1h"]
+_SD_CACHE = {}
+
+
+class LongCase(Case):
+    """Long-form golden (oracle/gen_golden.py:run_long_case): the unmodified reference decoded chunk by chunk with batch 1;
+    per chunk the greedy tokens and the rescoring winner (tokens, times, score, confidence), plus a strided encoder sample
+    and the per-frame top-1 CTC log-prob / argmax of the first and the last chunk.  r640_1h is bench.py's workload."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        assert self.c.get("long")
+
+    @property
+    def sd(self):
+        key = (self.c["dims"], self.c["seed"], self.js["gamma"], self.js["beta"])
+        if key not in _SD_CACHE:
+            _SD_CACHE.clear()            # one big state dict at a time (r640: 2.7 GB)
+            _SD_CACHE[key] = synth.make_state_dict(self.cfg, self.c["seed"], self.js["gamma"], self.js["beta"])
+        return _SD_CACHE[key]
+
+    def chunk_feats(self, c):
+        """(x [1, chunk, 80], lens [1]) of chunk c from the oracle fbank of only the samples that chunk covers."""
+        f0 = c * self.chunk
+        n = self.js["lens"][c]
+        pcm = self.pcm[f0 * 160:(f0 + n - 1) * 160 + 400]
+        feats = fbank_ref.fbank(pcm)
+        assert feats.shape[0] == n
+        x = np.zeros((1, self.chunk, 80), np.float32)
+        x[0, :n] = feats
+        return x, np.array([n], np.int32)

@@ -59,6 +59,42 @@ def test_gemm_epilogue(lib, dtype, act, alpha, use_res, out_f32):
         np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("flags,group_m", [(0, 0), (1, 0), (1, 8), (3, 4), (0, 8), (1, 3)])
+@pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32", [
+    (300, 200, 128, 0, 1.0, False, 1),        # one partial tile, aligned rows: LDS-transposed vector epilogue
+    (513, 330, 192, 1, 1.0, False, 0),        # unaligned bf16 rows: element-wise epilogue, SiLU
+    (1000, 1024, 256, 0, 0.5, True, 1),       # 4 x 4 tiles, fp32 residual
+    (2100, 520, 64, 2, 1.0, False, 0),        # 9 x 3 tiles (ragged last column tile), one K step, ReLU, bf16 out
+    (2600, 1280, 320, 0, 1.0, True, 1),       # 11 x 5 tiles: grouped orders with a ragged last group
+])
+def test_gemm2_tuning_switches_keep_results(lib, flags, group_m, M, N, K, act, alpha, use_res, out_f32):
+    """gemm2.hip's tuning switches (32x32x16 MFMAs with their own fragment / accumulator / epilogue mapping, grouped
+    tile order, wave priority) against fp64 on asymmetric random operands, every epilogue form."""
+    dtype = BF16
+    rng = np.random.default_rng(M + N + K)
+    A = rnd(dtype, rng.standard_normal((M, K)))
+    W = rnd(dtype, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    res = f32(rng.standard_normal((M, N))) if use_res else None
+    C = np.full((M, N), np.nan, np.float32)
+    lib.rvb_test_set_gemm2_opts(flags, group_m)
+    try:
+        _lib.check(lib.rvb_test_gemm(dtype, fptr(A), fptr(W), fptr(bias), fptr(res), fptr(C), M, N, K, alpha, act, out_f32,
+                                     0, 0, 0, 0, 0))
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+    v = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    if act == 1:
+        v = v / (1 + np.exp(-v))
+    elif act == 2:
+        v = np.maximum(v, 0)
+    v = v * alpha + (res if use_res else 0)
+    if out_f32:
+        np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
+    else:
+        np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)      # one bf16 rounding of the output
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("Cc,N", [(16, 24), (64, 72), (128, 260)])
 def test_gemm_implicit_conv(lib, dtype, Cc, N):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, MODES, Case, GOLDEN
+from golden_util import CASES, MODES, Case, GOLDEN, LongCase
 from oracle import fbank_ref, model_ref as M, search_ref as S
 
 
@@ -109,3 +109,30 @@ def test_chunk_masked_encoder_oracle_matches_reference_golden():
         a, _ = M.encoder_forward(sd, case.cfg, torch.from_numpy(x[:1]), torch.from_numpy(lens[:1]), torch.tensor(case.cat), decoding_chunk_size=16)
         b, _ = M.encoder_forward(sd, case.cfg, torch.from_numpy(x[:1]), torch.from_numpy(lens[:1]), torch.tensor(case.cat))
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,chunks", [("small_66", (0, 1, 33, 64, 65)), ("r640_chunk", (0, 1)), ("r640_1h", (100,))])
+def test_oracle_matches_long_form_reference_golden(name, chunks):
+    """Long-form goldens (the reference decoded chunk by chunk, batch 1): the oracle reproduces the reference's greedy and
+    rescored winners on sampled chunks -- including one chunk of the 1 h r640 recording bench.py times, whose weights are
+    the frozen-beta ones (`synth.calibrated_state_dict`)."""
+    from reverb_amd import synth
+    case = LongCase(name)
+    if case.c.get("frozen_beta"):
+        assert case.js["beta"] == synth.CTC_BLANK_BIAS[(case.c["dims"], case.c["seed"])]
+    sd = M.to_torch_sd(case.sd)
+    for c in chunks:
+        x, lens = case.chunk_feats(c)
+        taps = {}
+        res = S.decode(sd, case.cfg, ["ctc_greedy_search", "attention_rescoring"], torch.from_numpy(x), torch.from_numpy(lens),
+                       case.beam, ctc_weight=case.ctc_weight, reverse_weight=case.reverse_weight, cat_embs=torch.tensor(case.cat), taps=taps)
+        assert taps["encoder_lens"].tolist() == [case.js["encoder_lens"][c]]
+        assert list(res["ctc_greedy_search"][0].tokens) == case.golden("ctc_greedy_search")[c]["tokens"], (name, c)
+        g = case.golden("attention_rescoring")[c]
+        r = res["attention_rescoring"][0]
+        assert list(r.tokens) == g["tokens"] and list(r.times) == g["times"], (name, c)
+        assert float(r.score) == g["score"] and r.confidence == g["confidence"]
+        key = f"encoder_out_{c}"
+        if key in case.arrays:
+            n = case.js["encoder_lens"][c]
+            np.testing.assert_array_equal(taps["encoder_out"][0, :n:16, ::8].numpy(), case.arrays[key])
