@@ -135,4 +135,5 @@ def test_oracle_matches_long_form_reference_golden(name, chunks):
         key = f"encoder_out_{c}"
         if key in case.arrays:
             n = case.js["encoder_lens"][c]
-            np.testing.assert_array_equal(taps["encoder_out"][0, :n:16, ::8].numpy(), case.arrays[key])
+            # (bit-identical on full chunks; a 1-frame tail chunk takes another torch GEMM path in nn.Linear than in F.linear)
+            np.testing.assert_allclose(taps["encoder_out"][0, :n:16, ::8].numpy(), case.arrays[key], rtol=0, atol=2e-5)
