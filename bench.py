@@ -251,6 +251,8 @@ def main():
         pcm[:] = synth.synth_audio(seconds, seed=1234 + rank)
         eng.upload_pcm(pcm)                               # inputs resident in HBM before the timed region
 
+    stats = {}
+
     def step(upload=False):
         if STUB:
             hyps = eng.decode()
@@ -260,6 +262,8 @@ def main():
             nf = eng.fbank()
             hyps = eng.decode_resident(nf, modes, chunk, args.beam, args.ctc_weight, args.reverse_weight)["attention_rescoring"]
         ntok = sum(len(h.tokens) for h in hyps)
+        if not STUB:
+            stats["decoder_rows"], stats["decoder_pairs"] = eng.rescore_stats()
         if use_dist:      # ONE all-gather of the per-chunk results over RCCL/xGMI; the other ranks'
             hyps = all_gather_results(hyps, device)     # rows stay packed until somebody reads them (dist.GatheredResults)
             ntok = hyps.total_tokens()
@@ -337,7 +341,9 @@ def main():
                        "chunks_per_launch": per_launch, "parallelism": f"chunk-shard x{world}",
                        "world_size_reported_by_process_group": world if use_dist else 1,
                        "backend": (dist.get_backend() if use_dist else None),
-                       "results_gathered": len(hyps), "tokens_per_step": int(ntok)},
+                       "results_gathered": len(hyps), "tokens_per_step": int(ntok),
+                       # rescoring: (hypothesis, position) log-probs served vs decoder rows computed (one per distinct prefix)
+                       "decoder_pairs_per_step": stats.get("decoder_pairs"), "decoder_rows_per_step": stats.get("decoder_rows")},
             "roofline": roof,
             "stage_ms_per_step": {k: round(v["ms"], 3) for k, v in stages.items()} if stages else None,
             "pcie_inclusive": pcie,

@@ -137,6 +137,10 @@ int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score
  * (T = rvb_encoder_frames) with -1 / 0 */
 int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_t* times_lens, int32_t* times,
                            float* scores, double* confidences, double* tokens_confidence);
+/* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's
+ * padded [N, L] decoder batch computes (search.py:391-412); `decoder_rows` = rows actually computed: one per DISTINCT
+ * hypothesis prefix of a chunk (the decoder is causal, so hypotheses of one beam share the rows of their common prefix). */
+int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs);
 /* per-hypothesis decoder log-probs of the last rescoring (parity tap): for hyp i of `chunk`,
  * out[j] = log p(w_j | ...) for j < len and out[len] = log p(eos); right=1 for the r2l decoder */
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out);
@@ -164,9 +168,16 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
                        const float* bias_u, const float* bias_v, float* out, int q_rows, int kv_rows, int p_rows,
                        int heads, int dk, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
                        const int32_t* kv_len, int nseq, int causal);
+/* decoder self attention over shared prefixes: sequence s has kv_len[s] keys in rows kv_index[kv_start[s] ..] and
+ * q_len[s] queries in rows q_start[s] .. at key positions q_pos0[s] .. (causal); q_block 16 = one-wave blocks + work list */
+int rvb_test_attention_trie(int dtype, const float* q, const float* k, const float* v, float* out, int rows, int heads, int dk,
+                            const int32_t* q_start, const int32_t* q_len, const int32_t* q_pos0, const int32_t* kv_start,
+                            const int32_t* kv_len, const int32_t* kv_index, int n_index, int nseq, int q_block);
 int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float blank_penalty, int blank_id,
                              float* topk_val, int32_t* topk_idx, float* logp);
 int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target, float* out);
+int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* ptr /* [R+1] */, const int32_t* target,
+                              int P, float* out /* [P] */);
 int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats /* [frames,80] */);
 /* native prefix beam search on host arrays: top-k log-probs/indices [T,beam] of one utterance */
 int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank,

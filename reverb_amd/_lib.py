@@ -66,6 +66,7 @@ SIGNATURES = {
     "rvb_get_attention_result": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _f32p]),
     "rvb_get_rescored": (C.c_int, [_eng, C.c_int, _i32p, _f32p, _f64p, _f64p]),
     "rvb_get_rescored_batch": (C.c_int, [_eng, _i32p, _i32p, _i32p, _i32p, _f32p, _f64p, _f64p]),
+    "rvb_get_rescore_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
     "rvb_reset_timings": (C.c_int, [_eng]),
@@ -79,8 +80,11 @@ SIGNATURES = {
                                       C.c_int]),
     "rvb_test_attention": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_int, C.c_int]),
+    "rvb_test_attention_trie": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p,
+                                          _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_logsoftmax_topk": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _f32p]),
     "rvb_test_lse_gather": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _f32p]),
+    "rvb_test_lse_gather_multi": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p]),
     "rvb_test_fbank": (C.c_int, [_i16p, C.c_int64, _f32p]),
     "rvb_test_set_gemm_variant": (C.c_int, [C.c_int]),
     "rvb_test_set_gemm2_opts": (C.c_int, [C.c_int, C.c_int]),

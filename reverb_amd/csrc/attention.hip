@@ -24,8 +24,6 @@
 namespace rvb {
 
 static constexpr int KT = 64;     // keys per tile
-static constexpr int NW = 8;      // waves per workgroup
-static constexpr int QT = 16 * NW;
 
 template <typename T, int DKP>
 struct AttnLds {
@@ -37,8 +35,11 @@ struct AttnLds {
   static constexpr int TOTAL = OFF_V + DKP * ROW_V;
 };
 
-template <typename T, int DKP, bool HAS_POS>
+// NW = waves per workgroup (16 queries each): 8 for the encoder and the cross attention (128-query blocks share a
+// staged key tile), 1 for the decoder's self attention over a hypothesis trie (a hypothesis owns a handful of rows).
+template <typename T, int DKP, bool HAS_POS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
+  constexpr int QT = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AttnLds<T, DKP>;
   constexpr bool BF = sizeof(T) == 2;
@@ -51,11 +52,18 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   constexpr int NT = 64 * NW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  // block -> (sequence, first query): the grid's (x, z), or one entry of a host-built work list (ragged batches of
+  // short sequences: no empty blocks)
+  const int head = blockIdx.y;
+  const int seq = a.work ? a.work[2 * blockIdx.x] : blockIdx.z;
+  const int q0 = a.work ? a.work[2 * blockIdx.x + 1] : blockIdx.x * QT;
   const int qlen = a.q_len[seq];
-  const int q0 = blockIdx.x * QT;
   if (q0 >= qlen) return;                       // block-uniform
   const int qs = a.q_start[seq], ks = a.kv_start[seq], kvlen = a.kv_len[seq];
+  // position of the sequence's first query among its keys (causal mask): 0 when queries and keys are the same rows;
+  // a hypothesis that shares its first d tokens with an earlier one only computes rows d.. (rescoring trie)
+  const int pos0 = a.q_pos0 ? a.q_pos0[seq] : 0;
+  const int* __restrict__ kvi = a.kv_index ? a.kv_index + ks : nullptr;   // key j lives in row kvi[j] instead of ks + j
   const int dk = a.dk;
   const T* Q = (const T*)a.q;
   const T* K = (const T*)a.k;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   char* sV = smem + L::OFF_V;
 
   int kend = kvlen, kbeg = 0;
-  if (a.causal) kend = min(kvlen, q0 + QT);
+  if (a.causal) kend = min(kvlen, pos0 + q0 + QT);
   // streaming-style chunk mask (utils/mask.py:86-123 subsequent_chunk_mask): query i sees keys
   // [max((i/cs - left)*cs, 0), (i/cs + 1)*cs); the tile loop covers the union over this block's queries
   const int cs = a.chunk;
@@ -136,8 +144,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       rk[n] = make_uint4(0, 0, 0, 0); rv[n] = make_uint4(0, 0, 0, 0);
       if constexpr (HAS_POS) rp[n] = make_uint4(0, 0, 0, 0);
       if (ok) {
-        rk[n] = *(const uint4*)(K + (size_t)(ks + key) * a.k_stride + head * dk + c * VE);
-        rv[n] = *(const uint4*)(V + (size_t)(ks + key) * a.v_stride + head * dk + c * VE);
+        const size_t krow = kvi ? (size_t)kvi[key] : (size_t)(ks + key);
+        rk[n] = *(const uint4*)(K + krow * a.k_stride + head * dk + c * VE);
+        rv[n] = *(const uint4*)(V + krow * a.v_stride + head * dk + c * VE);
         if constexpr (HAS_POS) rp[n] = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
       }
     }
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt0 + nf * 16 + lgrp * 4 + r;
-          if (key >= hi || key < lo || (a.causal && key > my_q)) s[nf][r] = -INFINITY;
+          if (key >= hi || key < lo || (a.causal && key > pos0 + my_q)) s[nf][r] = -INFINITY;
         }
     }
     float mx = -INFINITY;
@@ -296,16 +305,18 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int DKP, bool HAS_POS>
+template <typename T, int DKP, bool HAS_POS, int NW>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
   using L = AttnLds<T, DKP>;
   static bool attr_set = false;
-  auto kern = attn_kernel<T, DKP, HAS_POS>;
+  auto kern = attn_kernel<T, DKP, HAS_POS, NW>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
     attr_set = true;
   }
-  dim3 grid(cdiv(a.max_q, QT), a.heads, a.nseq);
+  dim3 grid(cdiv(a.max_q, 16 * NW), a.heads, a.nseq);
+  if (a.work) grid = dim3(a.n_work, a.heads, 1);
+  if (grid.x == 0) return OK;
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), L::TOTAL, s, a);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
@@ -316,7 +327,10 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   const bool pos = a.p != nullptr;
   const int dk = a.dk;
 #define RVB_ATTN_CASE(D)                                                           \
-  if (dk <= D) return pos ? launch_attn<T, D, true>(s, a) : launch_attn<T, D, false>(s, a);
+  if (dk <= D) {                                                                   \
+    if (a.q_block == 16) return launch_attn<T, D, false, 1>(s, a);                 \
+    return pos ? launch_attn<T, D, true, 8>(s, a) : launch_attn<T, D, false, 8>(s, a); \
+  }
   RVB_ATTN_CASE(32)
   RVB_ATTN_CASE(64)
   RVB_ATTN_CASE(96)
@@ -334,6 +348,8 @@ int attention(hipStream_t s, int dtype, const AttnArgs& a) {
     return E_ARG;
   }
   if ((a.bias_u == nullptr) != (a.bias_v == nullptr)) { set_error("attention: bias_u/bias_v must come together"); return E_ARG; }
+  if (a.q_block != 0 && a.q_block != 16 && a.q_block != 128) { set_error("attention: q_block must be 0 (= 128), 16 or 128"); return E_ARG; }
+  if (a.q_block == 16 && a.p) { set_error("attention: 16-query blocks are built for the decoder forms (no positional keys)"); return E_ARG; }
   return dtype == DT_BF16 ? dispatch_attn<bf16_t>(s, a) : dispatch_attn<float>(s, a);
 }
 

@@ -112,6 +112,8 @@ struct rvb_engine {
   // decoder workspace
   rvb::DevBuf dx, dxn, dy, dh, dqkv, dq, dao, kvmem, d_tok, d_pos, d_tgt, d_logp;
   rvb::DevBuf d_hq_start, d_hq_len, d_hkv_start, d_hkv_len;
+  rvb::DevBuf d_hq_pos0, d_hpath_start, d_hpath_len, d_path, d_work, d_tgt_ptr;    // rescoring over the hypothesis trie
+  int64_t rescore_rows = 0, rescore_pairs = 0;      // decoder rows computed / (hypothesis, position) pairs served, last call
 
   // ---- profiling ----
   int profiling = 0;     // 0 off, 1 every stage, 2 GEMM launches only (what the roofline needs; half the events)

@@ -628,18 +628,101 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
 }
 
 // ------------------------------------------------------------------------------------ rescoring
-struct HypRef { int chunk, idx, len, row0; };
+// The n-best hypotheses of a chunk share long prefixes (they come out of one prefix beam), and the decoder is causal:
+// decoder row j of a hypothesis depends only on its tokens 0..j-1 and on the chunk's memory.  The reference runs the
+// decoder on the padded [N, L] batch (search.py:391-412, asr_model.py:868-978), i.e. it recomputes a shared prefix N
+// times; here every DISTINCT prefix of a chunk is one decoder row (a trie, built per decoder direction: the
+// right-to-left decoder sees the reversed hypotheses, search.py:427-433).  Row results do not depend on the batch they
+// are computed in (GEMM rows are independent, an attention row walks its own keys in order), so every hypothesis
+// reads exactly the log-probs the padded batch would give it.  On the bench workload 13-35 % of the rows remain.
+struct HypRef { int chunk, idx, len, row0; };      // row0: first of the hypothesis' len+1 (hyp, j) pairs
 
-static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>& hyps, int R, int maxL,
-                           const std::vector<int32_t>& tok, const std::vector<int32_t>& pos,
-                           const std::vector<int32_t>& tgt, std::vector<float>* logp) {
+struct TrieBatch {
+  int R = 0, P = 0, max_chunk_rows = 0;            // unique rows, (hyp, j) pairs, most rows of one chunk
+  std::vector<int32_t> tok, pos;                   // per row: input token, position
+  std::vector<int32_t> path;                       // per hypothesis: the rows of its prefixes 0..len (flat)
+  std::vector<int32_t> hq_start, hq_len, hq_pos0, hkv_start, hkv_len;   // per hypothesis: owned rows / path
+  std::vector<int32_t> crow_start, crow_len;       // per chunk: its rows (contiguous)
+  std::vector<int32_t> tgt_ptr, tgt;               // CSR over rows: the targets asked of a row
+  std::vector<int32_t> pair_slot;                  // (hyp, j) pair -> position in tgt / in the gathered log-probs
+  std::vector<int32_t> work;                       // self-attention blocks: {hypothesis, first owned query}
+};
+
+// seq(h, j) = j-th decoder input token AFTER <sos> of hypothesis h; target of pair (h, j) = seq(h, j) for j < len, else eos
+template <typename SeqFn>
+static void build_trie(const std::vector<HypRef>& hyps, int B, int sos, int eos, SeqFn seq, TrieBatch* t) {
+  *t = TrieBatch();
+  std::vector<std::pair<int32_t, int32_t>> asks;   // (row, target) in pair order
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> kids;   // per row: (token, child row) -- fan-out is tiny
+  t->crow_start.assign(B, 0); t->crow_len.assign(B, 0);
+  int cur_chunk = -1, root = -1;
+  for (const HypRef& h : hyps) {
+    if (h.chunk != cur_chunk) {
+      if (cur_chunk >= 0) t->crow_len[cur_chunk] = t->R - t->crow_start[cur_chunk];
+      cur_chunk = h.chunk;
+      t->crow_start[cur_chunk] = t->R;
+      root = -1;
+    }
+    const int first_new = t->R;
+    int own_pos0 = -1;
+    t->hkv_start.push_back((int32_t)t->path.size());
+    int node = root;
+    for (int j = 0; j <= h.len; ++j) {
+      int next = -1;
+      if (j == 0) {
+        next = root;
+      } else {
+        const int tk = seq(h, j - 1);
+        for (auto& kv : kids[node]) if (kv.first == tk) { next = kv.second; break; }
+      }
+      if (next < 0) {
+        next = t->R++;
+        t->tok.push_back(j == 0 ? sos : seq(h, j - 1));
+        t->pos.push_back(j);
+        kids.emplace_back();
+        if (j == 0) root = next; else kids[node].push_back({seq(h, j - 1), next});
+        if (own_pos0 < 0) own_pos0 = j;
+      }
+      node = next;
+      t->path.push_back(node);
+      asks.push_back({node, j < h.len ? seq(h, j) : eos});
+    }
+    const int n_own = t->R - first_new;             // new rows are a suffix of the path and contiguous
+    t->hq_start.push_back(first_new); t->hq_len.push_back(n_own); t->hq_pos0.push_back(n_own ? own_pos0 : 0);
+    t->hkv_len.push_back(h.len + 1);
+    for (int q0 = 0; q0 < n_own; q0 += 16) { t->work.push_back((int32_t)t->hq_start.size() - 1); t->work.push_back(q0); }
+  }
+  if (cur_chunk >= 0) t->crow_len[cur_chunk] = t->R - t->crow_start[cur_chunk];
+  for (int b = 0; b < B; ++b) t->max_chunk_rows = std::max(t->max_chunk_rows, t->crow_len[b]);
+  // CSR of the asks by row (counting sort keeps pair order inside a row)
+  t->P = (int)asks.size();
+  t->tgt_ptr.assign(t->R + 1, 0);
+  for (auto& a : asks) t->tgt_ptr[a.first + 1]++;
+  for (int r = 0; r < t->R; ++r) t->tgt_ptr[r + 1] += t->tgt_ptr[r];
+  std::vector<int32_t> fill(t->tgt_ptr.begin(), t->tgt_ptr.end() - 1);
+  t->tgt.assign(t->P, 0); t->pair_slot.assign(t->P, 0);
+  for (int p = 0; p < t->P; ++p) { const int slot = fill[asks[p].first]++; t->tgt[slot] = asks[p].second; t->pair_slot[p] = slot; }
+}
+
+// one decoder over the trie rows; logp[slot] = log p(target | prefix) for every ask (TrieBatch::pair_slot maps pairs)
+static int decoder_forward(rvb_engine* e, Decoder& D, const TrieBatch& t, std::vector<float>* logp) {
   const rvb_model_cfg& c = e->cfg;
   const int d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
-  const int M = e->B * e->T2;
+  const int M = e->B * e->T2, R = t.R, nhyp = (int)t.hq_start.size();
   const size_t es = dt_size(e->dtype);
-  RVB_TRY(upload_i32(e, e->d_tok, tok.data(), R));
-  RVB_TRY(upload_i32(e, e->d_pos, pos.data(), R));
-  RVB_TRY(upload_i32(e, e->d_tgt, tgt.data(), R));
+  RVB_TRY(upload_i32(e, e->d_tok, t.tok.data(), R));
+  RVB_TRY(upload_i32(e, e->d_pos, t.pos.data(), R));
+  RVB_TRY(upload_i32(e, e->d_tgt, t.tgt.data(), t.P));
+  RVB_TRY(upload_i32(e, e->d_tgt_ptr, t.tgt_ptr.data(), R + 1));
+  RVB_TRY(upload_i32(e, e->d_path, t.path.data(), t.path.size()));
+  RVB_TRY(upload_i32(e, e->d_work, t.work.data(), t.work.size()));
+  RVB_TRY(upload_i32(e, e->d_hq_start, t.hq_start.data(), nhyp));
+  RVB_TRY(upload_i32(e, e->d_hq_len, t.hq_len.data(), nhyp));
+  RVB_TRY(upload_i32(e, e->d_hq_pos0, t.hq_pos0.data(), nhyp));
+  RVB_TRY(upload_i32(e, e->d_hpath_start, t.hkv_start.data(), nhyp));
+  RVB_TRY(upload_i32(e, e->d_hpath_len, t.hkv_len.data(), nhyp));
+  RVB_TRY(upload_i32(e, e->d_hkv_start, t.crow_start.data(), e->B));
+  RVB_TRY(upload_i32(e, e->d_hkv_len, t.crow_len.data(), e->B));
   RVB_TRY(e->dx.ensure((size_t)R * d * 4));
   RVB_TRY(e->dxn.ensure((size_t)R * d * es));
   RVB_TRY(e->dy.ensure((size_t)R * d * es));
@@ -648,7 +731,7 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>&
   RVB_TRY(e->dqkv.ensure((size_t)R * 3 * d * es));
   RVB_TRY(e->dh.ensure((size_t)R * ff * es));
   RVB_TRY(e->kvmem.ensure((size_t)M * 2 * d * es));
-  RVB_TRY(e->d_logp.ensure((size_t)R * 4));
+  RVB_TRY(e->d_logp.ensure((size_t)t.P * 4));
   float* x = e->dx.as<float>();
   {
     Scope sc(e, "embed");
@@ -656,16 +739,18 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>&
                          x, R, d, std::sqrt((float)d)));
   }
   for (auto& L : D.layers) {
-    // self attention (causal, per hypothesis)            decoder_layer.py:91-110, decoder.py:150-156
+    // self attention (causal): a hypothesis' owned rows are the queries, the rows of its whole prefix path the keys
+    // decoder_layer.py:91-110, decoder.py:150-156
     RVB_TRY(run_norm(e, x, L.n1, e->dxn.p, false, R, d));
     RVB_TRY(run_gemm(e, e->dxn.p, d, L.self_qkv, e->dqkv.p, 3 * d, R, false));
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = e->dqkv.p; a.k = (const char*)e->dqkv.p + (size_t)d * es; a.v = (const char*)e->dqkv.p + (size_t)2 * d * es;
     a.q_stride = a.k_stride = a.v_stride = 3 * d; a.o_stride = d; a.out = e->dao.p;
-    a.q_start = e->d_hq_start.as<int>(); a.q_len = e->d_hq_len.as<int>();
-    a.kv_start = e->d_hq_start.as<int>(); a.kv_len = e->d_hq_len.as<int>();
-    a.nseq = (int)hyps.size(); a.heads = heads; a.dk = dk; a.max_q = maxL; a.causal = 1; a.sqrt_dk = std::sqrt((float)dk);
+    a.q_start = e->d_hq_start.as<int>(); a.q_len = e->d_hq_len.as<int>(); a.q_pos0 = e->d_hq_pos0.as<int>();
+    a.kv_start = e->d_hpath_start.as<int>(); a.kv_len = e->d_hpath_len.as<int>(); a.kv_index = e->d_path.as<int>();
+    a.work = e->d_work.as<int>(); a.n_work = (int)t.work.size() / 2; a.q_block = 16;
+    a.nseq = nhyp; a.heads = heads; a.dk = dk; a.max_q = 16; a.causal = 1; a.sqrt_dk = std::sqrt((float)dk);
     {
       Scope sc(e, "attention");
       RVB_TRY(attention(e->stream, e->dtype, a));
@@ -676,14 +761,14 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>&
     RVB_TRY(run_norm(e, x, L.n2, e->dxn.p, false, R, d));
     RVB_TRY(run_gemm(e, e->dxn.p, d, L.src_q, e->dq.p, d, R, false));
     RVB_TRY(run_gemm(e, e->enc_out.p, d, L.src_kv, e->kvmem.p, 2 * d, M, false));
+    memset(&a, 0, sizeof(a));
     a.q = e->dq.p; a.k = e->kvmem.p; a.v = (const char*)e->kvmem.p + (size_t)d * es;
-    a.q_stride = d; a.k_stride = a.v_stride = 2 * d;
-    // all hypotheses of a chunk attend to the same memory and there is no causal mask: their rows
-    // form ONE query sequence per chunk, so the chunk's K/V tiles are staged once per 128 rows
+    a.q_stride = d; a.k_stride = a.v_stride = 2 * d; a.o_stride = d; a.out = e->dao.p;
+    // all rows of a chunk attend to the same memory and there is no causal mask: they form ONE query sequence per
+    // chunk, so the chunk's K/V tiles are staged once per 128 rows
     a.q_start = e->d_hkv_start.as<int>(); a.q_len = e->d_hkv_len.as<int>();
     a.kv_start = e->d_aux_i32.as<int>(); a.kv_len = e->d_aux_i32.as<int>() + e->B;
-    a.nseq = e->B; a.max_q = e->xattn_max_rows;
-    a.causal = 0;
+    a.nseq = e->B; a.heads = heads; a.dk = dk; a.max_q = t.max_chunk_rows; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
     {
       Scope sc(e, "attention");
       RVB_TRY(attention(e->stream, e->dtype, a));
@@ -705,10 +790,11 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const std::vector<HypRef>&
     const int rows = std::min(LOGIT_SLAB, R - r0);
     RVB_TRY(run_gemm(e, (const char*)e->dxn.p + (size_t)r0 * d * es, d, D.out, e->logits.p, Vld, rows, true));
     Scope sc(e, "lse_gather");
-    RVB_TRY(lse_gather(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt.as<int>() + r0, e->d_logp.as<float>() + r0));
+    RVB_TRY(lse_gather_multi(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt_ptr.as<int>() + r0, e->d_tgt.as<int>(),
+                             e->d_logp.as<float>()));
   }
-  logp->resize(R);
-  RVB_HIP_CHECK(hipMemcpyAsync(logp->data(), e->d_logp.p, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
+  logp->resize(t.P);
+  RVB_HIP_CHECK(hipMemcpyAsync(logp->data(), e->d_logp.p, (size_t)t.P * 4, hipMemcpyDeviceToHost, e->stream));
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   return OK;
 }
@@ -721,43 +807,35 @@ static int rescore_impl(rvb_engine* e, double ctc_weight, double reverse_weight)
   if (use_r && !e->dec_r.present) { set_error("reverse_weight > 0 but model has no right-to-left decoder"); return E_STATE; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   const int B = e->B, T2 = e->T2, eos = e->cfg.eos_id, sos = e->cfg.sos_id;
-  // ragged batch: every hypothesis of every chunk contributes len+1 rows ([sos] + tokens)
+  // every hypothesis of every chunk asks for len+1 log-probs ([sos] + tokens -> tokens + [eos]; add_sos_eos,
+  // common.py:112-155, search.py:417-425)
   std::vector<HypRef> hyps;
-  std::vector<int32_t> tok, rtok, pos, tgt, rtgt, hq_start, hq_len, hkv_start, hkv_len;
-  int R = 0, maxL = 0;
+  int P = 0;
   std::vector<int32_t> ckv(2 * (size_t)B);
-  e->xattn_max_rows = 0;
   for (int b = 0; b < B; ++b) {
     const PrefixResult& pr = e->nbest[b];
-    hkv_start.push_back(R);                       // first decoder row of this chunk's hypotheses
     ckv[b] = b * T2; ckv[B + b] = e->enc_lens[b];
     for (size_t i = 0; i < pr.nbest.size(); ++i) {
-      const std::vector<int>& hy = pr.nbest[i];
-      const int len = (int)hy.size();
+      const int len = (int)pr.nbest[i].size();
       if (len + 1 > e->pe_rows) { set_error("hypothesis longer than the positional table"); return E_UNSUPPORTED; }
-      hyps.push_back({b, (int)i, len, R});
-      hq_start.push_back(R); hq_len.push_back(len + 1);
-      for (int j = 0; j <= len; ++j) {
-        tok.push_back(j == 0 ? sos : hy[j - 1]);                  // add_sos_eos, common.py:112-155
-        rtok.push_back(j == 0 ? sos : hy[len - j]);               // reversed input, asr_model.py:896-953
-        pos.push_back(j);
-        tgt.push_back(j < len ? hy[j] : eos);                      // search.py:417-425
-        rtgt.push_back(j < len ? hy[len - 1 - j] : eos);           // search.py:427-433
-      }
-      R += len + 1;
-      maxL = std::max(maxL, len + 1);
+      hyps.push_back({b, (int)i, len, P});
+      P += len + 1;
     }
-    hkv_len.push_back(R - hkv_start.back());
-    e->xattn_max_rows = std::max(e->xattn_max_rows, R - hkv_start.back());
   }
   RVB_TRY(upload_i32(e, e->d_aux_i32, ckv.data(), ckv.size()));
-  RVB_TRY(upload_i32(e, e->d_hq_start, hq_start.data(), hq_start.size()));
-  RVB_TRY(upload_i32(e, e->d_hq_len, hq_len.data(), hq_len.size()));
-  RVB_TRY(upload_i32(e, e->d_hkv_start, hkv_start.data(), hkv_start.size()));
-  RVB_TRY(upload_i32(e, e->d_hkv_len, hkv_len.data(), hkv_len.size()));
-  std::vector<float> logp, rlogp;
-  RVB_TRY(decoder_forward(e, e->dec_l, hyps, R, maxL, tok, pos, tgt, &logp));
-  if (use_r) RVB_TRY(decoder_forward(e, e->dec_r, hyps, R, maxL, rtok, pos, rtgt, &rlogp));
+  TrieBatch tl, tr;
+  build_trie(hyps, B, sos, eos, [&](const HypRef& h, int j) { return e->nbest[h.chunk].nbest[h.idx][j]; }, &tl);
+  std::vector<float> lslot, rslot;
+  RVB_TRY(decoder_forward(e, e->dec_l, tl, &lslot));
+  e->xattn_max_rows = tl.max_chunk_rows;
+  e->rescore_rows = tl.R; e->rescore_pairs = tl.P;
+  if (use_r) {   // reversed input and targets, asr_model.py:896-953, search.py:427-433
+    build_trie(hyps, B, sos, eos, [&](const HypRef& h, int j) { return e->nbest[h.chunk].nbest[h.idx][h.len - 1 - j]; }, &tr);
+    RVB_TRY(decoder_forward(e, e->dec_r, tr, &rslot));
+    e->rescore_rows += tr.R; e->rescore_pairs += tr.P;
+  }
+  std::vector<float> logp(P), rlogp(use_r ? P : 0);
+  for (int p = 0; p < P; ++p) { logp[p] = lslot[tl.pair_slot[p]]; if (use_r) rlogp[p] = rslot[tr.pair_slot[p]]; }
 
   // score accumulation exactly as search.py:413-441: fp32 running sums (0-dim float32 tensors),
   // python-float exp() for confidences, strict '>' so the first maximum wins
@@ -1034,6 +1112,7 @@ void rvb_destroy(rvb_engine* e) {
                     &e->logits, &e->topv, &e->topi, &e->d_enc_lens, &e->d_seq_start, &e->d_seq_len, &e->d_aux_i32,
                     &e->dx, &e->dxn, &e->dy, &e->dh, &e->dqkv, &e->dq, &e->dao, &e->kvmem, &e->d_tok, &e->d_pos,
                     &e->d_tgt, &e->d_logp, &e->d_hq_start, &e->d_hq_len, &e->d_hkv_start, &e->d_hkv_len,
+                    &e->d_hq_pos0, &e->d_hpath_start, &e->d_hpath_len, &e->d_path, &e->d_work, &e->d_tgt_ptr,
                     &e->fb_window, &e->fb_twiddle, &e->fb_melw, &e->fb_lo, &e->fb_hi,
                     &e->conv2.w, &e->conv2.b, &e->embed_out.w, &e->embed_out.b, &e->ctc.w, &e->ctc.b,
                     &e->enc_after.g, &e->enc_after.b};
@@ -1339,6 +1418,12 @@ int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_
       if (tokens_confidence) tokens_confidence[(size_t)b * T + j] = j < (int)r.tok_conf.size() ? r.tok_conf[j] : 0.0;
     }
   }
+  return OK;
+}
+int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs) {
+  if (!e) { set_error("rvb_get_rescore_stats: null engine"); return E_ARG; }
+  if (decoder_rows) *decoder_rows = e->rescore_rows;
+  if (pairs) *pairs = e->rescore_pairs;
   return OK;
 }
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out) {

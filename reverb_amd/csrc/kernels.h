@@ -93,6 +93,8 @@ int logsoftmax_topk(hipStream_t s, const float* logits, int M, int V, int ld, in
 
 // out[r] = logits[r][target[r]] - logsumexp(logits[r][:V])
 int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out);
+// CSR form for rows with several targets: out[p] = logits[r][target[p]] - lse(r) for p in [ptr[r], ptr[r+1])
+int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, const int* ptr, const int* target, float* out);
 
 // dst[r][t][:] = src[parent[r]][t][:], t < rows: caches [R][L][row_bytes]
 int gather_cache(hipStream_t s, const void* src, void* dst, const int* parent, int R, int L, int rows, int row_bytes);
@@ -113,6 +115,12 @@ struct AttnArgs {
   int causal;
   int chunk, left;   // chunk > 0: streaming chunk mask (utils/mask.py:86-123), left < 0 = all left chunks
   float sqrt_dk;   // scores are divided by this (attention.py:384,395: `/ math.sqrt(self.d_k)`)
+  // ---- ragged / shared-prefix batches (all nullable / 0) ----
+  const int* kv_index;   // key j of sequence s is row kv_index[kv_start[s] + j] of k / v (instead of kv_start[s] + j)
+  const int* q_pos0;     // per sequence: position of its first query among its keys (causal mask), default 0
+  const int* work;       // [n_work][2] = {sequence, first query} per block instead of the (max_q / q_block, nseq) grid
+  int n_work;
+  int q_block;           // queries per workgroup: 0 / 128 (8 waves) or 16 (1 wave; decoder forms only)
 };
 int attention(hipStream_t s, int dtype, const AttnArgs& a);
 

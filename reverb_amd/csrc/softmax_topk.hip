@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
   }
   const float lse = st.wave_lse();
   if constexpr (!TOPK) {
-    if (lane == 0) gathered[row] = rd.x[target[row]] - lse;
+    if (k < 0) {      // CSR form: row r owns targets [ti[r], ti[r+1]) of `target`, results land at the same positions
+      for (int p = ti[row] + lane; p < ti[row + 1]; p += 64) gathered[p] = rd.x[target[p]] - lse;
+    } else if (lane == 0) {
+      gathered[row] = rd.x[target[row]] - lse;
+    }
     return;
   } else {
     if (lp) {
@@ -200,6 +204,16 @@ int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const i
   if (R <= 0) return OK;
   hipLaunchKernelGGL(row_lse_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, R, V, ld, 0, 0.f, -1,
                      (float*)nullptr, (int*)nullptr, (float*)nullptr, target, out);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// rows shared by several hypotheses (rescoring over a prefix trie): row r has targets target[ptr[r] .. ptr[r+1]) and
+// out[p] = logits[r][target[p]] - logsumexp(logits[r][:V]) for each of them
+int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, const int* ptr, const int* target, float* out) {
+  if (R <= 0) return OK;
+  hipLaunchKernelGGL(row_lse_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, R, V, ld, -1, 0.f, -1,
+                     (float*)nullptr, const_cast<int*>(ptr), (float*)nullptr, target, out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -169,6 +169,46 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
   return down_T(dout, dtype, false, out, (size_t)q_rows * d);
 }
 
+// ragged / shared-prefix form of the decoder self attention: keys through an index list, queries that start at
+// position q_pos0 of their key sequence, 16-query blocks from a work list
+int rvb_test_attention_trie(int dtype, const float* q, const float* k, const float* v, float* out, int rows, int heads, int dk,
+                            const int32_t* q_start, const int32_t* q_len, const int32_t* q_pos0, const int32_t* kv_start,
+                            const int32_t* kv_len, const int32_t* kv_index, int n_index, int nseq, int q_block) {
+  T_TRY(need_gpu());
+  const int d = heads * dk;
+  Dev dq, dkk, dv, dout, qs, ql, qp, ks, kl, ki, wk;
+  T_TRY(up_T(dq, dtype, q, (size_t)rows * d));
+  T_TRY(up_T(dkk, dtype, k, (size_t)rows * d));
+  T_TRY(up_T(dv, dtype, v, (size_t)rows * d));
+  T_TRY(up_raw(qs, q_start, (size_t)nseq * 4)); T_TRY(up_raw(ql, q_len, (size_t)nseq * 4)); T_TRY(up_raw(qp, q_pos0, (size_t)nseq * 4));
+  T_TRY(up_raw(ks, kv_start, (size_t)nseq * 4)); T_TRY(up_raw(kl, kv_len, (size_t)nseq * 4));
+  T_TRY(up_raw(ki, kv_index, (size_t)n_index * 4));
+  T_TRY(dout.alloc((size_t)rows * d * dt_size(dtype)));
+  RVB_HIP_CHECK(hipMemset(dout.p, 0, (size_t)rows * d * dt_size(dtype)));
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = dq.p; a.k = dkk.p; a.v = dv.p;
+  a.q_stride = a.k_stride = a.v_stride = a.o_stride = d; a.out = dout.p;
+  a.q_start = (const int*)qs.p; a.q_len = (const int*)ql.p; a.q_pos0 = (const int*)qp.p;
+  a.kv_start = (const int*)ks.p; a.kv_len = (const int*)kl.p; a.kv_index = (const int*)ki.p;
+  a.nseq = nseq; a.heads = heads; a.dk = dk; a.causal = 1; a.sqrt_dk = sqrtf((float)dk); a.q_block = q_block;
+  int mq = 0;
+  std::vector<int32_t> work;
+  const int qb = q_block == 16 ? 16 : 128;
+  for (int i = 0; i < nseq; ++i) {
+    mq = q_len[i] > mq ? q_len[i] : mq;
+    for (int q0 = 0; q0 < q_len[i]; q0 += qb) { work.push_back(i); work.push_back(q0); }
+  }
+  a.max_q = mq;
+  if (q_block == 16) {      // the work-list launch (what the engine uses); q_block 0: the plain (x, z) grid
+    T_TRY(up_raw(wk, work.data(), work.size() * 4));
+    a.work = (const int*)wk.p; a.n_work = (int)work.size() / 2;
+  }
+  T_TRY(attention(nullptr, dtype, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dout, dtype, false, out, (size_t)rows * d);
+}
+
 int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float blank_penalty, int blank_id,
                              float* topk_val, int32_t* topk_idx, float* logp) {
   T_TRY(need_gpu());
@@ -195,6 +235,19 @@ int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target
   T_TRY(lse_gather(nullptr, (const float*)dl.p, R, V, V, (const int*)dt.p, (float*)dout.p));
   RVB_HIP_CHECK(hipDeviceSynchronize());
   RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+  return OK;
+}
+
+int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* ptr, const int32_t* target, int P, float* out) {
+  T_TRY(need_gpu());
+  Dev dl, dp, dt, dout;
+  T_TRY(up_raw(dl, logits, (size_t)R * V * 4));
+  T_TRY(up_raw(dp, ptr, (size_t)(R + 1) * 4));
+  T_TRY(up_raw(dt, target, (size_t)P * 4));
+  T_TRY(dout.alloc((size_t)(P > 0 ? P : 1) * 4));
+  T_TRY(lse_gather_multi(nullptr, (const float*)dl.p, R, V, V, (const int*)dp.p, (const int*)dt.p, (float*)dout.p));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  if (P > 0) RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)P * 4, hipMemcpyDeviceToHost));
   return OK;
 }
 

@@ -277,6 +277,13 @@ class Engine:
         return [DecodeResult(tuple(tok[b, :lens[b]].tolist()), float(sc[b]), confidence=float(cf[b]),
                              times=tim[b, :tl[b]].tolist(), tokens_confidence=tc[b, :lens[b]].tolist()) for b in range(B)]
 
+    def rescore_stats(self):
+        """(decoder rows computed, (hypothesis, position) pairs served) of the last rescoring: distinct prefixes vs the
+        padded batch the reference runs."""
+        r, p = C.c_int64(0), C.c_int64(0)
+        check(self.lib.rvb_get_rescore_stats(self.handle, C.byref(r), C.byref(p)))
+        return int(r.value), int(p.value)
+
     def rescore_logp(self, chunk: int, hyp: int, length: int, right: bool = False) -> np.ndarray:
         out = np.empty(length + 1, np.float32)
         check(self.lib.rvb_get_rescore_logp(self.handle, chunk, hyp, 1 if right else 0, fptr(out)))

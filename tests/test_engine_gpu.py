@@ -106,8 +106,12 @@ def test_bf16_engine_within_tolerance(name):
         tot += len(g)
         r = res["attention_rescoring"][b]
         assert len(r.times) == len(r.tokens) or case.js["outputs"]["attention_rescoring"].get("error")
-    # synthetic random-weight models have tiny CTC margins (79 vs 73 tokens under bf16 autocast)
-    assert err <= 0.25 * max(tot, 1), f"token error rate {err}/{tot}"
+    # synthetic random-weight models have tiny CTC margins (79 vs 73 tokens under bf16 autocast); measured on
+    # the long-form goldens (tests/test_longform_gpu.py: 1.5 % on 4 664 tokens for the d=128 model, 4.7 % on 11 417 for
+    # r640); these cases have 66-150 tokens, where one near-tie is 1 %
+    from test_longform_gpu import _record
+    _record(case=name, dtype="bf16", ter={"ctc_greedy_search": [err, tot]})
+    assert err <= 0.12 * max(tot, 1), f"token error rate {err}/{tot}"
     eng.close()
 
 

@@ -253,6 +253,45 @@ def test_attention_decoder_forms(lib, dtype):
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("q_block", [16, 0])
+def test_attention_over_a_hypothesis_trie(lib, dtype, q_block):
+    """Rescoring computes one decoder row per DISTINCT hypothesis prefix: a hypothesis' queries are the rows it adds to
+    the trie (positions q_pos0..), its keys the rows of its whole prefix path (an index list).  Reference: plain causal
+    attention of every hypothesis over its own gathered rows."""
+    heads, dk = 4, 32
+    d = heads * dk
+    rng = np.random.default_rng(3 + q_block)
+    # a trie of 5 hypotheses: rows in creation order; paths share prefixes of different lengths
+    paths = [list(range(0, 90)),                                   # hyp 0 owns rows 0..89 (positions 0..89)
+             list(range(0, 70)) + list(range(90, 110)),            # shares 70, owns 20 (positions 70..89)
+             list(range(0, 70)) + list(range(90, 95)) + [110],     # shares 75 with hyp 1, owns 1 row
+             list(range(0, 3)),                                    # a strict prefix of hyp 0: owns nothing
+             list(range(0, 1)) + list(range(111, 260))]            # shares only <sos>, owns 149 (ten 16-query blocks)
+    rows = 260
+    q, k, v = (rnd(dtype, rng.standard_normal((rows, d))) for _ in range(3))
+    q_start, q_len, q_pos0, kv_start, kv_len, index = [], [], [], [], [], []
+    seen = set()
+    for p in paths:
+        own = [r for r in p if r not in seen]
+        seen.update(p)
+        kv_start.append(len(index)); kv_len.append(len(p)); index += p
+        q_start.append(own[0] if own else 0); q_len.append(len(own)); q_pos0.append(p.index(own[0]) if own else 0)
+        assert own == list(range(q_start[-1], q_start[-1] + len(own))) and own == p[len(p) - len(own):]
+    out = np.empty((rows, d), np.float32)
+    _lib.check(lib.rvb_test_attention_trie(dtype, fptr(q), fptr(k), fptr(v), fptr(out), rows, heads, dk, iptr(i32(q_start)),
+                                           iptr(i32(q_len)), iptr(i32(q_pos0)), iptr(i32(kv_start)), iptr(i32(kv_len)),
+                                           iptr(i32(index)), len(index), len(paths), q_block))
+    ref = np.zeros((rows, d))
+    for p in paths:
+        idx = np.array(p)
+        L = len(p)
+        full = _ref_attention(q[idx], k[idx], v[idx], None, None, None, heads, dk, i32([0]), i32([L]), i32([0]), i32([L]), True)
+        ref[idx] = full                      # shared rows are written several times with the same values
+    tol = 2e-5 if dtype == F32 else 3e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
 @pytest.mark.parametrize("V", [1001, 1000, 10004])
 def test_logsoftmax_topk(lib, V):
     M, k = 37, 10
@@ -276,6 +315,21 @@ def test_logsoftmax_topk(lib, V):
     _lib.check(lib.rvb_test_logsoftmax_topk(fptr(x), M, V, k, 2.5, 0, fptr(tv), iptr(ti), fptr(lp)))
     x2 = x.copy(); x2[:, 0] -= 2.5
     np.testing.assert_allclose(lp, torch.from_numpy(x2).double().log_softmax(-1).numpy(), rtol=0, atol=2e-6)
+
+
+def test_lse_gather_multi_targets_per_row(lib):
+    """CSR form used by the trie rescoring: a row shared by several hypotheses is asked for several targets."""
+    V, R = 10001, 9
+    rng = np.random.default_rng(8)
+    x = f32(rng.standard_normal((R, V)) * 2)
+    counts = [1, 3, 0, 70, 2, 1, 1, 5, 2]            # a row without asks, a row with more asks than lanes
+    ptr = i32(np.concatenate([[0], np.cumsum(counts)]))
+    tgt = i32(rng.integers(0, V, int(ptr[-1])))
+    out = np.full(int(ptr[-1]), np.nan, np.float32)
+    _lib.check(lib.rvb_test_lse_gather_multi(fptr(x), R, V, iptr(ptr), iptr(tgt), int(ptr[-1]), fptr(out)))
+    ref = torch.from_numpy(x).double().log_softmax(-1).numpy()
+    want = np.concatenate([ref[r, tgt[ptr[r]:ptr[r + 1]]] for r in range(R)])
+    np.testing.assert_allclose(out, want, rtol=0, atol=3e-6)
 
 
 @pytest.mark.parametrize("V", [10001, 10004])

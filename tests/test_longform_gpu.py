@@ -92,15 +92,21 @@ def test_small_66_chunks_two_slice_pipeline(dtype):
             assert abs(r.score - g["score"]) <= 2e-2 + 1e-4 * abs(g["score"])
         assert m0["cos"] > 0.999999 and m0["logp_max_abs"] < 2e-3
     else:
-        assert m0["cos"] > 0.999
+        assert m0["cos"] > BF16_COS and m0["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m0["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m0
         for m in MODES:          # measured r2: see the module docstring; bound = measured + margin
             assert ter[m][0] <= BF16_TER_BOUND["small_66"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
     eng.close()
 
 
-# measured bf16 token error rates vs the reference (round 2, profiles/r02_parity_metrics.jsonl) + margin
-BF16_TER_BOUND = {"small_66": 0.25, "r640_chunk": 0.25, "r640_1h": 0.25}
-BF16_LOGP_MEAN_ABS = 5e-2       # CTC log-probs within 5e-2 (mean over frames whose argmax agrees)
+# Measured bf16 token error rates vs the reference (round 2, profiles/r02_parity_metrics.jsonl): small_66 greedy 1.5 % /
+# rescored 3.4 % of 4 666 tokens; r640_1h (the bench workload) greedy 4.7 % of 11 417 / rescored 8.7 % of 13 935;
+# r640_chunk 4/66 and 6/84.  Rescoring is the more sensitive figure: it picks one of ten near-tied hypotheses.  The f32
+# mode of the same engine has 0 edits in all of them.  Bound = measured + margin for box-to-box summation-order noise.
+BF16_TER_BOUND = {"small_66": 0.06, "r640_chunk": 0.15, "r640_1h": 0.12}
+# SURVEY.md 8d asks CTC log-probs within 5e-2 in bf16; measured on the frames whose argmax agrees with the reference:
+# mean 0.009, 99th percentile 0.041, max 0.054 (r640).  Asserted: p99 <= 5e-2 and mean <= 2e-2; encoder cos-sim > 0.9999
+# (measured 0.99998).
+BF16_LOGP_P99_ABS, BF16_LOGP_MEAN_ABS, BF16_COS = 5e-2, 2e-2, 0.9999
 
 
 # ------------------------------------------------------------------------------------------------ r640 (the bench model)
@@ -122,8 +128,7 @@ def test_r640_chunk_against_reference(dtype):
         assert list(res["attention_rescoring"][0].times) == case.golden("attention_rescoring")[0]["times"]
         assert m0["cos"] > 0.999999 and m0["enc_max_abs"] < 5e-3 and m0["logp_max_abs"] < 5e-3
     else:
-        assert m0["cos"] > 0.999, m0
-        assert m0["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m0
+        assert m0["cos"] > BF16_COS and m0["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m0["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m0
         for m in MODES:
             assert ter[m][0] <= BF16_TER_BOUND["r640_chunk"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
     eng.close()
@@ -150,8 +155,7 @@ def test_r640_one_hour_bench_workload_against_reference(dtype):
             assert ter[m][0] <= 0.002 * ter[m][1], f"{m}: {ter[m]}"
         assert m_last["cos"] > 0.99999
     else:
-        assert m_last["cos"] > 0.999, m_last
-        assert m_last["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m_last
+        assert m_last["cos"] > BF16_COS and m_last["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m_last["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m_last
         for m in MODES:
             assert ter[m][0] <= BF16_TER_BOUND["r640_1h"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
     eng.close()
