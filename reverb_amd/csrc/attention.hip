@@ -254,10 +254,10 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       if constexpr (BF) {
         const f32x4_t& x0 = s[2 * kc];
         const f32x4_t& x1 = s[2 * kc + 1];
-        pb.x = (uint32_t)f32_to_bf16(x0[0]) | ((uint32_t)f32_to_bf16(x0[1]) << 16);
-        pb.y = (uint32_t)f32_to_bf16(x0[2]) | ((uint32_t)f32_to_bf16(x0[3]) << 16);
-        pb.z = (uint32_t)f32_to_bf16(x1[0]) | ((uint32_t)f32_to_bf16(x1[1]) << 16);
-        pb.w = (uint32_t)f32_to_bf16(x1[2]) | ((uint32_t)f32_to_bf16(x1[3]) << 16);
+        pb.x = pack2_bf16(x0[0], x0[1]);
+        pb.y = pack2_bf16(x0[2], x0[3]);
+        pb.z = pack2_bf16(x1[0], x1[1]);
+        pb.w = pack2_bf16(x1[2], x1[3]);
       } else {
         const f32x4_t& x0 = s[kc];
         pb = make_uint4(__float_as_uint(x0[0]), __float_as_uint(x0[1]), __float_as_uint(x0[2]), __float_as_uint(x0[3]));
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       if (c0 + 4 <= dk && ((a.o_stride * (int)sizeof(T)) % (BF ? 8 : 16)) == 0) {
         if constexpr (BF) {
           uint2 pk;
-          pk.x = (uint32_t)f32_to_bf16(o[f][0] * inv) | ((uint32_t)f32_to_bf16(o[f][1] * inv) << 16);
-          pk.y = (uint32_t)f32_to_bf16(o[f][2] * inv) | ((uint32_t)f32_to_bf16(o[f][3] * inv) << 16);
+          pk.x = pack2_bf16(o[f][0] * inv, o[f][1] * inv);
+          pk.y = pack2_bf16(o[f][2] * inv, o[f][3] * inv);
           *(uint2*)(orow + c0) = pk;
         } else {
           *(float4*)(orow + c0) = make_float4(o[f][0] * inv, o[f][1] * inv, o[f][2] * inv, o[f][3] * inv);

@@ -17,13 +17,28 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   x.u = ((uint32_t)v) << 16;
   return x.f;
 }
-// round-to-nearest-even (matches torch's float->bfloat16 conversion)
+// round-to-nearest-even (matches torch's float->bfloat16 conversion).  Device code uses the gfx950 conversion instruction
+// (v_cvt_pk_bf16_f32, RNE; one instruction per PAIR through pack2_bf16 below instead of ~8 VALU + a divergent NaN branch
+// per value -- the software form was a third of the attention kernel's instruction stream)
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __bf16 r = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, r);
+#else
   union { uint32_t u; float f; } x;
   x.f = f;
   if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);  // NaN
   x.u += 0x7fffu + ((x.u >> 16) & 1u);
   return (bf16_t)(x.u >> 16);
+#endif
+}
+// two floats -> two bf16 packed in one dword (lo in bits 0..15)
+__device__ inline uint32_t pack2_bf16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
 }
 
 template <typename T> struct Cvt;

@@ -8,6 +8,8 @@
 //   embed_tokens      decoder.py:82-87,157 + embedding.py:73-76
 //   logsoftmax_topk   ctc.py:106-114, asr_model.py:318-329, search.py:111,155
 //   lse_gather        asr_model.py:969 + search.py:417-437 (only the needed log-probs)
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -28,19 +30,21 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
     s_in[i] = (feats[((size_t)b * T0 + 2 * t1 + kh) * F0 + f] - mean[f]) * istd[f];
   }
   __syncthreads();
-  const int ncg = d >> 2;                       // channel groups of 4
+  // a thread owns 8 adjacent output channels (one 16-byte bf16 store, two for f32): full-width stores -- 8-byte
+  // stores reached 3.4 TB/s on the 14.4 GB this kernel writes per hour of audio
+  const int ncg = d >> 3;                       // channel groups of 8
   const int per = ncg < 256 ? ncg : 256;        // groups handled per pass
   const int nslots = 256 / per;                 // f1 slots sharing the block
   const int cgl = threadIdx.x % per, fslot = threadIdx.x / per;
   if (fslot >= nslots) return;
   T* orow = out + ((size_t)b * T1 + t1) * F1 * d;
   for (int cg = cgl; cg < ncg; cg += per) {
-    float wr[4][9], br[4];
+    float wr[8][9], br[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      br[c] = bias[cg * 4 + c];
+    for (int c = 0; c < 8; ++c) {
+      br[c] = bias[cg * 8 + c];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 4 + c) * 9 + k];
+      for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 8 + c) * 9 + k];
     }
     for (int f1 = fslot; f1 < F1; f1 += nslots) {
       float xin[9];
@@ -48,22 +52,20 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) xin[kh * 3 + kw] = s_in[kh * F0 + 2 * f1 + kw];
-      T o[4];
+      float o[8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < 8; ++c) {
         float acc = br[c];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc += wr[c][k] * xin[k];
-        o[c] = Cvt<T>::from_f32(fmaxf(acc, 0.f));
+        o[c] = fmaxf(acc, 0.f);
       }
-      T* dst = orow + (size_t)f1 * d + cg * 4;
+      T* dst = orow + (size_t)f1 * d + cg * 8;
       if constexpr (sizeof(T) == 2) {
-        uint2 pk;
-        pk.x = (uint32_t)(*(uint16_t*)&o[0]) | ((uint32_t)(*(uint16_t*)&o[1]) << 16);
-        pk.y = (uint32_t)(*(uint16_t*)&o[2]) | ((uint32_t)(*(uint16_t*)&o[3]) << 16);
-        *(uint2*)dst = pk;
+        *(uint4*)dst = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
       } else {
-        *(float4*)dst = make_float4(*(float*)&o[0], *(float*)&o[1], *(float*)&o[2], *(float*)&o[3]);
+        ((float4*)dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
+        ((float4*)dst)[1] = make_float4(o[4], o[5], o[6], o[7]);
       }
     }
   }
@@ -73,7 +75,7 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
                     const float* w, const float* b, void* out, int B, int T0, int F0, int d) {
   const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1;
   if (B <= 0 || T1 <= 0) return OK;
-  if (d % 4) { set_error("subsample_conv1: d must be a multiple of 4"); return E_ARG; }
+  if (d % 8) { set_error("subsample_conv1: d must be a multiple of 8"); return E_ARG; }
   dim3 grid(T1, B);
   const size_t sh = 3 * F0 * sizeof(float);
   if (dtype == DT_BF16)
@@ -85,73 +87,139 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row normalisation: one wave64 per row, shuffle reductions, fp32 statistics
+// Row normalisation: a wave64 walks rows (grid-stride), gamma / beta live in registers, the next row's loads are in
+// flight while the current one is reduced and stored; shuffle reductions, fp32 statistics.  Optional second stage:
+// out2 = LN2(result) in the compute dtype -- the encoder's `norm_final` is always followed by the next block's first
+// LayerNorm (or `after_norm`), so the pair is one pass over the row (encoder_layer.py:242-244 -> :199-201).
 // ------------------------------------------------------------------------------------------------
-template <typename OutT, typename AddT>
+template <typename OutT, typename AddT, int NV>
 __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
-  constexpr int NV = 8;  // float4 per lane -> d <= 2048
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.M) return;
   const int d = a.d;
-  const float* x = a.x + (size_t)row * d;
-  float4 v[NV];
-  float sum = 0.f;
+  const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float4 g[NV], be[NV], g2[NV], be2[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    v[i] = c < d ? *(const float4*)(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    const bool ok = c < d;
+    g[i] = ok ? *(const float4*)(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    be[i] = ok ? *(const float4*)(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.out2) {
+      g2[i] = ok ? *(const float4*)(a.gamma2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      be2[i] = ok ? *(const float4*)(a.beta2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  float mean = 0.f, rstd = 1.f;
-  if (a.mode == NORM_LN) {
-    mean = wave_sum(sum) / (float)d;
-    float sq = 0.f;
+  auto load_row = [&](int row, float4* v) {
+    const float* x = a.x + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < d) {
-        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-        sq += dx * dx + dy * dy + dz * dz + dw * dw;
+      v[i] = (row < a.M && c < d) ? *(const float4*)(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float4 v[NV], nx[NV];
+  load_row(wave0, v);
+  for (int row = wave0; row < a.M; row += nwaves) {
+    load_row(row + nwaves, nx);                 // next row of this wave: in flight under the reductions below
+    float mean = 0.f, rstd = 1.f;
+    if (a.mode == NORM_LN) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
+      mean = wave_sum(sum) / (float)d;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+          const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+          sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+      }
+      rstd = rsqrtf(wave_sum(sq) / (float)d + a.eps);
+    }
+    OutT* out = (OutT*)a.out + (size_t)row * d;
+    const AddT* add = a.add ? (const AddT*)a.add + (size_t)row * d : nullptr;
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c >= d) continue;
+      float o[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
+                    (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
+      if (a.silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (sizeof(OutT) == 2) o[e] = o[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * o[e]));
+          else o[e] = o[e] / (1.0f + expf(-o[e]));
+        }
+      }
+      if (add) {
+        if constexpr (sizeof(AddT) == 2) {
+          const uint2 u = *(const uint2*)(add + c);
+          o[0] += bf16_to_f32((bf16_t)(u.x & 0xffffu)); o[1] += bf16_to_f32((bf16_t)(u.x >> 16));
+          o[2] += bf16_to_f32((bf16_t)(u.y & 0xffffu)); o[3] += bf16_to_f32((bf16_t)(u.y >> 16));
+        } else {
+          const float4 u = *(const float4*)(add + c);
+          o[0] += u.x; o[1] += u.y; o[2] += u.z; o[3] += u.w;
+        }
+      }
+      if constexpr (sizeof(OutT) == 2) {
+        *(uint2*)(out + c) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+      } else {
+        *(float4*)(out + c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      v[i] = make_float4(o[0], o[1], o[2], o[3]);      // kept for the second stage
+      sum2 += o[0] + o[1] + o[2] + o[3];
+    }
+    if (a.out2) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
+      const float mean2 = wave_sum(sum2) / (float)d;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+          const float dx = v[i].x - mean2, dy = v[i].y - mean2, dz = v[i].z - mean2, dw = v[i].w - mean2;
+          sq += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+      }
+      const float rstd2 = rsqrtf(wave_sum(sq) / (float)d + a.eps2);
+      AddT* o2 = (AddT*)a.out2 + (size_t)row * d;      // AddT is the compute dtype
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c >= d) continue;
+        const float q0 = (v[i].x - mean2) * rstd2 * g2[i].x + be2[i].x, q1 = (v[i].y - mean2) * rstd2 * g2[i].y + be2[i].y;
+        const float q2 = (v[i].z - mean2) * rstd2 * g2[i].z + be2[i].z, q3 = (v[i].w - mean2) * rstd2 * g2[i].w + be2[i].w;
+        if constexpr (sizeof(AddT) == 2) *(uint2*)(o2 + c) = make_uint2(pack2_bf16(q0, q1), pack2_bf16(q2, q3));
+        else *(float4*)(o2 + c) = make_float4(q0, q1, q2, q3);
       }
     }
-    rstd = rsqrtf(wave_sum(sq) / (float)d + a.eps);
-  }
-  OutT* out = (OutT*)a.out + (size_t)row * d;
-  const AddT* add = a.add ? (const AddT*)a.add + (size_t)row * d : nullptr;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c >= d) continue;
-    const float4 g = *(const float4*)(a.gamma + c);
-    const float4 be = *(const float4*)(a.beta + c);
-    float o[4] = {(v[i].x - mean) * rstd * g.x + be.x, (v[i].y - mean) * rstd * g.y + be.y,
-                  (v[i].z - mean) * rstd * g.z + be.z, (v[i].w - mean) * rstd * g.w + be.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (a.silu) o[e] = o[e] / (1.0f + expf(-o[e]));
-      if (add) o[e] += Cvt<AddT>::to_f32(add[c + e]);
-    }
-    if constexpr (sizeof(OutT) == 2) {
-      uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-      *(uint2*)(out + c) = pk;
-    } else {
-      *(float4*)(out + c) = make_float4(o[0], o[1], o[2], o[3]);
-    }
+    for (int i = 0; i < NV; ++i) v[i] = nx[i];
   }
+}
+
+template <typename OutT, typename AddT>
+static void launch_rownorm(hipStream_t s, const NormArgs& a) {
+  // enough waves to cover the latency of a row's loads, few enough that gamma / beta are fetched once per many rows
+  const int blocks = std::min(cdiv(a.M, 4), 256 * 8);
+  if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2>), dim3(blocks), dim3(256), 0, s, a);
+  else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
   if (a.M <= 0) return OK;
   if (a.d % 4 || a.d > 2048) { set_error("rownorm: d must be a multiple of 4 and <= 2048"); return E_ARG; }
-  dim3 grid(cdiv(a.M, 4));
+  if (a.out2 && (a.mode != NORM_LN || !(a.out_f32 || dtype == DT_F32))) {
+    set_error("rownorm: the fused second LayerNorm follows a LayerNorm with fp32 output"); return E_ARG;
+  }
   if (dtype == DT_BF16) {
-    if (a.out_f32) hipLaunchKernelGGL((rownorm_kernel<float, bf16_t>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rownorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+    if (a.out_f32) launch_rownorm<float, bf16_t>(s, a);
+    else launch_rownorm<bf16_t, bf16_t>(s, a);
   } else {
-    hipLaunchKernelGGL((rownorm_kernel<float, float>), grid, dim3(256), 0, s, a);
+    launch_rownorm<float, float>(s, a);
   }
   RVB_HIP_CHECK(hipGetLastError());
   return OK;

@@ -218,10 +218,12 @@ static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void
   return gemm(e->stream, e->dtype, g);
 }
 static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bool out_f32, int M, int d,
-                    int mode = NORM_LN, int silu = 0, const void* add = nullptr) {
+                    int mode = NORM_LN, int silu = 0, const void* add = nullptr, const LNorm* second = nullptr,
+                    void* out2 = nullptr) {
   NormArgs a;
   a.x = x; a.gamma = n.g.as<float>(); a.beta = n.b.as<float>(); a.eps = n.eps; a.mode = mode; a.silu = silu;
   a.add = add; a.out = out; a.out_f32 = out_f32 ? 1 : 0; a.M = M; a.d = d;
+  if (second) { a.gamma2 = second->g.as<float>(); a.beta2 = second->b.as<float>(); a.eps2 = second->eps; a.out2 = out2; }
   Scope sc(e, "rownorm");
   return rownorm(e->stream, e->dtype, a);
 }
@@ -391,11 +393,12 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
 }
 
 // ------------------------------------------------------------------------------------ encoder
-static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
+// One conformer block.  On entry e->xn already holds norm_ff_macaron(x) (written by the previous block's fused final
+// norm, or by encode_impl for the first block); on exit the block has written `next`(x) to next_out the same way.
+static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const LNorm& next, void* next_out) {
   const int d = e->cfg.d_model, ff = e->cfg.ffn_dim, heads = e->cfg.heads, dk = d / heads;
   float* x = e->x.as<float>();
   // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
-  RVB_TRY(run_norm(e, x, L.n_ffm, e->xn.p, false, M, d));
   RVB_TRY(run_gemm(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, false, 1.f, ACT_SILU));
   RVB_TRY(run_gemm(e, e->h.p, ff, L.ffm2, x, d, M, true, 0.5f, ACT_NONE, x, d));
   // rel-pos self attention: x += MHSA(LN(x))              encoder_layer.py:208-216
@@ -439,7 +442,9 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T) {
   }
   RVB_TRY(run_gemm(e, ffin, d, L.ff1, e->h.p, ff, M, false, 1.f, ACT_SILU));
   RVB_TRY(run_gemm(e, e->h.p, ff, L.ff2, x, d, M, true, 0.5f, ACT_NONE, x, d));
-  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr));
+  // x = norm_final(x) (+ y for the language-specific block, encoder_layer.py:400), and in the same pass the LayerNorm
+  // that always reads it next: the following block's norm_ff_macaron, or the encoder's after_norm (encoder.py:147-148)
+  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr, &next, next_out));
   return OK;
 }
 
@@ -543,9 +548,12 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
       RVB_TRY(gemm(e->stream, e->dtype, g));
     }
     RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, m, true, std::sqrt((float)d)));
-    for (auto& L : e->enc) RVB_TRY(encoder_layer(e, L, m, nb, T2));
     void* eo = (char*)e->enc_out.p + (size_t)row0 * d * es;
-    RVB_TRY(run_norm(e, e->x.as<float>(), e->enc_after, eo, false, m, d));
+    RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, m, d));
+    for (size_t li = 0; li < e->enc.size(); ++li) {
+      const bool last = li + 1 == e->enc.size();
+      RVB_TRY(encoder_layer(e, e->enc[li], m, nb, T2, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p));
+    }
     // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
     for (int r0 = 0; r0 < m; r0 += LOGIT_SLAB) {
       const int rows = std::min(LOGIT_SLAB, m - r0);

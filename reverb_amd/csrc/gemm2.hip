@@ -26,7 +26,7 @@ static constexpr int B2M = 256, B2N = 256;
 static constexpr int ROW2 = 128;                         // bytes of K per tile row
 static constexpr int STAGE2 = (B2M + B2N) * ROW2;        // 64 KiB
 static constexpr int GEMM2_LDS = 2 * STAGE2;             // 128 KiB
-static constexpr int GEMM2_DEFAULT_FLAGS = 0, GEMM2_DEFAULT_GROUP_M = 0;
+static constexpr int GEMM2_DEFAULT_FLAGS = 0, GEMM2_DEFAULT_GROUP_M = 8;   // measured r2 (gpurun_out/s2): group_m 8 -0.9 % of the step, priority -0.3 %, 32x32x16 MFMAs +3.4 %
 
 __device__ inline float act_apply2(float v, int act) {
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
@@ -395,14 +395,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
           }
           if constexpr (sizeof(OutT) == 2) {
             uint4 o0, o1;
-            o0.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o0.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            o0.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-            o0.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-            o1.x = (uint32_t)f32_to_bf16(v[8]) | ((uint32_t)f32_to_bf16(v[9]) << 16);
-            o1.y = (uint32_t)f32_to_bf16(v[10]) | ((uint32_t)f32_to_bf16(v[11]) << 16);
-            o1.z = (uint32_t)f32_to_bf16(v[12]) | ((uint32_t)f32_to_bf16(v[13]) << 16);
-            o1.w = (uint32_t)f32_to_bf16(v[14]) | ((uint32_t)f32_to_bf16(v[15]) << 16);
+            o0.x = pack2_bf16(v[0], v[1]);
+            o0.y = pack2_bf16(v[2], v[3]);
+            o0.z = pack2_bf16(v[4], v[5]);
+            o0.w = pack2_bf16(v[6], v[7]);
+            o1.x = pack2_bf16(v[8], v[9]);
+            o1.y = pack2_bf16(v[10], v[11]);
+            o1.z = pack2_bf16(v[12], v[13]);
+            o1.w = pack2_bf16(v[14], v[15]);
             ((uint4*)cp)[0] = o0;
             ((uint4*)cp)[1] = o1;
           } else {

@@ -66,6 +66,11 @@ struct NormArgs {
   void* out;           // T or fp32 [M, d]
   int out_f32;
   int M, d;
+  // optional second stage (NORM_LN only): out2 = LayerNorm(result; gamma2, beta2, eps2) as T [M, d]
+  const float* gamma2 = nullptr;
+  const float* beta2 = nullptr;
+  float eps2 = 0.f;
+  void* out2 = nullptr;
 };
 int rownorm(hipStream_t s, int dtype, const NormArgs& a);
 

@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void emb_conv1_kernel(const float* __restrict_
     T* o = out + (((size_t)b * (F + 2) + f + 1) * (NT_ + 2) + t + 1) * C + cg * CG;
     if constexpr (sizeof(T) == 2) {
       uint4 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-      pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+      pk.x = pack2_bf16(v[0], v[1]);
+      pk.y = pack2_bf16(v[2], v[3]);
+      pk.z = pack2_bf16(v[4], v[5]);
+      pk.w = pack2_bf16(v[6], v[7]);
       *(uint4*)o = pk;
     } else {
       ((float4*)o)[0] = make_float4(v[0], v[1], v[2], v[3]);
