@@ -25,14 +25,18 @@ namespace rvb {
 
 static constexpr int KT = 64;     // keys per tile
 
-template <typename T, int DKP>
+template <typename T, int DKP, bool HAS_POS>
 struct AttnLds {
+  static constexpr bool BF = sizeof(T) == 2;
   static constexpr int ROW_K = DKP * (int)sizeof(T) + 16;   // K / P rows (bytes)
-  static constexpr int ROW_V = KT * (int)sizeof(T) + 16;    // V^T rows (bytes)
+  // f32: V^T rows [dim][key] written transposed.  bf16: V rows [key][dim] as they come (one 16-byte store per staged
+  // vector) and the transposition happens in the LDS read (ds_read_b64_tr_b16); the 32-byte pad makes the eight rows a
+  // 32-lane half touches start 40 banks apart (DKP = 64): conflict-free.
+  static constexpr int ROW_V = BF ? DKP * 2 + 32 : KT * (int)sizeof(T) + 16;
   static constexpr int OFF_K = 0;
   static constexpr int OFF_P = OFF_K + KT * ROW_K;
-  static constexpr int OFF_V = OFF_P + KT * ROW_K;
-  static constexpr int TOTAL = OFF_V + DKP * ROW_V;
+  static constexpr int OFF_V = HAS_POS ? OFF_P + KT * ROW_K : OFF_P;     // no positional keys: no P tile
+  static constexpr int TOTAL = OFF_V + (BF ? KT : DKP) * ROW_V;
 };
 
 // NW = waves per workgroup (16 queries each): 8 for the encoder and the cross attention (128-query blocks share a
@@ -41,7 +45,7 @@ template <typename T, int DKP, bool HAS_POS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   constexpr int QT = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = AttnLds<T, DKP>;
+  using L = AttnLds<T, DKP, HAS_POS>;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int VE = Mma16<T>::VE;
   constexpr int KC = Mma16<T>::KC;
@@ -159,11 +163,15 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
         const int r = i / VPR, c = i - r * VPR;
         *(uint4*)(sK + r * L::ROW_K + c * 16) = rk[n];
         if constexpr (HAS_POS) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
-        T tv[VE];
-        *(uint4*)tv = rv[n];
-        const int kcol = r ^ ((c & 7) << 2);
+        if constexpr (BF) {
+          *(uint4*)(sV + r * L::ROW_V + c * 16) = rv[n];
+        } else {
+          T tv[VE];
+          *(uint4*)tv = rv[n];
+          const int kcol = r ^ ((c & 7) << 2);
 #pragma unroll
-        for (int e = 0; e < VE; ++e) *(T*)(sV + (c * VE + e) * L::ROW_V + kcol * sizeof(T)) = tv[e];
+          for (int e = 0; e < VE; ++e) *(T*)(sV + (c * VE + e) * L::ROW_V + kcol * sizeof(T)) = tv[e];
+        }
       }
     }
   };
@@ -269,9 +277,15 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
         const int swz = ((dim / VE) & 7) << 2;          // same key-group swizzle as the transposed store
         uint4 va;
         if constexpr (BF) {
-          const uint2 lo = *(const uint2*)(vrow + ((32 * kc + 4 * lgrp) ^ swz) * 2);
-          const uint2 hi = *(const uint2*)(vrow + ((32 * kc + 16 + 4 * lgrp) ^ swz) * 2);
-          va = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          // transpose read: the 16 lanes of a group pass the addresses of the 8-byte pieces of a [4 keys][16 dims] block
+          // (lane i: key i>>2, dims 4*(i&3)..+3) and lane i receives column i = dim 16f + lrow of the four keys -- its
+          // A-operand share for k slots (lgrp, 0..3); a second read 16 keys on fills slots (lgrp, 4..7)
+          typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+          const char* vb = sV + (32 * kc + 4 * lgrp + (lrow >> 2)) * L::ROW_V + (f * 16 + 4 * (lrow & 3)) * 2;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)vb);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + 16 * L::ROW_V));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          va = make_uint4(l2.x, l2.y, h2.x, h2.y);
         } else {
           va = *(const uint4*)(vrow + ((16 * kc + 4 * lgrp) ^ swz) * 4);
         }
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
 
 template <typename T, int DKP, bool HAS_POS, int NW>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
-  using L = AttnLds<T, DKP>;
+  using L = AttnLds<T, DKP, HAS_POS>;
   static bool attr_set = false;
   auto kern = attn_kernel<T, DKP, HAS_POS, NW>;
   if (!attr_set) {

@@ -180,6 +180,33 @@ def test_embedding_bf16_close_to_oracle(case, emb_case):
     eng.close()
 
 
+def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch):
+    """conv_gemm.hip (stages 3-4 of the ResNet34, default) against resnet.hip's direct convolution kernel on the same
+    bf16 weights and inputs: the two differ only in fp32 summation order, so the embeddings agree far tighter than
+    either does with the fp32 oracle; the timing keys prove that both kernels really ran."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, flops, ig = {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_IGEMM", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        flops[flag] = eng.timing("emb_conv_128")[1] + eng.timing("emb_conv_256")[1]
+        ig[flag] = eng.timing("emb_conv_igemm")[2]
+        eng.close()
+    assert flops["0"] == flops["1"] > 0
+    assert ig["0"] == 0 and ig["1"] >= 16          # 11 + 5 stride-1 3x3 convolutions of stages 3-4 per trunk pass
+    active = emb_case["masks"].sum(1) > 0
+    a, b = out["0"][active], out["1"][active]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() > 0.9995, cos
+    want = emb_case["want"][active]
+    cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
+    assert cosw.min() > 0.995, cosw
+
+
 # ------------------------------------------------------------------------------------ clustering on the GPU
 @pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3)])
 def test_centroid_linkage_matches_scipy(case, n, d, seed):
