@@ -102,6 +102,19 @@ int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks);
  * lens: valid input frames per chunk (feats_batcher, cli/reverb.py:148-180). */
 int rvb_encode(rvb_engine* e, const float* feats, int64_t first_chunk, const int32_t* lens, int B, int T0,
                int beam, float blank_penalty);
+/* Streaming encoder: BaseEncoder.forward_chunk / forward_chunk_by_chunk (asr/wenet/transformer/encoder.py:231-402) for
+ * one stream.  rvb_stream_begin empties the attention cache; rvb_stream_chunk encodes one chunk of `n_frames` input frames
+ * ((chunk-1)*4 + 7 for a full chunk, encoder.py:378-381) against the cached keys / values of earlier chunks, positional keys
+ * at absolute frame positions, and keeps the last `required_cache_size` frames (< 0: all, 0: none) as forward_chunk does;
+ * `out` (nullable) receives the chunk's encoder output [n_out, d] fp32.  The cache lives in the engine (the reference
+ * returns att_cache / cnn_cache tensors; models with a non-causal convolution module have no cnn cache).
+ * rvb_stream_finish runs the CTC head + top-k over all frames produced and makes them the current batch (one "chunk"), so
+ * that rvb_ctc_greedy / rvb_ctc_prefix_beam / rvb_attention_rescore / rvb_get_encoder_out work on the streamed output --
+ * ASRModel.decode(simulate_streaming=True) (asr_model.py:301-306). */
+int rvb_stream_begin(rvb_engine* e);
+int rvb_stream_chunk(rvb_engine* e, const float* feats, int n_frames, int required_cache_size, float* out, int32_t* n_out);
+int rvb_stream_state(rvb_engine* e, int32_t* offset, int32_t* cache_frames);
+int rvb_stream_finish(rvb_engine* e, int beam, float blank_penalty);
 int rvb_encoder_frames(rvb_engine* e, int32_t* T_out);                 /* encoder frames per chunk (512) */
 int rvb_get_encoder_lens(rvb_engine* e, int32_t* lens /* [B] */);      /* encoder_mask.sum (asr_model.py:387) */
 int rvb_get_encoder_out(rvb_engine* e, float* out /* [B,T,d] */);      /* parity tap */

@@ -187,6 +187,79 @@ def encoder_forward(sd: SD, cfg: dict, feats: torch.Tensor, feats_lens: torch.Te
     return x, masks
 
 
+# --------------------------------------------------------------------------- streaming encoder
+def encoder_forward_chunk(sd: SD, cfg: dict, xs: torch.Tensor, offset: int, required_cache_size: int, att_cache,
+                          cat_embs: torch.Tensor):
+    """BaseEncoder.forward_chunk (transformer/encoder.py:231-341) for models whose convolution module is not causal
+    (lorder = 0: no cnn cache, convolution.py:118-123).  xs (1, time, 80); att_cache: None or a list with one
+    (k, v) pair of (1, h, cache_t1, dk) tensors per layer.  Returns (ys (1, chunk, d), new att_cache)."""
+    ec = cfg["encoder_conf"]
+    h, nb, norm = ec["attention_heads"], ec["num_blocks"], ec.get("cnn_module_norm", "batch_norm")
+    assert xs.shape[0] == 1 and not ec.get("causal", False)
+    x = global_cmvn(sd, xs)
+    fake = torch.ones(1, 1, xs.shape[1], dtype=torch.bool)
+    x, _, _ = conv2d_subsampling4(sd, x, fake)                      # x * sqrt(d); pos_emb is recomputed below
+    d = x.shape[-1]
+    chunk = x.shape[1]
+    cache_t1 = 0 if att_cache is None else att_cache[0][0].shape[2]
+    key_size = cache_t1 + chunk
+    pos_emb = sinusoid_pe(offset + chunk, d)[offset - cache_t1:offset + chunk].unsqueeze(0)     # encoder.py:305-306
+    if required_cache_size < 0:
+        start = 0
+    elif required_cache_size == 0:
+        start = key_size
+    else:
+        start = max(key_size - required_cache_size, 0)
+    has_lsl = "encoder.encoders.0.language_layers.0.weight" in sd
+    dk = d // h
+    new_cache = []
+    for i in range(nb):
+        p = f"encoder.encoders.{i}"
+        is_lsl = has_lsl and i in (0, nb - 1)
+        x = x + 0.5 * ffn(sd, p + ".feed_forward_macaron", _ln(sd, p + ".norm_ff_macaron", x, 1e-5), F.silu)
+        # attention.py:317-399 with the cache branch :361-369 and no mask (fake (0,0,0) att_mask, :112)
+        z = _ln(sd, p + ".norm_mha", x, 1e-5)
+        a = p + ".self_attn"
+        q = _lin(sd, a + ".linear_q", z).view(1, chunk, h, dk)
+        k = _lin(sd, a + ".linear_k", z).view(1, chunk, h, dk).transpose(1, 2)
+        v = _lin(sd, a + ".linear_v", z).view(1, chunk, h, dk).transpose(1, 2)
+        if att_cache is not None:
+            k = torch.cat([att_cache[i][0], k], dim=2)
+            v = torch.cat([att_cache[i][1], v], dim=2)
+        new_cache.append((k[:, :, start:], v[:, :, start:]))
+        pp = F.linear(pos_emb, sd[a + ".linear_pos.weight"]).view(1, -1, h, dk).transpose(1, 2)
+        q_u = (q + sd[a + ".pos_bias_u"]).transpose(1, 2)
+        q_v = (q + sd[a + ".pos_bias_v"]).transpose(1, 2)
+        scores = (torch.matmul(q_u, k.transpose(-2, -1)) + torch.matmul(q_v, pp.transpose(-2, -1))) / math.sqrt(dk)
+        o = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).contiguous().view(1, chunk, d)
+        x = x + _lin(sd, a + ".linear_out", o)
+        x = x + conv_module(sd, p + ".conv_module", _ln(sd, p + ".norm_conv", x, 1e-5), torch.ones(1, 1, chunk, dtype=torch.bool), norm)
+        residual = x
+        z = _ln(sd, p + ".norm_ff", x, 1e-5)
+        if is_lsl:
+            y = lsl_mix(sd, p, z, cat_embs)
+            x = _ln(sd, p + ".norm_final", residual + 0.5 * ffn(sd, p + ".feed_forward", y, F.silu), 1e-5) + y
+        else:
+            x = _ln(sd, p + ".norm_final", residual + 0.5 * ffn(sd, p + ".feed_forward", z, F.silu), 1e-5)
+    return _ln(sd, "encoder.after_norm", x, 1e-5), new_cache
+
+
+def encoder_forward_chunk_by_chunk(sd: SD, cfg: dict, xs: torch.Tensor, decoding_chunk_size: int,
+                                   num_decoding_left_chunks: int, cat_embs: torch.Tensor):
+    """BaseEncoder.forward_chunk_by_chunk (encoder.py:343-402).  xs (1, T, 80) -> (1, T', d), final cache length."""
+    assert decoding_chunk_size > 0
+    subsampling, context = 4, 7
+    stride = subsampling * decoding_chunk_size
+    window = (decoding_chunk_size - 1) * subsampling + context
+    required = decoding_chunk_size * num_decoding_left_chunks
+    cache, outs, offset = None, [], 0
+    for cur in range(0, xs.shape[1] - context + 1, stride):
+        y, cache = encoder_forward_chunk(sd, cfg, xs[:, cur:min(cur + window, xs.shape[1])], offset, required, cache, cat_embs)
+        outs.append(y)
+        offset += y.shape[1]
+    return torch.cat(outs, 1), (0 if cache is None else cache[0][0].shape[2])
+
+
 def ctc_logprobs(sd: SD, enc: torch.Tensor, blank_penalty: float = 0.0, blank_id: int = 0):
     """asr_model.py:318-329 + ctc.py:106-114."""
     logits = _lin(sd, "ctc.ctc_lo", enc)

@@ -52,6 +52,10 @@ SIGNATURES = {
     "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_encode": (C.c_int, [_eng, _f32p, C.c_int64, _i32p, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "rvb_stream_begin": (C.c_int, [_eng]),
+    "rvb_stream_chunk": (C.c_int, [_eng, _f32p, C.c_int, C.c_int, _f32p, _i32p]),
+    "rvb_stream_state": (C.c_int, [_eng, _i32p, _i32p]),
+    "rvb_stream_finish": (C.c_int, [_eng, C.c_int, C.c_float]),
     "rvb_encoder_frames": (C.c_int, [_eng, _i32p]),
     "rvb_get_encoder_lens": (C.c_int, [_eng, _i32p]),
     "rvb_get_encoder_out": (C.c_int, [_eng, _f32p]),

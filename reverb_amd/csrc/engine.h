@@ -115,6 +115,15 @@ struct rvb_engine {
   rvb::DevBuf d_hq_pos0, d_hpath_start, d_hpath_len, d_path, d_work, d_tgt_ptr;    // rescoring over the hypothesis trie
   int64_t rescore_rows = 0, rescore_pairs = 0;      // decoder rows computed / (hypothesis, position) pairs served, last call
 
+  // ---- streaming encoder (forward_chunk with caches, encoder.py:231-402) ----
+  struct StreamState {
+    bool active = false;
+    int offset = 0;                 // encoder frames produced so far (`offset` of forward_chunk)
+    int cache_len = 0;              // frames in the attention cache (cache_t1)
+    std::vector<rvb::DevBuf> kv, kv2;   // per layer T [pe_rows][2d]: key | value rows of the cached frames (+ spare for trimming)
+  } stream_st;
+  rvb::DevBuf d_stream_i32;         // {kv_start = 0, kv_len = cache + chunk}
+
   // ---- profiling ----
   int profiling = 0;     // 0 off, 1 every stage, 2 GEMM launches only (what the roofline needs; half the events)
   std::map<std::string, rvb::ProfEntry> prof;

@@ -302,7 +302,8 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
 
     // sinusoid table for encoder positions and decoder positions
     const int Tmax = out_frames(c.chunk_frames);
-    e->pe_rows = std::max(Tmax + 2, 64);
+    // 5000 rows = the reference's positional table (`max_len`, embedding.py:33,130): streaming offsets index it absolutely
+    e->pe_rows = std::max(Tmax + 2, 5000);
     std::vector<float> pe;
     make_pe(e->pe_rows, d, &pe);
     RVB_TRY(upload_f32(e, e->pe_f32, pe.data(), pe.size()));
@@ -395,7 +396,9 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
 // ------------------------------------------------------------------------------------ encoder
 // One conformer block.  On entry e->xn already holds norm_ff_macaron(x) (written by the previous block's fused final
 // norm, or by encode_impl for the first block); on exit the block has written `next`(x) to next_out the same way.
-static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const LNorm& next, void* next_out) {
+// `li` >= 0 selects the streaming form (forward_chunk, encoder.py:231-341): this chunk's keys / values are appended to
+// layer li's cache and attention runs over cache + chunk, positional keys taken at the frames' absolute positions.
+static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const LNorm& next, void* next_out, int li = -1) {
   const int d = e->cfg.d_model, ff = e->cfg.ffn_dim, heads = e->cfg.heads, dk = d / heads;
   float* x = e->x.as<float>();
   // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
@@ -417,7 +420,21 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const 
     a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->cur_lens;
     a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
     a.chunk = e->dec_chunk; a.left = e->dec_left;          // add_optional_chunk_mask, encoder.py:140-145
-    Scope sc(e, "attention", 6.0 * B * (double)T * T * d);
+    double keys = T;
+    if (li >= 0) {
+      // attention.py:361-369: k = cat(key_cache, k), v = cat(value_cache, v); pos_emb = position_encoding(offset -
+      // cache_t1, cache_t1 + chunk) (encoder.py:305-306), no mask (att_mask is the fake (0,0,0) one)
+      auto& st = e->stream_st;
+      char* kvb = (char*)st.kv[li].p;
+      RVB_HIP_CHECK(hipMemcpy2DAsync(kvb + (size_t)st.cache_len * 2 * d * es, (size_t)2 * d * es, (const char*)e->h.p + (size_t)d * es,
+                                     (size_t)3 * d * es, (size_t)2 * d * es, M, hipMemcpyDeviceToDevice, e->stream));
+      a.k = kvb; a.v = kvb + (size_t)d * es; a.k_stride = a.v_stride = 2 * d;
+      a.p = (const char*)L.pos_keys.p + (size_t)(st.offset - st.cache_len) * d * es;
+      a.kv_start = e->d_stream_i32.as<int>(); a.kv_len = e->d_stream_i32.as<int>() + 1;
+      a.chunk = 0; a.left = -1;
+      keys = st.cache_len + M;
+    }
+    Scope sc(e, "attention", 6.0 * B * (double)T * keys * d);
     RVB_TRY(attention(e->stream, e->dtype, a));
   }
   RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
@@ -583,6 +600,152 @@ static int wait_slices(rvb_engine* e, int i) {
     e->slice_event_pool.push_back(sl.ev);
     sl.done = true;
   }
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ streaming encoder
+// BaseEncoder.forward_chunk / forward_chunk_by_chunk (encoder.py:231-402) for one stream: the attention cache (keys
+// and values of the frames already seen, per layer) lives in the engine; the reference hands it back and forth as
+// a tensor.  Non-causal convolution modules carry no cnn cache (lorder = 0, convolution.py:118-123): the depthwise
+// convolution sees zeros beyond the chunk, exactly as the reference's Conv1d padding does.
+static int stream_begin_impl(rvb_engine* e) {
+  if (!e->finalized) { set_error("rvb_stream_begin before rvb_finalize"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(wait_slices(e, -1));
+  const int d = e->cfg.d_model;
+  const size_t es = dt_size(e->dtype);
+  auto& st = e->stream_st;
+  st.kv.resize(e->enc.size()); st.kv2.resize(e->enc.size());
+  for (size_t l = 0; l < e->enc.size(); ++l) {
+    RVB_TRY(st.kv[l].ensure((size_t)e->pe_rows * 2 * d * es));
+    RVB_TRY(st.kv2[l].ensure((size_t)e->pe_rows * 2 * d * es));
+  }
+  RVB_TRY(e->enc_out.ensure((size_t)e->pe_rows * d * es));
+  st.active = true; st.offset = 0; st.cache_len = 0;
+  e->B = 0; e->nbest.clear(); e->rescored.clear(); e->slices.clear();
+  return OK;
+}
+
+static int stream_chunk_impl(rvb_engine* e, const float* feats, int T0, int required_cache_size, float* out, int32_t* n_out) {
+  const rvb_model_cfg& c = e->cfg;
+  auto& st = e->stream_st;
+  if (!st.active) { set_error("rvb_stream_chunk before rvb_stream_begin"); return E_STATE; }
+  if (T0 < 7) { set_error("rvb_stream_chunk: a chunk needs at least 7 input frames (Conv2dSubsampling4)"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int d = c.d_model, F0 = c.input_dim;
+  const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  const int M = T2;
+  const size_t es = dt_size(e->dtype);
+  if (st.offset + M > e->pe_rows) {
+    set_error("rvb_stream_chunk: more than " + std::to_string(e->pe_rows) + " encoder frames in one stream (the reference's positional "
+              "table has max_len 5000 rows, embedding.py:33)");
+    return E_UNSUPPORTED;
+  }
+  RVB_TRY(e->X1.ensure((size_t)T1 * F1 * d * es));
+  RVB_TRY(e->X2.ensure((size_t)T2 * F2 * d * es));
+  RVB_TRY(e->x.ensure((size_t)M * d * 4));
+  RVB_TRY(e->xn.ensure((size_t)M * d * es));
+  RVB_TRY(e->y.ensure((size_t)M * d * es));
+  RVB_TRY(e->ao.ensure((size_t)M * d * es));
+  RVB_TRY(e->dconv.ensure((size_t)M * d * 4));
+  RVB_TRY(e->h.ensure((size_t)M * std::max(c.ffn_dim, 3 * d) * es));
+  RVB_TRY(upload_f32(e, e->d_feats_in, feats, (size_t)T0 * F0));
+  const int32_t zero = 0, mm = M, kv[2] = {0, st.cache_len + M};
+  RVB_TRY(upload_i32(e, e->d_seq_start, &zero, 1));
+  RVB_TRY(upload_i32(e, e->d_seq_len, &mm, 1));
+  RVB_TRY(upload_i32(e, e->d_enc_lens, &mm, 1));
+  RVB_TRY(upload_i32(e, e->d_stream_i32, kv, 2));
+  e->cur_lens = e->d_enc_lens.as<int>();
+  {
+    Scope sc(e, "subsample");
+    RVB_TRY(subsample_conv1(e->stream, e->dtype, e->d_feats_in.as<float>(), e->cmvn_mean.as<float>(), e->cmvn_istd.as<float>(),
+                            e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, 1, T0, F0, d));
+  }
+  {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
+    g.M = T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
+    g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
+    Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
+    RVB_TRY(gemm(e->stream, e->dtype, g));
+  }
+  RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, M, true, std::sqrt((float)d)));
+  void* eo = (char*)e->enc_out.p + (size_t)st.offset * d * es;
+  RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, M, d));
+  for (size_t li = 0; li < e->enc.size(); ++li) {
+    const bool last = li + 1 == e->enc.size();
+    RVB_TRY(encoder_layer(e, e->enc[li], M, 1, M, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p, (int)li));
+  }
+  if (out) {
+    if (e->dtype == DT_F32) {
+      RVB_HIP_CHECK(hipMemcpyAsync(out, eo, (size_t)M * d * 4, hipMemcpyDeviceToHost, e->stream));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    } else {
+      std::vector<bf16_t> tmp((size_t)M * d);
+      RVB_HIP_CHECK(hipMemcpyAsync(tmp.data(), eo, tmp.size() * 2, hipMemcpyDeviceToHost, e->stream));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+      for (size_t i = 0; i < tmp.size(); ++i) out[i] = bf16_to_f32(tmp[i]);
+    }
+  }
+  // r_att_cache = new_att_cache[:, :, next_cache_start:, :] (encoder.py:307-312,331)
+  const int key_size = st.cache_len + M;
+  int start = 0;
+  if (required_cache_size == 0) start = key_size;
+  else if (required_cache_size > 0) start = std::max(key_size - required_cache_size, 0);
+  const int keep = key_size - start;
+  if (start > 0 && keep > 0) {
+    for (size_t l = 0; l < e->enc.size(); ++l) {
+      RVB_HIP_CHECK(hipMemcpyAsync(st.kv2[l].p, (const char*)st.kv[l].p + (size_t)start * 2 * d * es, (size_t)keep * 2 * d * es,
+                                   hipMemcpyDeviceToDevice, e->stream));
+      std::swap(st.kv[l], st.kv2[l]);
+    }
+  }
+  st.cache_len = keep;
+  st.offset += M;
+  if (n_out) *n_out = M;
+  return OK;
+}
+
+// CTC head + top-k over everything the stream produced: from here on the stream is one encoded "chunk" of st.offset
+// frames and the search entry points work on it (ASRModel._forward_encoder with simulate_streaming, asr_model.py:301-306)
+static int stream_finish_impl(rvb_engine* e, int beam, float blank_penalty) {
+  const rvb_model_cfg& c = e->cfg;
+  auto& st = e->stream_st;
+  if (!st.active) { set_error("rvb_stream_finish before rvb_stream_begin"); return E_STATE; }
+  if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_stream_finish: beam must be in [1,16]"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  const int d = c.d_model, V = c.vocab, M = st.offset;
+  const size_t es = dt_size(e->dtype);
+  if (M <= 0) { set_error("rvb_stream_finish: the stream produced no encoder frame"); return E_STATE; }
+  e->B = 1; e->T2 = M; e->beam = beam; e->T0 = 0;
+  e->in_lens.assign(1, 0); e->enc_lens.assign(1, M);
+  e->nbest.clear(); e->rescored.clear();
+  const int Vld = (V + 3) & ~3;
+  RVB_TRY(e->logits.ensure((size_t)LOGIT_SLAB * Vld * 4));
+  RVB_TRY(e->topv.ensure((size_t)M * beam * 4));
+  RVB_TRY(e->topi.ensure((size_t)M * beam * 4));
+  if (e->h_top_cap < (size_t)M * beam) {
+    if (e->h_topv) (void)hipHostFree(e->h_topv);
+    if (e->h_topi) (void)hipHostFree(e->h_topi);
+    e->h_topv = nullptr; e->h_topi = nullptr; e->h_top_cap = 0;
+    RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topv, (size_t)M * beam * 4, hipHostMallocDefault));
+    RVB_HIP_CHECK(hipHostMalloc((void**)&e->h_topi, (size_t)M * beam * 4, hipHostMallocDefault));
+    e->h_top_cap = (size_t)M * beam;
+  }
+  for (int r0 = 0; r0 < M; r0 += LOGIT_SLAB) {
+    const int rows = std::min(LOGIT_SLAB, M - r0);
+    RVB_TRY(run_gemm(e, (const char*)e->enc_out.p + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
+    Scope sc(e, "ctc_topk");
+    RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), rows, V, Vld, beam, blank_penalty, c.blank_id,
+                            e->topv.as<float>() + (size_t)r0 * beam, e->topi.as<int>() + (size_t)r0 * beam, nullptr));
+  }
+  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topv, e->topv.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipMemcpyAsync(e->h_topi, e->topi.p, (size_t)M * beam * 4, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->slices.clear();
+  e->slices.push_back({0, 1, nullptr, true});
+  st.active = false;
   return OK;
 }
 
@@ -1125,7 +1288,8 @@ void rvb_destroy(rvb_engine* e) {
                     &e->conv2.w, &e->conv2.b, &e->embed_out.w, &e->embed_out.b, &e->ctc.w, &e->ctc.b,
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
-  e->atopv.release(); e->atopi.release();
+  e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
+  for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2}) for (auto& b : *v) b.release();
   for (auto* v : {&e->kcache, &e->vcache, &e->kcache2, &e->vcache2, &e->memkv}) for (auto& b : *v) b.release();
   auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); };
   auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };
@@ -1283,6 +1447,25 @@ int rvb_encode(rvb_engine* e, const float* feats, int64_t first_chunk, const int
                float blank_penalty) {
   if (!e || !lens) { set_error("rvb_encode: null argument"); return E_ARG; }
   return encode_impl(e, feats, first_chunk, lens, B, T0, beam, blank_penalty);
+}
+
+int rvb_stream_begin(rvb_engine* e) {
+  if (!e) { set_error("rvb_stream_begin: null engine"); return E_ARG; }
+  return stream_begin_impl(e);
+}
+int rvb_stream_chunk(rvb_engine* e, const float* feats, int n_frames, int required_cache_size, float* out, int32_t* n_out) {
+  if (!e || !feats) { set_error("rvb_stream_chunk: null argument"); return E_ARG; }
+  return stream_chunk_impl(e, feats, n_frames, required_cache_size, out, n_out);
+}
+int rvb_stream_state(rvb_engine* e, int32_t* offset, int32_t* cache_frames) {
+  if (!e) { set_error("rvb_stream_state: null engine"); return E_ARG; }
+  if (offset) *offset = e->stream_st.offset;
+  if (cache_frames) *cache_frames = e->stream_st.cache_len;
+  return OK;
+}
+int rvb_stream_finish(rvb_engine* e, int beam, float blank_penalty) {
+  if (!e) { set_error("rvb_stream_finish: null engine"); return E_ARG; }
+  return stream_finish_impl(e, beam, blank_penalty);
 }
 
 int rvb_encoder_frames(rvb_engine* e, int32_t* T_out) {

@@ -201,6 +201,57 @@ class Engine:
         check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
         self.batch, self.enc_frames, self.beam = B, int(t.value), int(beam)
 
+    # -------------------------------------------------------------------------------- streaming encoder
+    def stream_begin(self):
+        """Empty the attention cache: the next forward_chunk starts a new stream (encoder.py:385-388)."""
+        check(self.lib.rvb_stream_begin(self.handle), "rvb_stream_begin")
+
+    def forward_chunk(self, xs: np.ndarray, required_cache_size: int = -1, return_output: bool = True):
+        """BaseEncoder.forward_chunk (encoder.py:231-341) on the engine's stream state: xs (time, 80) raw log-mel of one
+        chunk -> (chunk_frames_out, d) encoder output; `offset` and the attention cache are kept by the engine
+        (stream_state())."""
+        xs = np.ascontiguousarray(xs, dtype=np.float32).reshape(-1, self.cfg.input_dim)
+        cap = max((xs.shape[0] - 3) // 2 + 1, 1)
+        out = np.empty((cap, self.cfg.d_model), np.float32) if return_output else None
+        n = C.c_int32(0)
+        check(self.lib.rvb_stream_chunk(self.handle, fptr(xs), xs.shape[0], int(required_cache_size), fptr(out), C.byref(n)),
+              "rvb_stream_chunk")
+        return out[:n.value] if return_output else n.value
+
+    def stream_state(self):
+        """(offset, cached frames): encoder frames produced so far / frames in the attention cache (att_cache.size(2))."""
+        o, c = C.c_int32(0), C.c_int32(0)
+        check(self.lib.rvb_stream_state(self.handle, C.byref(o), C.byref(c)))
+        return int(o.value), int(c.value)
+
+    def forward_chunk_by_chunk(self, xs: np.ndarray, decoding_chunk_size: int, num_decoding_left_chunks: int = -1,
+                               return_output: bool = True):
+        """BaseEncoder.forward_chunk_by_chunk (encoder.py:343-402): overlapping input windows of (chunk-1)*4 + 7 frames every
+        4*chunk frames, attention cache of chunk * left frames.  xs (T, 80) -> (T', d)."""
+        assert decoding_chunk_size > 0
+        xs = np.ascontiguousarray(xs, dtype=np.float32).reshape(-1, self.cfg.input_dim)
+        subsampling, context = 4, 7                       # Conv2dSubsampling4: rate 4, right_context 6 (+ current frame)
+        stride = subsampling * decoding_chunk_size
+        window = (decoding_chunk_size - 1) * subsampling + context
+        required = decoding_chunk_size * num_decoding_left_chunks
+        self.stream_begin()
+        outs = []
+        for cur in range(0, xs.shape[0] - context + 1, stride):
+            y = self.forward_chunk(xs[cur:min(cur + window, xs.shape[0])], required, return_output)
+            if return_output:
+                outs.append(y)
+        if not return_output:
+            return None
+        return np.concatenate(outs) if outs else np.zeros((0, self.cfg.d_model), np.float32)
+
+    def stream_finish(self, beam: int, blank_penalty: float = 0.0):
+        """CTC head + top-k over the streamed frames; greedy() / prefix_beam() / rescore() / encoder_out() then see the
+        stream as one chunk."""
+        check(self.lib.rvb_stream_finish(self.handle, int(beam), float(blank_penalty)), "rvb_stream_finish")
+        t = C.c_int32(0)
+        check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
+        self.batch, self.enc_frames, self.beam = 1, int(t.value), int(beam)
+
     def encoder_lens(self) -> np.ndarray:
         out = np.empty(self.batch, np.int32)
         check(self.lib.rvb_get_encoder_lens(self.handle, iptr(out)))

@@ -64,10 +64,6 @@ class RvbASRModel:
                length_penalty: float = 0.0, infos=None, cat_embs=None, cv=None, cv_lengths=None):
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
-        if simulate_streaming:
-            raise NotImplementedError("simulate_streaming is not built: the reference's forward_chunk_by_chunk path drops cat_embs "
-                                      "(asr_model.py:301-306) and asserts in the language-specific layers for Reverb models")
-        self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         if context_graph is not None:
             raise NotImplementedError("context biasing is out of scope")
         if blank_id != self.engine.cfg.blank_id:
@@ -77,6 +73,19 @@ class RvbASRModel:
         feats = speech.detach().cpu().numpy() if hasattr(speech, "detach") else np.asarray(speech)
         lens = speech_lengths.detach().cpu().numpy() if hasattr(speech_lengths, "detach") else np.asarray(speech_lengths)
         results = {}
+        if simulate_streaming and decoding_chunk_size > 0:
+            # asr_model.py:301-306: the encoder runs chunk by chunk with attention caches (encoder.py:343-402) on the whole
+            # (zero padded) input, lengths are not consulted and every output frame is valid.  The reference's call leaves
+            # cat_embs out, which its language-specific layers refuse (encoder_layer.py:379); here the embeddings set on
+            # the engine apply, and each item of the batch is its own stream (the reference asserts batch 1).
+            for b in range(feats.shape[0]):
+                self.engine.forward_chunk_by_chunk(feats[b], decoding_chunk_size, num_decoding_left_chunks, return_output=False)
+                self.engine.stream_finish(beam_size, blank_penalty)
+                part = self.engine.search(methods, ctc_weight, reverse_weight, length_penalty)
+                for k, v in part.items():
+                    results.setdefault(k, []).extend(v)
+            return results
+        self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         mc = self.engine.cfg.max_chunks
         for s in range(0, feats.shape[0], mc):
             self.engine.encode(feats[s:s + mc], lens[s:s + mc], beam_size, blank_penalty)
@@ -189,10 +198,6 @@ class ReverbASR:
                          decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1, ctc_weight: float = 0.1,
                          simulate_streaming: bool = False, reverse_weight: float = 0.0, blank_penalty: float = 0.0,
                          length_penalty: float = 0.0, timings_adjustment: float = 230) -> list[str]:
-        if simulate_streaming:
-            raise NotImplementedError("simulate_streaming is not built: the reference's forward_chunk_by_chunk path drops cat_embs "
-                                      "(asr_model.py:301-306) and asserts in the language-specific layers for Reverb models")
-        self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         fc = self.test_conf["fbank_conf"]
         if (fc["num_mel_bins"], fc["frame_length"], fc["frame_shift"]) != (80, 25, 10):
             raise NotImplementedError("the device fbank is built for 80 bins / 25 ms / 10 ms")
@@ -200,8 +205,20 @@ class ReverbASR:
             raise ValueError("chunk_size must be at least 7 frames (Conv2dSubsampling4 needs 7 input frames, subsampling.py:201-226)")
         eng = self._engine_for_chunk(chunk_size)
         eng.upload_pcm(*self._load_pcm(audio_file, 16000))
-        n_frames = eng.fbank()
         eng.set_cat_embs([verbatimicity, 1.0 - verbatimicity])
+        if simulate_streaming and decoding_chunk_size > 0:
+            # the reference's loop (cli/reverb.py:220-253) with the encoder run chunk by chunk inside model.decode
+            _, feats = eng.fbank(return_feats=True)
+            hyps = {m: [] for m in modes}
+            for x, lens in self.feats_batcher(_torch().from_numpy(feats).unsqueeze(0), chunk_size, batch_size):
+                part = self.model.decode(modes, x, lens, beam_size, decoding_chunk_size, num_decoding_left_chunks, ctc_weight,
+                                         True, reverse_weight, blank_id=self.blank_id, blank_penalty=blank_penalty, length_penalty=length_penalty)
+                for m in modes:
+                    hyps[m].extend(part[m])
+            return [get_output(format, self.tokenizer, Path(audio_file).name, hyps[mode], timings_adjustment, chunk_size,
+                               self.input_frame_length, self.output_frame_length) for mode in modes]
+        eng.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
+        n_frames = eng.fbank()
         hyps = self.decode_resident(n_frames, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, length_penalty)
         return [get_output(format, self.tokenizer, Path(audio_file).name, hyps[mode], timings_adjustment, chunk_size,
                            self.input_frame_length, self.output_frame_length) for mode in modes]

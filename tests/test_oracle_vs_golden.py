@@ -137,3 +137,24 @@ def test_oracle_matches_long_form_reference_golden(name, chunks):
             n = case.js["encoder_lens"][c]
             # (bit-identical on full chunks; a 1-frame tail chunk takes another torch GEMM path in nn.Linear than in F.linear)
             np.testing.assert_allclose(taps["encoder_out"][0, :n:16, ::8].numpy(), case.arrays[key], rtol=0, atol=2e-5)
+
+
+def test_streaming_encoder_oracle_matches_reference_golden():
+    """forward_chunk / forward_chunk_by_chunk with attention caches (encoder.py:231-402): the oracle's restatement against
+    the unmodified reference on the language-specific tiny model (oracle/gen_golden_streaming.py)."""
+    import json
+    case = Case("tiny_ln")
+    with open(GOLDEN + "/tiny_ln_streaming.json") as f:
+        gold = json.load(f)
+    arrays = np.load(GOLDEN + "/tiny_ln_streaming.npz")
+    feats = torch.from_numpy(fbank_ref.fbank(case.pcm)).unsqueeze(0)
+    assert feats.shape[1] == gold["frames"]
+    sd = M.to_torch_sd(case.sd)
+    with torch.no_grad():
+        for run in gold["runs"]:
+            cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+            ys, cache_frames = M.encoder_forward_chunk_by_chunk(sd, case.cfg, feats, cs, left, torch.tensor(case.cat))
+            assert ys.shape[1] == run["out_frames"] and cache_frames == run["final_cache_frames"], (cs, left)
+            np.testing.assert_allclose(ys[0, ::4].numpy(), arrays[f"ys_{cs}_{left}".replace("-", "m")], rtol=0, atol=2e-5)
+            got = S.ctc_greedy_search(M.ctc_logprobs(sd, ys), torch.tensor([ys.shape[1]]), 0)
+            assert list(got[0].tokens) == run["greedy"], (cs, left)
