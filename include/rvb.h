@@ -197,6 +197,11 @@ int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, 
                          int32_t* n_hyps, int32_t* tokens /* [beam][T] */, int32_t* lens, int32_t* times,
                          int32_t* times_lens, double* scores);
 
+/* Word error counts of a hypothesis against a reference, both as word-id sequences (host code, no GPU): minimal Levenshtein
+ * alignment, counts = {errors, substitutions, deletions, insertions} -- the numbers `fstalign wer` logs as bestWER and
+ * asr/wer_evaluation/aggregate_scoring.py:37-44 sums (reverb_amd/wer_evaluation/align.py is the caller). */
+int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_t n_hyp, int64_t* counts /* [4] */);
+
 /* GEMM kernel selection / micro-benchmark hooks (tests and tuning only) */
 int rvb_test_set_gemm_variant(int variant /* 0 auto, 1 gemm.hip 128x128, 2 gemm2.hip 256x256 LDS-DMA */);
 /* gemm2.hip tuning switches: flags bit 0 = 32x32x16 MFMAs, bit 1 = s_setprio for the later-dispatched waves;

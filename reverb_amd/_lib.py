@@ -75,6 +75,7 @@ SIGNATURES = {
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
     "rvb_reset_timings": (C.c_int, [_eng]),
     "rvb_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),
+    "rvb_wer_counts": (C.c_int, [_i32p, C.c_int64, _i32p, C.c_int64, _i64p]),
     "rvb_test_gemm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,

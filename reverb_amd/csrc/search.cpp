@@ -203,4 +203,29 @@ void greedy_collapse(const int* top1, int T_valid, int stride, int blank, std::v
   }
 }
 
+// Word-level Levenshtein alignment of a hypothesis against a reference (what `fstalign wer` reports as bestWER for
+// plain token sequences; asr/wer_evaluation/README.md): minimum number of edits, and among minimal alignments the one a
+// fixed preference order (match/substitution, then deletion, then insertion) reaches, so that the S / D / I split is
+// deterministic.  O(n*m) time, O(m) memory: every cell carries its own (cost, S, D, I).
+void edit_counts(const int32_t* ref, int64_t n, const int32_t* hyp, int64_t m, int64_t counts[4]) {
+  struct Cell { int64_t c, s, d, i; };
+  std::vector<Cell> prev((size_t)m + 1), cur((size_t)m + 1);
+  for (int64_t j = 0; j <= m; ++j) prev[j] = {j, 0, 0, j};
+  for (int64_t i = 1; i <= n; ++i) {
+    cur[0] = {i, 0, i, 0};
+    for (int64_t j = 1; j <= m; ++j) {
+      const bool eq = ref[i - 1] == hyp[j - 1];
+      Cell best = prev[j - 1];
+      if (!eq) { best.c += 1; best.s += 1; }
+      const Cell& up = prev[j];          // reference word i has no counterpart: deletion
+      if (up.c + 1 < best.c) { best = up; best.c += 1; best.d += 1; }
+      const Cell& left = cur[j - 1];     // hypothesis word j has no counterpart: insertion
+      if (left.c + 1 < best.c) { best = left; best.c += 1; best.i += 1; }
+      cur[j] = best;
+    }
+    prev.swap(cur);
+  }
+  counts[0] = prev[m].c; counts[1] = prev[m].s; counts[2] = prev[m].d; counts[3] = prev[m].i;
+}
+
 }  // namespace rvb

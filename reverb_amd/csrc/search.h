@@ -19,4 +19,7 @@ void prefix_beam_search(const float* tv, const int* ti, int T, int kstride, int 
 void greedy_collapse(const int* top1, int T_valid, int stride, int blank, std::vector<int>* tokens,
                      std::vector<int>* frames);
 
+// counts = {errors, substitutions, deletions, insertions} of the minimal word alignment of hyp against ref
+void edit_counts(const int32_t* ref, int64_t n, const int32_t* hyp, int64_t m, int64_t counts[4]);
+
 }  // namespace rvb

@@ -251,6 +251,13 @@ int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* 
   return OK;
 }
 
+// host only (no GPU needed): word alignment counts for reverb_amd/wer_evaluation/align.py
+int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_t n_hyp, int64_t* counts) {
+  if ((!ref && n_ref > 0) || (!hyp && n_hyp > 0) || !counts || n_ref < 0 || n_hyp < 0) { set_error("rvb_wer_counts: bad argument"); return E_ARG; }
+  edit_counts(ref, n_ref, hyp, n_hyp, counts);
+  return OK;
+}
+
 int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank, int32_t* n_hyps,
                          int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens, double* scores) {
   if (!topk_val || !topk_idx || !n_hyps || T < 0 || beam < 1) { set_error("rvb_test_prefix_beam: bad argument"); return E_ARG; }
