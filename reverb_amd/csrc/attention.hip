@@ -223,8 +223,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nf][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_max(mx);
     const float m_new = fmaxf(m_run, mx);
     float al = 1.f, ps = 0.f;
     if (m_new == -INFINITY) {                     // every key so far is masked for this query
@@ -245,8 +244,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
           for (int r = 0; r < 4; ++r) { const float pv = expf(s[nf][r] - m_new); s[nf][r] = pv; ps += pv; }
       }
     }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
+    ps = rows_sum(ps);
     l_run = l_run * al + ps;
     m_run = m_new;
 #pragma unroll

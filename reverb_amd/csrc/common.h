@@ -91,6 +91,23 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// reductions over the four lanes {l, l^16, l^32, l^48} (the 16-lane rows of a wave) with gfx950's row-swap instructions:
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, so with both
+// operands = v the two results hold v[l] and v[l^16] between them; v_permlane32_swap likewise for the 32-lane halves.
+// VALU only -- __shfl_xor(.., 16 / 32) goes through ds_bpermute (an LDS round trip on the softmax's critical path).
+__device__ inline float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ inline float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ status codes (include/rvb.h)
