@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 STUB = bool(os.environ.get("RVB_BENCH_STUB"))     # CPU test hook of the launcher: gloo + a host stub instead of the engine
 
 
@@ -49,7 +49,9 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--model", default="r640", choices=["tiny", "small", "r268", "r640"],
                    help="synthetic planning point (SURVEY.md section 8): r640 = d1024/16h/ff4096, 665 M params")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                   help="fp8 = the bf16 engine with the encoder's feed-forward / qkv / pointwise GEMMs in fp8 (BASELINE configs[4]); "
+                        "the warm-up step calibrates the activation scales")
     p.add_argument("--hours", type=float, default=1.0, help="audio per GPU")
     p.add_argument("--chunks-per-launch", type=int, default=0, help="device batch (0 = all chunks of the audio)")
     p.add_argument("--beam", type=int, default=10)
@@ -296,16 +298,17 @@ def main():
         eng.reset_timings()
         eng.set_profiling(not args.no_profile, gemm_only=True)      # timed region: HIP events around the GEMM launches only
     dt, (hyps, ntok) = timed(args.steps)
-    g, stages, pcie = None, None, None
+    g, g8, stages, pcie = None, None, None, None
     if not STUB:
         eng.set_profiling(False)
         g = eng.timing("gemm")
+        g8 = eng.timing("gemm_fp8")
         if not args.no_profile:       # the per-stage table comes from ONE extra, untimed step with every stage bracketed
             eng.reset_timings()
             eng.set_profiling(True)
             step()
             eng.set_profiling(False)
-            stages = {k: eng.timing(k) for k in ("fbank", "subsample", "gemm", "attention", "rownorm", "glu_dwconv",
+            stages = {k: eng.timing(k) for k in ("fbank", "subsample", "gemm", "gemm_fp8", "attention", "rownorm", "glu_dwconv",
                                                  "ctc_topk", "embed", "lse_gather", "search_host")}
         if world == 1 and not args.no_pcie:
             # the same step from PCM in (page-locked) HOST memory: SURVEY.md 8d's end-to-end definition; reported beside
@@ -318,7 +321,19 @@ def main():
     if rank == 0:
         audio_total = seconds * world * args.steps
         roof = None
-        if g and g["ms"] > 0:
+        if args.dtype == "fp8" and g8 and g8["ms"] > 0:
+            # the dominant kernel of this mode is the fp8 GEMM (priced against the 5 PFLOP/s dense fp8 peak); the GEMMs
+            # that stay in bf16 (subsampling, attention output, CTC head, decoder) are listed beside it
+            ach = g8["flops"] / (g8["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp8"], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS["fp8"], 4), "traffic": None,
+                    "kernel": "rvb::gemm2_kernel<fp8> (fp8 GEMM launches of the timed steps)",
+                    "launches": g8["launches"], "avg_launch_us": round(g8["ms"] * 1e3 / max(g8["launches"], 1), 2),
+                    "flops_per_launch": round(g8["flops"] / max(g8["launches"], 1), 1),
+                    "bf16_gemms": {"achieved": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2) if g["ms"] > 0 else None,
+                                   "launches": g["launches"], "ms_per_step": round(g["ms"] / args.steps, 3)},
+                    "fp8_ms_per_step": round(g8["ms"] / args.steps, 3)}
+        elif g and g["ms"] > 0:
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
@@ -366,7 +381,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and not STUB and world == 1:
         # the engine is closed and the GPU idle: nested measurements of the same workload
-        if args.traffic == "auto" and out["roofline"] is not None:
+        if args.traffic == "auto" and out["roofline"] is not None and args.dtype != "fp8":
             t = measure_traffic(args)
             if t is not None:
                 out["roofline"]["traffic"] = t["bytes_per_launch"]

@@ -29,6 +29,9 @@ extern "C" {
 
 #define RVB_F32 0  /* parity mode: v_mfma_f32_16x16x4_f32, exact f32 fma chains */
 #define RVB_BF16 1 /* throughput mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate/residual */
+#define RVB_FP8 2  /* BASELINE configs[4]: the bf16 engine with the encoder's feed-forward, qkv and pointwise-conv GEMMs on
+                      v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 operands: weights scaled per output channel, activations per
+                      tensor, scales calibrated by the FIRST rvb_encode call, which itself runs in bf16) */
 
 typedef struct rvb_engine rvb_engine;
 
@@ -150,6 +153,8 @@ int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score
  * (T = rvb_encoder_frames) with -1 / 0 */
 int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_t* times_lens, int32_t* times,
                            float* scores, double* confidences, double* tokens_confidence);
+/* fp8 engines: forget the activation scales; the next rvb_encode calibrates again (in bf16) on its batch */
+int rvb_fp8_recalibrate(rvb_engine* e);
 /* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's
  * padded [N, L] decoder batch computes (search.py:391-412); `decoder_rows` = rows actually computed: one per DISTINCT
  * hypothesis prefix of a chunk (the decoder is causal, so hypotheses of one beam share the rows of their common prefix). */
@@ -189,6 +194,11 @@ int rvb_test_attention_trie(int dtype, const float* q, const float* k, const flo
 int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float blank_penalty, int blank_id,
                              float* topk_val, int32_t* topk_idx, float* logp);
 int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target, float* out);
+/* fp8 (e4m3) GEMM / LayerNorm-to-fp8 of the RVB_FP8 mode on host floats (operands quantised as the engine does) */
+int rvb_test_gemm_fp8(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K,
+                      float a_scale, float alpha, int act, int out_kind, float out_scale, float* a_deq, float* w_deq);
+int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, float eps, int silu, int M, int d, float scale,
+                         float* out, const float* gamma2, const float* beta2, float eps2, float scale2, float* out1_f32, float* out2);
 int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* ptr /* [R+1] */, const int32_t* target,
                               int P, float* out /* [P] */);
 int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats /* [frames,80] */);

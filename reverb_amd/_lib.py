@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librvb.so")
 
-RVB_F32, RVB_BF16 = 0, 1
+RVB_F32, RVB_BF16, RVB_FP8 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 NORM_LN, NORM_AFFINE = 0, 1
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "rvb_get_attention_result": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _f32p]),
     "rvb_get_rescored": (C.c_int, [_eng, C.c_int, _i32p, _f32p, _f64p, _f64p]),
     "rvb_get_rescored_batch": (C.c_int, [_eng, _i32p, _i32p, _i32p, _i32p, _f32p, _f64p, _f64p]),
+    "rvb_fp8_recalibrate": (C.c_int, [_eng]),
     "rvb_get_rescore_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
@@ -89,6 +90,10 @@ SIGNATURES = {
                                           _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_logsoftmax_topk": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _f32p]),
     "rvb_test_lse_gather": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _f32p]),
+    "rvb_test_gemm_fp8": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                    C.c_float, _f32p, _f32p]),
+    "rvb_test_rownorm_fp8": (C.c_int, [_f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, _f32p, _f32p,
+                                       C.c_float, C.c_float, _f32p, _f32p]),
     "rvb_test_lse_gather_multi": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p]),
     "rvb_test_fbank": (C.c_int, [_i16p, C.c_int64, _f32p]),
     "rvb_test_set_gemm_variant": (C.c_int, [C.c_int]),

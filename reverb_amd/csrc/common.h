@@ -1,6 +1,7 @@
 // Shared device/host helpers for librvb (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -41,10 +42,49 @@ __device__ inline uint32_t pack2_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, r);
 }
 
+typedef uint8_t fp8_t;    // raw OCP e4m3 ("e4m3fn": no infinities, max 448) bits
+
+// four floats -> four fp8 bytes in one dword (a in bits 0..7), round-to-nearest-even, saturating at +-448
+__device__ inline uint32_t pack4_fp8(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+// host-side e4m3 encode (weights) / decode (tests), same rounding
+__host__ __device__ inline uint8_t f32_to_fp8_host(float f) {
+  if (f != f) return 0x7f;
+  const uint8_t sgn = f < 0.f ? 0x80 : 0;
+  float v = f < 0.f ? -f : f;
+  if (v >= 448.f) return sgn | 0x7e;
+  if (v < 0.0009765625f) return sgn;                       // below half of the smallest subnormal (2^-9 / 2): zero
+  int e;
+  const float m = frexpf(v, &e);                             // v = m * 2^e, m in [0.5, 1)
+  int E = e - 1 + 7;
+  if (E <= 0) {                                              // subnormal: multiples of 2^-9
+    const int M = (int)nearbyintf(ldexpf(v, 9));
+    return sgn | (uint8_t)(M >= 8 ? 0x08 : M);
+  }
+  int M = (int)nearbyintf((m * 2.f - 1.f) * 8.f);
+  if (M == 8) { M = 0; E += 1; }
+  if (E > 15 || (E == 15 && M == 7)) return sgn | 0x7e;
+  return sgn | (uint8_t)((E << 3) | M);
+}
+__host__ __device__ inline float fp8_to_f32_host(uint8_t b) {
+  const int E = (b >> 3) & 15, M = b & 7;
+  const float v = E == 0 ? ldexpf((float)M, -9) : ldexpf(1.f + M / 8.f, E - 7);
+  return (b & 0x80) ? -v : v;
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   __host__ __device__ static inline float to_f32(float v) { return v; }
   __host__ __device__ static inline float from_f32(float v) { return v; }
+};
+template <> struct Cvt<fp8_t> {     // only so that generic code instantiates; fp8 stores go through pack4_fp8
+  __host__ __device__ static inline float to_f32(fp8_t v) { return fp8_to_f32_host(v); }
+  __host__ __device__ static inline fp8_t from_f32(float v) { return f32_to_fp8_host(v); }
 };
 template <> struct Cvt<bf16_t> {
   __host__ __device__ static inline float to_f32(bf16_t v) { return bf16_to_f32(v); }

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
       if (a.silu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (sizeof(OutT) == 2) o[e] = o[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * o[e]));
+          if constexpr (sizeof(OutT) <= 2) o[e] = o[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * o[e]));
           else o[e] = o[e] / (1.0f + expf(-o[e]));
         }
       }
@@ -164,7 +164,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
           o[0] += u.x; o[1] += u.y; o[2] += u.z; o[3] += u.w;
         }
       }
-      if constexpr (sizeof(OutT) == 2) {
+      if constexpr (sizeof(OutT) == 1) {
+        const float qs = a.out_inv_scale;             // fp8 operand of the next GEMM: value / (calibrated per-tensor scale)
+        *(uint32_t*)(out + c) = pack4_fp8(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
+      } else if constexpr (sizeof(OutT) == 2) {
         *(uint2*)(out + c) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
       } else {
         *(float4*)(out + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -191,8 +194,14 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
         if (c >= d) continue;
         const float q0 = (v[i].x - mean2) * rstd2 * g2[i].x + be2[i].x, q1 = (v[i].y - mean2) * rstd2 * g2[i].y + be2[i].y;
         const float q2 = (v[i].z - mean2) * rstd2 * g2[i].z + be2[i].z, q3 = (v[i].w - mean2) * rstd2 * g2[i].w + be2[i].w;
-        if constexpr (sizeof(AddT) == 2) *(uint2*)(o2 + c) = make_uint2(pack2_bf16(q0, q1), pack2_bf16(q2, q3));
-        else *(float4*)(o2 + c) = make_float4(q0, q1, q2, q3);
+        if (a.out2_fp8) {
+          const float qs = a.out2_inv_scale;
+          *(uint32_t*)((fp8_t*)a.out2 + (size_t)row * d + c) = pack4_fp8(q0 * qs, q1 * qs, q2 * qs, q3 * qs);
+        } else if constexpr (sizeof(AddT) == 2) {
+          *(uint2*)(o2 + c) = make_uint2(pack2_bf16(q0, q1), pack2_bf16(q2, q3));
+        } else {
+          *(float4*)(o2 + c) = make_float4(q0, q1, q2, q3);
+        }
       }
     }
 #pragma unroll
@@ -215,8 +224,10 @@ int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
   if (a.out2 && (a.mode != NORM_LN || !(a.out_f32 || dtype == DT_F32))) {
     set_error("rownorm: the fused second LayerNorm follows a LayerNorm with fp32 output"); return E_ARG;
   }
+  if ((a.out_fp8 || a.out2_fp8) && dtype != DT_BF16) { set_error("rownorm: fp8 outputs belong to the bf16 engine"); return E_ARG; }
   if (dtype == DT_BF16) {
-    if (a.out_f32) launch_rownorm<float, bf16_t>(s, a);
+    if (a.out_fp8) launch_rownorm<fp8_t, bf16_t>(s, a);
+    else if (a.out_f32) launch_rownorm<float, bf16_t>(s, a);
     else launch_rownorm<bf16_t, bf16_t>(s, a);
   } else {
     launch_rownorm<float, float>(s, a);
@@ -360,6 +371,24 @@ int embed_tokens(hipStream_t s, const float* E, const float* pe, const int* tok,
                  int rows, int d, float scale) {
   if (rows <= 0) return OK;
   hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, s, E, pe, tok, pos, out, rows, d, scale);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// calibration of the fp8 activation scales: running max |x| of a tensor
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, size_t n, float* __restrict__ slot) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(Cvt<T>::to_f32(x[i])));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned int*)slot, __float_as_uint(m));     // non-negative floats order as their bits
+}
+int amax_abs(hipStream_t s, int dtype, const void* x, size_t n, float* slot) {
+  if (n == 0) return OK;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, n, slot);
+  else hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, n, slot);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

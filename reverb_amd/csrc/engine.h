@@ -27,7 +27,10 @@ struct DevBuf {
 struct Linear {      // y = x.W^T + b, W packed to the compute dtype [out][in]
   DevBuf w, b;
   int out = 0, in = 0;
+  DevBuf w8, wscale;   // fp8 mode: e4m3 copy [out][in] and its per-output-channel scales fp32 [out]
 };
+// per-tensor scales of the activations an fp8 GEMM reads (value = fp8 * scale), one set per conformer block
+struct F8Scales { float in_ffm1 = 1, h_ffm = 1, in_qkv = 1, in_pw1 = 1, in_pw2 = 1, in_ff1 = 1, h_ff = 1; };
 struct LNorm { DevBuf g, b; float eps = 1e-5f; };
 
 struct EncLayer {
@@ -67,6 +70,10 @@ struct rvb_engine {
   rvb_model_cfg cfg;
   int device = 0;
   int dtype = 0;
+  bool fp8 = false;              // RVB_FP8: dtype stays DT_BF16, the encoder's feed-forward / qkv / pointwise GEMMs run in fp8
+  int f8_state = 0;              // 0 not calibrated, 1 calibrating (bf16 pass collecting max |.|), 2 fp8 GEMMs active
+  std::vector<rvb::F8Scales> f8;
+  rvb::DevBuf d_amax;            // fp32 [blocks][8]
   hipStream_t stream = nullptr;
   bool finalized = false;
 

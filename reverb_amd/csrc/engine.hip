@@ -41,7 +41,7 @@ struct Scope {
   Scope(rvb_engine* e_, const char* n, double flops = 0.0) : e(e_), name(n) {
     auto& pe = e->prof[name];
     pe.launches += 1; pe.flops += flops;
-    if (e->profiling == 0 || (e->profiling == 2 && name != "gemm")) return;
+    if (e->profiling == 0 || (e->profiling == 2 && name != "gemm" && name != "gemm_fp8")) return;
     auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
     a = get(); b = get();
     (void)hipEventRecord(a, e->stream);
@@ -86,10 +86,28 @@ static int pack_T(rvb_engine* e, DevBuf& dst, const float* src, size_t n) {
   RVB_HIP_CHECK(hipMemcpyAsync(e->stage.p, src, n * 4, hipMemcpyHostToDevice, e->stream));
   return convert_f32(e->stream, e->dtype, e->stage.as<float>(), dst.p, n);
 }
-static int pack_linear(rvb_engine* e, Linear& L, const float* w, const float* b, int out, int in) {
+// f8: also keep an fp8 (OCP e4m3) copy with one scale per output channel: w8[n][k] = rne(w[n][k] / s_n), s_n = max|w[n]| / 448
+static int pack_linear(rvb_engine* e, Linear& L, const float* w, const float* b, int out, int in, bool f8 = false) {
   L.out = out; L.in = in;
   RVB_TRY(pack_T(e, L.w, w, (size_t)out * in));
   if (b) RVB_TRY(upload_f32(e, L.b, b, out)); else L.b.release();
+  if (f8 && e->fp8 && in % 128 == 0) {
+    std::vector<uint8_t> q((size_t)out * in);
+    std::vector<float> sc(out);
+    for (int n = 0; n < out; ++n) {
+      const float* row = w + (size_t)n * in;
+      float am = 0.f;
+      for (int k = 0; k < in; ++k) am = std::max(am, std::fabs(row[k]));
+      const float sn = am > 0.f ? am / 448.f : 1.f;
+      sc[n] = sn;
+      const float inv = 1.f / sn;
+      for (int k = 0; k < in; ++k) q[(size_t)n * in + k] = f32_to_fp8_host(row[k] * inv);
+    }
+    RVB_TRY(L.w8.ensure(q.size()));
+    RVB_HIP_CHECK(hipMemcpyAsync(L.w8.p, q.data(), q.size(), hipMemcpyHostToDevice, e->stream));
+    RVB_TRY(upload_f32(e, L.wscale, sc.data(), out));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  }
   return OK;
 }
 
@@ -107,11 +125,11 @@ static int need(rvb_engine* e, const std::string& name, size_t numel, const Host
   *out = t;
   return OK;
 }
-static int pack_named_linear(rvb_engine* e, Linear& L, const std::string& p, int out, int in, bool bias = true) {
+static int pack_named_linear(rvb_engine* e, Linear& L, const std::string& p, int out, int in, bool bias = true, bool f8 = false) {
   const HostTensor *w, *b = nullptr;
   RVB_TRY(need(e, p + ".weight", (size_t)out * in, &w));
   if (bias) RVB_TRY(need(e, p + ".bias", out, &b));
-  return pack_linear(e, L, w->data.data(), b ? b->data.data() : nullptr, out, in);
+  return pack_linear(e, L, w->data.data(), b ? b->data.data() : nullptr, out, in, f8);
 }
 static int pack_norm(rvb_engine* e, LNorm& n, const std::string& p, int d, float eps) {
   const HostTensor *g, *b;
@@ -122,7 +140,7 @@ static int pack_norm(rvb_engine* e, LNorm& n, const std::string& p, int d, float
   return upload_f32(e, n.b, b->data.data(), d);
 }
 // concatenate several [rows_i, in] linears along the output dim
-static int pack_concat(rvb_engine* e, Linear& L, const std::vector<std::string>& names, int out_each, int in) {
+static int pack_concat(rvb_engine* e, Linear& L, const std::vector<std::string>& names, int out_each, int in, bool f8 = false) {
   std::vector<float> w((size_t)names.size() * out_each * in), b((size_t)names.size() * out_each);
   for (size_t i = 0; i < names.size(); ++i) {
     const HostTensor *tw, *tb;
@@ -131,7 +149,7 @@ static int pack_concat(rvb_engine* e, Linear& L, const std::vector<std::string>&
     memcpy(w.data() + i * (size_t)out_each * in, tw->data.data(), (size_t)out_each * in * 4);
     memcpy(b.data() + i * (size_t)out_each, tb->data.data(), (size_t)out_each * 4);
   }
-  int r = pack_linear(e, L, w.data(), b.data(), (int)names.size() * out_each, in);
+  int r = pack_linear(e, L, w.data(), b.data(), (int)names.size() * out_each, in, f8);
   if (r == OK) (void)hipStreamSynchronize(e->stream);   // w/b go out of scope
   return r;
 }
@@ -217,15 +235,31 @@ static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void
   Scope sc(e, "gemm", 2.0 * M * (double)L.out * L.in);
   return gemm(e->stream, e->dtype, g);
 }
+// out8 / out2_8 > 0: that output is fp8 bytes of value / scale (the calibrated per-tensor scale of the GEMM that reads it)
 static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bool out_f32, int M, int d,
                     int mode = NORM_LN, int silu = 0, const void* add = nullptr, const LNorm* second = nullptr,
-                    void* out2 = nullptr) {
+                    void* out2 = nullptr, float out8 = 0.f, float out2_8 = 0.f) {
   NormArgs a;
   a.x = x; a.gamma = n.g.as<float>(); a.beta = n.b.as<float>(); a.eps = n.eps; a.mode = mode; a.silu = silu;
   a.add = add; a.out = out; a.out_f32 = out_f32 ? 1 : 0; a.M = M; a.d = d;
   if (second) { a.gamma2 = second->g.as<float>(); a.beta2 = second->b.as<float>(); a.eps2 = second->eps; a.out2 = out2; }
+  if (out8 > 0.f) { a.out_fp8 = 1; a.out_inv_scale = 1.f / out8; }
+  if (out2_8 > 0.f) { a.out2_fp8 = 1; a.out2_inv_scale = 1.f / out2_8; }
   Scope sc(e, "rownorm");
   return rownorm(e->stream, e->dtype, a);
+}
+// fp8 GEMM: A8 [M, lda] bytes (values / a_scale), L.w8 / L.wscale; out_kind 0 = compute dtype, 1 = fp32, 2 = fp8 (/ out_scale)
+static int run_gemm8(rvb_engine* e, const void* A8, int lda, const Linear& L, void* C, int ldc, int M, float a_scale, int out_kind,
+                     float out_scale = 1.f, float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A8; g.W = L.w8.p; g.bias = L.b.as<float>(); g.res = res; g.C = C;
+  g.M = M; g.N = L.out; g.K = L.in; g.lda = lda; g.ldw = L.in; g.ldc = ldc; g.ldres = ldres;
+  g.alpha = alpha; g.act = act; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.in_fp8 = 1;
+  g.a_scale = a_scale; g.w_scale = L.wscale.as<float>(); g.out_inv_scale = 1.f / out_scale;
+  if (!L.w8.p) { set_error("fp8 GEMM on a layer without fp8 weights"); return E_STATE; }
+  Scope sc(e, "gemm_fp8", 2.0 * M * (double)L.out * L.in);
+  return gemm(e->stream, e->dtype, g);
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -316,14 +350,16 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
       EncLayer& L = e->enc[i];
       const std::string p = "encoder.encoders." + std::to_string(i);
       L.is_lsl = find(e, p + ".language_layers.0.weight") != nullptr;
-      RVB_TRY(pack_named_linear(e, L.ffm1, p + ".feed_forward_macaron.w_1", ff, d));
-      RVB_TRY(pack_named_linear(e, L.ffm2, p + ".feed_forward_macaron.w_2", d, ff));
-      RVB_TRY(pack_named_linear(e, L.ff1, p + ".feed_forward.w_1", ff, d));
-      RVB_TRY(pack_named_linear(e, L.ff2, p + ".feed_forward.w_2", d, ff));
-      RVB_TRY(pack_concat(e, L.qkv, {p + ".self_attn.linear_q", p + ".self_attn.linear_k", p + ".self_attn.linear_v"}, d, d));
+      // fp8 mode: the GEMMs whose A operand is written by a LayerNorm or by a GEMM epilogue (95 % of a block's GEMM work);
+      // the language-specific blocks keep their second feed-forward in bf16 (its input is the mixed projection y)
+      RVB_TRY(pack_named_linear(e, L.ffm1, p + ".feed_forward_macaron.w_1", ff, d, true, true));
+      RVB_TRY(pack_named_linear(e, L.ffm2, p + ".feed_forward_macaron.w_2", d, ff, true, true));
+      RVB_TRY(pack_named_linear(e, L.ff1, p + ".feed_forward.w_1", ff, d, true, !L.is_lsl));
+      RVB_TRY(pack_named_linear(e, L.ff2, p + ".feed_forward.w_2", d, ff, true, !L.is_lsl));
+      RVB_TRY(pack_concat(e, L.qkv, {p + ".self_attn.linear_q", p + ".self_attn.linear_k", p + ".self_attn.linear_v"}, d, d, true));
       RVB_TRY(pack_named_linear(e, L.att_out, p + ".self_attn.linear_out", d, d));
-      RVB_TRY(pack_named_linear(e, L.pw1, p + ".conv_module.pointwise_conv1", 2 * d, d));
-      RVB_TRY(pack_named_linear(e, L.pw2, p + ".conv_module.pointwise_conv2", d, d));
+      RVB_TRY(pack_named_linear(e, L.pw1, p + ".conv_module.pointwise_conv1", 2 * d, d, true, true));
+      RVB_TRY(pack_named_linear(e, L.pw2, p + ".conv_module.pointwise_conv2", d, d, true, true));
       RVB_TRY(need(e, p + ".self_attn.pos_bias_u", d, &t));
       RVB_TRY(upload_f32(e, L.bias_u, t->data.data(), d));
       RVB_TRY(need(e, p + ".self_attn.pos_bias_v", d, &t));
@@ -383,6 +419,13 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
     }
   }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (e->fp8) {
+    for (auto& L : e->enc)
+      if (!L.ffm1.w8.p || !L.ffm2.w8.p || !L.qkv.w8.p || !L.pw1.w8.p || !L.pw2.w8.p || (!L.is_lsl && (!L.ff1.w8.p || !L.ff2.w8.p))) {
+        set_error("fp8 mode needs encoder_conf.output_size and linear_units to be multiples of 128 (one fp8 K step)");
+        return E_UNSUPPORTED;
+      }
+  }
   if (!e->finalized) {   // keep only what a later re-finalize needs
     for (auto it = e->host.begin(); it != e->host.end();) {
       if (it->first.find(".language_layers.") == std::string::npos) it = e->host.erase(it); else ++it;
@@ -398,15 +441,38 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
 // norm, or by encode_impl for the first block); on exit the block has written `next`(x) to next_out the same way.
 // `li` >= 0 selects the streaming form (forward_chunk, encoder.py:231-341): this chunk's keys / values are appended to
 // layer li's cache and attention runs over cache + chunk, positional keys taken at the frames' absolute positions.
-static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const LNorm& next, void* next_out, int li = -1) {
+// fp8 mode (e->f8_state 2, offline only): the LayerNorms write fp8 operands at the calibrated per-tensor scales, the
+// feed-forward / qkv / pointwise GEMMs run on the fp8 MFMA path, intermediate h stays fp8; state 1 is the calibration
+// pass: the bf16 flow with the running max |.| of every tensor that will be quantised.
+static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int T, const LNorm& next, void* next_out,
+                         float next8 = 0.f, int li = -1) {
   const int d = e->cfg.d_model, ff = e->cfg.ffn_dim, heads = e->cfg.heads, dk = d / heads;
   float* x = e->x.as<float>();
+  const bool f8 = e->fp8 && e->f8_state == 2 && li < 0;
+  const bool cal = e->fp8 && e->f8_state == 1 && li < 0;
+  const F8Scales sc8 = f8 ? e->f8[lidx] : F8Scales();
+  auto note = [&](int slot, const void* t, size_t n) -> int {
+    return cal ? amax_abs(e->stream, e->dtype, t, n, e->d_amax.as<float>() + (size_t)lidx * 8 + slot) : OK;
+  };
   // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
-  RVB_TRY(run_gemm(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, false, 1.f, ACT_SILU));
-  RVB_TRY(run_gemm(e, e->h.p, ff, L.ffm2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  if (f8) {
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, sc8.in_ffm1, 2, sc8.h_ffm, 1.f, ACT_SILU));
+    RVB_TRY(run_gemm8(e, e->h.p, ff, L.ffm2, x, d, M, sc8.h_ffm, 1, 1.f, 0.5f, ACT_NONE, x, d));
+  } else {
+    RVB_TRY(note(0, e->xn.p, (size_t)M * d));
+    RVB_TRY(run_gemm(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, false, 1.f, ACT_SILU));
+    RVB_TRY(note(1, e->h.p, (size_t)M * ff));
+    RVB_TRY(run_gemm(e, e->h.p, ff, L.ffm2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  }
   // rel-pos self attention: x += MHSA(LN(x))              encoder_layer.py:208-216
-  RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d));
-  RVB_TRY(run_gemm(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, false));
+  if (f8) {
+    RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_qkv));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, sc8.in_qkv, 0));
+  } else {
+    RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d));
+    RVB_TRY(note(2, e->xn.p, (size_t)M * d));
+    RVB_TRY(run_gemm(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, false));
+  }
   {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -439,8 +505,14 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const 
   }
   RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
   // convolution module: x += Conv(LN(x))                   encoder_layer.py:218-229, convolution.py:89-144
-  RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d));
-  RVB_TRY(run_gemm(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, false));
+  if (f8) {
+    RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_pw1));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, sc8.in_pw1, 0));
+  } else {
+    RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d));
+    RVB_TRY(note(3, e->xn.p, (size_t)M * d));
+    RVB_TRY(run_gemm(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, false));
+  }
   {
     GluDwArgs g;
     g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
@@ -448,20 +520,36 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int M, int B, int T, const 
     Scope sc(e, "glu_dwconv");
     RVB_TRY(glu_dwconv(e->stream, e->dtype, g));
   }
-  RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE, 1));
-  RVB_TRY(run_gemm(e, e->xn.p, d, L.pw2, x, d, M, true, 1.f, ACT_NONE, x, d));
-  // feed-forward (+ language-specific mix), final norm     encoder_layer.py:231-244 / :372-402
-  RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d));
-  const void* ffin = e->xn.p;
-  if (L.is_lsl) {
-    RVB_TRY(run_gemm(e, e->xn.p, d, L.lsl, e->y.p, d, M, false));
-    ffin = e->y.p;
+  const int cmode = e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE;
+  if (f8) {
+    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw2, x, d, M, sc8.in_pw2, 1, 1.f, 1.f, ACT_NONE, x, d));
+  } else {
+    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1));
+    RVB_TRY(note(4, e->xn.p, (size_t)M * d));
+    RVB_TRY(run_gemm(e, e->xn.p, d, L.pw2, x, d, M, true, 1.f, ACT_NONE, x, d));
   }
-  RVB_TRY(run_gemm(e, ffin, d, L.ff1, e->h.p, ff, M, false, 1.f, ACT_SILU));
-  RVB_TRY(run_gemm(e, e->h.p, ff, L.ff2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  // feed-forward (+ language-specific mix), final norm     encoder_layer.py:231-244 / :372-402
+  if (f8 && !L.is_lsl) {
+    RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_ff1));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ff1, e->h.p, ff, M, sc8.in_ff1, 2, sc8.h_ff, 1.f, ACT_SILU));
+    RVB_TRY(run_gemm8(e, e->h.p, ff, L.ff2, x, d, M, sc8.h_ff, 1, 1.f, 0.5f, ACT_NONE, x, d));
+  } else {
+    RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d));
+    const void* ffin = e->xn.p;
+    if (L.is_lsl) {
+      RVB_TRY(run_gemm(e, e->xn.p, d, L.lsl, e->y.p, d, M, false));
+      ffin = e->y.p;
+    } else {
+      RVB_TRY(note(5, e->xn.p, (size_t)M * d));
+    }
+    RVB_TRY(run_gemm(e, ffin, d, L.ff1, e->h.p, ff, M, false, 1.f, ACT_SILU));
+    if (!L.is_lsl) RVB_TRY(note(6, e->h.p, (size_t)M * ff));
+    RVB_TRY(run_gemm(e, e->h.p, ff, L.ff2, x, d, M, true, 0.5f, ACT_NONE, x, d));
+  }
   // x = norm_final(x) (+ y for the language-specific block, encoder_layer.py:400), and in the same pass the LayerNorm
   // that always reads it next: the following block's norm_ff_macaron, or the encoder's after_norm (encoder.py:147-148)
-  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr, &next, next_out));
+  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr, &next, next_out, 0.f, f8 ? next8 : 0.f));
   return OK;
 }
 
@@ -544,6 +632,11 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     e->h_top_cap = (size_t)M * beam;
   }
   e->slices.clear();
+  if (e->fp8 && e->f8_state == 0) {     // first batch of an fp8 engine: bf16 pass that records the activation ranges
+    RVB_TRY(e->d_amax.ensure(e->enc.size() * 8 * 4));
+    RVB_HIP_CHECK(hipMemsetAsync(e->d_amax.p, 0, e->enc.size() * 8 * 4, e->stream));
+    e->f8_state = 1;
+  }
   for (int c0 = 0; c0 < B; c0 += SB) {
     const int nb = std::min(SB, B - c0);               // first slice SB chunks, second slice the rest (<= SB)
     const int m = nb * T2;
@@ -566,10 +659,13 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     }
     RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, m, true, std::sqrt((float)d)));
     void* eo = (char*)e->enc_out.p + (size_t)row0 * d * es;
-    RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, m, d));
+    const bool f8 = e->fp8 && e->f8_state == 2;
+    RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, m, d, NORM_LN, 0, nullptr, nullptr, nullptr,
+                     f8 ? e->f8[0].in_ffm1 : 0.f));
     for (size_t li = 0; li < e->enc.size(); ++li) {
       const bool last = li + 1 == e->enc.size();
-      RVB_TRY(encoder_layer(e, e->enc[li], m, nb, T2, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p));
+      RVB_TRY(encoder_layer(e, e->enc[li], (int)li, m, nb, T2, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p,
+                            (f8 && !last) ? e->f8[li + 1].in_ffm1 : 0.f));
     }
     // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
     for (int r0 = 0; r0 < m; r0 += LOGIT_SLAB) {
@@ -586,6 +682,20 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     else RVB_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     RVB_HIP_CHECK(hipEventRecord(ev, e->stream));
     e->slices.push_back({c0, nb, ev, false});
+  }
+  if (e->f8_state == 1) {
+    // per-tensor scales: a power of two with headroom (2 * amax maps inside +-448; fp8 is floating point, so headroom
+    // costs no relative precision); later batches saturate only beyond twice the calibration batch's maximum
+    std::vector<float> am(e->enc.size() * 8);
+    RVB_HIP_CHECK(hipMemcpyAsync(am.data(), e->d_amax.p, am.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->f8.resize(e->enc.size());
+    auto sc = [](float a) { return a > 0.f ? std::exp2(std::ceil(std::log2(2.f * a / 448.f))) : 1.f; };
+    for (size_t l = 0; l < e->enc.size(); ++l) {
+      const float* a = am.data() + l * 8;
+      e->f8[l] = {sc(a[0]), sc(a[1]), sc(a[2]), sc(a[3]), sc(a[4]), sc(a[5]), sc(a[6])};
+    }
+    e->f8_state = 2;
   }
   return OK;
 }
@@ -675,7 +785,7 @@ static int stream_chunk_impl(rvb_engine* e, const float* feats, int T0, int requ
   RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, M, d));
   for (size_t li = 0; li < e->enc.size(); ++li) {
     const bool last = li + 1 == e->enc.size();
-    RVB_TRY(encoder_layer(e, e->enc[li], M, 1, M, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p, (int)li));
+    RVB_TRY(encoder_layer(e, e->enc[li], (int)li, M, 1, M, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p, 0.f, (int)li));
   }
   if (out) {
     if (e->dtype == DT_F32) {
@@ -1252,7 +1362,7 @@ const char* rvb_version(void) { return "librvb 0.1 (gfx950)"; }
 
 int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
   if (!cfg || !out) { set_error("rvb_create: null argument"); return E_ARG; }
-  if (cfg->dtype != RVB_F32 && cfg->dtype != RVB_BF16) { set_error("rvb_create: bad dtype"); return E_ARG; }
+  if (cfg->dtype != RVB_F32 && cfg->dtype != RVB_BF16 && cfg->dtype != RVB_FP8) { set_error("rvb_create: bad dtype"); return E_ARG; }
   if (cfg->d_model <= 0 || cfg->heads <= 0 || cfg->d_model % cfg->heads || cfg->d_model % 8 || cfg->ffn_dim % 8 ||
       cfg->dec_ffn_dim % 8 || cfg->input_dim != 80 || cfg->vocab < 2 || cfg->num_blocks < 1 ||
       (cfg->cnn_kernel % 2) == 0 || cfg->chunk_frames < 7 || cfg->max_chunks < 1 ||
@@ -1266,7 +1376,9 @@ int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
   if (device < 0 || device >= ndev) { set_error("rvb_create: device index out of range"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(device));
   rvb_engine* e = new rvb_engine();
-  e->cfg = *cfg; e->device = device; e->dtype = cfg->dtype;
+  e->cfg = *cfg; e->device = device;
+  e->fp8 = cfg->dtype == RVB_FP8;                 // the bf16 engine with the encoder's large GEMMs on the fp8 MFMA path
+  e->dtype = e->fp8 ? (int)DT_BF16 : cfg->dtype;
   hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return E_HIP; }
   *out = e;
@@ -1291,7 +1403,7 @@ void rvb_destroy(rvb_engine* e) {
   e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
   for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2}) for (auto& b : *v) b.release();
   for (auto* v : {&e->kcache, &e->vcache, &e->kcache2, &e->vcache2, &e->memkv}) for (auto& b : *v) b.release();
-  auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); };
+  auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); l.w8.release(); l.wscale.release(); };
   auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };
   for (auto& L : e->enc) {
     for (Linear* l : {&L.ffm1, &L.ffm2, &L.ff1, &L.ff2, &L.qkv, &L.att_out, &L.pw1, &L.pw2, &L.lsl}) rel_lin(*l);
@@ -1609,6 +1721,12 @@ int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_
       if (tokens_confidence) tokens_confidence[(size_t)b * T + j] = j < (int)r.tok_conf.size() ? r.tok_conf[j] : 0.0;
     }
   }
+  return OK;
+}
+int rvb_fp8_recalibrate(rvb_engine* e) {
+  if (!e) { set_error("rvb_fp8_recalibrate: null engine"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_fp8_recalibrate: not an fp8 engine"); return E_STATE; }
+  e->f8_state = 0;
   return OK;
 }
 int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs) {

@@ -193,6 +193,10 @@ int gemm(hipStream_t s, int dtype, const GemmArgs& p) {
     return E_ARG;
   }
   if (p.M == 0) return OK;
+  if (p.in_fp8) {       // fp8 operands exist only on the LDS-DMA kernel
+    if (!gemm2_applicable(dtype, p)) { set_error("gemm: fp8 operands need the bf16 engine, K % 128 == 0 and per-channel weight scales"); return E_ARG; }
+    return gemm2(s, dtype, p);
+  }
   // auto: the 256x256 LDS-DMA kernel for bf16 (1.5-2x); f32 stays on the 128x128 kernel, which already
   // runs at ~70 % of the 157 TFLOP/s f32 MFMA peak (profiles/r01_gemm_microbench.md)
   if (g_gemm_variant != 1 && (dtype == DT_BF16 || g_gemm_variant == 2) && gemm2_applicable(dtype, p))

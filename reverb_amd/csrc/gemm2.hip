@@ -44,10 +44,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // MMA32 (bf16 only): v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_16x16x32_bf16 -- the same LDS bytes per flop (a lane's
 // 16-byte vector is 8 k-values of one of 32 rows instead of one of 16), half the MFMA instructions, and the shape whose
 // issue rate reaches the 2.5 PFLOP/s peak (16x16x32 tops out ~13 % lower, MI355X_MICROARCH.md / cdna_hip_programming.md 3).
+//
+// T = fp8_t (one byte, OCP e4m3): the same tile geometry with twice the K per 128-byte row, multiplied by
+// v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales (twice the bf16 MFMA rate, half the fill and fragment bytes per
+// flop).  Scaling is per tensor for the activations (a_scale, calibrated) and per output channel for the weights (w_scale):
+// C = act(a_scale * w_scale[n] * sum_k A8[m][k] W8[n][k] + bias[n]) ...; OutT = fp8_t divides by out_scale and saturates.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
 template <typename T, typename OutT, bool CONV, bool MMA32>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int VE = Mma16<T>::VE;
+  constexpr bool F8 = std::is_same<T, fp8_t>::value;
+  constexpr int VE = 16 / (int)sizeof(T);
   constexpr int BKE = ROW2 / (int)sizeof(T);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         : "memory", "scc");
   };
 
-  constexpr bool M32 = MMA32 && sizeof(T) == 2;
+  constexpr bool M32 = (MMA32 && sizeof(T) == 2) || F8;     // 32x32 accumulator blocks
   // 16x16 fragments: acc[i][j] = rows 16i.., cols 16j.. of the wave's 128x64 tile (C/D: col = lane&15, row = 4*(lane>>4)+r).
   // 32x32 blocks (M32): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
   f32x4_t acc[M32 ? 1 : 8][M32 ? 1 : 4];
@@ -187,9 +195,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   int roff[2];     // byte offset of this lane's 16-byte vector inside a row, per 64-byte chunk
   roff[0] = ((0 * 4 + lgrp) ^ swz) << 4;
   roff[1] = ((1 * 4 + lgrp) ^ swz) << 4;
-  int roff_t1[2];  // M32: second MFMA of the slice (columns 2 + g)
+  int roff_t1[2];  // M32 bf16: second MFMA of the slice (columns 2 + g)
   roff_t1[0] = ((0 * 4 + 2 + lgrp) ^ swz) << 4;
   roff_t1[1] = ((1 * 4 + 2 + lgrp) ^ swz) << 4;
+  if constexpr (F8) {   // one 32x32x64 MFMA per k64 slice: the lane's 32 bytes = 16-byte columns 2g, 2g + 1 of the slice
+    roff[0] = ((0 * 4 + 2 * lgrp) ^ swz) << 4; roff_t1[0] = ((0 * 4 + 2 * lgrp + 1) ^ swz) << 4;
+    roff[1] = ((1 * 4 + 2 * lgrp) ^ swz) << 4; roff_t1[1] = ((1 * 4 + 2 * lgrp + 1) ^ swz) << 4;
+  }
 
   // ---- main loop: k32 slices q = 2*kt + s stream through two register buffers of fragments.  Block u multiplies
   // slice u while slice u+1 is read (two MFMAs, one ds_read, ... so the reads leave early and land under the MFMAs);
@@ -197,7 +209,42 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   // blocks, so there is MFMA work on both sides of every barrier.  Measured against the plain
   // wait-barrier-refill-read-multiply loop in scripts/micro/gemm_lab.hip: +7..11 % on the engine's shapes.
   const int nk = p.K / BKE;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (F8) {
+    // fp8: the plain loop.  A k64 slice is eight 64-cycle MFMAs per wave, and the SIMD's other wave multiplies while this
+    // one waits for its 12 fragment reads; the register-pipelined form of the bf16 path spills here (fragments are
+    // 8-register tuples: 36 scratch accesses per K step).
+    const int a_off = (wr * 128 + frow) * ROW2;
+    const int b_off = B2M * ROW2 + (wc * 64 + frow) * ROW2;
+    if (p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of stage kt have landed
+      __syncthreads();                                   // ... and so have everybody else's
+      if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+      const char* st = smem + cur * STAGE2;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        i32x8_t a8[4], b8[2];
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+          const uint4 lo = *(const uint4*)(st + a_off + bi * 32 * ROW2 + roff[sl]), hi = *(const uint4*)(st + a_off + bi * 32 * ROW2 + roff_t1[sl]);
+          a8[bi] = (i32x8_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const uint4 lo = *(const uint4*)(st + b_off + bj * 32 * ROW2 + roff[sl]), hi = *(const uint4*)(st + b_off + bj * 32 * ROW2 + roff_t1[sl]);
+          b8[bj] = (i32x8_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj)
+            acc32[bi][bj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[bi], b8[bj], acc32[bi][bj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    }
+    if (p.prio && wave >= 4) __builtin_amdgcn_s_setprio(0);
+  } else if constexpr (sizeof(T) == 2) {
     const int nq = 2 * nk;
     uint4 fa[2][8], fb[2][4];
     const int a_off = (wr * 128 + frow) * ROW2;
@@ -346,9 +393,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     const int orow = lane >> 2;                            // row of the slab this lane finishes
     const int ocol = (lane & 3) * 16;                      // first of its 16 columns
     const int col0 = n0 + wc * 64 + ocol;
-    float bias16[16];
+    float bias16[16], sc16[F8 ? 16 : 1];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bias16[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
+    if constexpr (F8) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc16[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
+    }
     const bool seg_full = col0 + 16 <= p.N;
     auto finish_v = [&](auto actf) {
 #pragma unroll
@@ -381,6 +432,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         }
         const int row = m0 + wr * 128 + i * 16 + orow;
         if (row >= p.M || col0 >= p.N) continue;
+        if constexpr (F8) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] *= sc16[e];
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = actf(v[e] + bias16[e]) * p.alpha;
         OutT* cp = C + (size_t)row * p.ldc + col0;
@@ -393,7 +448,11 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
               v[q * 4 + 0] += t.x; v[q * 4 + 1] += t.y; v[q * 4 + 2] += t.z; v[q * 4 + 3] += t.w;
             }
           }
-          if constexpr (sizeof(OutT) == 2) {
+          if constexpr (sizeof(OutT) == 1) {
+            const float qs = p.out_inv_scale;
+            *(uint4*)cp = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                                     pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+          } else if constexpr (sizeof(OutT) == 2) {
             uint4 o0, o1;
             o0.x = pack2_bf16(v[0], v[1]);
             o0.y = pack2_bf16(v[2], v[3]);
@@ -414,14 +473,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
           for (int e = 0; e < 16 && col0 + e < p.N; ++e) {
             float o = v[e];
             if (p.res) o += p.res[(size_t)row * p.ldres + col0 + e];
-            cp[e] = Cvt<OutT>::from_f32(o);
+            if constexpr (sizeof(OutT) == 1) cp[e] = (OutT)(pack4_fp8(o * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
+            else cp[e] = Cvt<OutT>::from_f32(o);
           }
         }
       }
     };
     if (p.act == ACT_SILU) {
       // raw v_exp_f32 / v_rcp_f32 (no denormal fix-ups): 5 VALU ops per element, the result is rounded to bf16 anyway
-      if constexpr (sizeof(T) == 2) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
+      if constexpr (sizeof(T) <= 2) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
       else finish_v([](float x) { return x / (1.0f + expf(-x)); });
     } else if (p.act == ACT_RELU) {
       finish_v([](float x) { return fmaxf(x, 0.0f); });
@@ -443,9 +503,12 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
           for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= p.M || col >= p.N) continue;
-            float v = actf(acc32[bi][bj][r] + bvv) * p.alpha;
+            float av = acc32[bi][bj][r];
+            if constexpr (F8) av *= (col < p.N ? p.a_scale * p.w_scale[col] : 0.f);
+            float v = actf(av + bvv) * p.alpha;
             if (p.res) v += p.res[(size_t)row * p.ldres + col];
-            C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
+            if constexpr (sizeof(OutT) == 1) C[(size_t)row * p.ldc + col] = (OutT)(pack4_fp8(v * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
+            else C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
           }
         }
     };
@@ -454,6 +517,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     else finish32([](float v) { return v; });
     return;
   }
+  if constexpr (!M32) {
   float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -488,6 +552,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   } else {
     finish([](float v) { return v; });
   }
+  }
 }
 
 template <typename T, typename OutT, bool CONV, bool MMA32 = false>
@@ -505,6 +570,8 @@ static int launch2(hipStream_t s, const GemmArgs& p) {
 }
 
 bool gemm2_applicable(int dtype, const GemmArgs& p) {
+  if (p.in_fp8) return dtype == DT_BF16 && !p.conv && p.K % 128 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.M >= 1 && p.N >= 64 &&
+                       p.act != ACT_LRELU && p.w_scale != nullptr;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   if (p.K % bke || p.lda % (bke / 8) || p.ldw % (bke / 8)) return false;
   if (p.conv && (p.cC % bke)) return false;
@@ -525,6 +592,11 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   GemmArgs p = p0;
   p.group_m = g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
+  if (p.in_fp8) {
+    if (p.out_fp8) return launch2<fp8_t, fp8_t, false, true>(s, p);
+    if (p.out_f32) return launch2<fp8_t, float, false, true>(s, p);
+    return launch2<fp8_t, bf16_t, false, true>(s, p);
+  }
   if (dtype == DT_BF16) {
     if (g_gemm2_flags & 1) {
       if (p.out_f32) return p.conv ? launch2<bf16_t, float, true, true>(s, p) : launch2<bf16_t, float, false, true>(s, p);

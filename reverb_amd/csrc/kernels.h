@@ -25,6 +25,11 @@ struct GemmArgs {
   int conv;           // implicit 3x3 stride-2 conv gather on A
   int cT1, cF1, cT2, cF2, cC;
   int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
+  // fp8 (OCP e4m3) operands, gemm2 only: A and W are bytes, the accumulator is multiplied by a_scale * w_scale[n];
+  // out_fp8: C is written as fp8 of value * out_inv_scale (saturating)
+  int in_fp8, out_fp8;
+  float a_scale, out_inv_scale;
+  const float* w_scale;   // [N]
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
 // gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)
@@ -71,6 +76,9 @@ struct NormArgs {
   const float* beta2 = nullptr;
   float eps2 = 0.f;
   void* out2 = nullptr;
+  // fp8 (e4m3) outputs for the bf16 engine's fp8 GEMMs: bytes of value * inv_scale, saturating
+  int out_fp8 = 0, out2_fp8 = 0;
+  float out_inv_scale = 1.f, out2_inv_scale = 1.f;
 };
 int rownorm(hipStream_t s, int dtype, const NormArgs& a);
 
@@ -103,6 +111,9 @@ int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, c
 
 // dst[r][t][:] = src[parent[r]][t][:], t < rows: caches [R][L][row_bytes]
 int gather_cache(hipStream_t s, const void* src, void* dst, const int* parent, int R, int L, int rows, int row_bytes);
+
+// max |x| over n elements of T (or fp32 when dtype says so) folded into *slot with atomicMax on the float bits (slot >= 0)
+int amax_abs(hipStream_t s, int dtype, const void* x, size_t n, float* slot);
 
 // fp32 -> T conversion copy (weight packing), n elements
 int convert_f32(hipStream_t s, int dtype, const float* src, void* dst, size_t n);

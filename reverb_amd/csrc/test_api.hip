@@ -251,6 +251,78 @@ int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* 
   return OK;
 }
 
+// fp8 GEMM of gemm2.hip on host floats: A is quantised per tensor (a_scale), W per output channel, exactly as the engine
+// does; a_deq / w_deq (nullable) receive the values the quantised operands stand for, so that the caller's fp64 reference
+// isolates the kernel from the quantisation.  out_kind 0 bf16, 1 fp32, 2 fp8 (values are returned de-quantised).
+int rvb_test_gemm_fp8(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K,
+                      float a_scale, float alpha, int act, int out_kind, float out_scale, float* a_deq, float* w_deq) {
+  T_TRY(need_gpu());
+  std::vector<uint8_t> qa((size_t)M * K), qw((size_t)N * K);
+  std::vector<float> ws(N);
+  for (size_t i = 0; i < qa.size(); ++i) { qa[i] = f32_to_fp8_host(A[i] / a_scale); if (a_deq) a_deq[i] = fp8_to_f32_host(qa[i]) * a_scale; }
+  for (int n = 0; n < N; ++n) {
+    float am = 0.f;
+    for (int k = 0; k < K; ++k) am = fmaxf(am, fabsf(W[(size_t)n * K + k]));
+    ws[n] = am > 0.f ? am / 448.f : 1.f;
+    for (int k = 0; k < K; ++k) {
+      qw[(size_t)n * K + k] = f32_to_fp8_host(W[(size_t)n * K + k] / ws[n]);
+      if (w_deq) w_deq[(size_t)n * K + k] = fp8_to_f32_host(qw[(size_t)n * K + k]) * ws[n];
+    }
+  }
+  Dev dA, dW, dS, dB, dR, dC;
+  T_TRY(up_raw(dA, qa.data(), qa.size())); T_TRY(up_raw(dW, qw.data(), qw.size())); T_TRY(up_raw(dS, ws.data(), (size_t)N * 4));
+  T_TRY(up_raw(dB, bias, (size_t)N * 4)); T_TRY(up_raw(dR, res, (size_t)M * N * 4));
+  const size_t osz = out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2;
+  T_TRY(dC.alloc((size_t)M * N * osz));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.res = (const float*)dR.p; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldres = N; g.alpha = alpha; g.act = act;
+  g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.in_fp8 = 1; g.a_scale = a_scale; g.w_scale = (const float*)dS.p;
+  g.out_inv_scale = 1.f / out_scale;
+  T_TRY(gemm(nullptr, DT_BF16, g));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  if (out_kind == 1) return down_T(dC, DT_F32, true, C, (size_t)M * N);
+  if (out_kind == 0) return down_T(dC, DT_BF16, false, C, (size_t)M * N);
+  std::vector<uint8_t> q((size_t)M * N);
+  RVB_HIP_CHECK(hipMemcpy(q.data(), dC.p, q.size(), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < q.size(); ++i) C[i] = fp8_to_f32_host(q[i]) * out_scale;
+  return OK;
+}
+
+// LayerNorm with fp8 outputs (first stage and / or the fused second LayerNorm); results returned de-quantised
+int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, float eps, int silu, int M, int d, float scale,
+                         float* out, const float* gamma2, const float* beta2, float eps2, float scale2, float* out1_f32, float* out2) {
+  T_TRY(need_gpu());
+  Dev dx, dg, db, dg2, db2, dout, dout2;
+  T_TRY(up_raw(dx, x, (size_t)M * d * 4)); T_TRY(up_raw(dg, gamma, (size_t)d * 4)); T_TRY(up_raw(db, beta, (size_t)d * 4));
+  T_TRY(up_raw(dg2, gamma2, (size_t)d * 4)); T_TRY(up_raw(db2, beta2, (size_t)d * 4));
+  NormArgs a;
+  a.x = (const float*)dx.p; a.gamma = (const float*)dg.p; a.beta = (const float*)db.p; a.eps = eps; a.mode = NORM_LN; a.silu = silu;
+  a.add = nullptr; a.M = M; a.d = d;
+  const bool two = gamma2 != nullptr;
+  if (two) {       // stage 1 fp32 (in place semantics of norm_final), stage 2 fp8
+    T_TRY(dout.alloc((size_t)M * d * 4)); T_TRY(dout2.alloc((size_t)M * d));
+    a.out = dout.p; a.out_f32 = 1; a.gamma2 = (const float*)dg2.p; a.beta2 = (const float*)db2.p; a.eps2 = eps2; a.out2 = dout2.p;
+    a.out2_fp8 = 1; a.out2_inv_scale = 1.f / scale2;
+  } else {
+    T_TRY(dout.alloc((size_t)M * d));
+    a.out = dout.p; a.out_f32 = 0; a.out_fp8 = 1; a.out_inv_scale = 1.f / scale;
+  }
+  T_TRY(rownorm(nullptr, DT_BF16, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<uint8_t> q((size_t)M * d);
+  if (two) {
+    RVB_HIP_CHECK(hipMemcpy(out1_f32, dout.p, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+    RVB_HIP_CHECK(hipMemcpy(q.data(), dout2.p, q.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < q.size(); ++i) out2[i] = fp8_to_f32_host(q[i]) * scale2;
+  } else {
+    RVB_HIP_CHECK(hipMemcpy(q.data(), dout.p, q.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < q.size(); ++i) out[i] = fp8_to_f32_host(q[i]) * scale;
+  }
+  return OK;
+}
+
 // host only (no GPU needed): word alignment counts for reverb_amd/wer_evaluation/align.py
 int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_t n_hyp, int64_t* counts) {
   if ((!ref && n_ref > 0) || (!hyp && n_hyp > 0) || !counts || n_ref < 0 || n_hyp < 0) { set_error("rvb_wer_counts: bad argument"); return E_ARG; }

@@ -14,7 +14,7 @@ from ._lib import ModelCfg, RvbError, check, dptr, fptr, iptr
 from .search import DecodeResult
 
 DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32,
-          "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16}
+          "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16, "fp8": _lib.RVB_FP8}
 SUPPORTED_MODES = ("attention", "ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring")
 
 

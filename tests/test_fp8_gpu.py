@@ -1,0 +1,127 @@
+"""RVB_FP8 mode (BASELINE configs[4] "fp8 MFMA GEMMs"): the fp8 (OCP e4m3) GEMM of gemm2.hip against fp64 on exactly the
+values its quantised operands stand for (so the check isolates the kernel: operand layout of
+v_mfma_scale_f32_32x32x64_f8f6f4, per-channel / per-tensor scales, every epilogue form), the LayerNorm-to-fp8 kernels, and
+the engine end to end against the reference goldens: token error rate with the measured bound written below."""
+import math
+
+import numpy as np
+import pytest
+
+from reverb_amd import _lib
+from reverb_amd._lib import fptr
+from util import f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _e4m3_grid():
+    v = [0.0]
+    for E in range(16):
+        for M in range(8):
+            if E == 15 and M == 7:
+                continue
+            v.append((M / 8.0) * 2.0 ** -6 if E == 0 else (1 + M / 8.0) * 2.0 ** (E - 7))
+    g = np.array(sorted(set(v)))
+    return np.concatenate([-g[::-1], g])
+
+
+@pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_kind", [
+    (300, 256, 128, 0, 1.0, False, 1),          # one K step, a partial row tile
+    (1000, 1024, 1024, 1, 1.0, False, 2),       # SiLU, fp8 output (the feed-forward's h)
+    (513, 3072, 256, 0, 1.0, False, 0),         # bf16 output (qkv)
+    (2100, 512, 512, 0, 0.5, True, 1),          # fp32 residual epilogue (feed-forward's second GEMM)
+    (130, 330, 384, 2, 1.0, False, 1),          # unaligned rows: element-wise epilogue
+])
+def test_fp8_gemm_against_fp64_on_the_quantised_values(lib, M, N, K, act, alpha, use_res, out_kind):
+    rng = np.random.default_rng(M + N + K)
+    A = f32(rng.standard_normal((M, K)) * 1.7)
+    W = f32(rng.standard_normal((N, K)) / math.sqrt(K) * (1 + rng.random((N, 1)) * 3))       # channels of different magnitude
+    bias = f32(rng.standard_normal(N))
+    res = f32(rng.standard_normal((M, N))) if use_res else None
+    a_scale = float(np.abs(A).max() * 2 / 448)
+    C = np.full((M, N), np.nan, np.float32)
+    Ad, Wd = np.empty_like(A), np.empty_like(W)
+    out_scale = 1.0
+    v = None
+    for attempt in range(2):          # the fp8 output scale comes from the result itself (as calibration does)
+        _lib.check(lib.rvb_test_gemm_fp8(fptr(A), fptr(W), fptr(bias), fptr(res), fptr(C), M, N, K, a_scale, alpha, act, out_kind,
+                                         out_scale, fptr(Ad), fptr(Wd)))
+        v = Ad.astype(np.float64) @ Wd.astype(np.float64).T + bias
+        if act == 1:
+            v = v / (1 + np.exp(-v))
+        elif act == 2:
+            v = np.maximum(v, 0)
+        v = v * alpha + (res if use_res else 0)
+        if out_kind != 2 or attempt == 1:
+            break
+        out_scale = float(np.abs(v).max() * 2 / 448)
+    # the operands really are e4m3 values at the stated scales
+    grid = _e4m3_grid()
+    assert np.isin(np.round(Ad[:8] / a_scale, 9), np.round(grid, 9)).all()
+    assert np.abs(Ad - A).max() <= np.abs(A).max() / 16 + 1e-6 and np.abs(Wd - W).max() <= np.abs(W).max() / 16 + 1e-6
+    if out_kind == 1:
+        np.testing.assert_allclose(C, v, rtol=1e-4, atol=1e-4)
+    elif out_kind == 0:
+        np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)                                   # one bf16 rounding
+    else:
+        np.testing.assert_allclose(C, v, rtol=0.07, atol=out_scale * 2.0 ** -9 * 1.01)           # one e4m3 rounding (3-bit mantissa)
+
+
+def test_layernorm_to_fp8(lib):
+    M, d = 37, 1024
+    rng = np.random.default_rng(4)
+    x = f32(rng.standard_normal((M, d)) * 3 + 1)
+    g, b = f32(1 + 0.1 * rng.standard_normal(d)), f32(0.1 * rng.standard_normal(d))
+    g2, b2 = f32(1 + 0.1 * rng.standard_normal(d)), f32(0.1 * rng.standard_normal(d))
+    xd = x.astype(np.float64)
+    ln = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-5) * g + b
+    scale = float(np.abs(ln).max() * 2 / 448)
+    out = np.empty((M, d), np.float32)
+    _lib.check(lib.rvb_test_rownorm_fp8(fptr(x), fptr(g), fptr(b), 1e-5, 0, M, d, scale, fptr(out), None, None, 0.0, 1.0, None, None))
+    np.testing.assert_allclose(out, ln, rtol=0.07, atol=scale * 2.0 ** -9 * 1.01)
+    # fused pair: stage 1 fp32 (norm_final), stage 2 = the next block's LayerNorm as fp8
+    ln2 = (ln - ln.mean(1, keepdims=True)) / np.sqrt(ln.var(1, keepdims=True) + 1e-5) * g2 + b2
+    scale2 = float(np.abs(ln2).max() * 2 / 448)
+    o1, o2 = np.empty((M, d), np.float32), np.empty((M, d), np.float32)
+    _lib.check(lib.rvb_test_rownorm_fp8(fptr(x), fptr(g), fptr(b), 1e-5, 0, M, d, 1.0, None, fptr(g2), fptr(b2), 1e-5, scale2,
+                                        fptr(o1), fptr(o2)))
+    np.testing.assert_allclose(o1, ln, rtol=1e-5, atol=4e-5)
+    np.testing.assert_allclose(o2, ln2, rtol=0.07, atol=scale2 * 2.0 ** -9 * 1.01)
+
+
+# measured round 2 (profiles/r02_parity_metrics.jsonl): token error rates of the fp8 mode against the unmodified reference
+FP8_TER_BOUND = {"small_66": 0.5, "r640_chunk": 0.5}
+
+
+@pytest.mark.parametrize("name", ["small_66", "r640_chunk"])
+def test_fp8_engine_against_reference(name):
+    from golden_util import LongCase
+    from reverb_amd.engine import Engine
+    from test_longform_gpu import MODES, _record, _tap_metrics, _ter
+    case = LongCase(name)
+    n = len(case.js["lens"]) if name == "small_66" else 2
+    x = np.concatenate([case.chunk_feats(c)[0] for c in range(n)])
+    lens = np.array(case.js["lens"][:n], np.int32)
+    eng = Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=n, chunk_frames=case.chunk, cat_embs=case.cat)
+    eng.encode(x, lens, case.beam)                      # calibration batch: runs in bf16, records the activation ranges
+    cal = _ter(eng.search(MODES, case.ctc_weight, case.reverse_weight), case)
+    eng.reset_timings()
+    eng.encode(x, lens, case.beam)                      # fp8 GEMMs
+    assert eng.timing("gemm_fp8")["launches"] > 0, "the fp8 GEMM path did not run"
+    m0 = _tap_metrics(eng, case, 0, 0)
+    ter = _ter(eng.search(MODES, case.ctc_weight, case.reverse_weight), case)
+    _record(case=name, dtype="fp8", ter={m: list(v) for m, v in ter.items()}, bf16_calibration_pass_ter={m: list(v) for m, v in cal.items()},
+            chunk0=m0)
+    assert m0["cos"] > 0.99, m0
+    for m in MODES:
+        assert ter[m][0] <= FP8_TER_BOUND[name] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+    eng.close()
+
+
+def test_fp8_needs_dims_of_128():
+    from golden_util import Case
+    from reverb_amd._lib import RvbError
+    from reverb_amd.engine import Engine
+    case = Case("tiny_ln")                                  # d = 32
+    with pytest.raises(RvbError, match="multiples of 128"):
+        Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
