@@ -57,7 +57,9 @@ def test_fp8_gemm_against_fp64_on_the_quantised_values(lib, M, N, K, act, alpha,
         out_scale = float(np.abs(v).max() * 2 / 448)
     # the operands really are e4m3 values at the stated scales
     grid = _e4m3_grid()
-    assert np.isin(np.round(Ad[:8] / a_scale, 9), np.round(grid, 9)).all()
+    q = Ad[:8].astype(np.float64) / a_scale
+    nearest = grid[np.abs(q[..., None] - grid).argmin(-1)]
+    assert np.abs(q - nearest).max() < 1e-4 * 448
     assert np.abs(Ad - A).max() <= np.abs(A).max() / 16 + 1e-6 and np.abs(Wd - W).max() <= np.abs(W).max() / 16 + 1e-6
     if out_kind == 1:
         np.testing.assert_allclose(C, v, rtol=1e-4, atol=1e-4)
@@ -90,7 +92,10 @@ def test_layernorm_to_fp8(lib):
 
 
 # measured round 2 (profiles/r02_parity_metrics.jsonl): token error rates of the fp8 mode against the unmodified reference
-FP8_TER_BOUND = {"small_66": 0.5, "r640_chunk": 0.5}
+# small_66: greedy 9.5 % / rescored 9.8 % of 4 666 tokens (bf16: 1.5 % / 3.4 %), encoder cos-sim 0.9995; r640_chunk: 9/66 and
+# 9/84 tokens (bf16 4/66, 6/84), cos-sim 0.9975.  Random-weight models have tiny CTC margins, so these are
+# upper bounds on what calibrated fp8 costs a trained model.  Bound = measured + margin.
+FP8_TER_BOUND = {"small_66": 0.14, "r640_chunk": 0.24}
 
 
 @pytest.mark.parametrize("name", ["small_66", "r640_chunk"])
