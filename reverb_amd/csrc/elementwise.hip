@@ -94,13 +94,16 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 // ------------------------------------------------------------------------------------------------
 template <typename OutT, typename AddT, int NV>
 __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
+  // a lane owns NV/2 runs of 8 consecutive columns (two float4 loads, one 16-byte bf16 / 8-byte fp8 store per run):
+  // vector i covers columns COL(i) .. COL(i)+3
   const int lane = threadIdx.x & 63;
   const int d = a.d;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+#define COL(i) ((((lane) + 64 * ((i) >> 1)) << 3) + (((i) & 1) << 2))
   float4 g[NV], be[NV], g2[NV], be2[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
+    const int c = COL(i);
     const bool ok = c < d;
     g[i] = ok ? *(const float4*)(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     be[i] = ok ? *(const float4*)(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
     const float* x = a.x + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
+      const int c = COL(i);
       v[i] = (row < a.M && c < d) ? *(const float4*)(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -130,8 +133,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
+        if (COL(i) < d) {
           const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
     float sum2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
+      const int c = COL(i);
       if (c >= d) continue;
       float o[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
                     (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
@@ -164,24 +166,31 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
           o[0] += u.x; o[1] += u.y; o[2] += u.z; o[3] += u.w;
         }
       }
-      if constexpr (sizeof(OutT) == 1) {
-        const float qs = a.out_inv_scale;             // fp8 operand of the next GEMM: value / (calibrated per-tensor scale)
-        *(uint32_t*)(out + c) = pack4_fp8(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
-      } else if constexpr (sizeof(OutT) == 2) {
-        *(uint2*)(out + c) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
-      } else {
-        *(float4*)(out + c) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-      v[i] = make_float4(o[0], o[1], o[2], o[3]);      // kept for the second stage
+      if constexpr (sizeof(OutT) == 4) *(float4*)(out + c) = make_float4(o[0], o[1], o[2], o[3]);
+      v[i] = make_float4(o[0], o[1], o[2], o[3]);      // kept for the narrow stores below and for the second stage
       sum2 += o[0] + o[1] + o[2] + o[3];
+    }
+    if constexpr (sizeof(OutT) <= 2) {                 // one store per 8-column run (d % 8 == 0 is checked by the launcher)
+#pragma unroll
+      for (int i = 0; i < NV; i += 2) {
+        const int c = COL(i);
+        if (c >= d) continue;
+        if constexpr (sizeof(OutT) == 1) {
+          const float qs = a.out_inv_scale;            // fp8 operand of the next GEMM: value / (calibrated per-tensor scale)
+          *(uint2*)(out + c) = make_uint2(pack4_fp8(v[i].x * qs, v[i].y * qs, v[i].z * qs, v[i].w * qs),
+                                          pack4_fp8(v[i + 1].x * qs, v[i + 1].y * qs, v[i + 1].z * qs, v[i + 1].w * qs));
+        } else {
+          *(uint4*)(out + c) = make_uint4(pack2_bf16(v[i].x, v[i].y), pack2_bf16(v[i].z, v[i].w),
+                                          pack2_bf16(v[i + 1].x, v[i + 1].y), pack2_bf16(v[i + 1].z, v[i + 1].w));
+        }
+      }
     }
     if (a.out2) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
       const float mean2 = wave_sum(sum2) / (float)d;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
+        if (COL(i) < d) {
           const float dx = v[i].x - mean2, dy = v[i].y - mean2, dz = v[i].z - mean2, dw = v[i].w - mean2;
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
@@ -189,24 +198,33 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
       const float rstd2 = rsqrtf(wave_sum(sq) / (float)d + a.eps2);
       AddT* o2 = (AddT*)a.out2 + (size_t)row * d;      // AddT is the compute dtype
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
+      for (int i = 0; i < NV; i += 2) {
+        const int c = COL(i);
         if (c >= d) continue;
-        const float q0 = (v[i].x - mean2) * rstd2 * g2[i].x + be2[i].x, q1 = (v[i].y - mean2) * rstd2 * g2[i].y + be2[i].y;
-        const float q2 = (v[i].z - mean2) * rstd2 * g2[i].z + be2[i].z, q3 = (v[i].w - mean2) * rstd2 * g2[i].w + be2[i].w;
+        float q[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          q[4 * h + 0] = (v[i + h].x - mean2) * rstd2 * g2[i + h].x + be2[i + h].x;
+          q[4 * h + 1] = (v[i + h].y - mean2) * rstd2 * g2[i + h].y + be2[i + h].y;
+          q[4 * h + 2] = (v[i + h].z - mean2) * rstd2 * g2[i + h].z + be2[i + h].z;
+          q[4 * h + 3] = (v[i + h].w - mean2) * rstd2 * g2[i + h].w + be2[i + h].w;
+        }
         if (a.out2_fp8) {
           const float qs = a.out2_inv_scale;
-          *(uint32_t*)((fp8_t*)a.out2 + (size_t)row * d + c) = pack4_fp8(q0 * qs, q1 * qs, q2 * qs, q3 * qs);
+          *(uint2*)((fp8_t*)a.out2 + (size_t)row * d + c) = make_uint2(pack4_fp8(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs),
+                                                                       pack4_fp8(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs));
         } else if constexpr (sizeof(AddT) == 2) {
-          *(uint2*)(o2 + c) = make_uint2(pack2_bf16(q0, q1), pack2_bf16(q2, q3));
+          *(uint4*)(o2 + c) = make_uint4(pack2_bf16(q[0], q[1]), pack2_bf16(q[2], q[3]), pack2_bf16(q[4], q[5]), pack2_bf16(q[6], q[7]));
         } else {
-          *(float4*)(o2 + c) = make_float4(q0, q1, q2, q3);
+          *(float4*)(o2 + c) = make_float4(q[0], q[1], q[2], q[3]);
+          *(float4*)(o2 + c + 4) = make_float4(q[4], q[5], q[6], q[7]);
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = nx[i];
   }
+#undef COL
 }
 
 template <typename OutT, typename AddT>
@@ -220,7 +238,7 @@ static void launch_rownorm(hipStream_t s, const NormArgs& a) {
 
 int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
   if (a.M <= 0) return OK;
-  if (a.d % 4 || a.d > 2048) { set_error("rownorm: d must be a multiple of 4 and <= 2048"); return E_ARG; }
+  if (a.d % 8 || a.d > 2048) { set_error("rownorm: d must be a multiple of 8 and <= 2048"); return E_ARG; }
   if (a.out2 && (a.mode != NORM_LN || !(a.out_f32 || dtype == DT_F32))) {
     set_error("rownorm: the fused second LayerNorm follows a LayerNorm with fp32 output"); return E_ARG;
   }

@@ -64,14 +64,47 @@ __global__ __launch_bounds__(256) void pdist_kernel(const double* __restrict__ X
 // ------------------------------------------------------------------------------------ block-wide (value, index) argmin
 struct MinPair { double v; int i; };
 __device__ inline MinPair min_pair(MinPair a, MinPair b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
-__device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    MinPair q;
-    q.v = __shfl_xor(p.v, o, 64);
-    q.i = __shfl_xor(p.i, o, 64);
-    p = min_pair(p, q);
+// wave-wide argmin without LDS: `__shfl_xor` is a ds_bpermute per 32-bit piece (18 LDS round trips for a (double, int) pair,
+// on the merge loop's critical path six times per merge); here the four steps inside a 16-lane row are DPP moves
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- min is commutative, any pairing that unifies the row works) and
+// the two steps across rows are gfx950's v_permlane16_swap / v_permlane32_swap.
+template <int CTRL> __device__ inline MinPair dpp_pair(const MinPair& p) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(p.v);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)bits, CTRL, 0xf, 0xf, false);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(bits >> 32), CTRL, 0xf, 0xf, false);
+  MinPair q;
+  q.v = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  q.i = (int)__builtin_amdgcn_update_dpp(0u, (unsigned)p.i, CTRL, 0xf, 0xf, false);
+  return q;
+}
+__device__ inline MinPair wave_argmin(MinPair p) {
+  p = min_pair(p, dpp_pair<0xB1>(p));      // quad_perm [1,0,3,2]
+  p = min_pair(p, dpp_pair<0x4E>(p));      // quad_perm [2,3,0,1]
+  p = min_pair(p, dpp_pair<0x141>(p));     // row_half_mirror
+  p = min_pair(p, dpp_pair<0x140>(p));     // row_mirror
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(p.v);
+  {
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned)bits, (unsigned)bits, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
+    auto c = __builtin_amdgcn_permlane16_swap((unsigned)p.i, (unsigned)p.i, false, false);
+    MinPair u{__longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0])), (int)c[0]};
+    MinPair w{__longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1])), (int)c[1]};
+    p = min_pair(u, w);
   }
+  const unsigned long long bits2 = (unsigned long long)__double_as_longlong(p.v);
+  {
+    auto a = __builtin_amdgcn_permlane32_swap((unsigned)bits2, (unsigned)bits2, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap((unsigned)(bits2 >> 32), (unsigned)(bits2 >> 32), false, false);
+    auto c = __builtin_amdgcn_permlane32_swap((unsigned)p.i, (unsigned)p.i, false, false);
+    MinPair u{__longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0])), (int)c[0]};
+    MinPair w{__longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1])), (int)c[1]};
+    p = min_pair(u, w);
+  }
+  return p;
+}
+
+__device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
+  p = wave_argmin(p);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wv] = p;
@@ -84,13 +117,7 @@ __device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
 // one-barrier variant for back-to-back reductions: the caller alternates between two result buffers, so the writes of
 // reduction k+1 cannot race with the reads of reduction k (those are separated by reduction k+1's own barrier from k+2)
 __device__ inline MinPair block_argmin_alt(MinPair p, MinPair (*red)[16], int& phase) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    MinPair q;
-    q.v = __shfl_xor(p.v, o, 64);
-    q.i = __shfl_xor(p.i, o, 64);
-    p = min_pair(p, q);
-  }
+  p = wave_argmin(p);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   MinPair* buf = red[phase & 1];
   ++phase;
