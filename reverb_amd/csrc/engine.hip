@@ -486,6 +486,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->cur_lens;
     a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
     a.chunk = e->dec_chunk; a.left = e->dec_left;          // add_optional_chunk_mask, encoder.py:140-145
+    { static const int qb = getenv("RVB_ATTN_QBLOCK") ? atoi(getenv("RVB_ATTN_QBLOCK")) : 0; a.q_block = qb; }   // tuning: 64 / 128 queries per workgroup
     double keys = T;
     if (li >= 0) {
       // attention.py:361-369: k = cat(key_cache, k), v = cat(value_cache, v); pos_emb = position_encoding(offset -
