@@ -18,6 +18,7 @@ At N = 1 the same JSON line also carries
                     (FETCH_SIZE, WRITE_SIZE; corrected as MI355X_MICROARCH.md prescribes), `--traffic off` skips them
   pcie_inclusive    the same step with the 115 MB/h PCM upload from host memory inside it (never `value`)
   diarization       BASELINE configs[3] as a sub-record (bench_diar.py's step: own value, roofline, cpu_baseline)
+  joint_fp8         BASELINE configs[4] as a sub-record (bench_joint.py: ASR in fp8 + diarization + word->speaker join)
   cpu_baseline      the oracle (CPU port of the reference) on the first chunks of the same workload
 """
 from __future__ import annotations
@@ -391,6 +392,11 @@ def main():
                 out["diarization"] = diarization_record(device)
             except Exception as ex:        # the headline line must not die with the second workload
                 out["diarization"] = {"error": f"{type(ex).__name__}: {ex}"}
+            try:                           # BASELINE configs[4]: joint pipeline, ASR encoder GEMMs in fp8
+                import bench_joint
+                out["joint_fp8"] = bench_joint.run(local_rank, steps=2, warmup=1, hours=args.hours, dtype="fp8", model=args.model)
+            except Exception as ex:
+                out["joint_fp8"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in the C stdout buffer: get it out first,

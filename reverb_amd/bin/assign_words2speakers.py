@@ -51,6 +51,41 @@ def speaker_for_segment(start: float, dur: float, turns: List[Turn]) -> str:
     return max(overlap, key=overlap.get)
 
 
+def speakers_for_words(starts, durs, turns: List[Turn], block: int = 1024) -> List[str]:
+    """`speaker_for_segment` for many words at once (an hour of speech is ~10^4 words against ~10^3 turns: the per-word
+    scan is seconds of Python): overlap tests and distances as numpy blocks, the three cases resolved exactly as above
+    (tests/test_diarization_host.py checks equality with the per-word function)."""
+    import numpy as np
+    starts = np.asarray(starts, np.float64)
+    ends = starts + np.asarray(durs, np.float64)
+    n = len(starts)
+    if not turns:
+        return [""] * n
+    S = np.array([t[0] for t in turns]); E = np.array([t[1] for t in turns])
+    labels = [t[2] for t in turns]
+    out: List[str] = [""] * n
+    for b0 in range(0, n, block):
+        st, en = starts[b0:b0 + block, None], ends[b0:b0 + block, None]
+        touch = (S[None, :] < en) & (E[None, :] > st)
+        hit = touch & (st < en)                       # a zero-length word overlaps nothing (the tree query is empty)
+        cnt = hit.sum(1)
+        first = hit.argmax(1)
+        # no overlapping turn: the nearest one (first of equally near turns), intervaltree's distance_to
+        dist = np.where(touch, 0.0, np.where(st < S[None, :], S[None, :] - en, st - E[None, :]))
+        near = dist.argmin(1)
+        for i in range(len(cnt)):
+            if cnt[i] == 1:
+                out[b0 + i] = labels[first[i]]
+            elif cnt[i] == 0:
+                out[b0 + i] = labels[near[i]]
+            else:
+                overlap = defaultdict(float)
+                for j in np.nonzero(hit[i])[0]:
+                    overlap[labels[j]] += min(en[i, 0], E[j]) - max(st[i, 0], S[j])
+                out[b0 + i] = max(overlap, key=overlap.get)
+    return out
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser('Assign words to speakers based on a diarization rttm file and ctm transcription')
     parser.add_argument('diarization_rttm', help='diarization rttm file')
@@ -61,10 +96,11 @@ def main(argv=None):
     keys = list(rttm.keys())
     assert len(keys) == 1, keys
     turns = make_turns(rttm[keys[0]])
+    rows = [(float(r[2]), float(r[3]), r[4]) for r in read_ctm(args.ctm_transcription)]
+    who = speakers_for_words([r[0] for r in rows], [r[1] for r in rows], turns)
     with open(args.output_stm_transcription, 'w') as f:
-        for _, channel, start, dur, token, _ in read_ctm(args.ctm_transcription):
-            start, dur = float(start), float(dur)
-            f.write(f'{keys[0]} 1 {speaker_for_segment(start, dur, turns)} {start:.3f} {(start + dur):.3f} {token}\n')
+        for (start, dur, token), spk in zip(rows, who):
+            f.write(f'{keys[0]} 1 {spk} {start:.3f} {(start + dur):.3f} {token}\n')
 
 
 if __name__ == '__main__':

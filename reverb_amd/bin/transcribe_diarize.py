@@ -15,12 +15,20 @@ import time
 import numpy as np
 
 
-def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, **decode_kw):
-    from reverb_amd.bin.assign_words2speakers import make_turns, speaker_for_segment
+def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, overlap=True, **decode_kw):
+    """overlap (single process): ASR and diarization run as two host threads on their own engines / HIP streams, so that the
+    diarization's clustering -- a 150 ms per hour merge loop on ONE compute unit -- and its host-side numpy run underneath
+    the ASR encoder instead of after it (ctypes releases the GIL inside librvb)."""
+    from reverb_amd.bin.assign_words2speakers import make_turns, speakers_for_words
     from reverb_amd.reverb import get_output
     from reverb_amd.wav import read_wav
-    stem = os.path.splitext(os.path.basename(audio))[0]
-    wave, rate = read_wav(audio)
+    if isinstance(audio, tuple):        # (name, int16 mono PCM at 16 kHz) already in memory
+        stem, pcm16 = audio
+        wave, rate = np.ascontiguousarray(pcm16, np.int16).reshape(1, -1), 16000
+        audio = {"waveform": wave[0], "sample_rate": 16000, "uri": stem}
+    else:
+        stem = os.path.splitext(os.path.basename(audio))[0]
+        wave, rate = read_wav(audio)
     timings = {}
     t0 = time.perf_counter()
     chunk = asr.engine.cfg.chunk_frames
@@ -31,28 +39,42 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
         if rate != 16000:
             raise NotImplementedError("sharded decoding slices 16 kHz PCM; resample the file first")
         hyps = decode_sharded(asr.engine, wave[0], [mode], chunk, kw["beam_size"], kw["ctc_weight"], kw["reverse_weight"], device)[mode]
-    else:
+
+    def asr_local():
+        ta = time.perf_counter()
         asr.engine.upload_pcm(wave[0], rate)
         nf = asr.engine.fbank()
-        hyps = asr.decode_resident(nf, [mode], chunk, kw["beam_size"], kw["ctc_weight"], kw["reverse_weight"])[mode]
-    ctm = get_output("ctm", asr.tokenizer, stem, hyps, 230, chunk, asr.input_frame_length, asr.output_frame_length)
-    timings["asr"] = time.perf_counter() - t0
-    t1 = time.perf_counter()
+        h = asr.decode_resident(nf, [mode], chunk, kw["beam_size"], kw["ctc_weight"], kw["reverse_weight"])[mode]
+        c = get_output("ctm", asr.tokenizer, stem, h, 230, chunk, asr.input_frame_length, asr.output_frame_length)
+        timings["asr"] = time.perf_counter() - ta
+        return c
+
+    def diar_local():
+        td = time.perf_counter()
+        a = pipe(audio)
+        timings["diarization"] = time.perf_counter() - td
+        return a
+
     if world > 1:
+        ctm = get_output("ctm", asr.tokenizer, stem, hyps, 230, chunk, asr.input_frame_length, asr.output_frame_length)
+        timings["asr"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
         mono = np.clip(np.rint(wave.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
         ann = diarize_sharded(pipe, mono, device, uri=stem)
+        timings["diarization"] = time.perf_counter() - t1
+    elif overlap:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            fd, fa = ex.submit(diar_local), ex.submit(asr_local)
+            ann, ctm = fd.result(), fa.result()
     else:
-        ann = pipe(audio)
-    timings["diarization"] = time.perf_counter() - t1
+        ctm = asr_local()
+        ann = diar_local()
     t2 = time.perf_counter()
     turns = make_turns(ann) if len(ann) else []
-    stm_lines = []
-    for line in ctm.splitlines():
-        parts = line.split(" ")
-        if len(parts) < 6:
-            continue
-        start, dur, token = float(parts[2]), float(parts[3]), parts[4]
-        stm_lines.append(f"{stem} 1 {speaker_for_segment(start, dur, turns)} {start:.3f} {(start + dur):.3f} {token}")
+    words = [(float(p_[2]), float(p_[3]), p_[4]) for p_ in (line.split(" ") for line in ctm.splitlines()) if len(p_) >= 6]
+    who = speakers_for_words([w[0] for w in words], [w[1] for w in words], turns)
+    stm_lines = [f"{stem} 1 {spk} {start:.3f} {(start + dur):.3f} {token}" for (start, dur, token), spk in zip(words, who)]
     timings["join"] = time.perf_counter() - t2
     if rank == 0 and out_dir:
         os.makedirs(out_dir, exist_ok=True)
@@ -73,7 +95,8 @@ def main(argv=None):
     p.add_argument("--pipeline-model", required=True, help="diarization pipeline directory (config.yaml, segmentation.pt, embedding.pt)")
     p.add_argument("--out-dir", required=True)
     p.add_argument("--mode", default="attention_rescoring")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"], help="fp8: ASR encoder GEMMs in fp8 (diarization stays bf16)")
+    p.add_argument("--sequential", action="store_true", help="do not overlap ASR and diarization")
     args = p.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,9 +110,9 @@ def main(argv=None):
     from reverb_amd.diarization import Pipeline
     from reverb_amd.reverb import load_model
     asr = load_model(args.asr_model, gpu=local, dtype=args.dtype, max_chunks=256)
-    pipe = Pipeline.from_pretrained(args.pipeline_model, dtype=args.dtype).to(f"cuda:{local}")
+    pipe = Pipeline.from_pretrained(args.pipeline_model, dtype="bf16" if args.dtype == "fp8" else args.dtype).to(f"cuda:{local}")
     for audio in args.audios:
-        _, ann, stm, t = run(audio, asr, pipe, args.out_dir, args.mode, device, world, rank)
+        _, ann, stm, t = run(audio, asr, pipe, args.out_dir, args.mode, device, world, rank, overlap=not args.sequential)
         if rank == 0:
             print(f"{audio}: {len(stm)} words, {len(ann.labels())} speakers, asr {t['asr']:.3f} s, diarization {t['diarization']:.3f} s")
     if world > 1:

@@ -256,3 +256,16 @@ def test_speaker_active_on_the_last_frame_only_gives_no_empty_turn():
     assert len(segs) == 1 and segs[0][2] == 0 and segs[0][1] > segs[0][0]
     b[-2:, 1] = 1                     # two frames: a real (one frame-step long) turn
     assert len(list(D.to_annotation(b, uri="x").itertracks(yield_label=True))) == 2
+
+
+def test_vectorised_word_speaker_join_equals_the_per_word_function():
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        n_turns = int(rng.integers(0, 40))
+        t0 = np.sort(rng.random(n_turns) * 100)
+        turns = sorted({(float(s), float(s + 0.2 + rng.random() * 6), f"SPEAKER_{int(rng.integers(0, 4)):02d}") for s in t0})
+        starts = rng.random(300) * 110 - 5
+        durs = np.where(rng.random(300) < 0.05, 0.0, rng.random(300) * 1.5)
+        want = [A.speaker_for_segment(float(s), float(d), turns) for s, d in zip(starts, durs)]
+        assert A.speakers_for_words(starts, durs, turns, block=64) == want
+    assert A.speakers_for_words([1.0], [0.5], []) == [""]

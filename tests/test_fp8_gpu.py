@@ -133,3 +133,24 @@ def test_fp8_needs_dims_of_128():
     case = Case("tiny_ln")                                  # d = 32
     with pytest.raises(RvbError, match="multiples of 128"):
         Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
+
+
+def test_fp8_bench_workload_against_reference():
+    """bench.py --dtype fp8, checked: the hour of audio bench.py decodes, from PCM, against the reference's tokens."""
+    from golden_util import LongCase
+    from reverb_amd.engine import Engine
+    from test_longform_gpu import MODES, _record, _tap_metrics, _ter
+    case = LongCase("r640_1h")
+    n = len(case.js["lens"])
+    eng = Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=n, chunk_frames=case.chunk, cat_embs=case.cat)
+    eng.upload_pcm(case.pcm)
+    nf = eng.fbank()
+    eng.decode_resident(nf, ["ctc_greedy_search"], case.chunk, case.beam, case.ctc_weight, case.reverse_weight)     # calibration (bf16)
+    res = eng.decode_resident(nf, MODES, case.chunk, case.beam, case.ctc_weight, case.reverse_weight)
+    ter = _ter(res, case)
+    m_last = _tap_metrics(eng, case, n - 1, n - 1)
+    _record(case="r640_1h", dtype="fp8", chunks=n, ter={m: list(v) for m, v in ter.items()}, last_chunk=m_last)
+    assert m_last["cos"] > 0.99, m_last
+    for m in MODES:
+        assert ter[m][0] <= 0.30 * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+    eng.close()
