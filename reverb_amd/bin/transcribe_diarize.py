@@ -16,9 +16,10 @@ import numpy as np
 
 
 def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, overlap=True, **decode_kw):
-    """overlap (single process): ASR and diarization run as two host threads on their own engines / HIP streams, so that the
-    diarization's clustering -- a 150 ms per hour merge loop on ONE compute unit -- and its host-side numpy run underneath
-    the ASR encoder instead of after it (ctypes releases the GIL inside librvb)."""
+    """overlap (single process): both diarization networks run first (they fill the GPU); then the diarization's host part --
+    speaker counting, the clustering (a 150 ms per hour merge loop on ONE compute unit), reconstruction -- runs in a second
+    host thread underneath the ASR encoder, which fills the other 255 compute units on its own HIP stream (ctypes releases
+    the GIL inside librvb)."""
     from reverb_amd.bin.assign_words2speakers import make_turns, speakers_for_words
     from reverb_amd.reverb import get_output
     from reverb_amd.wav import read_wav
@@ -64,9 +65,15 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
         timings["diarization"] = time.perf_counter() - t1
     elif overlap:
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(2) as ex:
-            fd, fa = ex.submit(diar_local), ex.submit(asr_local)
-            ann, ctm = fd.result(), fa.result()
+        td = time.perf_counter()
+        pcm_d, uri = pipe._load(audio)
+        classes, emb = pipe.networks(pcm_d)
+        timings["diarization_networks"] = time.perf_counter() - td
+        with ThreadPoolExecutor(1) as ex:
+            fd = ex.submit(pipe.finish, classes, emb, uri)
+            ctm = asr_local()
+            ann = fd.result()
+        timings["diarization"] = time.perf_counter() - td
     else:
         ctm = asr_local()
         ann = diar_local()
