@@ -163,6 +163,16 @@ int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs);
  * out[j] = log p(w_j | ...) for j < len and out[len] = log p(eos); right=1 for the r2l decoder */
 int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* out);
 
+/* Collectives of the chunk-sharded path (no data-path collective, ONE all-gather of the packed per-chunk results).
+ * RCCL is bound directly (resolved with dlopen on first use; PyTorch is not needed): one rank calls rvb_comm_unique_id and
+ * hands the 128 bytes to the others by any side channel, every rank calls rvb_comm_init on its engine (one engine = one GPU =
+ * one rank), rvb_allgather_results gathers `bytes` bytes per rank (host buffers; recv = world * bytes) in rank order on the
+ * engine's stream.  reverb_amd/dist.py uses torch.distributed by default and this through `RvbComm`. */
+int rvb_comm_unique_id(void* id128 /* out: 128 bytes */);
+int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128);
+int rvb_allgather_results(rvb_engine* e, const void* send, int64_t bytes, void* recv);
+int rvb_comm_destroy(rvb_engine* e);
+
 /* Stage timing (HIP events on the engine stream).  level 1: every kernel family is bracketed;
  * names: "fbank","subsample","gemm","attention","rownorm","glu_dwconv","ctc_topk","embed",
  * "lse_gather","search_host".  level 2: only the GEMM launches (the dominant kernel; half the

@@ -73,6 +73,10 @@ SIGNATURES = {
     "rvb_fp8_recalibrate": (C.c_int, [_eng]),
     "rvb_get_rescore_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
+    "rvb_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rvb_comm_init": (C.c_int, [_eng, C.c_int, C.c_int, C.c_void_p]),
+    "rvb_allgather_results": (C.c_int, [_eng, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rvb_comm_destroy": (C.c_int, [_eng]),
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
     "rvb_reset_timings": (C.c_int, [_eng]),
     "rvb_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),

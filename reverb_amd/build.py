@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librvb.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "linkage.hip", "diar_engine.hip", "test_api.hip", "search.cpp"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "linkage.hip", "diar_engine.hip", "test_api.hip", "comm.hip", "search.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable"]
@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread", "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

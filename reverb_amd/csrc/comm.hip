@@ -1,0 +1,119 @@
+// C-ABI collectives of librvb: the chunk-sharded path has ONE exchange step, the all-gather of the packed
+// per-chunk results (~1.3 KB per chunk, latency-bound on xGMI).  This file binds RCCL directly -- ncclGetUniqueId /
+// ncclCommInitRank / ncclAllGather resolved with dlopen at first use, so librvb has no link-time dependency on a particular
+// librccl (PyTorch ships its own copy; whichever is already in the process is used) -- for hosts that do not want
+// torch.distributed in the loop.  The 128-byte unique id travels by whatever side channel the host has (a file, MPI, a TCP
+// socket; reverb_amd/dist.py's RvbComm broadcasts it over an existing torch.distributed group or takes it from a file).
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include <cstring>
+
+#include "engine.h"
+
+#define RVB_TRY_RC(expr) do { int _r = (expr); if (_r != rvb::OK) return _r; } while (0)
+
+namespace {
+
+typedef int (*GetUniqueIdFn)(void*);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int /* ncclDataType_t */, void*, hipStream_t);
+typedef int (*CommDestroyFn)(void*);
+typedef const char* (*GetErrorStringFn)(int);
+
+}  // namespace
+struct Id128 { char b[128]; };
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  GetUniqueIdFn get_id = nullptr;
+  int (*init_rank)(void**, int, Id128, int) = nullptr;
+  AllGatherFn all_gather = nullptr;
+  CommDestroyFn destroy = nullptr;
+  GetErrorStringFn err = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_once;
+
+int load_rccl() {
+  std::call_once(g_once, [] {
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return;
+    g_rccl.get_id = (GetUniqueIdFn)dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.all_gather = (AllGatherFn)dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.destroy = (CommDestroyFn)dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.err = (GetErrorStringFn)dlsym(g_rccl.lib, "ncclGetErrorString");
+  });
+  if (!g_rccl.lib || !g_rccl.get_id || !g_rccl.init_rank || !g_rccl.all_gather || !g_rccl.destroy) {
+    rvb::set_error("RCCL (librccl.so) could not be loaded: " + std::string(dlerror() ? dlerror() : "symbols missing"));
+    return rvb::E_UNSUPPORTED;
+  }
+  return rvb::OK;
+}
+int nccl_fail(const char* what, int rc) {
+  rvb::set_error(std::string(what) + ": " + (g_rccl.err ? g_rccl.err(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+  return rvb::E_HIP;
+}
+
+}  // namespace
+
+using namespace rvb;
+
+extern "C" {
+
+int rvb_comm_unique_id(void* id128) {
+  if (!id128) { set_error("rvb_comm_unique_id: null argument"); return E_ARG; }
+  RVB_TRY_RC(load_rccl());
+  const int rc = g_rccl.get_id(id128);
+  return rc == 0 ? OK : nccl_fail("ncclGetUniqueId", rc);
+}
+
+int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128) {
+  if (!e || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("rvb_comm_init: bad argument"); return E_ARG; }
+  if (e->comm) { set_error("rvb_comm_init: the engine already has a communicator"); return E_STATE; }
+  RVB_TRY_RC(load_rccl());
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  Id128 id;
+  memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int rc = g_rccl.init_rank(&comm, world, id, rank);
+  if (rc != 0) return nccl_fail("ncclCommInitRank", rc);
+  e->comm = comm; e->comm_world = world; e->comm_rank = rank;
+  return OK;
+}
+
+// every rank contributes `bytes` bytes (host memory); `recv` (host, world * bytes) receives them in rank order
+int rvb_allgather_results(rvb_engine* e, const void* send, int64_t bytes, void* recv) {
+  if (!e || !send || !recv || bytes <= 0) { set_error("rvb_allgather_results: bad argument"); return E_ARG; }
+  if (!e->comm) { set_error("rvb_allgather_results before rvb_comm_init"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  int r = e->comm_send.ensure((size_t)bytes);
+  if (r != OK) return r;
+  r = e->comm_recv.ensure((size_t)bytes * e->comm_world);
+  if (r != OK) return r;
+  RVB_HIP_CHECK(hipMemcpyAsync(e->comm_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+  const int rc = g_rccl.all_gather(e->comm_send.p, e->comm_recv.p, (size_t)bytes, 0 /* ncclInt8 */, e->comm, e->stream);
+  if (rc != 0) return nccl_fail("ncclAllGather", rc);
+  RVB_HIP_CHECK(hipMemcpyAsync(recv, e->comm_recv.p, (size_t)bytes * e->comm_world, hipMemcpyDeviceToHost, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
+int rvb_comm_destroy(rvb_engine* e) {
+  if (!e) { set_error("rvb_comm_destroy: null engine"); return E_ARG; }
+  if (e->comm) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    g_rccl.destroy(e->comm);
+    e->comm = nullptr;
+  }
+  e->comm_send.release(); e->comm_recv.release();
+  return OK;
+}
+
+}  // extern "C"

@@ -131,6 +131,11 @@ struct rvb_engine {
   } stream_st;
   rvb::DevBuf d_stream_i32;         // {kv_start = 0, kv_len = cache + chunk}
 
+  // ---- RCCL communicator of the C-ABI collectives (comm.hip; optional) ----
+  void* comm = nullptr;
+  int comm_world = 1, comm_rank = 0;
+  rvb::DevBuf comm_send, comm_recv;
+
   // ---- profiling ----
   int profiling = 0;     // 0 off, 1 every stage, 2 GEMM launches only (what the roofline needs; half the events)
   std::map<std::string, rvb::ProfEntry> prof;

@@ -1388,6 +1388,7 @@ int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
 
 void rvb_destroy(rvb_engine* e) {
   if (!e) return;
+  (void)rvb_comm_destroy(e);
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   // DevBuf members are released explicitly: list the big ones, the rest die with the process

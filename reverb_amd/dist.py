@@ -150,15 +150,74 @@ class GatheredResults(Sequence):
 N_COLLECTIVES = 0        # all-gathers issued by all_gather_results so far (tests assert the common case is one per call)
 
 
-def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = None) -> "GatheredResults":
+class RvbComm:
+    """The C-ABI collective (include/rvb.h: rvb_comm_unique_id / rvb_comm_init / rvb_allgather_results): RCCL bound directly by
+    librvb on the engine's own stream, for hosts that do not run torch.distributed.  One communicator per engine (= per GPU =
+    per rank).  The 128-byte id reaches the other ranks by a side channel: `from_torch_group` broadcasts it over an existing
+    process group, `from_file` through a file on a shared directory (rank 0 writes it atomically, the others wait for it)."""
+
+    def __init__(self, engine, world: int, rank: int, unique_id: bytes):
+        import ctypes as C
+        from ._lib import check
+        assert len(unique_id) == 128
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        self._id = C.create_string_buffer(unique_id, 128)
+        check(engine.lib.rvb_comm_init(engine.handle, self.world, self.rank, C.cast(self._id, C.c_void_p)), "rvb_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().rvb_comm_unique_id(C.cast(buf, C.c_void_p)), "rvb_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, engine):
+        import torch.distributed as dist
+        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(engine, dist.get_world_size(), dist.get_rank(), box[0])
+
+    @classmethod
+    def from_file(cls, engine, world: int, rank: int, path: str, timeout: float = 120.0):
+        import os
+        import time
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(cls.unique_id())
+            os.replace(tmp, path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"no RCCL id at {path}")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return cls(engine, world, rank, f.read())
+
+    def all_gather(self, send: np.ndarray) -> np.ndarray:
+        """send: C-contiguous array, equal size on every rank -> [world, ...] in rank order."""
+        from ._lib import check
+        send = np.ascontiguousarray(send)
+        recv = np.empty((self.world,) + send.shape, send.dtype)
+        check(self.engine.lib.rvb_allgather_results(self.engine.handle, send.ctypes.data, send.nbytes, recv.ctypes.data), "rvb_allgather_results")
+        return recv
+
+    def close(self):
+        self.engine.lib.rvb_comm_destroy(self.engine.handle)
+
+
+def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = None, comm: "RvbComm" = None) -> "GatheredResults":
     """All ranks end up with every rank's results in rank (= chunk) order after ONE all-gather.  Payload: tokens,
     CTC peak frames, score, confidences -- about 1.3 KB per chunk, latency-bound on xGMI.
     `max_count` = the largest number of results any rank contributes; it sizes the fixed-capacity buffer and must
-    be the same on every rank (default: len(hyps), i.e. every rank holds equally many)."""
+    be the same on every rank (default: len(hyps), i.e. every rank holds equally many).  `comm`: an RvbComm to use
+    librvb's C-ABI collective instead of torch.distributed."""
     import torch
     import torch.distributed as dist
     global _ROW_WORDS, N_COLLECTIVES
-    world = dist.get_world_size()
+    world = comm.world if comm is not None else dist.get_world_size()
     buf = pack_results(hyps)
     count = max(int(max_count if max_count is not None else len(hyps)), 1)
     while True:
@@ -166,11 +225,14 @@ def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = No
         send = np.zeros(cap, np.int32)
         m = min(cap, buf.size)
         send[:m] = buf[:m]                         # the header always fits and states what this rank needs
-        t = torch.from_numpy(send).to(device)
-        g = torch.empty(world * cap, dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(g, t)
+        if comm is not None:                       # librvb's own RCCL binding (rvb_allgather_results), no torch in the loop
+            host = comm.all_gather(send)
+        else:
+            t = torch.from_numpy(send).to(device)
+            g = torch.empty(world * cap, dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(g, t)
+            host = g.cpu().numpy().reshape(world, cap)  # one device-to-host copy
         N_COLLECTIVES += 1
-        host = g.cpu().numpy().reshape(world, cap)  # one device-to-host copy
         need = int((_HDR + host[:, 2].astype(np.int64) + 2 * host[:, 3].astype(np.int64)).max())
         if need <= cap:
             break

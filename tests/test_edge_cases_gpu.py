@@ -105,3 +105,25 @@ def test_api_is_callable_from_a_worker_thread(tmp_path):
         t.start(); t.join()
     assert not err, err
     assert got == [want, want]
+
+
+def test_cabi_collective_on_one_rank():
+    """rvb_comm_unique_id / rvb_comm_init / rvb_allgather_results (RCCL bound directly by librvb) with a world of one:
+    the only size a 1-GPU box can run; the packed-result gather through it returns what went in."""
+    from golden_util import Case
+    from reverb_amd import dist as rdist
+    from reverb_amd.engine import Engine
+    from reverb_amd.search import DecodeResult
+    case = Case("tiny_ln")
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
+    uid = rdist.RvbComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = rdist.RvbComm(eng, 1, 0, uid)
+    x = np.arange(1000, dtype=np.int32)
+    np.testing.assert_array_equal(comm.all_gather(x), x[None])
+    hyps = [DecodeResult((1, 2, 3), -1.5, confidence=0.5, times=[4, 5, 6], tokens_confidence=[0.1, 0.2, 0.3]), DecodeResult([7])]
+    hyps[1].ctc_frames = [9]
+    got = rdist.all_gather_results(hyps, None, comm=comm)
+    assert [(list(h.tokens), h.times, h.ctc_frames, h.score) for h in got] == [([1, 2, 3], [4, 5, 6], None, -1.5), ([7], None, [9], 0.0)]
+    comm.close()
+    eng.close()
