@@ -256,6 +256,11 @@ def main():
 
     stats = {}
 
+    comm = None
+    if use_dist and not STUB and os.environ.get("RVB_COMM") == "cabi":      # the result gather through librvb's own RCCL binding
+        from reverb_amd.dist import RvbComm
+        comm = RvbComm.from_torch_group(eng)
+
     def step(upload=False):
         if STUB:
             hyps = eng.decode()
@@ -268,7 +273,7 @@ def main():
         if not STUB:
             stats["decoder_rows"], stats["decoder_pairs"] = eng.rescore_stats()
         if use_dist:      # ONE all-gather of the per-chunk results over RCCL/xGMI; the other ranks'
-            hyps = all_gather_results(hyps, device)     # rows stay packed until somebody reads them (dist.GatheredResults)
+            hyps = all_gather_results(hyps, device, comm=comm)     # rows stay packed until somebody reads them (dist.GatheredResults)
             ntok = hyps.total_tokens()
         return hyps, ntok
 
@@ -356,7 +361,7 @@ def main():
                                    f"ctc_weight {args.ctc_weight}, reverse_weight {args.reverse_weight}",
                        "chunks_per_launch": per_launch, "parallelism": f"chunk-shard x{world}",
                        "world_size_reported_by_process_group": world if use_dist else 1,
-                       "backend": (dist.get_backend() if use_dist else None),
+                       "backend": (("librvb rvb_allgather_results (RCCL)" if comm else dist.get_backend()) if use_dist else None),
                        "results_gathered": len(hyps), "tokens_per_step": int(ntok),
                        # rescoring: (hypothesis, position) log-probs served vs decoder rows computed (one per distinct prefix)
                        "decoder_pairs_per_step": stats.get("decoder_pairs"), "decoder_rows_per_step": stats.get("decoder_rows")},
@@ -376,6 +381,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x, lens, args)
         else:
             out["cpu_baseline"] = None
+    if comm is not None:
+        comm.close()
     if not STUB:
         eng.close()
     if use_dist:
