@@ -12,7 +12,8 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "roofline": dict, "cpu_baseline": dict}
 
 
-@pytest.mark.parametrize("log", ["r01_bench_r640_1h_bf16.json.log", "r01_bench_r268_1h_bf16.json.log", "r01_bench_diar_1h_bf16.json.log"])
+@pytest.mark.parametrize("log", ["r01_bench_r640_1h_bf16.json.log", "r01_bench_r268_1h_bf16.json.log", "r01_bench_diar_1h_bf16.json.log",
+                                 "r02_bench_r640_1h_bf16.json.log", "r02_bench_r268_1h_bf16.json.log", "r02_bench_diar_1h_bf16.json.log"])
 def test_committed_bench_line_has_the_contract_fields(log):
     lines = [l for l in open(os.path.join(ROOT, "profiles", log)).read().splitlines() if l.strip()]
     d = json.loads(lines[-1])                      # the JSON line is the LAST line of stdout
@@ -65,3 +66,19 @@ def test_bench_scripts_parse_and_default_to_one_gpu():
         src = open(os.path.join(ROOT, name)).read()
         ast.parse(src)
         assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
+
+
+def test_round2_bench_line_carries_the_measured_sub_records():
+    """The default `python bench.py` line of round 2: live PMC traffic, the PCIe-inclusive leg, diarization (configs[3]) and
+    the joint fp8 pipeline (configs[4]) as sub-records with their own contract fields."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_r640_1h_bf16.json.log")).read().splitlines()[-1])
+    assert d["roofline"]["traffic"] > 1e8 and "rocprofv3 --pmc" in d["roofline"]["traffic_detail"]["method"]
+    assert d["pcie_inclusive"]["value"] <= d["value"] * 1.02 and d["pcie_inclusive"]["h2d_bytes_per_step"] == 115200000
+    assert d["config"]["decoder_rows_per_step"] < d["config"]["decoder_pairs_per_step"]
+    for key in ("diarization", "joint_fp8"):
+        r = d[key]
+        assert "error" not in r and r["value"] > 0 and r["ms_per_step"] > 0 and r["data"] == "synthetic", key
+    assert d["diarization"]["roofline"]["bound"] == "mfma" and d["diarization"]["cpu_baseline"]["kind"] == "port"
+    assert d["joint_fp8"]["dtype"] == "fp8" and d["joint_fp8"]["ms_per_step"] < d["joint_fp8"]["sequential_ms_per_step"]
+    f = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_r640_1h_fp8.json.log")).read().splitlines()[-1])
+    assert f["dtype"] == "fp8" and f["roofline"]["peak"] == 5000.0 and f["value"] > d["value"]
