@@ -211,6 +211,10 @@ int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, 
                          float* out, const float* gamma2, const float* beta2, float eps2, float scale2, float* out1_f32, float* out2);
 int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* ptr /* [R+1] */, const int32_t* target,
                               int P, float* out /* [P] */);
+/* host only: the trie of distinct hypothesis prefixes attention rescoring computes decoder rows for (engine.hip build_trie) */
+int rvb_test_build_trie(const int32_t* tokens, const int32_t* lens, const int32_t* chunk_of, int n_hyps, int n_chunks, int sos, int eos,
+                        int reversed, int32_t* n_rows, int32_t* tok, int32_t* pos, int32_t* path, int32_t* hq_start, int32_t* hq_len,
+                        int32_t* hq_pos0, int32_t* tgt_ptr, int32_t* tgt, int32_t* pair_slot, int32_t* n_work);
 int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats /* [frames,80] */);
 /* native prefix beam search on host arrays: top-k log-probs/indices [T,beam] of one utterance */
 int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank,

@@ -1759,6 +1759,27 @@ int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, i
 
 }  // extern "C"
 
+// host only: the rescoring trie of given hypotheses (tests/test_search_native.py checks it against a Python trie).
+// tokens: the hypotheses back to back; lens / chunk_of: per hypothesis (chunk ids ascending).  Outputs sized by the caller:
+// rows <= P = sum(len + 1); tok, pos [rows]; path, tgt, pair_slot [P]; hq_start, hq_len, hq_pos0 [n_hyps]; tgt_ptr [rows + 1].
+extern "C" int rvb_test_build_trie(const int32_t* tokens, const int32_t* lens, const int32_t* chunk_of, int n_hyps, int n_chunks, int sos,
+                                   int eos, int reversed, int32_t* n_rows, int32_t* tok, int32_t* pos, int32_t* path, int32_t* hq_start,
+                                   int32_t* hq_len, int32_t* hq_pos0, int32_t* tgt_ptr, int32_t* tgt, int32_t* pair_slot, int32_t* n_work) {
+  if (!tokens || !lens || !chunk_of || !n_rows || n_hyps < 0) { set_error("rvb_test_build_trie: bad argument"); return E_ARG; }
+  std::vector<HypRef> hyps;
+  std::vector<int> first(n_hyps);
+  int P = 0, off = 0;
+  for (int i = 0; i < n_hyps; ++i) { hyps.push_back({chunk_of[i], i, lens[i], P}); first[i] = off; P += lens[i] + 1; off += lens[i]; }
+  TrieBatch t;
+  build_trie(hyps, n_chunks, sos, eos, [&](const HypRef& h, int j) { return tokens[first[h.idx] + (reversed ? h.len - 1 - j : j)]; }, &t);
+  *n_rows = t.R;
+  if (n_work) *n_work = (int32_t)t.work.size() / 2;
+  auto cp = [](int32_t* dst, const std::vector<int32_t>& v) { if (dst) memcpy(dst, v.data(), v.size() * 4); };
+  cp(tok, t.tok); cp(pos, t.pos); cp(path, t.path); cp(hq_start, t.hq_start); cp(hq_len, t.hq_len); cp(hq_pos0, t.hq_pos0);
+  cp(tgt_ptr, t.tgt_ptr); cp(tgt, t.tgt); cp(pair_slot, t.pair_slot);
+  return OK;
+}
+
 extern "C" int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: librvb has no CPU fallback"); return E_HIP; }

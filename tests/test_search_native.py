@@ -1,6 +1,7 @@
 """Native (C++) CTC prefix beam search vs the reference's own known answers and vs the oracle
 restatement.  Runs on CPU: the search is host code behind the C ABI (rvb_test_prefix_beam)."""
 import numpy as np
+import pytest
 import torch
 
 from reverb_amd import _lib
@@ -116,3 +117,58 @@ def test_native_search_on_the_reference_goldens():
             assert sc[:k].tolist() == pytest.approx(g["nbest_scores"], rel=0, abs=1e-9), (name, b)
             checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize("reversed_", [0, 1])
+def test_rescoring_trie_against_a_python_trie(reversed_):
+    """engine.hip build_trie (host code): one decoder row per distinct prefix of a chunk's hypotheses; every (hypothesis, j)
+    pair must map to the row of ITS prefix and to its own target, a hypothesis' new rows must be a contiguous suffix of its
+    path, and nothing may be shared across chunks."""
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(5 + reversed_)
+    sos = eos = 99
+    hyps, chunk_of = [], []
+    for chunk in range(4):
+        base = rng.integers(1, 6, int(rng.integers(0, 30))).tolist()
+        n = int(rng.integers(0, 7)) if chunk != 2 else 0            # chunk 2 has no hypothesis at all
+        for i in range(n):
+            h = list(base)
+            for _ in range(int(rng.integers(0, 4))):                # a few edits: shared prefixes of every length, duplicates, prefixes
+                k = int(rng.integers(0, len(h) + 1))
+                if h and rng.random() < 0.5:
+                    h = h[:k]
+                else:
+                    h = h[:k] + [int(rng.integers(1, 6))] + h[k:]
+            hyps.append(h); chunk_of.append(chunk)
+    hyps.append([]); chunk_of.append(3)                              # an empty hypothesis
+    lens = np.array([len(h) for h in hyps], np.int32)
+    toks = np.array([t for h in hyps for t in h] + [0], np.int32)
+    P = int(lens.sum() + len(hyps))
+    out = {k: np.full(n, -7, np.int32) for k, n in dict(tok=P, pos=P, path=P, hq_start=len(hyps), hq_len=len(hyps), hq_pos0=len(hyps),
+                                                         tgt_ptr=P + 1, tgt=P, pair_slot=P).items()}
+    n_rows, n_work = C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.rvb_test_build_trie(iptr(toks), iptr(lens), iptr(np.array(chunk_of, np.int32)), len(hyps), 4, sos, eos, reversed_,
+                                       C.byref(n_rows), *(iptr(out[k]) for k in ("tok", "pos", "path", "hq_start", "hq_len", "hq_pos0",
+                                                                                 "tgt_ptr", "tgt", "pair_slot")), C.byref(n_work)))
+    R = n_rows.value
+    seqs = [h[::-1] if reversed_ else h for h in hyps]
+    want_rows = len({(c, tuple(s[:j])) for s, c in zip(seqs, chunk_of) for j in range(len(s) + 1)})
+    assert R == want_rows
+    row_of, p = {}, 0
+    for i, (s, c) in enumerate(zip(seqs, chunk_of)):
+        path = out["path"][p:p + len(s) + 1].tolist()
+        new = [r for r in path if r >= out["hq_start"][i]] if out["hq_len"][i] else []
+        for j, r in enumerate(path):
+            key = (c, tuple(s[:j]))
+            assert row_of.setdefault(key, r) == r and 0 <= r < R                      # same prefix <-> same row
+            assert out["tok"][r] == (sos if j == 0 else s[j - 1]) and out["pos"][r] == j
+            slot = out["pair_slot"][p + j]
+            assert out["tgt_ptr"][r] <= slot < out["tgt_ptr"][r + 1] and out["tgt"][slot] == (s[j] if j < len(s) else eos)
+        # the rows this hypothesis adds: contiguous, a suffix of its path, starting at position hq_pos0
+        n_own = int(out["hq_len"][i])
+        assert path[len(path) - n_own:] == list(range(out["hq_start"][i], out["hq_start"][i] + n_own)) if n_own else True
+        assert n_own == 0 or out["hq_pos0"][i] == len(path) - n_own
+        p += len(s) + 1
+    assert len(set(row_of.values())) == R and out["tgt_ptr"][R] == P and sorted(out["pair_slot"].tolist()) == list(range(P))
+    assert n_work.value == sum(-(-int(n) // 16) for n in out["hq_len"])
