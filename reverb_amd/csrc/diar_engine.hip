@@ -778,6 +778,7 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     }
     { double retries = 0.0;
       (void)hipMemcpy(&retries, dM.as<double>() + (n - 1), 8, hipMemcpyDeviceToHost);
+      if (retries < 0.0) { set_error("rvd_centroid_linkage: the merge loop found no candidate pair (non-finite embeddings?)"); rc = E_ARG; break; }
       e->prof["linkage"].flops += retries; }      // reported through rvd_get_timing("linkage").flops
     // slots -> scipy cluster ids: the merged cluster lives on in slot y under the new id n + k
     std::vector<int> cid(n);

@@ -77,13 +77,37 @@ template <int CTRL> __device__ inline MinPair dpp_pair(const MinPair& p) {
   q.i = (int)__builtin_amdgcn_update_dpp(0u, (unsigned)p.i, CTRL, 0xf, 0xf, false);
   return q;
 }
+// The value is reduced first (fp64 min: two DPP moves + v_min_f64 per step), then the smallest index among the lanes that
+// hold that value (integer min) -- the same (value, index) lexicographic minimum as comparing pairs, in about 30
+// instructions instead of 66.  The merge loop is VALU-issue-bound on its one CU (16 waves share 4 SIMDs and every wave
+// runs every reduction), so instruction count is what a reduction costs.
+template <int CTRL> __device__ inline double dpp_f64(double v) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)bits, CTRL, 0xf, 0xf, false);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(bits >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL> __device__ inline int dpp_i32(int v) { return (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, false); }
+__device__ inline double min_f64(double a, double b) { return a < b ? a : b; }      // no NaNs here: distances or +inf
+// minimum over the 16 lanes of each DPP row (every lane of the row ends up with it)
+__device__ inline MinPair row_argmin(MinPair p) {
+  double m = p.v;
+  m = min_f64(m, dpp_f64<0xB1>(m));       // quad_perm [1,0,3,2]
+  m = min_f64(m, dpp_f64<0x4E>(m));       // quad_perm [2,3,0,1]
+  m = min_f64(m, dpp_f64<0x141>(m));      // row_half_mirror
+  m = min_f64(m, dpp_f64<0x140>(m));      // row_mirror
+  int i = p.v == m ? p.i : 0x7fffffff;
+  i = min(i, dpp_i32<0xB1>(i));
+  i = min(i, dpp_i32<0x4E>(i));
+  i = min(i, dpp_i32<0x141>(i));
+  i = min(i, dpp_i32<0x140>(i));
+  return MinPair{m, i};
+}
 __device__ inline MinPair wave_argmin(MinPair p) {
-  p = min_pair(p, dpp_pair<0xB1>(p));      // quad_perm [1,0,3,2]
-  p = min_pair(p, dpp_pair<0x4E>(p));      // quad_perm [2,3,0,1]
-  p = min_pair(p, dpp_pair<0x141>(p));     // row_half_mirror
-  p = min_pair(p, dpp_pair<0x140>(p));     // row_mirror
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(p.v);
+  p = row_argmin(p);
+  // across the four rows: gfx950's v_permlane16_swap / v_permlane32_swap hand every lane both halves
   {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(p.v);
     auto a = __builtin_amdgcn_permlane16_swap((unsigned)bits, (unsigned)bits, false, false);
     auto b = __builtin_amdgcn_permlane16_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
     auto c = __builtin_amdgcn_permlane16_swap((unsigned)p.i, (unsigned)p.i, false, false);
@@ -91,8 +115,8 @@ __device__ inline MinPair wave_argmin(MinPair p) {
     MinPair w{__longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1])), (int)c[1]};
     p = min_pair(u, w);
   }
-  const unsigned long long bits2 = (unsigned long long)__double_as_longlong(p.v);
   {
+    const unsigned long long bits2 = (unsigned long long)__double_as_longlong(p.v);
     auto a = __builtin_amdgcn_permlane32_swap((unsigned)bits2, (unsigned)bits2, false, false);
     auto b = __builtin_amdgcn_permlane32_swap((unsigned)(bits2 >> 32), (unsigned)(bits2 >> 32), false, false);
     auto c = __builtin_amdgcn_permlane32_swap((unsigned)p.i, (unsigned)p.i, false, false);
@@ -115,7 +139,9 @@ __device__ inline MinPair block_argmin(MinPair p, MinPair* red) {
 }
 
 // one-barrier variant for back-to-back reductions: the caller alternates between two result buffers, so the writes of
-// reduction k+1 cannot race with the reads of reduction k (those are separated by reduction k+1's own barrier from k+2)
+// reduction k+1 cannot race with the reads of reduction k (those are separated by reduction k+1's own barrier from k+2).
+// Second level: lane l reads wave (l mod 16)'s result and the 16 values are reduced inside each DPP row -- one LDS read
+// and ~25 instructions per wave instead of a 16-step serial loop.  Buffers hold 16 entries; unused ones stay +inf.
 __device__ inline MinPair block_argmin_alt(MinPair p, MinPair (*red)[16], int& phase) {
   p = wave_argmin(p);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -123,9 +149,7 @@ __device__ inline MinPair block_argmin_alt(MinPair p, MinPair (*red)[16], int& p
   ++phase;
   if (lane == 0) buf[wv] = p;
   __syncthreads();
-  MinPair r = buf[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = min_pair(r, buf[w]);
-  return r;
+  return row_argmin(buf[lane & 15]);
 }
 
 // nearest neighbour of every x among y > x (scipy find_min_dist: first index on ties); one block per row
@@ -142,16 +166,23 @@ __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__
 // ------------------------------------------------------------------------------------ merge loop (one workgroup)
 // LDS_STATE: the per-cluster state (candidate distance fp64, candidate neighbour, cluster size) lives in LDS
 // (14 bytes per point: up to ~11 500 points = one hour of audio at 3 speakers per hop), so an iteration
-// touches HBM/L2 only for the validity check D[x][y] and for the two merged rows.
-template <bool LDS_STATE>
-__global__ __launch_bounds__(1024) void linkage_kernel(int getenv_prof, double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
+// touches HBM/L2 only for the two merged rows (and the row of a stale candidate).
+//
+// Ownership: thread t owns the slots z = t (mod 1024) -- it is the only writer of their state and the one that visits
+// them in the merge pass and in a row rescan.  Each thread keeps the minimum of ITS candidates in registers (`loc`), so
+// a candidate round is one block reduction of register values (one barrier) instead of a scan of the LDS table; the
+// owner re-reads its <= n/1024 entries only when the entry that was its minimum goes up (dropped row, rescanned row,
+// merged row).  Every thread derives (x, y, dist) from the same reduction result, so nothing is broadcast through
+// shared variables, and state writes sit right after a reduction's barrier: 1 barrier per candidate round, per row
+// rescan and per merge.
+static constexpr int LK_E = 10;      // elements per thread and batch (registers: 2 x LK_E doubles in the merge pass)
+template <bool LDS_STATE, int NTH>
+__global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
                                                        int* __restrict__ cluster_id, int* __restrict__ g_neighbor,
                                                        double* __restrict__ g_min_dist, double* __restrict__ Z) {
   extern __shared__ __attribute__((aligned(16))) char lk_smem[];
   __shared__ MinPair red[2][16];
   int rphase = 0;
-  __shared__ int s_x, s_y, s_ok;
-  __shared__ double s_dist;
   double* s_md = (double*)lk_smem;
   int* s_nb = (int*)(s_md + (LDS_STATE ? n : 0));
   uint16_t* s_sz = (uint16_t*)(s_nb + (LDS_STATE ? n : 0));
@@ -159,89 +190,126 @@ __global__ __launch_bounds__(1024) void linkage_kernel(int getenv_prof, double* 
   auto NB = [&](int i) -> int& { if constexpr (LDS_STATE) return s_nb[i]; else return g_neighbor[i]; };
   auto SZ = [&](int i) -> uint16_t& { if constexpr (LDS_STATE) return s_sz[i]; else return g_size[i]; };
   const int tid = threadIdx.x;
+  if (tid < 32) red[tid >> 4][tid & 15] = MinPair{INFINITY, 0x7fffffff};
   long long retries = 0;
   long long t_arg = 0, t_scan = 0, t_merge = 0, t0c = 0;
-  const bool prof = getenv_prof;
+  const bool prof = getenv_prof & 1;
   if (LDS_STATE) {
-    for (int i = tid; i < n; i += 1024) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }
-    __syncthreads();
+    for (int i = tid; i < n; i += NTH) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }
   }
+  __syncthreads();
+  auto own_min = [&]() {                      // dropped rows hold +inf; slot n-1 has no candidate (no y > n-1)
+    MinPair m{INFINITY, 0x7fffffff};
+    for (int z = tid; z < n - 1; z += NTH) m = min_pair(m, MinPair{MD(z), z});
+    return m;
+  };
+  MinPair loc = own_min();
+  const long long cyc0 = clock64(), wc0 = wall_clock64();
   for (int k = 0; k < n - 1; ++k) {
     // ---- closest valid candidate pair (lazy validation of the nearest-neighbour guesses) ----
-    for (int it = 0; it < n - k; ++it) {
+    int x = 0, y = -1;
+    double dist = 0.0;
+    for (int it = 0; it <= n - k; ++it) {
       if (prof) t0c = wall_clock64();
-      MinPair p{INFINITY, 0x7fffffff};
-      for (int z = tid; z < n - 1; z += 1024) p = min_pair(p, MinPair{MD(z), z});      // dropped rows hold +inf
-      p = block_argmin_alt(p, red, rphase);
-      if (tid == 0) {
-        // scipy validates the candidate lazily with `dist == D[x, neighbor[x]]`; here that predicate is kept up to
-        // date where D changes (the merge pass below), encoded in the sign of the neighbour: nb >= 0 valid,
-        // nb <= -2 stale (neighbour -2-nb), -1 none -- no global read on the critical path
-        const int x = p.i, y = NB(x);
-        s_x = x; s_y = y; s_dist = p.v;
-        s_ok = y >= 0 ? 1 : 0;
-      }
-      __syncthreads();
+      const MinPair p = block_argmin_alt(loc, red, rphase);
+      // scipy validates the candidate lazily with `dist == D[x, neighbor[x]]`; here that predicate is kept up to
+      // date where D changes (the merge pass below), encoded in the sign of the neighbour: nb >= 0 valid,
+      // nb <= -2 stale (neighbour -2-nb), -1 none -- no global read on the critical path
+      x = p.i; dist = p.v;
+      if (x >= n - 1) break;                  // no candidate at all: cannot happen while two clusters are alive
+      const int nbx = NB(x);
       if (prof) { const long long t1 = wall_clock64(); t_arg += t1 - t0c; t0c = t1; }
-      if (s_ok) break;
+      if (nbx >= 0) { y = nbx; break; }
       ++retries;
-      const int x = s_x;
+      const double* rowx = D + (size_t)x * n;
       MinPair q{INFINITY, 0x7fffffff};
-      for (int j = x + 1 + tid; j < n; j += 1024)
-        if (SZ(j) > 0) q = min_pair(q, MinPair{D[(size_t)x * n + j], j});
+      // all of a thread's loads are issued before the first is used (LK_E per batch): one memory latency per rescan,
+      // not one per element -- with a runtime trip count the compiler serialises load -> compare -> next load
+      for (int base = 0; base < n; base += LK_E * NTH) {
+        double dv[LK_E];
+#pragma unroll
+        for (int e = 0; e < LK_E; ++e) {
+          const int j = base + tid + e * NTH;
+          dv[e] = (j < n && j > x && SZ(j) > 0) ? rowx[j] : INFINITY;
+        }
+#pragma unroll
+        for (int e = 0; e < LK_E; ++e) q = min_pair(q, MinPair{dv[e], base + tid + e * NTH});
+      }
       q = block_argmin_alt(q, red, rphase);
-      if (tid == 0) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; }
-      __syncthreads();
+      if (tid == (x & (NTH - 1))) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; loc = own_min(); }
       if (prof) { const long long t1 = wall_clock64(); t_scan += t1 - t0c; }
     }
-    if (prof) t0c = wall_clock64();
-    const int x = s_x, y = s_y;
-    const double dist = s_dist;
-    const int nx = SZ(x), ny = SZ(y);
-    __syncthreads();
-    if (tid == 0) {
-      SZ(x) = 0; SZ(y) = (uint16_t)(nx + ny);
-      MD(x) = INFINITY;
+    if (y < 0) {                              // uniform across the block (every thread holds the same reduction results)
+      if (tid == 0) g_min_dist[n - 1] = -1.0;
+      return;
     }
+    if (prof) t0c = wall_clock64();
+    const int nx = SZ(x), ny = SZ(y);
     if (tid == 64) {      // dendrogram row as (slot x, slot y): stores only; the host turns slots into cluster ids
       Z[4 * (size_t)k + 0] = x; Z[4 * (size_t)k + 1] = y; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
     }
-    __syncthreads();
     // ---- one pass over the merged rows: Lance-Williams centroid update, candidate maintenance, and the
     // new cluster's own nearest neighbour ----
     const double* rx = D + (size_t)x * n;
     double* ry = D + (size_t)y * n;
     const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
     const double sub = (fx * fy * dist * dist) / fs;
-    // one exactly rounded reciprocal per merge instead of an exactly rounded division per element (the merge pass is
-    // fp64-ALU-bound on its one CU): distances differ from scipy's by <= 1 ulp, far inside the 1e-9 the dendrogram is
-    // compared at, and equal inputs still give equal outputs, so ties break as before
+    // one exactly rounded reciprocal per merge instead of an exactly rounded division per element: distances differ
+    // from scipy's by <= 1 ulp, far inside the 1e-9 the dendrogram is compared at, and equal inputs still give equal
+    // outputs, so ties break as before
     const double inv_fs = 1.0 / fs;
     MinPair best{INFINITY, 0x7fffffff};
-    for (int z = tid; z < n; z += 1024) {
-      if (z == y || SZ(z) == 0) continue;
-      const double dxi = rx[z], dyi = ry[z];
-      const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) * inv_fs);
-      ry[z] = nd;
-      D[(size_t)z * n + y] = nd;
-      if (z < y) {
-        const int nb0 = NB(z);
-        int nb = nb0;
-        int dec = nb <= -2 ? -2 - nb : nb;                 // neighbour whatever the validity
-        if (z < x && dec == x) dec = y;                    // scipy: "reassign neighbor candidates from x to y"
-        if (dec == y) nb = (MD(z) == nd) ? y : -2 - y;     // D[z][y] just changed: re-evaluate `dist == D[z, neighbor]`
-        if (nd < MD(z)) { nb = y; MD(z) = nd; }            // lower-bound update
-        if (nb != nb0) NB(z) = nb;
-      } else {
-        best = min_pair(best, MinPair{nd, z});
+    for (int base = 0; base < n; base += LK_E * NTH) {
+      // both rows' elements of this thread in registers first (see the rescan above); no element written below is read
+      // by this pass (writes go to row y / column y at z, reads come from rows x and y at other z)
+      double dxv[LK_E], dyv[LK_E];
+      unsigned okm = 0;
+#pragma unroll
+      for (int e = 0; e < LK_E; ++e) {
+        const int z = base + tid + e * NTH;
+        const bool ok = z < n && z != x && z != y && SZ(z) != 0;
+        okm |= ok ? 1u << e : 0u;
+        dxv[e] = ok ? rx[z] : 0.0;
+        dyv[e] = ok ? ry[z] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < LK_E; ++e) {
+        if (!(okm >> e & 1)) continue;
+        int z = base + tid + e * NTH;
+        asm volatile("" : "+v"(z));              // addresses are formed here, not hoisted for all LK_E elements at once
+        const double dxi = dxv[e], dyi = dyv[e];
+        const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) * inv_fs);
+        ry[z] = nd;
+        D[(size_t)z * n + y] = nd;
+        if (z < y) {
+          const int nb0 = NB(z);
+          int nb = nb0;
+          int dec = nb <= -2 ? -2 - nb : nb;                 // neighbour whatever the validity
+          if (z < x && dec == x) dec = y;                    // scipy: "reassign neighbor candidates from x to y"
+          if (dec == y) nb = (MD(z) == nd) ? y : -2 - y;     // D[z][y] just changed: re-evaluate `dist == D[z, neighbor]`
+          if (nd < MD(z)) { nb = y; MD(z) = nd; loc = min_pair(loc, MinPair{nd, z}); }      // lower-bound update
+          if (nb != nb0) NB(z) = nb;
+        } else {
+          best = min_pair(best, MinPair{nd, z});
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the unrolled elements apart: interleaving them spills (128 VGPRs per wave)
       }
     }
     best = block_argmin_alt(best, red, rphase);
-    if (tid == 0 && y < n - 1) { NB(y) = best.v < INFINITY ? best.i : -1; MD(y) = best.v; }
-    __syncthreads();
+    // state of the two merged slots, by their owners; everybody has read SZ(x), SZ(y) before the barrier above
+    bool mine = false;
+    if (tid == (x & (NTH - 1))) { SZ(x) = 0; MD(x) = INFINITY; mine = true; }
+    if (tid == (y & (NTH - 1))) {
+      SZ(y) = (uint16_t)(nx + ny);
+      if (y < n - 1) { NB(y) = best.v < INFINITY ? best.i : -1; MD(y) = best.v; }
+      mine = true;
+    }
+    if (mine) loc = own_min();
     if (prof) t_merge += wall_clock64() - t0c;
   }
+  if (tid == 0 && prof) printf("shader clock %.0f MHz over %.1f ms\n", (double)(clock64() - cyc0) / (double)(wall_clock64() - wc0) * 100.0, (wall_clock64() - wc0) * 1e-5);
   if (tid == 0 && prof) printf("linkage n=%d: argmin+validate %.1f ms, row rescans %.1f ms, merge pass %.1f ms (100 MHz wall clock), retries %lld\n", n, t_arg * 1e-5, t_scan * 1e-5, t_merge * 1e-5, retries);
+  __syncthreads();
   if (tid == 0) g_min_dist[n - 1] = (double)retries;     // statistics: invalid candidates re-evaluated (slot n-1 is unused)
 }
 
@@ -255,15 +323,16 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   RVB_HIP_CHECK(hipGetLastError());
   const size_t lds = (size_t)n * 14 + 16;
   const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
+  const int flags = getenv("RVD_LINKAGE_PROF") ? 1 : 0;
   if (lds <= 158 * 1024 && !force_global) {
     static bool attr_set = false;
     if (!attr_set) {
-      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(linkage_kernel<true>, dim3(1), dim3(1024), lds, s, getenv("RVD_LINKAGE_PROF") ? 1 : 0, D, n, size, cluster_id, neighbor, min_dist, Z);
+    hipLaunchKernelGGL((linkage_kernel<true, 1024>), dim3(1), dim3(1024), lds, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
   } else {
-    hipLaunchKernelGGL(linkage_kernel<false>, dim3(1), dim3(1024), 0, s, getenv("RVD_LINKAGE_PROF") ? 1 : 0, D, n, size, cluster_id, neighbor, min_dist, Z);
+    hipLaunchKernelGGL((linkage_kernel<false, 1024>), dim3(1), dim3(1024), 0, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
   }
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
