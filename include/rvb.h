@@ -231,6 +231,8 @@ int rvb_test_set_gemm_variant(int variant /* 0 auto, 1 gemm.hip 128x128, 2 gemm2
 /* gemm2.hip tuning switches: flags bit 0 = 32x32x16 MFMAs, bit 1 = s_setprio for the later-dispatched waves;
  * group_m = tile order (0/1 row-major inside an XCD's run, n = n row tiles down then the next column); -1 = defaults */
 int rvb_test_set_gemm2_opts(int flags, int group_m);
+/* per-workgroup phase timestamps of one bf16 gemm2 launch (measurement aid, scripts/gemm_timeline.py) */
+int rvb_test_gemm_timeline(int M, int N, int K, int act, int out_f32, int with_res, long long* out, int cap, int* n_wg);
 int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, int iters, int act, int out_f32, int with_res,
                         double* ms_out, double* max_abs_diff_vs_variant1);
 

@@ -104,6 +104,7 @@ SIGNATURES = {
     "rvb_test_fbank": (C.c_int, [_i16p, C.c_int64, _f32p]),
     "rvb_test_set_gemm_variant": (C.c_int, [C.c_int]),
     "rvb_test_set_gemm2_opts": (C.c_int, [C.c_int, C.c_int]),
+    "rvb_test_gemm_timeline": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_longlong), C.c_int, _i32p]),
     "rvb_test_gemm_bench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _f64p, _f64p]),
     "rvb_test_prefix_beam": (C.c_int, [_f32p, _i32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p,

@@ -61,6 +61,11 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  if (p.dbg && tid == 0) {
+    p.dbg[blockIdx.x * 6 + 0] = wall_clock64();
+    p.dbg[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+    p.dbg[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+  }
 
   const int tiles_n = (p.N + B2N - 1) / B2N;
   const int nwg = gridDim.x;
@@ -209,6 +214,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   // blocks, so there is MFMA work on both sides of every barrier.  Measured against the plain
   // wait-barrier-refill-read-multiply loop in scripts/micro/gemm_lab.hip: +7..11 % on the engine's shapes.
   const int nk = p.K / BKE;
+  // bf16 16x16 path: a residual with no activation in front of it starts out in the accumulators (see the prologue)
+  const bool res_acc = sizeof(T) == 2 && !M32 && !F8 && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f;
   if constexpr (F8) {
     // fp8: the plain loop.  A k64 slice is eight 64-cycle MFMAs per wave, and the SIMD's other wave multiplies while this
     // one waits for its 12 fragment reads; the register-pipelined form of the bf16 path spills here (fragments are
@@ -322,14 +329,54 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     std::integral_constant<int, 0> b0;
     std::integral_constant<int, 1> b1;
     if (p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
-    issue(0, 0);
-    if (nk > 1) {
-      issue(1, 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 (the older group of 8 pieces)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool stage1_issued = false;
+    if constexpr (!M32) {
+      if (res_acc) {
+        // C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias): the fp32 residual tile starts out in
+        // the accumulators instead of being added in the epilogue -- there, every slab of every wave waited a full memory
+        // latency for its residual rows before it could store (17 of the 24.5 us a K = 1024 tile spent in its epilogue,
+        // scripts/gemm_timeline.py).  The wave's 128 x 64 sub-tile is read as 32 row-contiguous 16-byte vectors per lane
+        // (4 rows x 256 B per instruction, all in flight together under stage 0's DMA) INTO the accumulator registers,
+        // and each 16-row slab is then turned into the MFMA C layout through the not-yet-used second LDS stage
+        // (accumulator-layout loads straight from memory are 64-byte scatters: 50 us per tile, measured).
+        const float inv_alpha = 1.0f / p.alpha;
+        const int lr = lane >> 4, lc = (lane & 15) * 4;
+        const int colr = min(n0 + wc * 64 + lc, p.N - 4);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int row = min(m0 + wr * 128 + (q >> 2) * 16 + (q & 3) * 4 + lr, p.M - 1);
+          acc[q >> 2][q & 3] = *(const f32x4_t*)(p.res + (size_t)row * p.ldres + colr);
+        }
+        issue(0, 0);      // behind the residual in the (in-order) vmcnt queue: slab i below waits for its own four loads only
+        constexpr int TROW = 64 * 4 + 16;
+        char* tb = smem + STAGE2 + wave * (16 * TROW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(f32x4_t*)(tb + (q * 4 + lr) * TROW + lc * 4) = acc[i][q];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = *(const float*)(tb + (lr * 4 + r) * TROW + (j * 16 + (lane & 15)) * 4) * inv_alpha;
+          __builtin_amdgcn_wave_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage 0's DMA pieces
+      }
+    }
+    if (!res_acc) {
+      issue(0, 0);
+      if (nk > 1) {
+        issue(1, 1);
+        stage1_issued = true;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 (the older group of 8 pieces)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
+    if (nk > 1 && !stage1_issued) issue(1, 1);             // the residual's transposition used stage 1 as scratch until here
+    if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 1] = wall_clock64();
     read_slice(b0, 0);
     block(b0, 1);
     if (nk > 1) {
@@ -375,6 +422,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     }
   }
 
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 2] = wall_clock64();
   // ---- epilogue ----
   // Accumulator fragments hold 4 rows x 1 column per lane: stored directly they make 2-byte/4-byte
   // scattered writes (32-64 B runs).  Each wave instead transposes one 16x64 slab at a time through
@@ -390,17 +438,26 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   if (vec_ok) {
     constexpr int SROW = 64 * 4 + 16;                      // padded slab row (bytes)
     char* slab = smem + ((nk & 1) ? STAGE2 : 0) + wave * (16 * SROW);   // the stage NOT used by the last K step
-    const int orow = lane >> 2;                            // row of the slab this lane finishes
-    const int ocol = (lane & 3) * 16;                      // first of its 16 columns
+    // Read-back mapping: the lanes of one store instruction cover whole rows of the slab's 64 columns -- 16 lanes x 4 fp32,
+    // 8 lanes x 8 bf16 or 4 lanes x 16 fp8, i.e. 256 / 128 / 64 contiguous bytes per row and instruction (and the same for
+    // the fp32 residual reads).  Sixteen consecutive columns per lane whatever the type -- the first form of this epilogue
+    // -- made every fp32 instruction touch 64 different 64-byte segments, 16 bytes each: the fp32 + residual epilogue of a
+    // tile then took as long as its K = 1024 main loop (24.5 us, scripts/gemm_timeline.py).
+    constexpr int CPL = sizeof(OutT) == 4 ? 4 : (sizeof(OutT) == 2 ? 8 : 16);   // columns per lane
+    constexpr int LPR = 64 / CPL;                                                // lanes per slab row
+    constexpr int RPP = 64 / LPR;                                                // rows per pass
+    constexpr int NQ = 16 / RPP;                                                 // passes per slab
+    const int orow = lane / LPR;                           // row (within a pass) this lane finishes
+    const int ocol = (lane % LPR) * CPL;                   // first of its columns
     const int col0 = n0 + wc * 64 + ocol;
-    float bias16[16], sc16[F8 ? 16 : 1];
+    float biasv[CPL], scv[F8 ? CPL : 1];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bias16[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
+    for (int e = 0; e < CPL; ++e) biasv[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
     if constexpr (F8) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sc16[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
+      for (int e = 0; e < CPL; ++e) scv[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
     }
-    const bool seg_full = col0 + 16 <= p.N;
+    const bool seg_full = col0 + CPL <= p.N;
     auto finish_v = [&](auto actf) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -424,57 +481,54 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
               *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
         }
         __builtin_amdgcn_wave_barrier();
-        float v[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 t = *(const float4*)(slab + orow * SROW + (ocol + q * 4) * 4);
-          v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
-        }
-        const int row = m0 + wr * 128 + i * 16 + orow;
-        if (row >= p.M || col0 >= p.N) continue;
-        if constexpr (F8) {
+        for (int q = 0; q < NQ; ++q) {
+          const int srow = q * RPP + orow;
+          float v[CPL];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] *= sc16[e];
-        }
+          for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            const float4 t = *(const float4*)(slab + srow * SROW + (ocol + c4 * 4) * 4);
+            v[c4 * 4 + 0] = t.x; v[c4 * 4 + 1] = t.y; v[c4 * 4 + 2] = t.z; v[c4 * 4 + 3] = t.w;
+          }
+          const int row = m0 + wr * 128 + i * 16 + srow;
+          if (row >= p.M || col0 >= p.N) continue;
+          if constexpr (F8) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = actf(v[e] + bias16[e]) * p.alpha;
-        OutT* cp = C + (size_t)row * p.ldc + col0;
-        if (seg_full) {
-          if (p.res) {
-            const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + col0);
+            for (int e = 0; e < CPL; ++e) v[e] *= scv[e];
+          }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 t = rp[q];
-              v[q * 4 + 0] += t.x; v[q * 4 + 1] += t.y; v[q * 4 + 2] += t.z; v[q * 4 + 3] += t.w;
+          for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
+          OutT* cp = C + (size_t)row * p.ldc + col0;
+          if (seg_full) {
+            if (p.res && !res_acc) {
+              const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + col0);
+#pragma unroll
+              for (int c4 = 0; c4 < CPL / 4; ++c4) {
+                const float4 t = rp[c4];
+                v[c4 * 4 + 0] += t.x; v[c4 * 4 + 1] += t.y; v[c4 * 4 + 2] += t.z; v[c4 * 4 + 3] += t.w;
+              }
             }
-          }
-          if constexpr (sizeof(OutT) == 1) {
-            const float qs = p.out_inv_scale;
-            *(uint4*)cp = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
-                                     pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
-          } else if constexpr (sizeof(OutT) == 2) {
-            uint4 o0, o1;
-            o0.x = pack2_bf16(v[0], v[1]);
-            o0.y = pack2_bf16(v[2], v[3]);
-            o0.z = pack2_bf16(v[4], v[5]);
-            o0.w = pack2_bf16(v[6], v[7]);
-            o1.x = pack2_bf16(v[8], v[9]);
-            o1.y = pack2_bf16(v[10], v[11]);
-            o1.z = pack2_bf16(v[12], v[13]);
-            o1.w = pack2_bf16(v[14], v[15]);
-            ((uint4*)cp)[0] = o0;
-            ((uint4*)cp)[1] = o1;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              ((float4*)cp)[q] = make_float4(v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
-          }
-        } else {            // ragged last column segment of the matrix
-          for (int e = 0; e < 16 && col0 + e < p.N; ++e) {
-            float o = v[e];
-            if (p.res) o += p.res[(size_t)row * p.ldres + col0 + e];
-            if constexpr (sizeof(OutT) == 1) cp[e] = (OutT)(pack4_fp8(o * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
-            else cp[e] = Cvt<OutT>::from_f32(o);
+            if constexpr (sizeof(OutT) == 1) {
+              const float qs = p.out_inv_scale;
+              *(uint4*)cp = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                                       pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+            } else if constexpr (sizeof(OutT) == 2) {
+              uint4 o0;
+              o0.x = pack2_bf16(v[0], v[1]);
+              o0.y = pack2_bf16(v[2], v[3]);
+              o0.z = pack2_bf16(v[4], v[5]);
+              o0.w = pack2_bf16(v[6], v[7]);
+              *(uint4*)cp = o0;
+            } else {
+              *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {            // ragged last column segment of the matrix
+            for (int e = 0; e < CPL && col0 + e < p.N; ++e) {
+              float o = v[e];
+              if (p.res && !res_acc) o += p.res[(size_t)row * p.ldres + col0 + e];
+              if constexpr (sizeof(OutT) == 1) cp[e] = (OutT)(pack4_fp8(o * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
+              else cp[e] = Cvt<OutT>::from_f32(o);
+            }
           }
         }
       }
@@ -488,6 +542,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     } else {
       finish_v([](float x) { return x; });
     }
+    if (p.dbg && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[blockIdx.x * 6 + 3] = wall_clock64(); }
     return;
   }
   // unaligned output / residual rows: element-wise stores
@@ -531,7 +586,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wr * 128 + i * 16 + crow + r;
         if (!full && row >= p.M) continue;
-        const float* rrow = p.res ? p.res + (size_t)row * p.ldres : nullptr;
+        const float* rrow = (p.res && !res_acc) ? p.res + (size_t)row * p.ldres : nullptr;
         OutT* crow_p = C + (size_t)row * p.ldc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

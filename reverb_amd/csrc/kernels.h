@@ -30,6 +30,7 @@ struct GemmArgs {
   int in_fp8, out_fp8;
   float a_scale, out_inv_scale;
   const float* w_scale;   // [N]
+  long long* dbg;         // test hook (rvb_test_gemm_timeline): per workgroup {start, stage 0 landed, main loop done, end} in 10 ns ticks + HW ids
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
 // gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)

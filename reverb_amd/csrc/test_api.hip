@@ -372,6 +372,34 @@ template <typename T> void fill(void* p, size_t n, unsigned seed, float scale) {
 extern "C" int rvb_test_set_gemm_variant(int v) { g_gemm_variant = v; return OK; }
 extern "C" int rvb_test_set_gemm2_opts(int flags, int group_m) { g_gemm2_flags = flags; g_gemm2_group_m = group_m; return OK; }
 
+// per-workgroup phase timestamps of one bf16 gemm2 launch (scripts/gemm_timeline.py): out[6 * wg + {0..3}] = start / stage 0
+// landed / main loop done / stores drained (10 ns ticks of the constant clock), [4] = HW_ID, [5] = XCC_ID
+extern "C" int rvb_test_gemm_timeline(int M, int N, int K, int act, int out_f32, int with_res, long long* out, int cap, int* n_wg) {
+  T_TRY(need_gpu());
+  Dev dA, dW, dB, dR, dC, dT;
+  T_TRY(dA.alloc((size_t)M * K * 2)); T_TRY(dW.alloc((size_t)N * K * 2)); T_TRY(dB.alloc((size_t)N * 4));
+  const int padc = getenv("RVB_BENCH_PADC") ? atoi(getenv("RVB_BENCH_PADC")) : 0;      // probe: output / residual row stride off the power of two
+  const int ldc = N + padc;
+  T_TRY(dR.alloc((size_t)M * ldc * 4)); T_TRY(dC.alloc((size_t)M * ldc * (out_f32 ? 4 : 2)));
+  fill<bf16_t>(dA.p, (size_t)M * K, 1u, 1.0f); fill<bf16_t>(dW.p, (size_t)N * K, 2u, 1.0f / sqrtf((float)K));
+  fill<float>(dB.p, N, 3u, 1.0f); fill<float>(dR.p, (size_t)M * ldc, 4u, 1.0f);
+  const int wgs = ((M + 255) / 256) * ((N + 255) / 256);
+  if (wgs > cap) { set_error("rvb_test_gemm_timeline: output too small"); return E_ARG; }
+  T_TRY(dT.alloc((size_t)wgs * 6 * 8));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.res = with_res ? (const float*)dR.p : nullptr; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = ldc; g.ldres = ldc; g.alpha = 0.5f; g.act = act; g.out_f32 = out_f32;
+  if (!gemm2_applicable(DT_BF16, g)) { set_error("rvb_test_gemm_timeline: shape not handled by gemm2"); return E_ARG; }
+  for (int i = 0; i < 3; ++i) T_TRY(gemm2(nullptr, DT_BF16, g));
+  g.dbg = (long long*)dT.p;
+  T_TRY(gemm2(nullptr, DT_BF16, g));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  RVB_HIP_CHECK(hipMemcpy(out, dT.p, (size_t)wgs * 6 * 8, hipMemcpyDeviceToHost));
+  *n_wg = wgs;
+  return OK;
+}
+
 extern "C" int rvb_test_gemm_bench(int dtype, int M, int N, int K, int variant, int iters, int act, int out_f32,
                                    int with_res, double* ms_out, double* max_abs_diff) {
   T_TRY(need_gpu());
