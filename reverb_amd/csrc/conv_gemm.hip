@@ -11,9 +11,10 @@
 // The epilogue is conv_kernel's: 16-row slabs transposed through LDS, bias + residual + ReLU, full 128-byte runs of
 // channels per pixel into the bordered output.
 //
-// STATUS: written after the round's GPU budget was spent -- selected only with RVD_CONV_IGEMM=1 (diar_engine.hip packs
-// the second weight layout only then); resnet.hip's kernel stays the default until this one has passed tests/ on an
-// MI355X.
+// STATUS (round 2): the default for the 128- and 256-channel stages (diar_engine.hip packs the second weight layout unless
+// RVD_CONV_IGEMM=0); tests/test_diar_gpu.py compares it with resnet.hip's direct kernel.  Tried and not kept: the
+// row-contiguous read-back + up-front residual prefetch that helped gemm2's fp32 epilogue (no change here: bf16 output and
+// residual are a quarter of those bytes, the tile is bound by its K loop).
 #include "common.h"
 #include "kernels.h"
 
