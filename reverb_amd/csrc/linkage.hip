@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__
 // shared variables, and state writes sit right after a reduction's barrier: 1 barrier per candidate round, per row
 // rescan and per merge.
 static constexpr int LK_E = 10;      // elements per thread and batch (registers: 2 x LK_E doubles in the merge pass)
-template <bool LDS_STATE, int NTH>
+// COMPACT (LDS_STATE, n <= LK_E * NTH): the slots a thread owns are re-dealt from the sorted list of live slots every 256
+// merges (registers `myz`), so that the passes walk ~the live clusters instead of all n slots -- dead slots are skipped per
+// lane anyway, but a wave instruction costs the same whether 64 or 20 of its lanes are alive, and the merge pass is
+// VALU-issue-bound.  Order is preserved (ascending slots per list position), so ties break as before.
+template <bool LDS_STATE, int NTH, bool COMPACT>
 __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* __restrict__ D, int n, uint16_t* __restrict__ g_size,
                                                        int* __restrict__ cluster_id, int* __restrict__ g_neighbor,
                                                        double* __restrict__ g_min_dist, double* __restrict__ Z) {
@@ -189,6 +193,8 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
   auto MD = [&](int i) -> double& { if constexpr (LDS_STATE) return s_md[i]; else return g_min_dist[i]; };
   auto NB = [&](int i) -> int& { if constexpr (LDS_STATE) return s_nb[i]; else return g_neighbor[i]; };
   auto SZ = [&](int i) -> uint16_t& { if constexpr (LDS_STATE) return s_sz[i]; else return g_size[i]; };
+  uint16_t* s_list = s_sz + (LDS_STATE ? n : 0);          // COMPACT: sorted live slots (rebuild scratch)
+  __shared__ int s_wtot[16];
   const int tid = threadIdx.x;
   if (tid < 32) red[tid >> 4][tid & 15] = MinPair{INFINITY, 0x7fffffff};
   long long retries = 0;
@@ -198,14 +204,63 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
     for (int i = tid; i < n; i += NTH) { s_md[i] = g_min_dist[i]; s_nb[i] = g_neighbor[i]; s_sz[i] = g_size[i]; }
   }
   __syncthreads();
+  int myz[COMPACT ? LK_E : 1];                // COMPACT: this thread's slots (-1 = none); else slot = base + tid + e * NTH
+  int ecount = LK_E;                          // COMPACT: batches of NTH list positions in use (uniform)
+  auto slot = [&](int base, int e) -> int {
+    if constexpr (COMPACT) { (void)base; return myz[e]; }
+    else { const int z = base + tid + e * NTH; return z < n ? z : -1; }
+  };
+  const int span = COMPACT ? 1 : n;           // COMPACT: one batch covers everything
   auto own_min = [&]() {                      // dropped rows hold +inf; slot n-1 has no candidate (no y > n-1)
     MinPair m{INFINITY, 0x7fffffff};
-    for (int z = tid; z < n - 1; z += NTH) m = min_pair(m, MinPair{MD(z), z});
+    for (int base = 0; base < span; base += LK_E * NTH) {
+#pragma unroll
+      for (int e = 0; e < LK_E; ++e) {
+        if (COMPACT && e >= ecount) break;
+        const int z = slot(base, e);
+        if (z >= 0 && z < n - 1) m = min_pair(m, MinPair{MD(z), z});
+      }
+    }
     return m;
   };
-  MinPair loc = own_min();
+  auto owns = [&](int z) -> bool {
+    if constexpr (COMPACT) {
+      bool o = false;
+#pragma unroll
+      for (int e = 0; e < LK_E; ++e) o |= myz[e] == z;
+      return o;
+    } else {
+      return tid == (z & (NTH - 1));
+    }
+  };
+  MinPair loc{INFINITY, 0x7fffffff};
+  auto rebuild = [&]() {                      // COMPACT: deal the live slots out again, ascending, position p -> thread p % NTH
+    if constexpr (COMPACT) {
+      __syncthreads();                        // the previous merge's owner writes
+      const int lane = tid & 63, wv = tid >> 6;
+      const int C = (n + NTH - 1) / NTH, z0 = tid * C;
+      int c = 0;
+      for (int j = 0; j < C; ++j) { const int z = z0 + j; if (z < n && SZ(z) != 0) ++c; }
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+      if (lane == 63) s_wtot[wv] = incl;
+      __syncthreads();
+      int woff = 0, total = 0;
+      for (int w = 0; w < NTH / 64; ++w) { const int t = s_wtot[w]; if (w < wv) woff += t; total += t; }
+      int pos = woff + incl - c;
+      for (int j = 0; j < C; ++j) { const int z = z0 + j; if (z < n && SZ(z) != 0) s_list[pos++] = (uint16_t)z; }
+      __syncthreads();
+      ecount = (total + NTH - 1) / NTH;
+#pragma unroll
+      for (int e = 0; e < LK_E; ++e) { const int p = tid + e * NTH; myz[e] = p < total ? (int)s_list[p] : -1; }
+      __syncthreads();
+    }
+  };
+  if constexpr (!COMPACT) loc = own_min();
   const long long cyc0 = clock64(), wc0 = wall_clock64();
   for (int k = 0; k < n - 1; ++k) {
+    if (COMPACT && (k & 255) == 0) { rebuild(); loc = own_min(); }
     // ---- closest valid candidate pair (lazy validation of the nearest-neighbour guesses) ----
     int x = 0, y = -1;
     double dist = 0.0;
@@ -225,18 +280,20 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
       MinPair q{INFINITY, 0x7fffffff};
       // all of a thread's loads are issued before the first is used (LK_E per batch): one memory latency per rescan,
       // not one per element -- with a runtime trip count the compiler serialises load -> compare -> next load
-      for (int base = 0; base < n; base += LK_E * NTH) {
+      for (int base = 0; base < span; base += LK_E * NTH) {
         double dv[LK_E];
+        int jz[LK_E];
 #pragma unroll
         for (int e = 0; e < LK_E; ++e) {
-          const int j = base + tid + e * NTH;
-          dv[e] = (j < n && j > x && SZ(j) > 0) ? rowx[j] : INFINITY;
+          const int j = (COMPACT && e >= ecount) ? -1 : slot(base, e);
+          jz[e] = j;
+          dv[e] = (j > x && SZ(j) > 0) ? rowx[j] : INFINITY;
         }
 #pragma unroll
-        for (int e = 0; e < LK_E; ++e) q = min_pair(q, MinPair{dv[e], base + tid + e * NTH});
+        for (int e = 0; e < LK_E; ++e) q = min_pair(q, MinPair{dv[e], jz[e] < 0 ? 0x7fffffff : jz[e]});
       }
       q = block_argmin_alt(q, red, rphase);
-      if (tid == (x & (NTH - 1))) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; loc = own_min(); }
+      if (owns(x)) { NB(x) = q.v < INFINITY ? q.i : -1; MD(x) = q.v; loc = own_min(); }
       if (prof) { const long long t1 = wall_clock64(); t_scan += t1 - t0c; }
     }
     if (y < 0) {                              // uniform across the block (every thread holds the same reduction results)
@@ -259,15 +316,15 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
     // outputs, so ties break as before
     const double inv_fs = 1.0 / fs;
     MinPair best{INFINITY, 0x7fffffff};
-    for (int base = 0; base < n; base += LK_E * NTH) {
+    for (int base = 0; base < span; base += LK_E * NTH) {
       // both rows' elements of this thread in registers first (see the rescan above); no element written below is read
       // by this pass (writes go to row y / column y at z, reads come from rows x and y at other z)
       double dxv[LK_E], dyv[LK_E];
       unsigned okm = 0;
 #pragma unroll
       for (int e = 0; e < LK_E; ++e) {
-        const int z = base + tid + e * NTH;
-        const bool ok = z < n && z != x && z != y && SZ(z) != 0;
+        const int z = (COMPACT && e >= ecount) ? -1 : slot(base, e);
+        const bool ok = z >= 0 && z != x && z != y && SZ(z) != 0;
         okm |= ok ? 1u << e : 0u;
         dxv[e] = ok ? rx[z] : 0.0;
         dyv[e] = ok ? ry[z] : 0.0;
@@ -275,7 +332,7 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
 #pragma unroll
       for (int e = 0; e < LK_E; ++e) {
         if (!(okm >> e & 1)) continue;
-        int z = base + tid + e * NTH;
+        int z = slot(base, e);
         asm volatile("" : "+v"(z));              // addresses are formed here, not hoisted for all LK_E elements at once
         const double dxi = dxv[e], dyi = dyv[e];
         const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) * inv_fs);
@@ -298,8 +355,8 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
     best = block_argmin_alt(best, red, rphase);
     // state of the two merged slots, by their owners; everybody has read SZ(x), SZ(y) before the barrier above
     bool mine = false;
-    if (tid == (x & (NTH - 1))) { SZ(x) = 0; MD(x) = INFINITY; mine = true; }
-    if (tid == (y & (NTH - 1))) {
+    if (owns(x)) { SZ(x) = 0; MD(x) = INFINITY; mine = true; }
+    if (owns(y)) {
       SZ(y) = (uint16_t)(nx + ny);
       if (y < n - 1) { NB(y) = best.v < INFINITY ? best.i : -1; MD(y) = best.v; }
       mine = true;
@@ -321,18 +378,22 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   RVB_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
   RVB_HIP_CHECK(hipGetLastError());
-  const size_t lds = (size_t)n * 14 + 16;
+  const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
   const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
+  const bool no_compact = getenv("RVD_LINKAGE_COMPACT") && atoi(getenv("RVD_LINKAGE_COMPACT")) == 0;
   const int flags = getenv("RVD_LINKAGE_PROF") ? 1 : 0;
-  if (lds <= 158 * 1024 && !force_global) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((linkage_kernel<true, 1024>), dim3(1), dim3(1024), lds, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    attr_set = true;
+  }
+  if (!force_global && !no_compact && lds_c <= 158 * 1024 && n <= LK_E * 1024) {
+    hipLaunchKernelGGL((linkage_kernel<true, 1024, true>), dim3(1), dim3(1024), lds_c, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+  } else if (lds <= 158 * 1024 && !force_global) {
+    hipLaunchKernelGGL((linkage_kernel<true, 1024, false>), dim3(1), dim3(1024), lds, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
   } else {
-    hipLaunchKernelGGL((linkage_kernel<false, 1024>), dim3(1), dim3(1024), 0, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+    hipLaunchKernelGGL((linkage_kernel<false, 1024, false>), dim3(1), dim3(1024), 0, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
   }
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
