@@ -208,9 +208,10 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
 
 
 # ------------------------------------------------------------------------------------ clustering on the GPU
-@pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3)])
+@pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3), (3100, 64, 4)])
 def test_centroid_linkage_matches_scipy(case, n, d, seed):
-    """scipy is what pyannote itself calls; it is installed on the GPU box, so the kernel is pinned to it."""
+    """scipy is what pyannote itself calls; it is installed on the GPU box, so the kernel is pinned to it.  n > 1024: several
+    batches of slots per thread, re-dealt from the live list every 256 merges (the batch count drops on the way)."""
     from scipy.cluster.hierarchy import fcluster, linkage
     from reverb_amd.diar_engine import DiarEngine
     rng = np.random.default_rng(seed)
@@ -225,6 +226,23 @@ def test_centroid_linkage_matches_scipy(case, n, d, seed):
     assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])          # same merges in the same order
     assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
     assert np.array_equal(fcluster(got, 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
+
+
+def test_centroid_linkage_without_slot_compaction_matches_scipy(case, monkeypatch):
+    """10 240 < n <= ~11 500 points keep the LDS-resident state but not the re-dealt slot lists (registers for ten batches of
+    1024): RVD_LINKAGE_COMPACT=0 runs that variant on a small input."""
+    from scipy.cluster.hierarchy import linkage
+    from reverb_amd.diar_engine import DiarEngine
+    monkeypatch.setenv("RVD_LINKAGE_COMPACT", "0")
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((4, 48))[rng.integers(4, size=1300)] + 0.3 * rng.standard_normal((1300, 48))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
+    got = eng.centroid_linkage(X)
+    eng.close()
+    want = linkage(X, method="centroid", metric="euclidean")
+    assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])
+    assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
 
 
 def test_centroid_linkage_large_n_variant_matches_scipy(case, monkeypatch):
