@@ -207,6 +207,27 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
     assert cosw.min() > 0.995, cosw
 
 
+def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
+    """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; default)
+    against the same block as two conv2d launches: same operand values, same accumulation order, same rounding points --
+    the embeddings must be IDENTICAL, and the counters prove which path ran."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, fused, flops = {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_FUSE", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        fused[flag] = eng.timing("emb_conv_fused")[2]
+        flops[flag] = eng.timing("emb_conv_32")[1]
+        eng.close()
+    assert fused["0"] == 0 and fused["1"] >= 3           # the three stride-1 blocks of stage 1, per trunk pass
+    assert flops["0"] == flops["1"] > 0                    # the algorithmic work is counted the same way
+    assert np.array_equal(out["0"], out["1"])
+
+
 # ------------------------------------------------------------------------------------ clustering on the GPU
 @pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3), (3100, 64, 4)])
 def test_centroid_linkage_matches_scipy(case, n, d, seed):
