@@ -235,6 +235,25 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   float bias_r[CW];
 #pragma unroll
   for (int e = 0; e < CW; ++e) bias_r[e] = p.bias ? p.bias[n0 + oseg + e] : 0.f;
+  // the residual vectors of all four slabs are requested before the first slab is transposed: inside the slab loop each
+  // slab waited a full memory latency for its own residual before it could store (round 2, by elimination: the 32-channel
+  // stage ran 74 -> 60 ms without the residual reads, 57 ms without the stores, 39 ms without both -- neither MFMAs nor
+  // LDS fragment reads moved it).  bf16 only (a quarter of a 128-channel f32 tile would be 64 registers).
+  constexpr int OVE0 = 16 / (int)sizeof(T);
+  constexpr bool RPF = sizeof(T) == 2 && NT <= 64;
+  uint4 rpre[RPF ? CV_MI : 1][RPF ? CW / OVE0 : 1];
+  if constexpr (RPF) {
+    if (p.res) {
+#pragma unroll
+      for (int mi = 0; mi < CV_MI; ++mi) {
+        const int t = t0 + mi * 16 + orow;
+        const bool ok = f < p.Fo && t < p.To;
+        const size_t pix = (((size_t)b * (p.Fo + 2) + (ok ? f : 0) + 1) * (p.To + 2) + (ok ? t : 0) + 1) * p.Cout + n0 + oseg;
+#pragma unroll
+        for (int q = 0; q < CW / OVE0; ++q) rpre[mi][q] = *(const uint4*)((const T*)p.res + pix + q * OVE0);
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < CV_MI; ++mi) {
     __builtin_amdgcn_wave_barrier();
@@ -258,7 +277,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
       const T* rp = (const T*)p.res + pix;
 #pragma unroll
       for (int q = 0; q < CW / OVE; ++q) {
-        const uint4 raw = *(const uint4*)(rp + q * OVE);
+        uint4 raw;
+        if constexpr (RPF) raw = rpre[mi][q]; else raw = *(const uint4*)(rp + q * OVE);
         const T* re = (const T*)&raw;
 #pragma unroll
         for (int e = 0; e < OVE; ++e) v[q * OVE + e] += Cvt<T>::to_f32(re[e]);
@@ -522,8 +542,10 @@ __global__ __launch_bounds__(256, 2) void conv_pair32_kernel(ConvPairArgs p) {
 }
 
 bool conv_pair32_applicable(int dtype, int cin, int cmid, int cout, int stride_a, int stride_b, int taps_a, int taps_b) {
+  // opt-in (RVD_CONV_FUSE=1): measured 73.5 ms for the 32-channel stage against 67 ms for two conv2d launches once their
+  // residual reads were taken off the slab loop -- two HBM passes instead of five, but five barriers per 124 output pixels
   const char* e = getenv("RVD_CONV_FUSE");          // read per call: the tests switch it between engines
-  const bool off = e && atoi(e) == 0;
+  const bool off = !(e && atoi(e) == 1);
   return !off && dtype == DT_BF16 && cin == 32 && cmid == 32 && cout == 32 && stride_a == 1 && stride_b == 1 && taps_a == 9 && taps_b == 9;
 }
 

@@ -208,7 +208,7 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
 
 
 def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
-    """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; default)
+    """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; RVD_CONV_FUSE=1)
     against the same block as two conv2d launches: same operand values, same accumulation order, same rounding points --
     the embeddings must be IDENTICAL, and the counters prove which path ran."""
     from reverb_amd.diar_engine import DiarEngine
