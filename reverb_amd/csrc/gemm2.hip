@@ -215,7 +215,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   // wait-barrier-refill-read-multiply loop in scripts/micro/gemm_lab.hip: +7..11 % on the engine's shapes.
   const int nk = p.K / BKE;
   // bf16 16x16 path: a residual with no activation in front of it starts out in the accumulators (see the prologue)
-  const bool res_acc = sizeof(T) == 2 && !M32 && !F8 && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f;
+  const bool res_acc = sizeof(T) == 2 && !M32 && !F8 && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f &&
+                       (p.N & 3) == 0 && (p.ldres & 3) == 0 && ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
   if constexpr (F8) {
     // fp8: the plain loop.  A k64 slice is eight 64-cycle MFMAs per wave, and the SIMD's other wave multiplies while this
     // one waits for its 12 fragment reads; the register-pipelined form of the bf16 path spills here (fragments are

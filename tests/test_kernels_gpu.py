@@ -66,6 +66,9 @@ def test_gemm_epilogue(lib, dtype, act, alpha, use_res, out_f32):
     (1000, 1024, 256, 0, 0.5, True, 1),       # 4 x 4 tiles, fp32 residual
     (2100, 520, 64, 2, 1.0, False, 0),        # 9 x 3 tiles (ragged last column tile), one K step, ReLU, bf16 out
     (2600, 1280, 320, 0, 1.0, True, 1),       # 11 x 5 tiles: grouped orders with a ragged last group
+    (700, 520, 128, 0, 0.5, True, 1),         # residual preloaded into the accumulators with a ragged last column tile and row tile
+    (515, 264, 64, 0, 1.0, True, 0),          # residual + bf16 output, one K step
+    (300, 262, 64, 0, 1.0, True, 1),          # N % 4 != 0: the residual stays in the (element-wise) epilogue
 ])
 def test_gemm2_tuning_switches_keep_results(lib, flags, group_m, M, N, K, act, alpha, use_res, out_f32):
     """gemm2.hip's tuning switches (32x32x16 MFMAs with their own fragment / accumulator / epilogue mapping, grouped
