@@ -45,7 +45,7 @@ typedef struct rvb_model_cfg {
   int32_t heads;         /* encoder_conf.attention_heads */
   int32_t ffn_dim;       /* encoder_conf.linear_units */
   int32_t num_blocks;    /* encoder_conf.num_blocks (first and last are language-specific if num_langs>0) */
-  int32_t cnn_kernel;    /* encoder_conf.cnn_module_kernel (odd) */
+  int32_t cnn_kernel;    /* encoder_conf.cnn_module_kernel (odd unless cnn_causal) */
   int32_t cnn_norm;      /* 0 layer_norm, 1 batch_norm (encoder_conf.cnn_module_norm) */
   int32_t num_langs;     /* dataset_conf.cat_emb_conf.emb_len when pass_cat_emb, else 0 */
   int32_t dec_heads;     /* decoder_conf.attention_heads */
@@ -57,6 +57,8 @@ typedef struct rvb_model_cfg {
   int32_t eos_id;
   int32_t max_chunks;    /* chunks per device batch (workspace sizing) */
   int32_t chunk_frames;  /* max input frames per chunk (2051, cli/reverb.py:188) */
+  int32_t cnn_causal;    /* encoder_conf.causal: the convolution module pads cnn_kernel-1 frames on the left only
+                            (convolution.py:55-57,113-121) and carries a cnn cache across streamed chunks */
 } rvb_model_cfg;
 
 const char* rvb_last_error(void);
@@ -109,8 +111,10 @@ int rvb_encode(rvb_engine* e, const float* feats, int64_t first_chunk, const int
  * one stream.  rvb_stream_begin empties the attention cache; rvb_stream_chunk encodes one chunk of `n_frames` input frames
  * ((chunk-1)*4 + 7 for a full chunk, encoder.py:378-381) against the cached keys / values of earlier chunks, positional keys
  * at absolute frame positions, and keeps the last `required_cache_size` frames (< 0: all, 0: none) as forward_chunk does;
- * `out` (nullable) receives the chunk's encoder output [n_out, d] fp32.  The cache lives in the engine (the reference
- * returns att_cache / cnn_cache tensors; models with a non-causal convolution module have no cnn cache).
+ * `out` (nullable) receives the chunk's encoder output [n_out, d] fp32.  The caches live in the engine (the reference
+ * returns att_cache / cnn_cache tensors): per block the key|value rows of the cached frames and, for a causal convolution
+ * module (cnn_causal), the pointwise-conv1 outputs of the last cnn_kernel-1 frames -- the reference's cnn_cache holds the
+ * module inputs of those frames and pushes them through pointwise_conv1 again with every chunk (convolution.py:113-125).
  * rvb_stream_finish runs the CTC head + top-k over all frames produced and makes them the current batch (one "chunk"), so
  * that rvb_ctc_greedy / rvb_ctc_prefix_beam / rvb_attention_rescore / rvb_get_encoder_out work on the streamed output --
  * ASRModel.decode(simulate_streaming=True) (asr_model.py:301-306). */
@@ -191,7 +195,8 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
 int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
                    const float* b, float* out, int B, int T0, int F0, int d);
 int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
-                        const int32_t* lens, float* out, int B, int T, int d, int K);
+                        const int32_t* lens, float* out, int B, int T, int d, int K, int causal,
+                        const float* hist /* nullable [K-1][2d] */, int hist_rows);
 int rvb_test_attention(int dtype, const float* q, const float* k, const float* v, const float* p,
                        const float* bias_u, const float* bias_v, float* out, int q_rows, int kv_rows, int p_rows,
                        int heads, int dk, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,

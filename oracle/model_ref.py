@@ -96,14 +96,21 @@ def rel_pos_mhsa(sd: SD, p: str, x: torch.Tensor, mask: torch.Tensor, pos_emb: t
     return _lin(sd, p + ".linear_out", o)
 
 
-def conv_module(sd: SD, p: str, x: torch.Tensor, mask_pad: torch.Tensor, norm: str):
-    """transformer/convolution.py:89-144 (non-causal)."""
+def conv_module(sd: SD, p: str, x: torch.Tensor, mask_pad: torch.Tensor, norm: str, causal: bool = False, cache=None):
+    """transformer/convolution.py:89-144.  causal (lorder = K-1, :55-57): the module INPUT is padded on the left with
+    lorder zero frames, or with `cache` (B, d, cache_t) when one is given (:113-121); returns (out, new_cache) with
+    new_cache = the last lorder input frames, or None for the symmetric convolution."""
     x = x.transpose(1, 2).clone()
     x.masked_fill_(~mask_pad, 0.0)
+    w = sd[p + ".depthwise_conv.weight"]
+    lorder = w.shape[-1] - 1 if causal else 0
+    new_cache = None
+    if lorder > 0:
+        x = F.pad(x, (lorder, 0)) if cache is None else torch.cat((cache, x), dim=2)
+        new_cache = x[:, :, -lorder:]
     x = F.conv1d(x, sd[p + ".pointwise_conv1.weight"], sd[p + ".pointwise_conv1.bias"])
     x = F.glu(x, dim=1)
-    w = sd[p + ".depthwise_conv.weight"]
-    x = F.conv1d(x, w, sd[p + ".depthwise_conv.bias"], padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
+    x = F.conv1d(x, w, sd[p + ".depthwise_conv.bias"], padding=0 if causal else (w.shape[-1] - 1) // 2, groups=w.shape[0])
     if norm == "layer_norm":
         x = _ln(sd, p + ".norm", x.transpose(1, 2), 1e-5).transpose(1, 2)
     else:  # BatchNorm1d in eval mode
@@ -112,7 +119,7 @@ def conv_module(sd: SD, p: str, x: torch.Tensor, mask_pad: torch.Tensor, norm: s
     x = F.silu(x)
     x = F.conv1d(x, sd[p + ".pointwise_conv2.weight"], sd[p + ".pointwise_conv2.bias"])
     x.masked_fill_(~mask_pad, 0.0)
-    return x.transpose(1, 2)
+    return (x.transpose(1, 2), new_cache) if causal else x.transpose(1, 2)
 
 
 def ffn(sd: SD, p: str, x: torch.Tensor, act) -> torch.Tensor:
@@ -131,11 +138,12 @@ def lsl_mix(sd: SD, p: str, x: torch.Tensor, cat_embs: torch.Tensor) -> torch.Te
     return y
 
 
-def conformer_layer(sd: SD, p: str, x, mask, pos_emb, mask_pad, h, norm, cat_embs, is_lsl):
+def conformer_layer(sd: SD, p: str, x, mask, pos_emb, mask_pad, h, norm, cat_embs, is_lsl, causal: bool = False):
     """encoder_layer.py:164-244 (regular) and :305-402 (language-specific)."""
     x = x + 0.5 * ffn(sd, p + ".feed_forward_macaron", _ln(sd, p + ".norm_ff_macaron", x, 1e-5), F.silu)
     x = x + rel_pos_mhsa(sd, p + ".self_attn", _ln(sd, p + ".norm_mha", x, 1e-5), mask, pos_emb, h)
-    x = x + conv_module(sd, p + ".conv_module", _ln(sd, p + ".norm_conv", x, 1e-5), mask_pad, norm)
+    c = conv_module(sd, p + ".conv_module", _ln(sd, p + ".norm_conv", x, 1e-5), mask_pad, norm, causal)
+    x = x + (c[0] if causal else c)
     residual = x
     z = _ln(sd, p + ".norm_ff", x, 1e-5)
     if is_lsl:
@@ -180,7 +188,8 @@ def encoder_forward(sd: SD, cfg: dict, feats: torch.Tensor, feats_lens: torch.Te
         att_mask = masks & subsequent_chunk_mask(L, int(ec["static_chunk_size"]), num_decoding_left_chunks).unsqueeze(0)
     for i in range(nb):
         is_lsl = has_lsl and i in (0, nb - 1)
-        x = conformer_layer(sd, f"encoder.encoders.{i}", x, att_mask, pos_emb, masks, h, norm, cat_embs, is_lsl)
+        x = conformer_layer(sd, f"encoder.encoders.{i}", x, att_mask, pos_emb, masks, h, norm, cat_embs, is_lsl,
+                            bool(ec.get("causal", False)))
         if taps is not None:
             taps[f"layer{i}"] = x.clone()
     x = _ln(sd, "encoder.after_norm", x, 1e-5)
@@ -189,13 +198,16 @@ def encoder_forward(sd: SD, cfg: dict, feats: torch.Tensor, feats_lens: torch.Te
 
 # --------------------------------------------------------------------------- streaming encoder
 def encoder_forward_chunk(sd: SD, cfg: dict, xs: torch.Tensor, offset: int, required_cache_size: int, att_cache,
-                          cat_embs: torch.Tensor):
-    """BaseEncoder.forward_chunk (transformer/encoder.py:231-341) for models whose convolution module is not causal
-    (lorder = 0: no cnn cache, convolution.py:118-123).  xs (1, time, 80); att_cache: None or a list with one
-    (k, v) pair of (1, h, cache_t1, dk) tensors per layer.  Returns (ys (1, chunk, d), new att_cache)."""
+                          cat_embs: torch.Tensor, cnn_cache=None):
+    """BaseEncoder.forward_chunk (transformer/encoder.py:231-341).  xs (1, time, 80); att_cache: None or a list with
+    one (k, v) pair of (1, h, cache_t1, dk) tensors per layer; cnn_cache (causal convolution modules only,
+    convolution.py:113-121): None or a list with one (1, d, lorder) tensor per layer.  Returns (ys (1, chunk, d),
+    new att_cache) -- and the new cnn_cache as a third value when the model is causal."""
     ec = cfg["encoder_conf"]
     h, nb, norm = ec["attention_heads"], ec["num_blocks"], ec.get("cnn_module_norm", "batch_norm")
-    assert xs.shape[0] == 1 and not ec.get("causal", False)
+    causal = bool(ec.get("causal", False))
+    new_cnn = []
+    assert xs.shape[0] == 1
     x = global_cmvn(sd, xs)
     fake = torch.ones(1, 1, xs.shape[1], dtype=torch.bool)
     x, _, _ = conv2d_subsampling4(sd, x, fake)                      # x * sqrt(d); pos_emb is recomputed below
@@ -233,7 +245,12 @@ def encoder_forward_chunk(sd: SD, cfg: dict, xs: torch.Tensor, offset: int, requ
         scores = (torch.matmul(q_u, k.transpose(-2, -1)) + torch.matmul(q_v, pp.transpose(-2, -1))) / math.sqrt(dk)
         o = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).contiguous().view(1, chunk, d)
         x = x + _lin(sd, a + ".linear_out", o)
-        x = x + conv_module(sd, p + ".conv_module", _ln(sd, p + ".norm_conv", x, 1e-5), torch.ones(1, 1, chunk, dtype=torch.bool), norm)
+        c = conv_module(sd, p + ".conv_module", _ln(sd, p + ".norm_conv", x, 1e-5), torch.ones(1, 1, chunk, dtype=torch.bool), norm,
+                        causal, None if cnn_cache is None else cnn_cache[i])
+        if causal:
+            new_cnn.append(c[1])
+            c = c[0]
+        x = x + c
         residual = x
         z = _ln(sd, p + ".norm_ff", x, 1e-5)
         if is_lsl:
@@ -241,23 +258,31 @@ def encoder_forward_chunk(sd: SD, cfg: dict, xs: torch.Tensor, offset: int, requ
             x = _ln(sd, p + ".norm_final", residual + 0.5 * ffn(sd, p + ".feed_forward", y, F.silu), 1e-5) + y
         else:
             x = _ln(sd, p + ".norm_final", residual + 0.5 * ffn(sd, p + ".feed_forward", z, F.silu), 1e-5)
+    if causal:
+        return _ln(sd, "encoder.after_norm", x, 1e-5), new_cache, new_cnn
     return _ln(sd, "encoder.after_norm", x, 1e-5), new_cache
 
 
 def encoder_forward_chunk_by_chunk(sd: SD, cfg: dict, xs: torch.Tensor, decoding_chunk_size: int,
-                                   num_decoding_left_chunks: int, cat_embs: torch.Tensor):
-    """BaseEncoder.forward_chunk_by_chunk (encoder.py:343-402).  xs (1, T, 80) -> (1, T', d), final cache length."""
+                                   num_decoding_left_chunks: int, cat_embs: torch.Tensor, return_cnn_cache: bool = False):
+    """BaseEncoder.forward_chunk_by_chunk (encoder.py:343-402).  xs (1, T, 80) -> (1, T', d), final cache length
+    (and, on request, the final cnn cache as the reference stacks it: (layers, 1, d, lorder), encoder.py:332,340)."""
     assert decoding_chunk_size > 0
     subsampling, context = 4, 7
     stride = subsampling * decoding_chunk_size
     window = (decoding_chunk_size - 1) * subsampling + context
     required = decoding_chunk_size * num_decoding_left_chunks
-    cache, outs, offset = None, [], 0
+    cache, cnn, outs, offset = None, None, [], 0
     for cur in range(0, xs.shape[1] - context + 1, stride):
-        y, cache = encoder_forward_chunk(sd, cfg, xs[:, cur:min(cur + window, xs.shape[1])], offset, required, cache, cat_embs)
+        r = encoder_forward_chunk(sd, cfg, xs[:, cur:min(cur + window, xs.shape[1])], offset, required, cache, cat_embs, cnn)
+        y, cache = r[0], r[1]
+        cnn = r[2] if len(r) > 2 else None
         outs.append(y)
         offset += y.shape[1]
-    return torch.cat(outs, 1), (0 if cache is None else cache[0][0].shape[2])
+    n_cache = 0 if cache is None else cache[0][0].shape[2]
+    if return_cnn_cache:
+        return torch.cat(outs, 1), n_cache, (None if cnn is None else torch.stack(cnn, 0))
+    return torch.cat(outs, 1), n_cache
 
 
 def ctc_logprobs(sd: SD, enc: torch.Tensor, blank_penalty: float = 0.0, blank_id: int = 0):

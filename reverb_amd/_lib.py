@@ -25,7 +25,7 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "input_dim", "vocab", "d_model", "heads", "ffn_dim", "num_blocks", "cnn_kernel",
         "cnn_norm", "num_langs", "dec_heads", "dec_ffn_dim", "dec_blocks", "dec_r_blocks", "blank_id",
-        "sos_id", "eos_id", "max_chunks", "chunk_frames")]
+        "sos_id", "eos_id", "max_chunks", "chunk_frames", "cnn_causal")]
 
 
 _f32p = C.POINTER(C.c_float)
@@ -87,7 +87,7 @@ SIGNATURES = {
                                    C.c_int, C.c_int]),
     "rvb_test_conv1": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_glu_dwconv": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p, C.c_int, C.c_int, C.c_int,
-                                      C.c_int]),
+                                      C.c_int, C.c_int, _f32p, C.c_int]),
     "rvb_test_attention": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_int, C.c_int]),
     "rvb_test_attention_trie": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p,

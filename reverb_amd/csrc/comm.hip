@@ -35,14 +35,18 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_once;
+std::string g_load_error;      // written once inside call_once (dlerror() reports a failure only once, to its first caller)
 
 int load_rccl() {
   std::call_once(g_once, [] {
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (g_rccl.lib) break;
+      const char* m = dlerror();
+      g_load_error = m ? m : "dlopen failed";
     }
     if (!g_rccl.lib) return;
+    g_load_error = "symbols missing";
     g_rccl.get_id = (GetUniqueIdFn)dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.init_rank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.all_gather = (AllGatherFn)dlsym(g_rccl.lib, "ncclAllGather");
@@ -50,7 +54,7 @@ int load_rccl() {
     g_rccl.err = (GetErrorStringFn)dlsym(g_rccl.lib, "ncclGetErrorString");
   });
   if (!g_rccl.lib || !g_rccl.get_id || !g_rccl.init_rank || !g_rccl.all_gather || !g_rccl.destroy) {
-    rvb::set_error("RCCL (librccl.so) could not be loaded: " + std::string(dlerror() ? dlerror() : "symbols missing"));
+    rvb::set_error("RCCL (librccl.so) could not be loaded: " + g_load_error);
     return rvb::E_UNSUPPORTED;
   }
   return rvb::OK;

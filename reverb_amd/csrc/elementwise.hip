@@ -283,8 +283,9 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
   const int ch = c0 + 2 * c;
   const bool cok = ch < a.d;            // d is even: both channels of the pair are in range together
-  const int K = a.K, pad = (K - 1) / 2;
+  const int K = a.K, pad = a.causal ? K - 1 : (K - 1) / 2;
   const int len = a.lens[b];
+  const int lorder = K - 1;
   const T* G = (const T*)a.G;
   constexpr int VE = 16 / (int)sizeof(T);          // channels per 16-byte vector
   constexpr int NG = DW_CT / VE;                   // vector groups per row
@@ -298,9 +299,11 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
     float g[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) g[e] = 0.f;
-    if (cg < a.d && t >= 0 && t < a.T && r < DW_TT + K - 1) {
-      if (t < len) {
-        const T* gr = G + ((size_t)b * a.T + t) * 2 * a.d;
+    // left context of a causal module: cached frames, or the zero padding seen through pointwise_conv1 + GLU
+    const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
+    if (cg < a.d && (t >= 0 || a.causal) && t < a.T && r < DW_TT + K - 1) {
+      if ((t >= 0 && t < len) || from_hist) {
+        const T* gr = from_hist ? (const T*)a.hist + (size_t)(lorder + t) * 2 * a.d : G + ((size_t)b * a.T + t) * 2 * a.d;
         T av[VE], bvv[VE];
         if (vec_ok) {
           *(uint4*)av = *(const uint4*)(gr + cg);
@@ -368,7 +371,12 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
 
 int glu_dwconv(hipStream_t s, int dtype, const GluDwArgs& a) {
   if (a.B <= 0 || a.T <= 0) return OK;
-  if (a.K > DW_KMAX || (a.K % 2) == 0 || (a.d % 2)) { set_error("glu_dwconv: kernel must be odd and <= 31, d even"); return E_ARG; }
+  if (a.K > DW_KMAX || a.K < 1 || (!a.causal && (a.K % 2) == 0) || (a.d % 2)) {
+    set_error("glu_dwconv: kernel must be <= 31 (and odd unless causal), d even"); return E_ARG;
+  }
+  if (a.hist_rows > 0 && (!a.causal || a.B != 1 || a.hist_rows > a.K - 1 || !a.hist)) {
+    set_error("glu_dwconv: a left-context history belongs to one causal stream"); return E_ARG;
+  }
   dim3 grid(cdiv(a.T, DW_TT), cdiv(a.d, DW_CT), a.B);
   if (dtype == DT_BF16) hipLaunchKernelGGL(glu_dw_kernel<bf16_t>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(256), 0, s, a);

@@ -128,6 +128,8 @@ struct rvb_engine {
     int offset = 0;                 // encoder frames produced so far (`offset` of forward_chunk)
     int cache_len = 0;              // frames in the attention cache (cache_t1)
     std::vector<rvb::DevBuf> kv, kv2;   // per layer T [pe_rows][2d]: key | value rows of the cached frames (+ spare for trimming)
+    int cnn_rows = 0;               // real frames in the cnn cache (cache_t2 grows to lorder = K-1; older = zero padding)
+    std::vector<rvb::DevBuf> cnn, cnn2; // causal conv module, per layer T [K-1][2d]: pointwise-conv1 outputs of the last frames
   } stream_st;
   rvb::DevBuf d_stream_i32;         // {kv_start = 0, kv_len = cache + chunk}
 

@@ -518,8 +518,30 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     GluDwArgs g;
     g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
     g.lens = e->cur_lens; g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
-    Scope sc(e, "glu_dwconv");
-    RVB_TRY(glu_dwconv(e->stream, e->dtype, g));
+    g.causal = e->cfg.cnn_causal ? 1 : 0;
+    const int lorder = g.K - 1;
+    const bool cached = li >= 0 && g.causal && lorder > 0;
+    if (cached) { g.hist = e->stream_st.cnn[li].p; g.hist_rows = e->stream_st.cnn_rows; }
+    {
+      Scope sc(e, "glu_dwconv");
+      RVB_TRY(glu_dwconv(e->stream, e->dtype, g));
+    }
+    if (cached) {
+      // new_cache = cat(cache, x)[:, :, -lorder:] (convolution.py:116-121), kept as pointwise-conv1 OUTPUT rows: that
+      // convolution is per frame, so what the reference recomputes from its cached inputs are these very rows
+      auto& st = e->stream_st;
+      const size_t es = dt_size(e->dtype), rb = (size_t)2 * d * es;
+      if (M >= lorder) {
+        RVB_HIP_CHECK(hipMemcpyAsync(st.cnn[li].p, (const char*)e->h.p + (size_t)(M - lorder) * rb, (size_t)lorder * rb,
+                                     hipMemcpyDeviceToDevice, e->stream));
+      } else {
+        RVB_HIP_CHECK(hipMemcpyAsync(st.cnn2[li].p, (const char*)st.cnn[li].p + (size_t)M * rb, (size_t)(lorder - M) * rb,
+                                     hipMemcpyDeviceToDevice, e->stream));
+        RVB_HIP_CHECK(hipMemcpyAsync((char*)st.cnn2[li].p + (size_t)(lorder - M) * rb, e->h.p, (size_t)M * rb,
+                                     hipMemcpyDeviceToDevice, e->stream));
+        std::swap(st.cnn[li], st.cnn2[li]);
+      }
+    }
   }
   const int cmode = e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE;
   if (f8) {
@@ -568,6 +590,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_encode: beam must be in [1,16]"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   RVB_TRY(wait_slices(e, -1));      // a previous batch may still be in flight
+  e->stream_st.active = false;      // the offline path reuses the stream's output buffer: an open stream ends here
   const int d = c.d_model, F0 = c.input_dim, V = c.vocab;
   const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   const int M = B * T2;
@@ -718,7 +741,8 @@ static int wait_slices(rvb_engine* e, int i) {
 // BaseEncoder.forward_chunk / forward_chunk_by_chunk (encoder.py:231-402) for one stream: the attention cache (keys
 // and values of the frames already seen, per layer) lives in the engine; the reference hands it back and forth as
 // a tensor.  Non-causal convolution modules carry no cnn cache (lorder = 0, convolution.py:118-123): the depthwise
-// convolution sees zeros beyond the chunk, exactly as the reference's Conv1d padding does.
+// convolution sees zeros beyond the chunk, exactly as the reference's Conv1d padding does.  Causal ones (cnn_causal)
+// keep, per block, the pointwise-conv1 outputs of the last K-1 frames (encoder_layer() below).
 static int stream_begin_impl(rvb_engine* e) {
   if (!e->finalized) { set_error("rvb_stream_begin before rvb_finalize"); return E_STATE; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
@@ -732,7 +756,14 @@ static int stream_begin_impl(rvb_engine* e) {
     RVB_TRY(st.kv2[l].ensure((size_t)e->pe_rows * 2 * d * es));
   }
   RVB_TRY(e->enc_out.ensure((size_t)e->pe_rows * d * es));
-  st.active = true; st.offset = 0; st.cache_len = 0;
+  if (e->cfg.cnn_causal && e->cfg.cnn_kernel > 1) {
+    st.cnn.resize(e->enc.size()); st.cnn2.resize(e->enc.size());
+    for (size_t l = 0; l < e->enc.size(); ++l) {
+      RVB_TRY(st.cnn[l].ensure((size_t)(e->cfg.cnn_kernel - 1) * 2 * d * es));
+      RVB_TRY(st.cnn2[l].ensure((size_t)(e->cfg.cnn_kernel - 1) * 2 * d * es));
+    }
+  }
+  st.active = true; st.offset = 0; st.cache_len = 0; st.cnn_rows = 0;
   e->B = 0; e->nbest.clear(); e->rescored.clear(); e->slices.clear();
   return OK;
 }
@@ -813,6 +844,7 @@ static int stream_chunk_impl(rvb_engine* e, const float* feats, int T0, int requ
     }
   }
   st.cache_len = keep;
+  st.cnn_rows = std::min(st.cnn_rows + M, std::max(c.cnn_kernel - 1, 0));
   st.offset += M;
   if (n_out) *n_out = M;
   return OK;
@@ -1366,9 +1398,10 @@ int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
   if (cfg->dtype != RVB_F32 && cfg->dtype != RVB_BF16 && cfg->dtype != RVB_FP8) { set_error("rvb_create: bad dtype"); return E_ARG; }
   if (cfg->d_model <= 0 || cfg->heads <= 0 || cfg->d_model % cfg->heads || cfg->d_model % 8 || cfg->ffn_dim % 8 ||
       cfg->dec_ffn_dim % 8 || cfg->input_dim != 80 || cfg->vocab < 2 || cfg->num_blocks < 1 ||
-      (cfg->cnn_kernel % 2) == 0 || cfg->chunk_frames < 7 || cfg->max_chunks < 1 ||
+      cfg->cnn_kernel < 1 || cfg->cnn_kernel > 31 || (!cfg->cnn_causal && (cfg->cnn_kernel % 2) == 0) ||
+      cfg->chunk_frames < 7 || cfg->max_chunks < 1 ||
       (cfg->dec_blocks > 0 && (cfg->dec_heads <= 0 || cfg->d_model % cfg->dec_heads))) {
-    set_error("rvb_create: unsupported model dimensions (need d, ffn dims % 8 == 0, d % heads == 0, input_dim 80, odd cnn kernel)");
+    set_error("rvb_create: unsupported model dimensions (need d, ffn dims % 8 == 0, d % heads == 0, input_dim 80, cnn kernel <= 31 and odd unless causal)");
     return E_ARG;
   }
   int ndev = 0;
@@ -1403,7 +1436,7 @@ void rvb_destroy(rvb_engine* e) {
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
   e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
-  for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2}) for (auto& b : *v) b.release();
+  for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2, &e->stream_st.cnn, &e->stream_st.cnn2}) for (auto& b : *v) b.release();
   for (auto* v : {&e->kcache, &e->vcache, &e->kcache2, &e->vcache2, &e->memkv}) for (auto& b : *v) b.release();
   auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); l.w8.release(); l.wscale.release(); };
   auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };

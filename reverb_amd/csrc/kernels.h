@@ -83,8 +83,13 @@ struct NormArgs {
 };
 int rownorm(hipStream_t s, int dtype, const NormArgs& a);
 
-// GLU over channel halves of G [M,2d] (T), then depthwise Conv1d (kernel K, same padding) along time
-// inside each chunk of T rows; rows t >= lens[b] see glu(pw1 bias) (convolution.py:107-118).
+// GLU over channel halves of G [M,2d] (T), then depthwise Conv1d (kernel K) along time inside each chunk of T
+// rows; rows t >= lens[b] see glu(pw1 bias) (convolution.py:107-118).  causal = 0: "same" padding, zeros outside
+// [0,T) (Conv1d padding, convolution.py:58-62).  causal = 1 (lorder = K-1, convolution.py:55-57,113-121): output t
+// reads frames t-K+1 .. t; frames before the chunk are the module's left context: the last `hist_rows` of them
+// come from `hist` (the pointwise-conv1 outputs of the frames that preceded this chunk in the stream = the
+// reference's cnn_cache pushed through pointwise_conv1, which is per frame), older ones are the reference's zero
+// padding, which pointwise_conv1 + GLU turn into glu(pw1 bias).
 struct GluDwArgs {
   const void* G;          // T [B*T, 2d]
   const float* pw1_bias;  // [2d]
@@ -93,6 +98,9 @@ struct GluDwArgs {
   const int* lens;        // [B] valid rows per chunk
   float* out;             // fp32 [B*T, d]
   int B, T, d, K;
+  int causal = 0;
+  const void* hist = nullptr;   // T [K-1][2d], row K-2 = the frame just before this chunk (causal, B = 1)
+  int hist_rows = 0;            // real frames in hist (its last hist_rows rows)
 };
 int glu_dwconv(hipStream_t s, int dtype, const GluDwArgs& a);
 

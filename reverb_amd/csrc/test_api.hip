@@ -115,9 +115,10 @@ int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float
 }
 
 int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
-                        const int32_t* lens, float* out, int B, int T, int d, int K) {
+                        const int32_t* lens, float* out, int B, int T, int d, int K, int causal, const float* hist,
+                        int hist_rows) {
   T_TRY(need_gpu());
-  Dev dG, dpb, dw, db, dl, dout;
+  Dev dG, dpb, dw, db, dl, dout, dh;
   T_TRY(up_T(dG, dtype, G, (size_t)B * T * 2 * d));
   T_TRY(up_raw(dpb, pw1_bias, (size_t)2 * d * 4));
   T_TRY(up_raw(dw, dw_w, (size_t)d * K * 4));
@@ -127,6 +128,11 @@ int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const 
   GluDwArgs a;
   a.G = dG.p; a.pw1_bias = (const float*)dpb.p; a.dw_w = (const float*)dw.p; a.dw_b = (const float*)db.p;
   a.lens = (const int*)dl.p; a.out = (float*)dout.p; a.B = B; a.T = T; a.d = d; a.K = K;
+  a.causal = causal;
+  if (hist && hist_rows > 0) {      // [K-1][2d], the last hist_rows rows are real frames
+    T_TRY(up_T(dh, dtype, hist, (size_t)(K - 1) * 2 * d));
+    a.hist = dh.p; a.hist_rows = hist_rows;
+  }
   T_TRY(glu_dwconv(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());
   RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)B * T * d * 4, hipMemcpyDeviceToHost));

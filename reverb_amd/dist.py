@@ -180,21 +180,42 @@ class RvbComm:
         return cls(engine, dist.get_world_size(), dist.get_rank(), box[0])
 
     @classmethod
-    def from_file(cls, engine, world: int, rank: int, path: str, timeout: float = 120.0):
+    def from_file(cls, engine, world: int, rank: int, path: str, timeout: float = 120.0, token: str = None):
+        """Rendezvous through a shared file.  The file carries a run token (default: MASTER_PORT / TORCHELASTIC_RUN_ID /
+        RVB_RUN_ID, else "0") in front of the 128-byte id, so that a file left by an earlier run is never mistaken for
+        this run's: rank 0 removes whatever is there before it writes, the others re-read until token and length match."""
         import os
         import time
+        if token is None:
+            token = os.environ.get("RVB_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
+        head = ("rvbid:" + token + ":").encode()
         if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
             tmp = path + ".tmp"
             with open(tmp, "wb") as f:
-                f.write(cls.unique_id())
+                f.write(head + cls.unique_id())
             os.replace(tmp, path)
         t0 = time.time()
-        while not os.path.exists(path):
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    blob = f.read()
+            except FileNotFoundError:
+                blob = b""
+            if blob.startswith(head) and len(blob) == len(head) + 128:
+                comm = cls(engine, world, rank, blob[len(head):])     # collective: returns once every rank has the id
+                if rank == 0:
+                    try:
+                        os.unlink(path)                               # nothing stale is left for the next run
+                    except OSError:
+                        pass
+                return comm
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"no RCCL id at {path}")
+                raise TimeoutError(f"no RCCL id for run {token!r} at {path}")
             time.sleep(0.01)
-        with open(path, "rb") as f:
-            return cls(engine, world, rank, f.read())
 
     def all_gather(self, send: np.ndarray) -> np.ndarray:
         """send: C-contiguous array, equal size on every rank -> [world, ...] in rank order."""

@@ -31,8 +31,6 @@ def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_fra
     for k, v in want.items():
         if ec.get(k, defaults[k]) != v:
             raise RvbError(f"encoder_conf.{k}={ec.get(k)!r} is not supported (need {v!r})")
-    if ec.get("causal", False):
-        raise RvbError("causal convolution (streaming models) is not supported yet")
     ds = configs.get("dataset_conf", {})
     lsl = bool(ds.get("pass_cat_emb", False))
     if ds.get("add_cat_emb", False):
@@ -50,6 +48,7 @@ def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_fra
     cfg.num_blocks = int(ec["num_blocks"])
     cfg.cnn_kernel = int(ec.get("cnn_module_kernel", 15))
     cfg.cnn_norm = 0 if ec.get("cnn_module_norm", "batch_norm") == "layer_norm" else 1
+    cfg.cnn_causal = 1 if ec.get("causal", False) else 0          # convolution.py:55-57: left padding cnn_kernel-1 only
     cfg.num_langs = nlang
     cfg.dec_heads = int(dc.get("attention_heads", 4))
     cfg.dec_ffn_dim = int(dc.get("linear_units", 2048))
@@ -72,6 +71,19 @@ def _as_numpy_f32(v) -> Optional[np.ndarray]:
     if v.dtype.kind != "f":
         return None
     return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class _PinnedBlock:
+    """Owner of one rvb_host_alloc block: frees it when the last numpy view over it is garbage-collected."""
+
+    def __init__(self, lib, ptr):
+        self._free, self._ptr = lib.rvb_host_free, ptr
+
+    def __del__(self):
+        try:
+            self._free(self._ptr)
+        except Exception:
+            pass
 
 
 class Engine:
@@ -97,13 +109,9 @@ class Engine:
         self.set_cat_embs(cat_embs)
         self.batch = 0
         self.enc_frames = 0
-        self._pinned = []
 
     # -------------------------------------------------------------------------------- lifecycle
     def close(self):
-        for p in getattr(self, "_pinned", []):
-            self.lib.rvb_host_free(p)
-        self._pinned = []
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.rvb_destroy(self.handle)
             self.handle = C.c_void_p()
@@ -128,11 +136,14 @@ class Engine:
     # -------------------------------------------------------------------------------- front end
     def pinned_pcm(self, n_samples: int) -> np.ndarray:
         """int16 array of page-locked host memory (rvb_host_alloc) for the audio reader to fill: upload_pcm from it runs
-        at the PCIe rate.  The memory belongs to the engine and is released by close()."""
+        at the PCIe rate.  The memory lives exactly as long as the array (or any view of it): it is owned by the
+        array's base object and released when the last view dies -- not by close(), so an array that outlives its
+        engine (ReverbASR re-creates the engine for a larger chunk_size) stays valid."""
         p = C.c_void_p()
         check(self.lib.rvb_host_alloc(C.byref(p), int(n_samples) * 2), "rvb_host_alloc")
-        self._pinned.append(p)
-        return np.ctypeslib.as_array((C.c_int16 * max(int(n_samples), 1)).from_address(p.value))[:int(n_samples)]
+        buf = (C.c_int16 * max(int(n_samples), 1)).from_address(p.value)
+        buf._rvb_owner = _PinnedBlock(self.lib, p)        # numpy keeps `buf` alive as the base of every view
+        return np.ctypeslib.as_array(buf)[:int(n_samples)]
 
     def upload_pcm(self, pcm: np.ndarray, sample_rate: int = 16000):
         """int16 mono PCM -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134)."""

@@ -51,10 +51,24 @@ CTC_BLANK_BIAS = {
 }
 
 
-def make_config(name: str = "r640", cnn_module_norm: str = "layer_norm") -> dict:
+def make_config(name: str = "r640", cnn_module_norm: str = "layer_norm", causal: bool = False,
+                use_dynamic_chunk: bool = False, cnn_module_kernel: int = None, pass_cat_emb: bool = True) -> dict:
     """Reverb-ASR style config.yaml contents (keys consumed by
-    `asr/wenet/utils/init_model.py:102-183,252-265` and `cli/reverb.py:62-98`)."""
-    m = MODEL_DIMS[name]
+    `asr/wenet/utils/init_model.py:102-183,252-265` and `cli/reverb.py:62-98`).  `causal` + `use_dynamic_chunk` give
+    the stock WeNet U2++ streaming recipe (causal convolution module, dynamic-chunk attention)."""
+    m = dict(MODEL_DIMS[name])
+    if cnn_module_kernel is not None:
+        m["K"] = int(cnn_module_kernel)
+    cfg = _make_config(m, cnn_module_norm)
+    cfg["encoder_conf"]["causal"] = bool(causal)
+    if use_dynamic_chunk:
+        cfg["encoder_conf"]["use_dynamic_chunk"] = True
+    if not pass_cat_emb:
+        cfg["dataset_conf"]["pass_cat_emb"] = False
+    return cfg
+
+
+def _make_config(m: dict, cnn_module_norm: str) -> dict:
     return {
         "model": "asr_model",
         "encoder": "conformer",

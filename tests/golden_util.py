@@ -91,3 +91,28 @@ class LongCase(Case):
         x = np.zeros((1, self.chunk, 80), np.float32)
         x[0, :n] = feats
         return x, np.array([n], np.int32)
+
+
+class CausalCase:
+    """Golden of a causal-convolution model (oracle/gen_golden_causal.py): config, weights and features rebuilt from the json."""
+
+    def __init__(self, name):
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.js = json.load(f)
+        c = self.c = self.js["case"]
+        self.cfg = synth.make_config(c["dims"], c["norm"], causal=c["causal"], use_dynamic_chunk=c["use_dynamic_chunk"],
+                                     cnn_module_kernel=c["cnn_module_kernel"], pass_cat_emb=c.get("pass_cat_emb", True))
+        self.sd = synth.make_state_dict(self.cfg, c["seed"], self.js["gamma"], self.js["beta"])
+        self.feats = fbank_ref.fbank(synth.synth_audio(c["seconds"], seed=1234 + c["seed"]))
+        npz = os.path.join(GOLDEN, name + ".npz")
+        self.arrays = np.load(npz) if os.path.exists(npz) else None
+        self.beam, self.ctc_weight, self.reverse_weight, self.cat, self.chunk = (c["beam"], c["ctc_weight"], c["reverse_weight"],
+                                                                                c["cat"], c["chunk"])
+        nch = -(-self.feats.shape[0] // self.chunk)
+        self.x = np.zeros((nch, self.chunk, 80), np.float32)
+        self.lens = np.zeros(nch, np.int32)
+        for i in range(nch):
+            part = self.feats[i * self.chunk:(i + 1) * self.chunk]
+            self.x[i, :len(part)] = part
+            self.lens[i] = len(part)
+        assert self.lens.tolist() == self.js["lens"]

@@ -171,7 +171,7 @@ def test_glu_dwconv(lib, dtype, K, d, T):
     G = rnd(dtype, rng.standard_normal((B, T, 2 * d)))
     pb = f32(rng.standard_normal(2 * d)); w = f32(rng.standard_normal((d, K)) / math.sqrt(K)); b = f32(rng.standard_normal(d))
     out = np.empty((B, T, d), np.float32)
-    _lib.check(lib.rvb_test_glu_dwconv(dtype, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(out), B, T, d, K))
+    _lib.check(lib.rvb_test_glu_dwconv(dtype, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(out), B, T, d, K, 0, None, 0))
     # reference semantics (convolution.py:107-131): padded frames were zeroed BEFORE pointwise_conv1,
     # so what the GLU sees there is the bias alone
     Gd = torch.from_numpy(G).double().clone()
@@ -180,6 +180,33 @@ def test_glu_dwconv(lib, dtype, K, d, T):
     glu = torch.nn.functional.glu(Gd.transpose(1, 2), dim=1)
     ref = torch.nn.functional.conv1d(glu, torch.from_numpy(w).double().unsqueeze(1), torch.from_numpy(b).double(),
                                      padding=(K - 1) // 2, groups=d).transpose(1, 2).numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("K,d,T,hist_rows", [(15, 32, 70, 0), (8, 200, 130, 7), (31, 64, 5, 11), (15, 32, 3, 14), (2, 16, 9, 1)])
+def test_glu_dwconv_causal(lib, dtype, K, d, T, hist_rows):
+    """Causal convolution module (convolution.py:55-57,113-125): K-1 frames of left context -- cached frames (the last
+    hist_rows of the K-1) or the zero padding seen through pointwise_conv1 + GLU; padded batch rows see the bias too."""
+    rng = np.random.default_rng(K * 100 + T)
+    B = 1 if hist_rows else 3
+    lens = i32([T] if hist_rows else [T, max(T - 9, 1), min(5, T)])
+    G = rnd(dtype, rng.standard_normal((B, T, 2 * d)))
+    hist = rnd(dtype, rng.standard_normal((K - 1, 2 * d)))
+    pb = f32(rng.standard_normal(2 * d)); w = f32(rng.standard_normal((d, K)) / math.sqrt(K)); b = f32(rng.standard_normal(d))
+    out = np.empty((B, T, d), np.float32)
+    _lib.check(lib.rvb_test_glu_dwconv(dtype, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(out), B, T, d, K, 1,
+                                       fptr(hist) if hist_rows else None, hist_rows))
+    Gd = torch.from_numpy(G).double().clone()
+    for bi in range(B):
+        Gd[bi, lens[bi]:, :] = torch.from_numpy(pb).double()
+    left = torch.from_numpy(pb).double().repeat(B, K - 1, 1)          # pointwise_conv1 of a zero frame = its bias
+    if hist_rows:
+        left[0, K - 1 - hist_rows:] = torch.from_numpy(hist).double()[K - 1 - hist_rows:]
+    glu = torch.nn.functional.glu(torch.cat([left, Gd], 1).transpose(1, 2), dim=1)
+    ref = torch.nn.functional.conv1d(glu, torch.from_numpy(w).double().unsqueeze(1), torch.from_numpy(b).double(),
+                                     groups=d).transpose(1, 2).numpy()
+    assert ref.shape == out.shape
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-4)
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, MODES, Case, GOLDEN, LongCase
+from golden_util import CASES, MODES, Case, CausalCase, GOLDEN, LongCase
 from oracle import fbank_ref, model_ref as M, search_ref as S
 
 
@@ -158,3 +158,67 @@ def test_streaming_encoder_oracle_matches_reference_golden():
             np.testing.assert_allclose(ys[0, ::4].numpy(), arrays[f"ys_{cs}_{left}".replace("-", "m")], rtol=0, atol=2e-5)
             got = S.ctc_greedy_search(M.ctc_logprobs(sd, ys), torch.tensor([ys.shape[1]]), 0)
             assert list(got[0].tokens) == run["greedy"], (cs, left)
+
+
+def _check_rows(res, rows, tag):
+    for b, want in enumerate(rows):
+        assert list(res["ctc_greedy_search"][b].tokens) == want["greedy"], tag
+        p = res["ctc_prefix_beam_search"][b]
+        assert list(p.tokens) == want["prefix"] and list(p.times) == want["prefix_times"], tag
+        assert [list(h) for h in p.nbest] == want["nbest"], tag
+        np.testing.assert_allclose(p.nbest_scores, want["nbest_scores"], rtol=0, atol=1e-4)
+        r = res["attention_rescoring"][b]
+        assert list(r.tokens) == want["rescoring"] and list(r.times) == want["rescoring_times"], tag
+        assert abs(float(r.score) - want["rescoring_score"]) < 1e-3, tag
+
+
+def test_causal_model_oracle_matches_reference_golden():
+    """encoder_conf.causal (convolution.py:55-57,113-121): the oracle's left-padded convolution module and its cnn cache
+    against the unmodified reference (oracle/gen_golden_causal.py) -- offline decode of a padded batch with chunk masks,
+    forward_chunk_by_chunk incl. chunks shorter than the cache, and the final cnn cache itself."""
+    case = CausalCase("tiny_causal")
+    sd = M.to_torch_sd(case.sd)
+    cat = torch.tensor(case.cat)
+    x, lens = torch.from_numpy(case.x), torch.from_numpy(case.lens)
+    for run in case.js["offline"]:
+        cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+        taps = {}
+        res = S.decode(sd, case.cfg, MODES, x, lens, case.beam, ctc_weight=case.ctc_weight, reverse_weight=case.reverse_weight,
+                       cat_embs=cat, taps=taps, decoding_chunk_size=cs, num_decoding_left_chunks=left)
+        assert taps["encoder_lens"].tolist() == run["encoder_lens"]
+        np.testing.assert_array_equal(taps["encoder_out"].numpy()[:, ::4], case.arrays[f"enc_{cs}_{left}".replace("-", "m")])
+        _check_rows(res, run["chunks"], (cs, left))
+    feats = torch.from_numpy(case.feats).unsqueeze(0)
+    with torch.no_grad():
+        for run in case.js["streaming"]:
+            cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+            key = f"{cs}_{left}".replace("-", "m")
+            ys, cache_frames, cnn = M.encoder_forward_chunk_by_chunk(sd, case.cfg, feats, cs, left, cat, return_cnn_cache=True)
+            assert ys.shape[1] == run["out_frames"] and cache_frames == run["final_cache_frames"], (cs, left)
+            np.testing.assert_allclose(ys[0, ::4].numpy(), case.arrays["ys_" + key], rtol=0, atol=2e-5)
+            assert list(cnn.shape) == run["cnn_cache_shape"]
+            np.testing.assert_allclose(cnn.numpy(), case.arrays["cnn_" + key], rtol=0, atol=2e-5)
+            got = S.ctc_greedy_search(M.ctc_logprobs(sd, ys), torch.tensor([ys.shape[1]]), 0)
+            assert list(got[0].tokens) == run["greedy"], (cs, left)
+
+
+def test_causal_plain_model_oracle_matches_reference_golden():
+    """Even depthwise kernel (K = 8, legal only when causal) + BatchNorm, no language-specific layers: offline decode and
+    the simulate_streaming seam (asr_model.py:301-306: forward_chunk_by_chunk of the whole padded input, lengths ignored)."""
+    case = CausalCase("tiny_causal_plain")
+    sd = M.to_torch_sd(case.sd)
+    x, lens = torch.from_numpy(case.x), torch.from_numpy(case.lens)
+    res = S.decode(sd, case.cfg, MODES, x, lens, case.beam, ctc_weight=case.ctc_weight, reverse_weight=case.reverse_weight)
+    _check_rows(res, case.js["offline"][0]["chunks"], "offline")
+    with torch.no_grad():
+        for run in case.js["streaming"]:
+            cs, left = run["decoding_chunk_size"], run["num_decoding_left_chunks"]
+            for b, want in enumerate(run["chunks"]):
+                ys, _ = M.encoder_forward_chunk_by_chunk(sd, case.cfg, x[b:b + 1], cs, left, None)
+                n = torch.tensor([ys.shape[1]])
+                probs = M.ctc_logprobs(sd, ys)
+                assert list(S.ctc_greedy_search(probs, n, 0)[0].tokens) == want["greedy"], (cs, left, b)
+                pref = S.ctc_prefix_beam_search(probs, n, case.beam, 0)
+                assert [list(h) for h in pref[0].nbest] == want["nbest"], (cs, left, b)
+                r = S.attention_rescoring(sd, case.cfg, pref, ys, n, case.ctc_weight, case.reverse_weight, None)[0]
+                assert list(r.tokens) == want["rescoring"] and abs(float(r.score) - want["rescoring_score"]) < 1e-3

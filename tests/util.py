@@ -19,3 +19,22 @@ def f32(a):
 
 def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def edit_distance(a, b):
+    """Levenshtein distance between two token sequences."""
+    a, b = list(a), list(b)
+    dp = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        prev, dp[0] = dp[0], i
+        for j in range(1, len(b) + 1):
+            cur = dp[j]
+            dp[j] = min(dp[j] + 1, dp[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+            prev = cur
+    return dp[-1]
+
+
+def token_error_rate(got, want):
+    """sum of edit distances / reference tokens over parallel lists of token lists."""
+    e = sum(edit_distance(g, w) for g, w in zip(got, want))
+    return e / max(sum(len(w) for w in want), 1)
