@@ -611,6 +611,420 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   }
 }
 
+// ================================================================================================
+// bf16, phase-interleaved main loop (round 3).  Same tile and fragment geometry as gemm2_kernel; what changes is
+// how the K loop is fed (derivation and side-by-side measurements: scripts/micro/gemm_lab.hip `phase`,
+// profiles/r03_gemm_lab_phase.txt -- +7..22 % over the register-pipelined loop above on the engine's shapes):
+//
+//   * a K step of 64 elements is four PHASES, one per 64x32 quadrant of the wave's 128x64 tile (16 MFMAs each), and
+//     its operands are four 16-KiB HALF-TILES -- A-h0 / A-h1 = the first / second 64 rows of each wave row's 128,
+//     B-h0 / B-h1 = the first / second 32 columns of each wave column's 64 -- one per phase, in consumption order:
+//
+//         phase   MFMAs      fragment reads issued (into the register set that just died)
+//           0     A0 x B0    B0 <- B-h0(t)     4 ds_read_b128
+//           1     A0 x B1    B1 <- B-h1(t)     4
+//           2     A1 x B1    A1 <- A-h1(t)     8
+//           3     A1 x B0    A0 <- A-h0(t+1)   8        (B0 stays in registers)
+//
+//   * the half-tiles stream through a ring of P_NSLOT LDS slots: phase p reads half-tile p+1, waits -- counted
+//     `vmcnt`, never 0 in steady state -- until half-tile p+2 has landed, and requests half-tile p+P_NSLOT-1 into the
+//     slot whose last reader finished two phases earlier: 3 half-tiles stay in flight ACROSS the barriers instead of
+//     one 64-KiB stage drained to zero at every K step;
+//   * a phase is {DMA issue, reads, vmcnt | s_barrier | lgkmcnt(0), 16 MFMAs | s_barrier}, and the second wave row
+//     runs ONE BARRIER BEHIND the first: on every SIMD one wave multiplies while the other reads and issues.  Without
+//     that stagger the same loop is slower than the old one (846 vs 919 TFLOP/s in the lab).
+//   RAW: a wave waits for its own pieces of half-tile h before the first barrier of phase h-2; every reader is past
+//   that barrier (or the one after it, for the staggered row) when it reads in phase h-1.  WAR: a slot is refilled two
+//   phases after the phase whose lgkmcnt(0) retired its last read.
+// The ring takes 96 KiB; the 34 KiB above it are the epilogue's transposition slabs (and the residual prologue's), so
+// neither ever shares a buffer with the operand stream.
+static constexpr int P_NSLOT = 6, P_HT = 128 * ROW2, P_DEPTH = P_NSLOT - 3;
+static constexpr int P_SROW = 64 * 4 + 16;                        // padded fp32 slab row (bytes)
+static constexpr int GEMM2P_LDS = P_NSLOT * P_HT + 8 * 16 * P_SROW;
+
+__device__ inline void dma2(unsigned off0, unsigned off1, const void* sbase, unsigned lds0) {
+  // two 1-KiB LDS-DMA pieces (8 rows x 128 B each, consecutive in LDS) from scalar base + per-lane 32-bit offsets.
+  // Inline asm on purpose (see issue() above); M0 belongs to the compiler: saved and restored.
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off0), "v"(off1), "s"(sbase), "s"(lds0)
+      : "memory", "scc");
+}
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// a wave-uniform pointer, provably so for the "s" operand of dma2 (uniform values that went through a VALU division live
+// in VGPRs otherwise); folds away when the value already sits in SGPRs
+__device__ inline const char* uniform_ptr(const char* q) {
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <typename OutT, bool CONV>
+__global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int BKE = ROW2 / 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  if (p.dbg && tid == 0) {
+    p.dbg[blockIdx.x * 6 + 0] = wall_clock64();
+    p.dbg[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+    p.dbg[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+  }
+  const int tiles_n = (p.N + B2N - 1) / B2N;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  if (p.group_m > 1) {
+    const int tiles_m = (p.M + B2M - 1) / B2M;
+    const int per_group = p.group_m * tiles_n;
+    const int g = bid / per_group;
+    const int first_m = g * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
+    const int in_g = bid - g * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  } else {
+    tm = bid / tiles_n; tn = bid - tm * tiles_n;
+  }
+  const int m0 = tm * B2M, n0 = tn * B2N;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA sources: every wave stages rows [16 wave, +16) of each half-tile = two 1-KiB pieces; 32-bit byte offsets
+  // from the tile's first row (rows past M / N are clamped, never stored), the K position goes into the scalar base
+  auto a_elem = [&](int m) -> size_t {                // element index of row m's first K element
+    if (CONV) {
+      const int tf = p.cT2 * p.cF2;
+      const int b = m / tf;
+      const int rem = m - b * tf;
+      const int t2 = rem / p.cF2, f2 = rem - t2 * p.cF2;
+      return (((size_t)b * p.cT1 + 2 * t2) * p.cF1 + 2 * f2) * (size_t)p.cC;
+    }
+    return (size_t)m * p.lda;
+  };
+  const size_t a_row0 = a_elem(m0);
+  const int lr = lane >> 3, lc = lane & 7;
+  unsigned offA[2][2], offW[2][2];                    // [half][piece]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 16 * wave + 8 * i + lr;             // row of the half-tile
+    const unsigned col = (unsigned)((lc ^ ((r >> 1) & 7)) * 16);      // swizzled 16-byte source column
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int m = min(m0 + (r >> 6) * 128 + hlf * 64 + (r & 63), p.M - 1);
+      const int n = min(n0 + (r >> 5) * 64 + hlf * 32 + (r & 31), p.N - 1);
+      offA[hlf][i] = (unsigned)((a_elem(m) - a_row0) * 2) + col;
+      offW[hlf][i] = (unsigned)((size_t)(n - n0) * p.ldw * 2) + col;
+    }
+  }
+  const char* a_base = uniform_ptr((const char*)((const T*)p.A + a_row0));
+  const char* w_base = uniform_ptr((const char*)((const T*)p.W + (size_t)n0 * p.ldw));
+  const int nk = p.K / BKE, nh = 4 * nk;
+  const unsigned lds_wave = lds_base + wave * 2048;
+  // byte offset of K step u in an A row, kept incrementally (no division in the loop): +128 per step; the implicit
+  // convolution walks the 3x3 taps, whose (kh, kw .. kw+2) channels are contiguous in NHWC -- only a new kernel row kh
+  // jumps, by (F1 - 3) pixels (the whole 128-byte K step lies inside one tap: cC % BKE == 0)
+  const int row_steps = CONV ? 3 * p.cC / BKE : 0x7fffffff;
+  const size_t row_jump = CONV ? (size_t)(p.cF1 - 3) * p.cC * 2 : 0;
+  auto advance = [&](size_t& off, int& cnt) __attribute__((always_inline)) {
+    off += ROW2;
+    if (++cnt == row_steps) { cnt = 0; off += row_jump; }
+  };
+  size_t ak1 = 0, ak2 = 0;          // offsets of K steps t+1 and t+2 (t = the K step being multiplied)
+  int ac1 = 0, ac2 = 0;
+  advance(ak1, ac1);
+  ak2 = ak1; ac2 = ac1;
+  advance(ak2, ac2);
+  // half-tile ty = {0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1} of K step t (whose A offset is ak) into ring slot `slot`
+  auto stage_ty = [&](auto tyc, int t, size_t ak, int slot) __attribute__((always_inline)) {
+    constexpr int ty = decltype(tyc)::value;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + slot * P_HT);
+    if constexpr (ty == 0) dma2(offA[0][0], offA[0][1], uniform_ptr(a_base + ak), dst);
+    else if constexpr (ty == 1) dma2(offW[0][0], offW[0][1], uniform_ptr(w_base + (size_t)t * ROW2), dst);
+    else if constexpr (ty == 2) dma2(offW[1][0], offW[1][1], uniform_ptr(w_base + (size_t)t * ROW2), dst);
+    else dma2(offA[1][0], offA[1][1], uniform_ptr(a_base + ak), dst);
+  };
+  auto stage = [&](int h, int slot) __attribute__((always_inline)) {       // prologue only: K steps 0 and 1
+    const int t = h >> 2, ty = h & 3;
+    const size_t ak = t == 0 ? 0 : ak1;
+    if (ty == 0) stage_ty(std::integral_constant<int, 0>(), t, ak, slot);
+    else if (ty == 1) stage_ty(std::integral_constant<int, 1>(), t, ak, slot);
+    else if (ty == 2) stage_ty(std::integral_constant<int, 2>(), t, ak, slot);
+    else stage_ty(std::integral_constant<int, 3>(), t, ak, slot);
+  };
+  static_assert(P_NSLOT - 2 < 8, "the prologue requests half-tiles of K steps 0 and 1 only");
+  // half-tile p+2 (read in the next phase) has landed: everything but the newest min(P_DEPTH, nh-3-p) half-tiles
+  auto wait_tail = [&](int pp) __attribute__((always_inline)) {
+    const int infl = nh - 3 - pp;
+    if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>();
+    else if (infl < 0) {}
+    else if (infl == 0) wait_vm<0>();
+    else if (infl == 1) wait_vm<2>();
+    else wait_vm<4>();
+  };
+  static_assert(P_DEPTH == 3, "wait_tail enumerates the counts below P_DEPTH");
+
+  f32x4_t acc[8][4];
+  const bool res_acc = p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
+                       ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
+  // ---- prologue: half-tiles 0 .. P_NSLOT-2 requested; then (optionally) the fp32 residual tile becomes the initial
+  // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
+  for (int h = 0; h < P_NSLOT - 1 && h < nh; ++h) stage(h, h);
+  if (res_acc) {
+    const float inv_alpha = 1.0f / p.alpha;
+    const int lr4 = lane >> 4, lc4 = (lane & 15) * 4;
+    const int colr = min(n0 + wc * 64 + lc4, p.N - 4);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int row = min(m0 + wr * 128 + (q >> 2) * 16 + (q & 3) * 4 + lr4, p.M - 1);
+      acc[q >> 2][q & 3] = *(const f32x4_t*)(p.res + (size_t)row * p.ldres + colr);
+    }
+    char* tb = smem + P_NSLOT * P_HT + wave * (16 * P_SROW);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(f32x4_t*)(tb + (q * 4 + lr4) * P_SROW + lc4 * 4) = acc[i][q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = *(const float*)(tb + (lr4 * 4 + r) * P_SROW + (j * 16 + (lane & 15)) * 4) * inv_alpha;
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    const int infl = (nh < P_NSLOT - 1 ? nh : P_NSLOT - 1) - 2;     // half-tiles 0 and 1 have landed
+    if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>(); else wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 1] = wall_clock64();
+
+  const int frow = lane & 15, lgrp = lane >> 4;
+  const int swz = (frow >> 1) & 7;
+  const int ro0 = ((0 * 4 + lgrp) ^ swz) << 4, ro1 = ((1 * 4 + lgrp) ^ swz) << 4;
+  const int a_off = (wr * 64 + frow) * ROW2;       // in an A half-tile: rows wr*64 + 16 i + frow
+  const int b_off = (wc * 32 + frow) * ROW2;       // in a B half-tile: rows wc*32 + 16 j + frow
+  uint4 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];          // [fragment][k32 slice]
+  auto read_a = [&](uint4 (&f)[4][2], int slot) __attribute__((always_inline)) {
+    const char* sp = smem + slot * P_HT + a_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i][0] = *(const uint4*)(sp + i * 2048 + ro0); f[i][1] = *(const uint4*)(sp + i * 2048 + ro1); }
+  };
+  auto read_b = [&](uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
+    const char* sp = smem + slot * P_HT + b_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { f[j][0] = *(const uint4*)(sp + j * 2048 + ro0); f[j][1] = *(const uint4*)(sp + j * 2048 + ro1); }
+  };
+  auto mma_q = [&](auto aic, auto bjc, const uint4 (&fa)[4][2], const uint4 (&fb)[2][2]) __attribute__((always_inline)) {
+    constexpr int ai = decltype(aic)::value, bj = decltype(bjc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Mma16<T>::run(fa[i][s], fb[j][s], acc[ai * 4 + i][bj * 2 + j]);
+  };
+  std::integral_constant<int, 0> c0;
+  std::integral_constant<int, 1> c1;
+  auto mid = [&]() __attribute__((always_inline)) {          // read section -> MFMA section
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  read_a(fa0, 0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind the first from here on
+  int ph = 0;                       // phase counter
+  int s_rd = 1 % P_NSLOT;           // slot of half-tile ph+1
+  int s_st = P_NSLOT - 1;           // slot of half-tile ph+P_NSLOT-1
+  auto adv = [&]() __attribute__((always_inline)) {
+    ++ph;
+    s_rd = s_rd + 1 == P_NSLOT ? 0 : s_rd + 1;
+    s_st = s_st + 1 == P_NSLOT ? 0 : s_st + 1;
+  };
+  // one K step = four phases.  TAIL = the last K steps, where the ring runs dry: requests and waits become conditional
+  auto kstep = [&](auto tailc, int t) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tailc)::value;
+    constexpr int LEAD = P_NSLOT - 1;                // phase ph requests half-tile ph + LEAD = K step t + (j + LEAD) / 4
+    auto ph_head = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int dt = (j + LEAD) / 4;             // 1 or 2 K steps ahead
+      static_assert(dt == 1 || dt == 2, "ring depth");
+      if (!TAIL || ph + LEAD < nh) stage_ty(std::integral_constant<int, (j + LEAD) & 3>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
+    };
+    auto ph_wait = [&]() __attribute__((always_inline)) {
+      if (TAIL) wait_tail(ph); else wait_vm<2 * P_DEPTH>();
+    };
+    ph_head(std::integral_constant<int, 0>()); read_b(fb0, s_rd); ph_wait();
+    mid(); mma_q(c0, c0, fa0, fb0); end(); adv();
+    ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait();
+    mid(); mma_q(c0, c1, fa0, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 2>()); read_a(fa1, s_rd); ph_wait();
+    mid(); mma_q(c1, c1, fa1, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 3>()); if (!TAIL || t + 1 < nk) read_a(fa0, s_rd); ph_wait();
+    mid(); mma_q(c1, c0, fa1, fb0); end(); adv();
+    ak1 = ak2; ac1 = ac2;
+    advance(ak2, ac2);
+  };
+  constexpr int NTAIL = (P_NSLOT - 1 + 3) / 4 + 1;   // K steps whose phases may find nothing left to request / wait for
+  int t = 0;
+  for (; t < nk - NTAIL; ++t) kstep(std::false_type(), t);
+  for (; t < nk; ++t) kstep(std::true_type(), t);
+  if (wr == 0) __builtin_amdgcn_s_barrier();       // balances the stagger: every wave has executed the same number of barriers
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 2] = wall_clock64();
+
+  // ---- epilogue (as gemm2_kernel's 16x16 path; the slabs have their own LDS above the ring)
+  OutT* __restrict__ C = (OutT*)p.C;
+  const int crow = (lane >> 4) * 4;
+  const int ccol = lane & 15;
+  const bool full = (m0 + B2M <= p.M) && (n0 + B2N <= p.N);
+  const bool vec_ok = ((p.ldc * (int)sizeof(OutT)) % 16 == 0) && (((size_t)p.C & 15) == 0) &&
+                      (p.res == nullptr || ((p.ldres % 4) == 0 && ((size_t)p.res & 15) == 0));
+  if (vec_ok) {
+    char* slab = smem + P_NSLOT * P_HT + wave * (16 * P_SROW);
+    constexpr int CPL = sizeof(OutT) == 4 ? 4 : 8;                               // columns per lane
+    constexpr int LPR = 64 / CPL;                                                // lanes per slab row
+    constexpr int RPP = 64 / LPR;                                                // rows per pass
+    constexpr int NQ = 16 / RPP;                                                 // passes per slab
+    const int orow = lane / LPR;
+    const int ocol = (lane % LPR) * CPL;
+    const int col0 = n0 + wc * 64 + ocol;
+    float biasv[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) biasv[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
+    const bool seg_full = col0 + CPL <= p.N;
+    auto finish_v = [&](auto actf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *(float*)(slab + (crow + r) * P_SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int srow = q * RPP + orow;
+          float v[CPL];
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            const float4 tt = *(const float4*)(slab + srow * P_SROW + (ocol + c4 * 4) * 4);
+            v[c4 * 4 + 0] = tt.x; v[c4 * 4 + 1] = tt.y; v[c4 * 4 + 2] = tt.z; v[c4 * 4 + 3] = tt.w;
+          }
+          const int row = m0 + wr * 128 + i * 16 + srow;
+          if (row >= p.M || col0 >= p.N) continue;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
+          OutT* cp = C + (size_t)row * p.ldc + col0;
+          if (seg_full) {
+            if (p.res && !res_acc) {
+              const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + col0);
+#pragma unroll
+              for (int c4 = 0; c4 < CPL / 4; ++c4) {
+                const float4 tt = rp[c4];
+                v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
+              }
+            }
+            if constexpr (sizeof(OutT) == 2) {
+              uint4 o0;
+              o0.x = pack2_bf16(v[0], v[1]);
+              o0.y = pack2_bf16(v[2], v[3]);
+              o0.z = pack2_bf16(v[4], v[5]);
+              o0.w = pack2_bf16(v[6], v[7]);
+              *(uint4*)cp = o0;
+            } else {
+              *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {            // ragged last column segment of the matrix
+            for (int e = 0; e < CPL && col0 + e < p.N; ++e) {
+              float o = v[e];
+              if (p.res && !res_acc) o += p.res[(size_t)row * p.ldres + col0 + e];
+              cp[e] = Cvt<OutT>::from_f32(o);
+            }
+          }
+        }
+      }
+    };
+    if (p.act == ACT_SILU) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
+    else if (p.act == ACT_RELU) finish_v([](float x) { return fmaxf(x, 0.0f); });
+    else finish_v([](float x) { return x; });
+    if (p.dbg && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[blockIdx.x * 6 + 3] = wall_clock64(); }
+    return;
+  }
+  // unaligned output / residual rows: element-wise stores
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wc * 64 + j * 16 + ccol;
+    bv[j] = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+  }
+  auto finish = [&](auto actf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 128 + i * 16 + crow + r;
+        if (!full && row >= p.M) continue;
+        const float* rrow = (p.res && !res_acc) ? p.res + (size_t)row * p.ldres : nullptr;
+        OutT* crow_p = C + (size_t)row * p.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = n0 + wc * 64 + j * 16 + ccol;
+          if (!full && col >= p.N) continue;
+          float v = actf(acc[i][j][r] + bv[j]) * p.alpha;
+          if (rrow) v += rrow[col];
+          crow_p[col] = Cvt<OutT>::from_f32(v);
+        }
+      }
+    }
+  };
+  if (p.act == ACT_SILU) finish([](float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); });
+  else if (p.act == ACT_RELU) finish([](float v) { return fmaxf(v, 0.0f); });
+  else finish([](float v) { return v; });
+}
+
+template <typename OutT, bool CONV>
+static int launch2p(hipStream_t s, const GemmArgs& p) {
+  static bool attr_set = false;
+  auto kern = gemm2p_kernel<OutT, CONV>;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    attr_set = true;
+  }
+  const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), GEMM2P_LDS, s, p);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 template <typename T, typename OutT, bool CONV, bool MMA32 = false>
 static int launch2(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
@@ -637,6 +1051,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 
 // tuning switches (tests / scripts/gemm_bench.py / environment; none changes results beyond fp32 summation order):
 //   bit 0  32x32x16 MFMAs        bit 1  s_setprio 1 for waves 4-7 in the K loop        group_m: tile order (0/1 = row-major)
+//   bit 2  bf16: the round-2 register-pipelined loop (one 64-KiB stage per K step) instead of the phase-interleaved one
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -657,6 +1072,10 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
     if (g_gemm2_flags & 1) {
       if (p.out_f32) return p.conv ? launch2<bf16_t, float, true, true>(s, p) : launch2<bf16_t, float, false, true>(s, p);
       return p.conv ? launch2<bf16_t, bf16_t, true, true>(s, p) : launch2<bf16_t, bf16_t, false, true>(s, p);
+    }
+    if (!(g_gemm2_flags & 4)) {     // the phase-interleaved loop (default)
+      if (p.out_f32) return p.conv ? launch2p<float, true>(s, p) : launch2p<float, false>(s, p);
+      return p.conv ? launch2p<bf16_t, true>(s, p) : launch2p<bf16_t, false>(s, p);
     }
     if (p.out_f32) return p.conv ? launch2<bf16_t, float, true>(s, p) : launch2<bf16_t, float, false>(s, p);
     return p.conv ? launch2<bf16_t, bf16_t, true>(s, p) : launch2<bf16_t, bf16_t, false>(s, p);

@@ -293,6 +293,217 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
     }
 }
 
+// ---- phase-interleaved main loop ("8-phase" schedule of cdna_hip_programming.md section 5, re-derived for this tile):
+// the K step of 64 elements is cut into four PHASES, one per 64x32 quadrant of the wave's 128x64 tile (16 MFMAs), and the
+// operands into four HALF-TILES of 16 KiB -- A-h0 / A-h1 = the first / second 64 rows of every wave row's 128, B-h0 / B-h1 =
+// the first / second 32 columns of every wave column's 64 -- which is exactly what one phase newly needs:
+//
+//     phase j of K step t     MFMAs        fragment reads issued in this phase (into the register set that just died)
+//       0                     A0 x B0      B0 <- B-h0(t)      4 ds_read_b128
+//       1                     A0 x B1      B1 <- B-h1(t)      4
+//       2                     A1 x B1      A1 <- A-h1(t)      8
+//       3                     A1 x B0      A0 <- A-h0(t+1)    8            (B0 stays in registers from phase 0)
+//
+// so the operand stream is ONE half-tile per phase, in consumption order, through a ring of NSLOT 16-KiB LDS slots:
+// phase p reads half-tile p+1, waits (counted vmcnt, never 0 in steady state) until half-tile p+2 has landed, and requests
+// half-tile p+NSLOT-1 into the slot whose last reader finished two phases ago -- NSLOT-3 half-tiles (80 KiB of 128) stay in
+// flight ACROSS the barriers instead of one 64-KiB stage that is drained to zero every K step.  A phase is
+// {reads + DMA issue + vmcnt | barrier | lgkmcnt(0), 16 MFMAs | barrier}; with STAGGER the second wave row runs one barrier
+// behind the first, so on every SIMD one wave multiplies while the other reads and issues (s_setprio around the MFMAs, PRIO).
+template <int HT> __device__ inline void dma2(unsigned off0, unsigned off1, const void* sbase, unsigned lds0) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off0), "v"(off1), "s"(sbase), "s"(lds0)
+      : "memory", "scc");
+}
+
+template <int NSLOT, int STAGGER, int PRIO, int STORE>
+__global__ __launch_bounds__(512) void gemm_ph(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                               float* __restrict__ C, int M, int N, int K, int /*unused*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HT = 128 * 128;                    // bytes of a half-tile: 128 rows x 128 bytes of K
+  constexpr int DEPTH = NSLOT - 3;                 // half-tiles in flight behind the one being waited for
+  static_assert(2 * DEPTH <= 63, "vmcnt is a 6-bit counter");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = N / 256;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA sources: every wave stages rows [16 wave, +16) of each half-tile = two 1-KiB pieces (8 rows x 128 B);
+  // 32-bit byte offsets from the tile's first row, the K position is added to the scalar base
+  const int lr = lane >> 3, lc = lane & 7;
+  unsigned offA[2][2], offW[2][2];                 // [half][piece]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 16 * wave + 8 * i + lr;          // row of the half-tile
+    const unsigned col = (unsigned)((lc ^ ((r >> 1) & 7)) * 16);
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      offA[hlf][i] = (unsigned)((r >> 6) * 128 + hlf * 64 + (r & 63)) * (unsigned)(K * 2) + col;
+      offW[hlf][i] = (unsigned)((r >> 5) * 64 + hlf * 32 + (r & 31)) * (unsigned)(K * 2) + col;
+    }
+  }
+  const char* a_base = (const char*)(A + (size_t)m0 * K);
+  const char* w_base = (const char*)(W + (size_t)n0 * K);
+  const int nk = K / 64, nh = 4 * nk;
+  const unsigned lds_wave = lds_base + wave * 2048;
+  // half-tile h = 4t + ty, ty = {0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1} of K step t, into ring slot `slot`
+  auto stage_ty = [&](auto tyc, int t, int slot) __attribute__((always_inline)) {
+    constexpr int ty = decltype(tyc)::value;
+    const unsigned dst = lds_wave + slot * HT;
+    if constexpr (ty == 0) dma2<HT>(offA[0][0], offA[0][1], a_base + (size_t)t * 128, dst);
+    else if constexpr (ty == 1) dma2<HT>(offW[0][0], offW[0][1], w_base + (size_t)t * 128, dst);
+    else if constexpr (ty == 2) dma2<HT>(offW[1][0], offW[1][1], w_base + (size_t)t * 128, dst);
+    else dma2<HT>(offA[1][0], offA[1][1], a_base + (size_t)t * 128, dst);
+  };
+  auto stage = [&](int h, int slot) __attribute__((always_inline)) {       // prologue only
+    const int t = h >> 2, ty = h & 3;
+    if (ty == 0) stage_ty(std::integral_constant<int, 0>(), t, slot);
+    else if (ty == 1) stage_ty(std::integral_constant<int, 1>(), t, slot);
+    else if (ty == 2) stage_ty(std::integral_constant<int, 2>(), t, slot);
+    else stage_ty(std::integral_constant<int, 3>(), t, slot);
+  };
+  // wait until half-tile p+2 (read in the next phase) has landed: everything but the newest min(DEPTH, nh-3-p) half-tiles
+  auto wait_tail = [&](int p) __attribute__((always_inline)) {
+    const int infl = nh - 3 - p;
+    if (infl >= DEPTH) wait_vm<2 * DEPTH>();
+    else if (infl < 0) {}
+    else if (infl == 0) wait_vm<0>();
+    else if (infl == 1) wait_vm<2>();
+    else if (infl == 2) wait_vm<4>();
+    else if (infl == 3) wait_vm<6>();
+    else if (infl == 4) wait_vm<8>();
+    else if (infl == 5) wait_vm<10>();
+    else wait_vm<12>();
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, lgrp = lane >> 4;
+  const int swz = (frow >> 1) & 7;
+  const int ro0 = ((0 * 4 + lgrp) ^ swz) << 4, ro1 = ((1 * 4 + lgrp) ^ swz) << 4;
+  const int a_off = (wr * 64 + frow) * 128;        // in an A half-tile: rows wr*64 + 16 i + frow
+  const int b_off = (wc * 32 + frow) * 128;        // in a B half-tile: rows wc*32 + 16 j + frow
+  uint4 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];          // [fragment][k32 slice]
+  auto read_a = [&](uint4 (&f)[4][2], int slot) __attribute__((always_inline)) {
+    const char* sp = smem + slot * HT + a_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i][0] = *(const uint4*)(sp + i * 2048 + ro0); f[i][1] = *(const uint4*)(sp + i * 2048 + ro1); }
+  };
+  auto read_b = [&](uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
+    const char* sp = smem + slot * HT + b_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { f[j][0] = *(const uint4*)(sp + j * 2048 + ro0); f[j][1] = *(const uint4*)(sp + j * 2048 + ro1); }
+  };
+  auto mma_q = [&](auto aic, auto bjc, const uint4 (&fa)[4][2], const uint4 (&fb)[2][2]) __attribute__((always_inline)) {
+    constexpr int ai = decltype(aic)::value, bj = decltype(bjc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma(fa[i][s], fb[j][s], acc[ai * 4 + i][bj * 2 + j]);
+  };
+  std::integral_constant<int, 0> c0;
+  std::integral_constant<int, 1> c1;
+  auto mid = [&]() __attribute__((always_inline)) {          // end of the read section -> MFMA section
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+  };
+  auto end = [&]() __attribute__((always_inline)) {
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: half-tiles 0 .. NSLOT-2 requested, 0 and 1 awaited, A0 of K step 0 read
+  for (int h = 0; h < NSLOT - 1 && h < nh; ++h) stage(h, h);
+  {
+    const int infl = (nh < NSLOT - 1 ? nh : NSLOT - 1) - 2;     // host guarantees nk >= 2
+    if (infl >= DEPTH) wait_vm<2 * DEPTH>(); else wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  read_a(fa0, 0);
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+  int p = 0;                       // phase counter
+  int s_rd = 1;                    // slot of half-tile p+1
+  int s_st = NSLOT - 1;            // slot of half-tile p+NSLOT-1
+  auto adv = [&]() __attribute__((always_inline)) {
+    ++p;
+    s_rd = s_rd + 1 == NSLOT ? 0 : s_rd + 1;
+    s_st = s_st + 1 == NSLOT ? 0 : s_st + 1;
+  };
+  // one K step = four phases.  TAIL = the last K steps, where the ring runs dry: requests and waits become conditional
+  auto kstep = [&](auto tailc, int t) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tailc)::value;
+    constexpr int LEAD = NSLOT - 1;                  // phase p requests half-tile p + LEAD = K step t + (j + LEAD) / 4
+    auto ph_head = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if (!TAIL || p + LEAD < nh) stage_ty(std::integral_constant<int, (j + LEAD) & 3>(), t + (j + LEAD) / 4, s_st);
+    };
+    auto ph_wait = [&]() __attribute__((always_inline)) {
+      if (TAIL) wait_tail(p); else wait_vm<2 * DEPTH>();
+    };
+    ph_head(std::integral_constant<int, 0>()); read_b(fb0, s_rd); ph_wait();
+    mid(); mma_q(c0, c0, fa0, fb0); end(); adv();
+    ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait();
+    mid(); mma_q(c0, c1, fa0, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 2>()); read_a(fa1, s_rd); ph_wait();
+    mid(); mma_q(c1, c1, fa1, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 3>()); if (!TAIL || t + 1 < nk) read_a(fa0, s_rd); ph_wait();
+    mid(); mma_q(c1, c0, fa1, fb0); end(); adv();
+  };
+  constexpr int NTAIL = (NSLOT - 1 + 3) / 4 + 1;     // K steps whose phases may find nothing left to request / wait for
+  int t = 0;
+  for (; t < nk - NTAIL; ++t) kstep(std::false_type(), t);
+  for (; t < nk; ++t) kstep(std::true_type(), t);
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+
+  const int crow = (lane >> 4) * 4, ccol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* crow_p = C + (size_t)(m0 + wr * 128 + i * 16 + crow + r) * N + n0 + wc * 64 + ccol;
+      if (STORE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) crow_p[j * 16] = acc[i][j][r];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (acc[i][j][r] == 12345.678f) crow_p[j * 16] = acc[i][j][r];
+      }
+    }
+}
+
 // ---- persistent variant of "8w 128x64 BK64 2st pipelined": one workgroup per CU walks the tiles (same XCD-aware order);
 // the first two stages of the NEXT tile are requested before the epilogue of the current one (stage 0 into the buffer
 // that frees up at the last barrier of the K loop, stage 1 after one more barrier into the buffer of the last K step),
@@ -979,7 +1190,21 @@ int main(int argc, char** argv) {
   vs.push_back(make<2, 4, 2, 2, 1>("8w pipelined  first wave in 8 phases", 8));
   vs.push_back(make<2, 4, 2, 2, 0>("8w simple     first wave in 4 phases", 4));
   if (argc > 2) vs.erase(vs.begin() + 2, vs.begin() + 10);      // short run: skip the 4-wave / BK32 variants
-  vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
+  if (argc > 2 && std::string(argv[2]) == "phase") vs.erase(vs.begin() + 2, vs.end());   // the two baselines + the phase-interleaved loops
+  {
+    auto addph = [&](const char* name, auto kern, int nslot) {
+      CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, nslot * 16384));
+      vs.push_back({name, kern, 512, nslot * 16384, 1, 0, 0});
+    };
+    addph("phases  8 slots                    ", gemm_ph<8, 0, 0, 1>, 8);
+    addph("phases  8 slots stagger            ", gemm_ph<8, 1, 0, 1>, 8);
+    addph("phases  8 slots stagger prio       ", gemm_ph<8, 1, 1, 1>, 8);
+    addph("phases  8 slots         prio       ", gemm_ph<8, 0, 1, 1>, 8);
+    addph("phases 10 slots stagger prio       ", gemm_ph<10, 1, 1, 1>, 10);
+    addph("phases 10 slots stagger            ", gemm_ph<10, 1, 0, 1>, 10);
+    addph("phases  6 slots stagger prio       ", gemm_ph<6, 1, 1, 1>, 6);
+  }
+  if (!(argc > 2 && std::string(argv[2]) == "phase")) vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
 
   struct Shape { int M, N, K; };
   const Shape shapes[] = {{90112, 1024, 1024}, {90112, 4096, 1024}, {90112, 1024, 4096}, {90112, 1024, 19456}};

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
-from golden_util import LongCase
+from golden_util import GOLDEN, LongCase
 from reverb_amd.engine import Engine
 
 pytestmark = pytest.mark.gpu
@@ -70,6 +70,49 @@ def _tap_metrics(eng, case, first_chunk_index_in_batch, c):
                 logp_mean_abs=float(d.mean()), logp_p99_abs=float(np.quantile(d, 0.99)), logp_max_abs=float(d.max()))
 
 
+class RefBf16:
+    """What bf16 costs the REFERENCE ITSELF on this case (oracle/gen_golden_bf16ref.py: the unmodified reference under
+    torch.autocast('cpu', bfloat16) against its own fp32 run): the yardstick of the engine's reduced-precision modes."""
+
+    def __init__(self, name):
+        with open(os.path.join(GOLDEN, name + "_refbf16.json")) as f:
+            self.js = json.load(f)
+        self.arrays = np.load(os.path.join(GOLDEN, name + "_refbf16.npz"))
+        self.ter = self.js["ter"]
+        self.tokens = self.js["ref_tokens"]
+
+    def ter_bound(self, mode):
+        """reference-bf16 TER + a margin for the different summation order (1 % of the tokens, at least 3 tokens)."""
+        return self.ter[mode] + max(0.01, 3.0 / self.tokens[mode])
+
+    def frame_disagreement(self, eng, first_chunk=0):
+        """Frames whose argmax differs from the fp32 reference's, over the engine's current batch: (all frames, frames where
+        the reference's own top-2 log-prob margin exceeds 0.1) for the engine and for the reference under bf16 autocast."""
+        _, ti = eng.ctc_topk()
+        nb = ti.shape[0]
+        a32 = self.arrays["argmax_f32"][first_chunk:first_chunk + nb].astype(np.int64)
+        abf = self.arrays["argmax_bf16"][first_chunk:first_chunk + nb].astype(np.int64)
+        gap = self.arrays["gap_f32"][first_chunk:first_chunk + nb].astype(np.float32)
+        T = min(a32.shape[1], ti.shape[1])
+        a32, abf, gap, got = a32[:, :T], abf[:, :T], gap[:, :T], ti[:, :T, 0].astype(np.int64)
+        valid = a32 >= 0
+        conf = valid & (gap > 0.1)
+        return dict(frames=int(valid.sum()), confident=int(conf.sum()),
+                    engine=int((valid & (got != a32)).sum()), engine_confident=int((conf & (got != a32)).sum()),
+                    ref_bf16=int((valid & (abf != a32)).sum()), ref_bf16_confident=int((conf & (abf != a32)).sum()))
+
+
+def _assert_reduced_precision(name, dtype, ter, fm, ref, slack=1.0):
+    """The engine's reduced-precision mode is held to the reference's own bf16 behaviour: token error rate against the fp32
+    reference no worse than the reference-under-autocast's (+ margin; x `slack` for fp8), and on frames where the fp32
+    reference decides with a margin > 0.1 it disagrees no more often than the reference-bf16 does (+ 0.05 % of the frames)."""
+    for m in MODES:
+        bound = slack * ref.ter_bound(m)
+        assert ter[m][0] <= bound * ter[m][1], f"{name} {dtype} {m}: TER {ter[m][0]}/{ter[m][1]} > {bound:.4f} (reference bf16 {ref.ter[m]:.4f})"
+    lim = slack * (fm["ref_bf16_confident"] + 0.0005 * fm["confident"])
+    assert fm["engine_confident"] <= lim, f"{name} {dtype}: {fm}"
+
+
 # ------------------------------------------------------------------------------------------------ small_66
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_small_66_chunks_two_slice_pipeline(dtype):
@@ -80,9 +123,12 @@ def test_small_66_chunks_two_slice_pipeline(dtype):
     eng.encode(x, lens, case.beam)                     # B = 66 >= 64: slices of 34 + 32 chunks, host search overlapped
     assert eng.encoder_lens().tolist() == case.js["encoder_lens"]
     m0 = _tap_metrics(eng, case, 0, 0)
+    ref = RefBf16("small_66")
+    fm = ref.frame_disagreement(eng)
     res = eng.search(MODES, case.ctc_weight, case.reverse_weight)
     ter = _ter(res, case)
-    _record(case="small_66", dtype=dtype, chunks=len(lens), ter={m: list(v) for m, v in ter.items()}, chunk0=m0)
+    _record(case="small_66", dtype=dtype, chunks=len(lens), ter={m: list(v) for m, v in ter.items()}, chunk0=m0, frames=fm,
+            reference_bf16_ter=ref.ter)
     if dtype == "f32":
         # exact-f32 MFMA: the reference's ids, chunk for chunk (and its CTC peak times)
         for m in MODES:
@@ -93,16 +139,14 @@ def test_small_66_chunks_two_slice_pipeline(dtype):
         assert m0["cos"] > 0.999999 and m0["logp_max_abs"] < 2e-3
     else:
         assert m0["cos"] > BF16_COS and m0["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m0["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m0
-        for m in MODES:          # measured r2: see the module docstring; bound = measured + margin
-            assert ter[m][0] <= BF16_TER_BOUND["small_66"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+        _assert_reduced_precision("small_66", dtype, ter, fm, ref)
     eng.close()
 
 
-# Measured bf16 token error rates vs the reference (round 2, profiles/r02_parity_metrics.jsonl): small_66 greedy 1.5 % /
-# rescored 3.4 % of 4 666 tokens; r640_1h (the bench workload) greedy 4.7 % of 11 417 / rescored 8.7 % of 13 935;
-# r640_chunk 4/66 and 6/84.  Rescoring is the more sensitive figure: it picks one of ten near-tied hypotheses.  The f32
-# mode of the same engine has 0 edits in all of them.  Bound = measured + margin for box-to-box summation-order noise.
-BF16_TER_BOUND = {"small_66": 0.06, "r640_chunk": 0.15, "r640_1h": 0.12}
+# bf16 token error rates are bounded by the REFERENCE's own bf16 behaviour (RefBf16 above; round 3), not by "measured +
+# margin": reference under torch.autocast(cpu, bf16) vs its fp32 run -- small_66 greedy 3.5 % / rescored 4.6 %, r640_chunk
+# 4/66 / 6/84, r640_1h (the bench workload) see tests/golden/r640_1h_refbf16.json; the engine (fp32 residual stream, fp32
+# LayerNorm / softmax statistics) measured 1.5 % / 3.4 %, 4/66 / 6/84 and 4.7 % / 8.9 % in round 2.  The f32 mode has 0 edits.
 # SURVEY.md 8d asks CTC log-probs within 5e-2 in bf16; measured on the frames whose argmax agrees with the reference:
 # mean 0.009, 99th percentile 0.041, max 0.054 (r640).  Asserted: p99 <= 5e-2 and mean <= 2e-2; encoder cos-sim > 0.9999
 # (measured 0.99998).
@@ -119,9 +163,11 @@ def test_r640_chunk_against_reference(dtype):
     eng.encode(x, lens, case.beam)
     assert eng.encoder_lens().tolist() == case.js["encoder_lens"]
     m0 = _tap_metrics(eng, case, 0, 0)
+    ref = RefBf16("r640_chunk")
+    fm = ref.frame_disagreement(eng)
     res = eng.search(MODES, case.ctc_weight, case.reverse_weight)
     ter = _ter(res, case)
-    _record(case="r640_chunk", dtype=dtype, ter={m: list(v) for m, v in ter.items()}, chunk0=m0)
+    _record(case="r640_chunk", dtype=dtype, ter={m: list(v) for m, v in ter.items()}, chunk0=m0, frames=fm, reference_bf16_ter=ref.ter)
     if dtype == "f32":
         for m in MODES:
             assert ter[m][0] == 0, f"{m}: {ter[m]}"
@@ -129,8 +175,7 @@ def test_r640_chunk_against_reference(dtype):
         assert m0["cos"] > 0.999999 and m0["enc_max_abs"] < 5e-3 and m0["logp_max_abs"] < 5e-3
     else:
         assert m0["cos"] > BF16_COS and m0["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m0["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m0
-        for m in MODES:
-            assert ter[m][0] <= BF16_TER_BOUND["r640_chunk"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+        _assert_reduced_precision("r640_chunk", dtype, ter, fm, ref)
     eng.close()
 
 
@@ -148,7 +193,10 @@ def test_r640_one_hour_bench_workload_against_reference(dtype):
     assert len(res["attention_rescoring"]) == n == 176
     ter = _ter(res, case)
     m_last = _tap_metrics(eng, case, n - 1, n - 1)        # the last chunk sits in the 32-chunk slice
-    _record(case="r640_1h", dtype=dtype, chunks=n, ter={m: list(v) for m, v in ter.items()}, last_chunk=m_last)
+    ref = RefBf16("r640_1h")
+    fm = ref.frame_disagreement(eng)
+    _record(case="r640_1h", dtype=dtype, chunks=n, ter={m: list(v) for m, v in ter.items()}, last_chunk=m_last, frames=fm,
+            reference_bf16_ter=ref.ter)
     if dtype == "f32":
         # the device fbank differs from the oracle features by ~1e-4 (fp32 FFT order): a near-tied frame may flip
         for m in MODES:
@@ -156,6 +204,5 @@ def test_r640_one_hour_bench_workload_against_reference(dtype):
         assert m_last["cos"] > 0.99999
     else:
         assert m_last["cos"] > BF16_COS and m_last["logp_p99_abs"] <= BF16_LOGP_P99_ABS and m_last["logp_mean_abs"] <= BF16_LOGP_MEAN_ABS, m_last
-        for m in MODES:
-            assert ter[m][0] <= BF16_TER_BOUND["r640_1h"] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+        _assert_reduced_precision("r640_1h", dtype, ter, fm, ref)
     eng.close()
