@@ -257,9 +257,9 @@ def main():
     stats = {}
 
     comm = None
-    if use_dist and not STUB and os.environ.get("RVB_COMM") == "cabi":      # the result gather through librvb's own RCCL binding
-        from reverb_amd.dist import RvbComm
-        comm = RvbComm.from_torch_group(eng)
+    if use_dist and not STUB:      # the result gather through librvb's own RCCL binding (RVB_COMM=torch: torch.distributed)
+        from reverb_amd.dist import default_comm
+        comm = default_comm(eng)
 
     def step(upload=False):
         if STUB:
@@ -361,7 +361,7 @@ def main():
                                    f"ctc_weight {args.ctc_weight}, reverse_weight {args.reverse_weight}",
                        "chunks_per_launch": per_launch, "parallelism": f"chunk-shard x{world}",
                        "world_size_reported_by_process_group": world if use_dist else 1,
-                       "backend": (("librvb rvb_allgather_results (RCCL)" if comm else dist.get_backend()) if use_dist else None),
+                       "backend": (("librvb rvb_comm_allgather (RCCL)" if comm else dist.get_backend()) if use_dist else None),
                        "results_gathered": len(hyps), "tokens_per_step": int(ntok),
                        # rescoring: (hypothesis, position) log-probs served vs decoder rows computed (one per distinct prefix)
                        "decoder_pairs_per_step": stats.get("decoder_pairs"), "decoder_rows_per_step": stats.get("decoder_rows")},

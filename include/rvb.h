@@ -171,8 +171,15 @@ int rvb_get_rescore_logp(rvb_engine* e, int chunk, int hyp, int right, float* ou
  * RCCL is bound directly (resolved with dlopen on first use; PyTorch is not needed): one rank calls rvb_comm_unique_id and
  * hands the 128 bytes to the others by any side channel, every rank calls rvb_comm_init on its engine (one engine = one GPU =
  * one rank), rvb_allgather_results gathers `bytes` bytes per rank (host buffers; recv = world * bytes) in rank order on the
- * engine's stream.  reverb_amd/dist.py uses torch.distributed by default and this through `RvbComm`. */
+ * engine's stream.  rvb_comm_create / rvb_comm_allgather / rvb_comm_free are the same collective on a stand-alone
+ * communicator (own stream; one per process = per GPU), which the ASR results and the diarization shard's classes / embeddings
+ * both travel on: reverb_amd/dist.py (`RvbComm`, default_comm) uses it whenever the ranks run on GPUs; torch.distributed only
+ * carries the 128-byte id once (or a file does: RvbComm.from_file) and serves the gloo CPU tests. */
+typedef struct rvb_comm rvb_comm;
 int rvb_comm_unique_id(void* id128 /* out: 128 bytes */);
+int rvb_comm_create(int device, int world, int rank, const void* id128, rvb_comm** out);
+int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv);
+int rvb_comm_free(rvb_comm* c);
 int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128);
 int rvb_allgather_results(rvb_engine* e, const void* send, int64_t bytes, void* recv);
 int rvb_comm_destroy(rvb_engine* e);

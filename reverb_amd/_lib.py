@@ -75,6 +75,9 @@ SIGNATURES = {
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
     "rvb_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rvb_comm_init": (C.c_int, [_eng, C.c_int, C.c_int, C.c_void_p]),
+    "rvb_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rvb_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rvb_comm_free": (C.c_int, [C.c_void_p]),
     "rvb_allgather_results": (C.c_int, [_eng, C.c_void_p, C.c_int64, C.c_void_p]),
     "rvb_comm_destroy": (C.c_int, [_eng]),
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),

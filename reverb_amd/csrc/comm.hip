@@ -77,6 +77,60 @@ int rvb_comm_unique_id(void* id128) {
   return rc == 0 ? OK : nccl_fail("ncclGetUniqueId", rc);
 }
 
+// ---- stand-alone communicator: one per process / GPU, shared by the ASR engine and the diarization engine of that rank
+struct rvb_comm {
+  int device = 0, world = 1, rank = 0;
+  void* nccl = nullptr;
+  hipStream_t stream = nullptr;
+  rvb::DevBuf send, recv;
+};
+
+int rvb_comm_create(int device, int world, int rank, const void* id128, rvb_comm** out) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("rvb_comm_create: bad argument"); return E_ARG; }
+  RVB_TRY_RC(load_rccl());
+  RVB_HIP_CHECK(hipSetDevice(device));
+  Id128 id;
+  memcpy(id.b, id128, 128);
+  void* nccl = nullptr;
+  const int rc = g_rccl.init_rank(&nccl, world, id, rank);
+  if (rc != 0) return nccl_fail("ncclCommInitRank", rc);
+  rvb_comm* c = new rvb_comm();
+  c->device = device; c->world = world; c->rank = rank; c->nccl = nccl;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_rccl.destroy(nccl); delete c; set_error("rvb_comm_create: hipStreamCreate failed"); return E_HIP;
+  }
+  *out = c;
+  return OK;
+}
+
+// every rank contributes `bytes` bytes (host memory); `recv` (host, world * bytes) receives them in rank order
+int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv) {
+  if (!c || !send || !recv || bytes <= 0) { set_error("rvb_comm_allgather: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(c->device));
+  int r = c->send.ensure((size_t)bytes);
+  if (r != OK) return r;
+  r = c->recv.ensure((size_t)bytes * c->world);
+  if (r != OK) return r;
+  RVB_HIP_CHECK(hipMemcpyAsync(c->send.p, send, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  const int rc = g_rccl.all_gather(c->send.p, c->recv.p, (size_t)bytes, 0 /* ncclInt8 */, c->nccl, c->stream);
+  if (rc != 0) return nccl_fail("ncclAllGather", rc);
+  RVB_HIP_CHECK(hipMemcpyAsync(recv, c->recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return OK;
+}
+
+int rvb_comm_free(rvb_comm* c) {
+  if (!c) return OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl) g_rccl.destroy(c->nccl);
+  c->send.release(); c->recv.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return OK;
+}
+
+// ---- the same collective bound to an ASR engine (its stream, its buffers)
 int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128) {
   if (!e || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("rvb_comm_init: bad argument"); return E_ARG; }
   if (e->comm) { set_error("rvb_comm_init: the engine already has a communicator"); return E_STATE; }

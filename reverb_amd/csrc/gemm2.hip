@@ -26,7 +26,10 @@ static constexpr int B2M = 256, B2N = 256;
 static constexpr int ROW2 = 128;                         // bytes of K per tile row
 static constexpr int STAGE2 = (B2M + B2N) * ROW2;        // 64 KiB
 static constexpr int GEMM2_LDS = 2 * STAGE2;             // 128 KiB
-static constexpr int GEMM2_DEFAULT_FLAGS = 0, GEMM2_DEFAULT_GROUP_M = 8;   // measured r2 (gpurun_out/s2): group_m 8 -0.9 % of the step, priority -0.3 %, 32x32x16 MFMAs +3.4 %
+static constexpr int GEMM2_DEFAULT_FLAGS = 0;
+// tile order: GROUP_M_AUTO = 8-row groups for short K, row-major for K >= 2048 (profiles/r03_gemm_bench_switches.txt: with the
+// phase-interleaved loop ffn2 runs 1031 vs 889 and embed 1314 vs 1181 TFLOP/s row-major, ffn1 / qkv 901 vs 858 / 1021 vs 967 grouped)
+static constexpr int GROUP_M_AUTO = -2, GEMM2_DEFAULT_GROUP_M = GROUP_M_AUTO;
 
 __device__ inline float act_apply2(float v, int act) {
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
@@ -620,25 +623,28 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 //     its operands are four 16-KiB HALF-TILES -- A-h0 / A-h1 = the first / second 64 rows of each wave row's 128,
 //     B-h0 / B-h1 = the first / second 32 columns of each wave column's 64 -- one per phase, in consumption order:
 //
-//         phase   MFMAs      fragment reads issued (into the register set that just died)
-//           0     A0 x B0    B0 <- B-h0(t)     4 ds_read_b128
-//           1     A0 x B1    B1 <- B-h1(t)     4
-//           2     A1 x B1    A1 <- A-h1(t)     8
-//           3     A1 x B0    A0 <- A-h0(t+1)   8        (B0 stays in registers)
+//         phase   MFMAs      fragment reads issued (into registers that just died)
+//           0     A0 x B0    B0 <- B-h0(t), k-half 1 of A0 <- A-h0(t)      4 + 4 ds_read_b128
+//           1     A0 x B1    B1 <- B-h1(t)                                 4
+//           2     A1 x B1    A  <- A-h1(t)  (both k-halves)                8
+//           3     A1 x B0    k-half 0 of the next A0 <- A-h0(t+1)          4      (B0 stays in registers)
 //
-//   * the half-tiles stream through a ring of P_NSLOT LDS slots: phase p reads half-tile p+1, waits -- counted
-//     `vmcnt`, never 0 in steady state -- until half-tile p+2 has landed, and requests half-tile p+P_NSLOT-1 into the
-//     slot whose last reader finished two phases earlier: 3 half-tiles stay in flight ACROSS the barriers instead of
-//     one 64-KiB stage drained to zero at every K step;
+//     One 32-register A set (whose k-half 1 serves A0 in phases 0-1 and A1 in phases 2-3) + a 16-register set for the
+//     prefetched k-half 0 of A0 + two 16-register B sets = 80 fragment registers next to the 128 accumulators; reads are
+//     8 / 4 / 8 / 4 per phase -- never more than the other wave row's 16 MFMAs cover;
+//   * the half-tiles stream through a ring of P_NSLOT LDS slots: phase p reads half-tile p+1 (and, for A-h0, finishes
+//     half-tile p), waits -- counted `vmcnt`, never 0 in steady state -- until half-tile p+2 has landed, and requests
+//     half-tile p+P_LEAD into the slot whose last reader finished two phases earlier: 3 half-tiles stay in flight ACROSS
+//     the barriers instead of one 64-KiB stage drained to zero at every K step;
 //   * a phase is {DMA issue, reads, vmcnt | s_barrier | lgkmcnt(0), 16 MFMAs | s_barrier}, and the second wave row
 //     runs ONE BARRIER BEHIND the first: on every SIMD one wave multiplies while the other reads and issues.  Without
 //     that stagger the same loop is slower than the old one (846 vs 919 TFLOP/s in the lab).
 //   RAW: a wave waits for its own pieces of half-tile h before the first barrier of phase h-2; every reader is past
 //   that barrier (or the one after it, for the staggered row) when it reads in phase h-1.  WAR: a slot is refilled two
 //   phases after the phase whose lgkmcnt(0) retired its last read.
-// The ring takes 96 KiB; the 34 KiB above it are the epilogue's transposition slabs (and the residual prologue's), so
+// The ring takes 112 KiB; the 34 KiB above it are the epilogue's transposition slabs (and the residual prologue's), so
 // neither ever shares a buffer with the operand stream.
-static constexpr int P_NSLOT = 6, P_HT = 128 * ROW2, P_DEPTH = P_NSLOT - 3;
+static constexpr int P_NSLOT = 7, P_HT = 128 * ROW2, P_LEAD = P_NSLOT - 2, P_DEPTH = P_LEAD - 2;
 static constexpr int P_SROW = 64 * 4 + 16;                        // padded fp32 slab row (bytes)
 static constexpr int GEMM2P_LDS = P_NSLOT * P_HT + 8 * 16 * P_SROW;
 
@@ -668,11 +674,15 @@ __device__ inline const char* uniform_ptr(const char* q) {
   return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <typename OutT, bool CONV>
+// T = bf16_t: 16x16x32 MFMAs on 16x16 accumulator fragments.  T = fp8_t (OCP e4m3, RVB_FP8 mode): the same ring and phases
+// with twice the K per 128-byte row and v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales on 32x32 accumulator blocks
+// -- a phase is then four 64-cycle MFMAs (a 64x32 quadrant = 2 x 1 blocks x two k64 slices), the same 256 matrix-pipe
+// cycles and the same 8 / 4 fragment reads; scaling as in gemm2_kernel (a_scale per tensor, w_scale per output channel).
+template <typename T, typename OutT, bool CONV>
 __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef bf16_t T;
-  constexpr int BKE = ROW2 / 2;
+  constexpr bool F8 = std::is_same<T, fp8_t>::value;
+  constexpr int BKE = ROW2 / (int)sizeof(T);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -729,8 +739,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     for (int hlf = 0; hlf < 2; ++hlf) {
       const int m = min(m0 + (r >> 6) * 128 + hlf * 64 + (r & 63), p.M - 1);
       const int n = min(n0 + (r >> 5) * 64 + hlf * 32 + (r & 31), p.N - 1);
-      offA[hlf][i] = (unsigned)((a_elem(m) - a_row0) * 2) + col;
-      offW[hlf][i] = (unsigned)((size_t)(n - n0) * p.ldw * 2) + col;
+      offA[hlf][i] = (unsigned)((a_elem(m) - a_row0) * sizeof(T)) + col;
+      offW[hlf][i] = (unsigned)((size_t)(n - n0) * p.ldw * sizeof(T)) + col;
     }
   }
   const char* a_base = uniform_ptr((const char*)((const T*)p.A + a_row0));
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // convolution walks the 3x3 taps, whose (kh, kw .. kw+2) channels are contiguous in NHWC -- only a new kernel row kh
   // jumps, by (F1 - 3) pixels (the whole 128-byte K step lies inside one tap: cC % BKE == 0)
   const int row_steps = CONV ? 3 * p.cC / BKE : 0x7fffffff;
-  const size_t row_jump = CONV ? (size_t)(p.cF1 - 3) * p.cC * 2 : 0;
+  const size_t row_jump = CONV ? (size_t)(p.cF1 - 3) * p.cC * sizeof(T) : 0;
   auto advance = [&](size_t& off, int& cnt) __attribute__((always_inline)) {
     off += ROW2;
     if (++cnt == row_steps) { cnt = 0; off += row_jump; }
@@ -768,7 +778,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     else if (ty == 2) stage_ty(std::integral_constant<int, 2>(), t, ak, slot);
     else stage_ty(std::integral_constant<int, 3>(), t, ak, slot);
   };
-  static_assert(P_NSLOT - 2 < 8, "the prologue requests half-tiles of K steps 0 and 1 only");
+  static_assert(P_LEAD - 1 < 8, "the prologue requests half-tiles of K steps 0 and 1 only");
   // half-tile p+2 (read in the next phase) has landed: everything but the newest min(P_DEPTH, nh-3-p) half-tiles
   auto wait_tail = [&](int pp) __attribute__((always_inline)) {
     const int infl = nh - 3 - pp;
@@ -780,70 +790,147 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   };
   static_assert(P_DEPTH == 3, "wait_tail enumerates the counts below P_DEPTH");
 
-  f32x4_t acc[8][4];
+  // 16x16 fragments: acc[i][j] = rows 16i.., cols 16j.. of the wave's 128x64 tile (C/D: col = lane&15, row = 4*(lane>>4)+r).
+  // 32x32 blocks (fp8): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+  f32x4_t acc[F8 ? 1 : 8][F8 ? 1 : 4];
+  f32x16_t acc32[F8 ? 4 : 1][F8 ? 2 : 1];
   const bool res_acc = p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
                        ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
-  // ---- prologue: half-tiles 0 .. P_NSLOT-2 requested; then (optionally) the fp32 residual tile becomes the initial
+  // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
   // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
-  for (int h = 0; h < P_NSLOT - 1 && h < nh; ++h) stage(h, h);
+  for (int h = 0; h < P_LEAD && h < nh; ++h) stage(h, h);
   if (res_acc) {
     const float inv_alpha = 1.0f / p.alpha;
     const int lr4 = lane >> 4, lc4 = (lane & 15) * 4;
     const int colr = min(n0 + wc * 64 + lc4, p.N - 4);
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-      const int row = min(m0 + wr * 128 + (q >> 2) * 16 + (q & 3) * 4 + lr4, p.M - 1);
-      acc[q >> 2][q & 3] = *(const f32x4_t*)(p.res + (size_t)row * p.ldres + colr);
-    }
     char* tb = smem + P_NSLOT * P_HT + wave * (16 * P_SROW);
+    float csc[2] = {inv_alpha, inv_alpha};          // fp8: the accumulator is multiplied by a_scale * w_scale[n] in the epilogue
+    if constexpr (F8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+      for (int bj = 0; bj < 2; ++bj) {
+        const int col = n0 + wc * 64 + bj * 32 + (lane & 31);
+        const float sc = col < p.N ? p.a_scale * p.w_scale[col] : 1.0f;
+        csc[bj] = sc != 0.f ? inv_alpha / sc : 0.f;
+      }
+    }
+    // the wave's 128 x 64 residual sub-tile, 4 rows x 256 B per instruction; bf16: all 32 vectors in flight together (they
+    // land in the accumulator registers themselves); fp8: two halves of 16 (the 16-register accumulator blocks cannot
+    // alias the staging vectors, and 128 + 128 registers do not exist)
+    constexpr int NPART = F8 ? 2 : 1, QP = 32 / NPART;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *(f32x4_t*)(tb + (q * 4 + lr4) * P_SROW + lc4 * 4) = acc[i][q];
-      __builtin_amdgcn_wave_barrier();
+    for (int part = 0; part < NPART; ++part) {
+      f32x4_t rv[QP];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int q = 0; q < QP; ++q) {
+        const int qq = part * QP + q;
+        const int row = min(m0 + wr * 128 + (qq >> 2) * 16 + (qq & 3) * 4 + lr4, p.M - 1);
+        rv[q] = *(const f32x4_t*)(p.res + (size_t)row * p.ldres + colr);
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = *(const float*)(tb + (lr4 * 4 + r) * P_SROW + (j * 16 + (lane & 15)) * 4) * inv_alpha;
-      __builtin_amdgcn_wave_barrier();
+      for (int ii = 0; ii < 8 / NPART; ++ii) {     // 16-row slab i: coalesced rows in, accumulator layout out
+        const int i = part * (8 / NPART) + ii;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4_t*)(tb + (q * 4 + lr4) * P_SROW + lc4 * 4) = rv[ii * 4 + q];
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (F8) {
+          const int bi = i >> 1, hh = i & 1;
+          const int r32 = 4 * (lane >> 5), c32 = lane & 31;
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc32[bi][bj][8 * hh + 4 * qq + r] = *(const float*)(tb + (8 * qq + r32 + r) * P_SROW + (bj * 32 + c32) * 4) * csc[bj];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = *(const float*)(tb + (lr4 * 4 + r) * P_SROW + (j * 16 + (lane & 15)) * 4) * inv_alpha;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   } else {
+    if constexpr (F8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
   }
   {
-    const int infl = (nh < P_NSLOT - 1 ? nh : P_NSLOT - 1) - 2;     // half-tiles 0 and 1 have landed
+    const int infl = (nh < P_LEAD ? nh : P_LEAD) - 2;     // half-tiles 0 and 1 have landed
     if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>(); else wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 1] = wall_clock64();
 
-  const int frow = lane & 15, lgrp = lane >> 4;
+  // fragment addressing (as gemm2_kernel).  bf16: lane = (row 0..15, 16-byte column group 0..3 of the 64-byte k32 slice), a
+  // fragment set is [16-row fragment][k32 slice].  fp8: lane = (row 0..31, half g); the lane's 32 bytes of a k64 slice are
+  // the 16-byte columns 2g, 2g+1; a set is [32-row block x k64 slice][column].
+  const int frow = F8 ? (lane & 31) : (lane & 15), lgrp = F8 ? (lane >> 5) : (lane >> 4);
   const int swz = (frow >> 1) & 7;
-  const int ro0 = ((0 * 4 + lgrp) ^ swz) << 4, ro1 = ((1 * 4 + lgrp) ^ swz) << 4;
-  const int a_off = (wr * 64 + frow) * ROW2;       // in an A half-tile: rows wr*64 + 16 i + frow
+  const int ro0 = F8 ? ((0 * 4 + 2 * lgrp) ^ swz) << 4 : ((0 * 4 + lgrp) ^ swz) << 4;
+  const int ro1 = F8 ? ((1 * 4 + 2 * lgrp) ^ swz) << 4 : ((1 * 4 + lgrp) ^ swz) << 4;
+  const int rh0 = ((0 * 4 + 2 * lgrp + 1) ^ swz) << 4, rh1 = ((1 * 4 + 2 * lgrp + 1) ^ swz) << 4;     // fp8: second column
+  const int a_off = (wr * 64 + frow) * ROW2;       // in an A half-tile: rows wr*64 + 16 i (32 bi) + frow
   const int b_off = (wc * 32 + frow) * ROW2;       // in a B half-tile: rows wc*32 + 16 j + frow
-  uint4 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];          // [fragment][k32 slice]
-  auto read_a = [&](uint4 (&f)[4][2], int slot) __attribute__((always_inline)) {
+  // A set: k-half 0 / 1 = the first / second 64 bytes of the 128-byte row.  bf16: [16-row fragment i]; fp8: [32-row block
+  // bi][16-byte column v] (a lane's 32 bytes of a k64 slice).  B sets: bf16 [fragment j][k32 slice], fp8 [k64 slice][v].
+  uint4 fa_lo[4], fa_hi[4], fh[4], fb0[2][2], fb1[2][2];
+  auto read_a_half = [&](auto halfc, uint4 (&f)[4], int slot) __attribute__((always_inline)) {
+    constexpr int hf = decltype(halfc)::value;
     const char* sp = smem + slot * P_HT + a_off;
+    if constexpr (F8) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[i][0] = *(const uint4*)(sp + i * 2048 + ro0); f[i][1] = *(const uint4*)(sp + i * 2048 + ro1); }
+      for (int bi = 0; bi < 2; ++bi) {
+        f[bi * 2 + 0] = *(const uint4*)(sp + bi * 4096 + (hf ? ro1 : ro0));
+        f[bi * 2 + 1] = *(const uint4*)(sp + bi * 4096 + (hf ? rh1 : rh0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = *(const uint4*)(sp + i * 2048 + (hf ? ro1 : ro0));
+    }
   };
   auto read_b = [&](uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
     const char* sp = smem + slot * P_HT + b_off;
+    if constexpr (F8) {
+      f[0][0] = *(const uint4*)(sp + ro0); f[0][1] = *(const uint4*)(sp + rh0);
+      f[1][0] = *(const uint4*)(sp + ro1); f[1][1] = *(const uint4*)(sp + rh1);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { f[j][0] = *(const uint4*)(sp + j * 2048 + ro0); f[j][1] = *(const uint4*)(sp + j * 2048 + ro1); }
+      for (int j = 0; j < 2; ++j) { f[j][0] = *(const uint4*)(sp + j * 2048 + ro0); f[j][1] = *(const uint4*)(sp + j * 2048 + ro1); }
+    }
   };
-  auto mma_q = [&](auto aic, auto bjc, const uint4 (&fa)[4][2], const uint4 (&fb)[2][2]) __attribute__((always_inline)) {
+  // quadrant (ai, bj) of the wave tile += A (k-halves alo, ahi) x B
+  auto mma_q = [&](auto aic, auto bjc, const uint4 (&alo)[4], const uint4 (&ahi)[4], const uint4 (&fb)[2][2]) __attribute__((always_inline)) {
     constexpr int ai = decltype(aic)::value, bj = decltype(bjc)::value;
+    if constexpr (F8) {
+      struct Pair { uint4 lo, hi; };      // the two 16-byte vectors of a lane = one 8-register operand
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int bi = 0; bi < 2; ++bi) {
+          const i32x8_t a8 = __builtin_bit_cast(i32x8_t, (Pair{sl ? ahi[bi * 2] : alo[bi * 2], sl ? ahi[bi * 2 + 1] : alo[bi * 2 + 1]}));
+          const i32x8_t b8 = __builtin_bit_cast(i32x8_t, (Pair{fb[sl][0], fb[sl][1]}));
+          acc32[ai * 2 + bi][bj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc32[ai * 2 + bi][bj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Mma16<T>::run(fa[i][s], fb[j][s], acc[ai * 4 + i][bj * 2 + j]);
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma16<T>::run(s ? ahi[i] : alo[i], fb[j][s], acc[ai * 4 + i][bj * 2 + j]);
+    }
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
@@ -859,41 +946,44 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  read_a(fa0, 0);
+  std::integral_constant<int, 0> h0;
+  std::integral_constant<int, 1> h1;
+  read_a_half(h0, fh, 0);
   if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind the first from here on
   int ph = 0;                       // phase counter
-  int s_rd = 1 % P_NSLOT;           // slot of half-tile ph+1
-  int s_st = P_NSLOT - 1;           // slot of half-tile ph+P_NSLOT-1
+  int s_cur = 0;                    // slot of half-tile ph
+  int s_rd = 1;                     // slot of half-tile ph+1
+  int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
   auto adv = [&]() __attribute__((always_inline)) {
     ++ph;
+    s_cur = s_rd;
     s_rd = s_rd + 1 == P_NSLOT ? 0 : s_rd + 1;
     s_st = s_st + 1 == P_NSLOT ? 0 : s_st + 1;
   };
   // one K step = four phases.  TAIL = the last K steps, where the ring runs dry: requests and waits become conditional
   auto kstep = [&](auto tailc, int t) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tailc)::value;
-    constexpr int LEAD = P_NSLOT - 1;                // phase ph requests half-tile ph + LEAD = K step t + (j + LEAD) / 4
     auto ph_head = [&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
-      constexpr int dt = (j + LEAD) / 4;             // 1 or 2 K steps ahead
+      constexpr int dt = (j + P_LEAD) / 4;           // 1 or 2 K steps ahead
       static_assert(dt == 1 || dt == 2, "ring depth");
-      if (!TAIL || ph + LEAD < nh) stage_ty(std::integral_constant<int, (j + LEAD) & 3>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
+      if (!TAIL || ph + P_LEAD < nh) stage_ty(std::integral_constant<int, (j + P_LEAD) & 3>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
     };
     auto ph_wait = [&]() __attribute__((always_inline)) {
       if (TAIL) wait_tail(ph); else wait_vm<2 * P_DEPTH>();
     };
-    ph_head(std::integral_constant<int, 0>()); read_b(fb0, s_rd); ph_wait();
-    mid(); mma_q(c0, c0, fa0, fb0); end(); adv();
+    ph_head(std::integral_constant<int, 0>()); read_a_half(h1, fa_hi, s_cur); read_b(fb0, s_rd); ph_wait();
+    mid(); mma_q(c0, c0, fh, fa_hi, fb0); end(); adv();
     ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait();
-    mid(); mma_q(c0, c1, fa0, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 2>()); read_a(fa1, s_rd); ph_wait();
-    mid(); mma_q(c1, c1, fa1, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 3>()); if (!TAIL || t + 1 < nk) read_a(fa0, s_rd); ph_wait();
-    mid(); mma_q(c1, c0, fa1, fb0); end(); adv();
+    mid(); mma_q(c0, c1, fh, fa_hi, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 2>()); read_a_half(h0, fa_lo, s_rd); read_a_half(h1, fa_hi, s_rd); ph_wait();
+    mid(); mma_q(c1, c1, fa_lo, fa_hi, fb1); end(); adv();
+    ph_head(std::integral_constant<int, 3>()); if (!TAIL || t + 1 < nk) read_a_half(h0, fh, s_rd); ph_wait();
+    mid(); mma_q(c1, c0, fa_lo, fa_hi, fb0); end(); adv();
     ak1 = ak2; ac1 = ac2;
     advance(ak2, ac2);
   };
-  constexpr int NTAIL = (P_NSLOT - 1 + 3) / 4 + 1;   // K steps whose phases may find nothing left to request / wait for
+  constexpr int NTAIL = (P_LEAD + 3) / 4 + 1;        // K steps whose phases may find nothing left to request / wait for
   int t = 0;
   for (; t < nk - NTAIL; ++t) kstep(std::false_type(), t);
   for (; t < nk; ++t) kstep(std::true_type(), t);
@@ -909,26 +999,43 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
                       (p.res == nullptr || ((p.ldres % 4) == 0 && ((size_t)p.res & 15) == 0));
   if (vec_ok) {
     char* slab = smem + P_NSLOT * P_HT + wave * (16 * P_SROW);
-    constexpr int CPL = sizeof(OutT) == 4 ? 4 : 8;                               // columns per lane
+    constexpr int CPL = sizeof(OutT) == 4 ? 4 : (sizeof(OutT) == 2 ? 8 : 16);   // columns per lane
     constexpr int LPR = 64 / CPL;                                                // lanes per slab row
     constexpr int RPP = 64 / LPR;                                                // rows per pass
     constexpr int NQ = 16 / RPP;                                                 // passes per slab
     const int orow = lane / LPR;
     const int ocol = (lane % LPR) * CPL;
     const int col0 = n0 + wc * 64 + ocol;
-    float biasv[CPL];
+    float biasv[CPL], scv[F8 ? CPL : 1];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) biasv[e] = (p.bias && col0 + e < p.N) ? p.bias[col0 + e] : 0.0f;
+    if constexpr (F8) {
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) scv[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
+    }
     const bool seg_full = col0 + CPL <= p.N;
     auto finish_v = [&](auto actf) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_wave_barrier();
+        if constexpr (F8) {
+          // rows [16i, 16i+16) of the wave tile = half hh = i&1 of block row bi = i>>1: registers 8hh .. 8hh+7
+          const int bi = i >> 1, hh = i & 1;
+          const int r32 = 4 * (lane >> 5), c32 = lane & 31;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *(float*)(slab + (crow + r) * P_SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(float*)(slab + (8 * qq + r32 + r) * P_SROW + (bj * 32 + c32) * 4) = acc32[bi][bj][8 * hh + 4 * qq + r];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(float*)(slab + (crow + r) * P_SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -941,6 +1048,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
           }
           const int row = m0 + wr * 128 + i * 16 + srow;
           if (row >= p.M || col0 >= p.N) continue;
+          if constexpr (F8) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] *= scv[e];
+          }
 #pragma unroll
           for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
           OutT* cp = C + (size_t)row * p.ldc + col0;
@@ -953,7 +1064,11 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
                 v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
               }
             }
-            if constexpr (sizeof(OutT) == 2) {
+            if constexpr (sizeof(OutT) == 1) {
+              const float qs = p.out_inv_scale;
+              *(uint4*)cp = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                                       pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+            } else if constexpr (sizeof(OutT) == 2) {
               uint4 o0;
               o0.x = pack2_bf16(v[0], v[1]);
               o0.y = pack2_bf16(v[2], v[3]);
@@ -967,7 +1082,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
             for (int e = 0; e < CPL && col0 + e < p.N; ++e) {
               float o = v[e];
               if (p.res && !res_acc) o += p.res[(size_t)row * p.ldres + col0 + e];
-              cp[e] = Cvt<OutT>::from_f32(o);
+              if constexpr (sizeof(OutT) == 1) cp[e] = (OutT)(pack4_fp8(o * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
+              else cp[e] = Cvt<OutT>::from_f32(o);
             }
           }
         }
@@ -980,6 +1096,31 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     return;
   }
   // unaligned output / residual rows: element-wise stores
+  if constexpr (F8) {
+    auto finish32 = [&](auto actf) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const int col = n0 + wc * 64 + bj * 32 + (lane & 31);
+          const float bvv = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+          const float sc = col < p.N ? p.a_scale * p.w_scale[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= p.M || col >= p.N) continue;
+            float v = actf(acc32[bi][bj][r] * sc + bvv) * p.alpha;
+            if (p.res && !res_acc) v += p.res[(size_t)row * p.ldres + col];
+            if constexpr (sizeof(OutT) == 1) C[(size_t)row * p.ldc + col] = (OutT)(pack4_fp8(v * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
+            else C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
+          }
+        }
+    };
+    if (p.act == ACT_SILU) finish32([](float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); });
+    else if (p.act == ACT_RELU) finish32([](float v) { return fmaxf(v, 0.0f); });
+    else finish32([](float v) { return v; });
+    return;
+  } else {
   float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1009,12 +1150,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   if (p.act == ACT_SILU) finish([](float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); });
   else if (p.act == ACT_RELU) finish([](float v) { return fmaxf(v, 0.0f); });
   else finish([](float v) { return v; });
+  }
 }
 
-template <typename OutT, bool CONV>
+template <typename T, typename OutT, bool CONV>
 static int launch2p(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
-  auto kern = gemm2p_kernel<OutT, CONV>;
+  auto kern = gemm2p_kernel<T, OutT, CONV>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
     attr_set = true;
@@ -1052,17 +1194,26 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 // tuning switches (tests / scripts/gemm_bench.py / environment; none changes results beyond fp32 summation order):
 //   bit 0  32x32x16 MFMAs        bit 1  s_setprio 1 for waves 4-7 in the K loop        group_m: tile order (0/1 = row-major)
 //   bit 2  bf16: the round-2 register-pipelined loop (one 64-KiB stage per K step) instead of the phase-interleaved one
+//   bit 3  fp8: the phase-interleaved loop (gemm2p_kernel<fp8_t>) instead of gemm2_kernel's plain loop.  Exact, but slower on
+//          the engine's shapes (1 h r640: fp8 GEMMs 58.6 vs 49.7 ms, step 141.4 vs 132.4 ms, gpurun_out/s5): K = 1024 is only 8
+//          fp8 K steps, so 3 of them run the tail form of the loop, and next to 16-register accumulator blocks the allocator
+//          spills (4-8 scratch accesses per K step in two of the three output variants)
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
-  if (g_gemm2_group_m < 0) { const char* e = getenv("RVB_GEMM2_GROUP_M"); g_gemm2_group_m = e ? atoi(e) : GEMM2_DEFAULT_GROUP_M; }
+  if (g_gemm2_group_m == -1) { const char* e = getenv("RVB_GEMM2_GROUP_M"); g_gemm2_group_m = e ? atoi(e) : GEMM2_DEFAULT_GROUP_M; }
 }
 
 int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   gemm2_opts_from_env();
   GemmArgs p = p0;
-  p.group_m = g_gemm2_group_m;
+  p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
+  if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
+    if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
+    if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);
+    return launch2p<fp8_t, bf16_t, false>(s, p);
+  }
   if (p.in_fp8) {
     if (p.out_fp8) return launch2<fp8_t, fp8_t, false, true>(s, p);
     if (p.out_f32) return launch2<fp8_t, float, false, true>(s, p);
@@ -1074,8 +1225,8 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
       return p.conv ? launch2<bf16_t, bf16_t, true, true>(s, p) : launch2<bf16_t, bf16_t, false, true>(s, p);
     }
     if (!(g_gemm2_flags & 4)) {     // the phase-interleaved loop (default)
-      if (p.out_f32) return p.conv ? launch2p<float, true>(s, p) : launch2p<float, false>(s, p);
-      return p.conv ? launch2p<bf16_t, true>(s, p) : launch2p<bf16_t, false>(s, p);
+      if (p.out_f32) return p.conv ? launch2p<bf16_t, float, true>(s, p) : launch2p<bf16_t, float, false>(s, p);
+      return p.conv ? launch2p<bf16_t, bf16_t, true>(s, p) : launch2p<bf16_t, bf16_t, false>(s, p);
     }
     if (p.out_f32) return p.conv ? launch2<bf16_t, float, true>(s, p) : launch2<bf16_t, float, false>(s, p);
     return p.conv ? launch2<bf16_t, bf16_t, true>(s, p) : launch2<bf16_t, bf16_t, false>(s, p);

@@ -46,6 +46,7 @@ class DiarEngine:
         c.emb_channels = int(cfg["emb_channels"]) if embedding_sd is not None else 0
         self.dtype = dtype
         self._h = C.c_void_p()
+        self.device_index = int(device)
         _check(self.lib.rvd_create(C.byref(c), device, C.byref(self._h)), "rvd_create")
         for prefix, sd in (("segmentation.", segmentation_sd), ("embedding.", embedding_sd or {})):
             for name, v in sd.items():

@@ -9,7 +9,7 @@ per-chunk time offset (`:320-325`) couples them, on the host.
 from __future__ import annotations
 
 from collections.abc import Sequence
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -151,18 +151,24 @@ N_COLLECTIVES = 0        # all-gathers issued by all_gather_results so far (test
 
 
 class RvbComm:
-    """The C-ABI collective (include/rvb.h: rvb_comm_unique_id / rvb_comm_init / rvb_allgather_results): RCCL bound directly by
-    librvb on the engine's own stream, for hosts that do not run torch.distributed.  One communicator per engine (= per GPU =
-    per rank).  The 128-byte id reaches the other ranks by a side channel: `from_torch_group` broadcasts it over an existing
-    process group, `from_file` through a file on a shared directory (rank 0 writes it atomically, the others wait for it)."""
+    """The C-ABI collective (include/rvb.h: rvb_comm_unique_id / rvb_comm_create / rvb_comm_allgather): RCCL bound directly by
+    librvb on a stream of its own, no torch tensor in the loop.  One communicator per process (= per GPU = per rank), shared
+    by the ASR engine and the diarization engine of that rank.  The 128-byte id reaches the other ranks by a side channel:
+    `from_torch_group` broadcasts it over an existing process group, `from_file` through a file on a shared directory
+    (rank 0 writes it atomically, the others wait for it).  `engine` may be an Engine / DiarEngine (its device is used) or a
+    device index."""
 
     def __init__(self, engine, world: int, rank: int, unique_id: bytes):
         import ctypes as C
-        from ._lib import check
+        from . import _lib
         assert len(unique_id) == 128
-        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        self.lib = _lib.load()
+        self.world, self.rank = int(world), int(rank)
+        device = engine if isinstance(engine, int) else int(getattr(engine, "device_index", getattr(engine, "device", 0)) or 0)
         self._id = C.create_string_buffer(unique_id, 128)
-        check(engine.lib.rvb_comm_init(engine.handle, self.world, self.rank, C.cast(self._id, C.c_void_p)), "rvb_comm_init")
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.rvb_comm_create(device, self.world, self.rank, C.cast(self._id, C.c_void_p), C.byref(self.handle)),
+                   "rvb_comm_create")
 
     @staticmethod
     def unique_id() -> bytes:
@@ -222,22 +228,65 @@ class RvbComm:
         from ._lib import check
         send = np.ascontiguousarray(send)
         recv = np.empty((self.world,) + send.shape, send.dtype)
-        check(self.engine.lib.rvb_allgather_results(self.engine.handle, send.ctypes.data, send.nbytes, recv.ctypes.data), "rvb_allgather_results")
+        check(self.lib.rvb_comm_allgather(self.handle, send.ctypes.data, send.nbytes, recv.ctypes.data), "rvb_comm_allgather")
         return recv
 
     def close(self):
-        self.engine.lib.rvb_comm_destroy(self.engine.handle)
+        if self.handle:
+            self.lib.rvb_comm_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_COMM = None
+
+
+def default_comm(engine):
+    """The transport of the result gathers: librvb's own RCCL binding (`rvb_comm_create` / `rvb_comm_allgather`,
+    csrc/comm.hip -- no torch tensor in the loop) whenever the process group runs on GPUs ("nccl" = RCCL) and `engine` is a
+    real librvb engine (ASR or diarization); None = torch.distributed (the gloo CPU tests with stub engines, or
+    RVB_COMM=torch).  The unique id travels once through the existing process group; the communicator is process-wide."""
+    import os
+    import torch.distributed as dist
+    global _DEFAULT_COMM
+    if os.environ.get("RVB_COMM", "cabi") == "torch" or dist.get_backend() != "nccl":
+        return None
+    if engine is None or not hasattr(engine, "lib"):
+        return None
+    if _DEFAULT_COMM is None or not _DEFAULT_COMM.handle:
+        _DEFAULT_COMM = RvbComm.from_torch_group(engine)
+    return _DEFAULT_COMM
+
+
+def gather_words(send: np.ndarray, device, comm: "RvbComm" = None) -> np.ndarray:
+    """ONE all-gather of equal-size int32 buffers: -> [world, len(send)] on the host, in rank order."""
+    global N_COLLECTIVES
+    send = np.ascontiguousarray(send, dtype=np.int32)
+    N_COLLECTIVES += 1
+    if comm is not None:                           # librvb's own RCCL binding (rvb_allgather_results)
+        return comm.all_gather(send)
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    t = torch.from_numpy(send).to(device)
+    g = torch.empty(world * send.size, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(g, t)
+    return g.cpu().numpy().reshape(world, send.size)   # one device-to-host copy
 
 
 def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = None, comm: "RvbComm" = None) -> "GatheredResults":
     """All ranks end up with every rank's results in rank (= chunk) order after ONE all-gather.  Payload: tokens,
     CTC peak frames, score, confidences -- about 1.3 KB per chunk, latency-bound on xGMI.
     `max_count` = the largest number of results any rank contributes; it sizes the fixed-capacity buffer and must
-    be the same on every rank (default: len(hyps), i.e. every rank holds equally many).  `comm`: an RvbComm to use
-    librvb's C-ABI collective instead of torch.distributed."""
-    import torch
+    be the same on every rank (default: len(hyps), i.e. every rank holds equally many).  `comm`: the RvbComm of
+    default_comm() -- librvb's C-ABI collective -- or None for torch.distributed."""
     import torch.distributed as dist
-    global _ROW_WORDS, N_COLLECTIVES
+    global _ROW_WORDS
     world = comm.world if comm is not None else dist.get_world_size()
     buf = pack_results(hyps)
     count = max(int(max_count if max_count is not None else len(hyps)), 1)
@@ -246,14 +295,7 @@ def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = No
         send = np.zeros(cap, np.int32)
         m = min(cap, buf.size)
         send[:m] = buf[:m]                         # the header always fits and states what this rank needs
-        if comm is not None:                       # librvb's own RCCL binding (rvb_allgather_results), no torch in the loop
-            host = comm.all_gather(send)
-        else:
-            t = torch.from_numpy(send).to(device)
-            g = torch.empty(world * cap, dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(g, t)
-            host = g.cpu().numpy().reshape(world, cap)  # one device-to-host copy
-        N_COLLECTIVES += 1
+        host = gather_words(send, device, comm)
         need = int((_HDR + host[:, 2].astype(np.int64) + 2 * host[:, 3].astype(np.int64)).max())
         if need <= cap:
             break
@@ -277,7 +319,7 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
         local = engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
     # every mode's rows travel in the same single all-gather: rank block = [mode 0 rows | mode 1 rows | ...]
     kmax = max(b - a for a, b in chunk_ranges(n_chunks, world))
-    merged = all_gather_results([h for m in modes for h in local[m]], device, max_count=kmax * len(modes))
+    merged = all_gather_results([h for m in modes for h in local[m]], device, max_count=kmax * len(modes), comm=default_comm(engine))
     out = {m: [] for m in modes}
     for r, (a, b) in enumerate(chunk_ranges(n_chunks, world)):
         rows = merged._rank(r)
@@ -296,13 +338,49 @@ def window_sample_range(n_samples: int, window: int, step: int, w0: int, w1: int
     return w0 * step, min(n_samples, (w1 - 1) * step + window)
 
 
+def segmentation_frames(window_samples: int) -> int:
+    """Output frames of the PyanNet segmentation model for one window: SincNet (conv k=251 stride 10, then three times
+    {max-pool 3, conv k=5} with the pool in front of the last two convolutions) -- 160 000 samples -> 589 frames."""
+    n = (window_samples - 251) // 10 + 1
+    n = n // 3
+    n = (n - 5 + 1) // 3
+    n = (n - 5 + 1) // 3
+    return n
+
+
+def pack_diar_shard(classes: Optional[np.ndarray], emb: Optional[np.ndarray], kmax: int, frames: int, dim: int) -> np.ndarray:
+    """One rank's windows as int32 words: [n_windows, frames, dim, 0 | classes uint8 (kmax x frames, padded to words) |
+    embeddings fp32 bit patterns (kmax x 3 x dim)]; fixed size for given (kmax, frames, dim)."""
+    cw = -(-(kmax * frames) // 4)
+    out = np.zeros(4 + cw + kmax * 3 * dim, np.int32)
+    n = 0 if classes is None else classes.shape[0]
+    out[:4] = (n, frames, dim, 0)
+    if n:
+        assert classes.shape == (n, frames) and emb.shape == (n, 3, dim) and n <= kmax
+        cb = np.zeros(cw * 4, np.uint8)
+        cb[:n * frames] = np.ascontiguousarray(classes, np.uint8).reshape(-1)
+        out[4:4 + cw] = cb.view(np.int32)
+        e = np.full((kmax, 3, dim), np.nan, np.float32)
+        e[:n] = emb
+        out[4 + cw:] = e.reshape(-1).view(np.int32)
+    return out
+
+
+def unpack_diar_shard(words: np.ndarray, kmax: int):
+    n, frames, dim = int(words[0]), int(words[1]), int(words[2])
+    cw = -(-(kmax * frames) // 4)
+    classes = words[4:4 + cw].view(np.uint8)[:n * frames].reshape(n, frames).copy()
+    emb = words[4 + cw:4 + cw + kmax * 3 * dim].view(np.float32).reshape(kmax, 3, dim)[:n].copy()
+    return classes, emb
+
+
 def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
     """Diarize one long recording with the 10 s windows of pyannote's sliding inference split into contiguous
     ranges, one per rank (one process per GPU).  Both networks run on the rank's own windows with no data-path
-    collective; one all-gather then brings the per-window powerset classes (uint8, 589 B per window) and the
-    speaker embeddings (3 x 256 fp32 per window) to every rank, and the global part -- speaker count,
-    clustering, reconstruction -- runs identically everywhere.  Returns the Annotation on every rank."""
-    import torch
+    collective; ONE all-gather (the same transport as the ASR results: librvb's rvb_allgather_results on GPUs) then
+    brings the per-window powerset classes (uint8, 589 B per window) and the speaker embeddings (3 x 256 fp32 per
+    window) of every rank to every rank in one packed buffer, and the global part -- speaker count, clustering,
+    reconstruction -- runs identically everywhere.  Returns the Annotation on every rank."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     cfg = pipeline.cfg
@@ -312,26 +390,18 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
     n_windows = full + (1 if (n < win or (n - win) % step > 0) else 0)
     ranges = chunk_ranges(n_windows, world)
     w0, w1 = ranges[rank]
-    frames = None
+    frames = segmentation_frames(win)               # known without running the network: ranks with no window need it too
+    dim = int(cfg["emb_dim"])
+    classes = emb = None
     if w1 > w0:
         s0, s1 = window_sample_range(n, win, step, w0, w1)
         classes, emb = pipeline.networks(pcm[s0:s1])
-        assert classes.shape[0] == w1 - w0, (classes.shape, w0, w1)
-        frames = classes.shape[1]
-    fr = torch.tensor([frames or 0], device=device, dtype=torch.int64)
-    dist.all_reduce(fr, op=dist.ReduceOp.MAX)
-    frames = int(fr.item())
-    dim = int(cfg["emb_dim"])
+        assert classes.shape == (w1 - w0, frames), (classes.shape, w0, w1, frames)
     kmax = max(b - a for a, b in ranges)
-    pc = np.zeros((kmax, frames), np.uint8)
-    pe = np.full((kmax, 3, dim), np.nan, np.float32)
-    if w1 > w0:
-        pc[:w1 - w0], pe[:w1 - w0] = classes, emb
-    tc, te = torch.from_numpy(pc).to(device), torch.from_numpy(pe).to(device)
-    gc = [torch.empty_like(tc) for _ in range(world)]
-    ge = [torch.empty_like(te) for _ in range(world)]
-    dist.all_gather(gc, tc)
-    dist.all_gather(ge, te)
-    all_c = np.concatenate([gc[r].cpu().numpy()[:b - a] for r, (a, b) in enumerate(ranges)])
-    all_e = np.concatenate([ge[r].cpu().numpy()[:b - a] for r, (a, b) in enumerate(ranges)])
+    host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, default_comm(getattr(pipeline, "_engine", None)))
+    parts = [unpack_diar_shard(host[r], kmax) for r in range(world)]
+    for r, (a, b) in enumerate(ranges):
+        assert parts[r][0].shape[0] == b - a, (r, parts[r][0].shape, a, b)
+    all_c = np.concatenate([c for c, _ in parts])
+    all_e = np.concatenate([e for _, e in parts])
     return pipeline.finish(all_c, all_e, uri, **kwargs)

@@ -96,6 +96,7 @@ class Engine:
         self.dtype = dtype
         self.cfg = model_cfg_from_configs(configs, dtype, max_chunks, chunk_frames)
         self.handle = C.c_void_p()
+        self.device_index = int(device)
         check(self.lib.rvb_create(C.byref(self.cfg), int(device), C.byref(self.handle)), "rvb_create")
         if "model0" in state_dict and isinstance(state_dict["model0"], dict):     # checkpoint.py:38-41
             state_dict = state_dict["model0"]

@@ -108,8 +108,9 @@ def test_api_is_callable_from_a_worker_thread(tmp_path):
 
 
 def test_cabi_collective_on_one_rank():
-    """rvb_comm_unique_id / rvb_comm_init / rvb_allgather_results (RCCL bound directly by librvb) with a world of one:
-    the only size a 1-GPU box can run; the packed-result gather through it returns what went in."""
+    """rvb_comm_unique_id / rvb_comm_create / rvb_comm_allgather (RCCL bound directly by librvb; the stand-alone communicator
+    reverb_amd.dist uses by default on GPUs) and the engine-bound rvb_comm_init / rvb_allgather_results, with a world of one:
+    the only size a 1-GPU box can run; the packed-result gather and the packed diarization shard return what went in."""
     from golden_util import Case
     from reverb_amd import dist as rdist
     from reverb_amd.engine import Engine
@@ -125,5 +126,24 @@ def test_cabi_collective_on_one_rank():
     hyps[1].ctc_frames = [9]
     got = rdist.all_gather_results(hyps, None, comm=comm)
     assert [(list(h.tokens), h.times, h.ctc_frames, h.score) for h in got] == [([1, 2, 3], [4, 5, 6], None, -1.5), ([7], None, [9], 0.0)]
+    # the diarization shard's one packed buffer through the same communicator
+    rng = np.random.default_rng(0)
+    classes = rng.integers(0, 7, size=(3, 589)).astype(np.uint8)
+    emb = rng.standard_normal((3, 3, 256)).astype(np.float32)
+    emb[1, 2] = np.nan
+    host = rdist.gather_words(rdist.pack_diar_shard(classes, emb, 5, 589, 256), None, comm)
+    c2, e2 = rdist.unpack_diar_shard(host[0], 5)
+    np.testing.assert_array_equal(c2, classes)
+    np.testing.assert_array_equal(np.isnan(e2), np.isnan(emb))
+    np.testing.assert_array_equal(np.nan_to_num(e2), np.nan_to_num(emb))
     comm.close()
+    # the engine-bound form of the same collective
+    import ctypes as C
+    from reverb_amd._lib import check
+    idbuf = C.create_string_buffer(rdist.RvbComm.unique_id(), 128)
+    check(eng.lib.rvb_comm_init(eng.handle, 1, 0, C.cast(idbuf, C.c_void_p)), "rvb_comm_init")
+    y = np.empty_like(x)
+    check(eng.lib.rvb_allgather_results(eng.handle, x.ctypes.data, x.nbytes, y.ctypes.data), "rvb_allgather_results")
+    np.testing.assert_array_equal(y, x)
+    check(eng.lib.rvb_comm_destroy(eng.handle), "rvb_comm_destroy")
     eng.close()

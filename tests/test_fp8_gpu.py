@@ -32,7 +32,16 @@ def _e4m3_grid():
     (2100, 512, 512, 0, 0.5, True, 1),          # fp32 residual epilogue (feed-forward's second GEMM)
     (130, 330, 384, 2, 1.0, False, 1),          # unaligned rows: element-wise epilogue
 ])
-def test_fp8_gemm_against_fp64_on_the_quantised_values(lib, M, N, K, act, alpha, use_res, out_kind):
+@pytest.mark.parametrize("flags", [0, 8])        # 8: the phase-interleaved loop (opt-in for fp8: measured slower on K = 1024)
+def test_fp8_gemm_against_fp64_on_the_quantised_values(lib, flags, M, N, K, act, alpha, use_res, out_kind):
+    lib.rvb_test_set_gemm2_opts(flags, -2)
+    try:
+        _fp8_gemm_case(lib, M, N, K, act, alpha, use_res, out_kind)
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+
+
+def _fp8_gemm_case(lib, M, N, K, act, alpha, use_res, out_kind):
     rng = np.random.default_rng(M + N + K)
     A = f32(rng.standard_normal((M, K)) * 1.7)
     W = f32(rng.standard_normal((N, K)) / math.sqrt(K) * (1 + rng.random((N, 1)) * 3))       # channels of different magnitude

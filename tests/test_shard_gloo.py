@@ -251,6 +251,23 @@ def _diar_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_diar_shard_packing_roundtrip():
+    """The one buffer a rank contributes to the diarization gather: classes bytes + embedding bit patterns (NaN = inactive
+    speaker survives), fixed size for (kmax, frames, dim), empty ranks included."""
+    assert rdist.segmentation_frames(160000) == 589 and rdist.segmentation_frames(80000) == 293
+    rng = np.random.default_rng(1)
+    classes = rng.integers(0, 7, size=(4, 589)).astype(np.uint8)
+    emb = rng.standard_normal((4, 3, 16)).astype(np.float32)
+    emb[2, 1] = np.nan
+    w = rdist.pack_diar_shard(classes, emb, 6, 589, 16)
+    assert w.dtype == np.int32 and w.size == rdist.pack_diar_shard(None, None, 6, 589, 16).size
+    c2, e2 = rdist.unpack_diar_shard(w, 6)
+    np.testing.assert_array_equal(c2, classes)
+    assert np.array_equal(np.isnan(e2), np.isnan(emb)) and np.array_equal(np.nan_to_num(e2), np.nan_to_num(emb))
+    c0, e0 = rdist.unpack_diar_shard(rdist.pack_diar_shard(None, None, 6, 589, 16), 6)
+    assert c0.shape == (0, 589) and e0.shape == (0, 3, 16)
+
+
 def test_window_sample_ranges():
     assert rdist.window_sample_range(1000000, 160000, 16000, 0, 3) == (0, 192000)
     assert rdist.window_sample_range(1000000, 160000, 16000, 3, 5) == (48000, 224000)
