@@ -128,19 +128,16 @@ def cpu_baseline(cfg, sd, feats_chunks, lens, args):
 
 
 # ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
-def measure_traffic(args):
-    """HBM bytes per GEMM launch of this workload: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate
-    passes (TCC slots, MI355X_MICROARCH.md) over one step of this same command; FETCH_SIZE doubled (gfx950 tallies the
-    128-byte requests of wide coalesced reads at 64 B), both counters in units of 1024 B.  Returns a dict or None."""
+def pmc_traffic(sub, match, what):
+    """HBM bytes per launch of the kernels whose name contains one of `match`, over one run of the command `sub`:
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots, MI355X_MICROARCH.md); FETCH_SIZE
+    doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B), both counters in units of 1024 B.
+    Returns a dict or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     import csv
     tmp = tempfile.mkdtemp(prefix="rvb_pmc_", dir="/tmp")
-    sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--model", args.model,
-           "--dtype", args.dtype, "--hours", str(args.hours), "--chunks-per-launch", str(args.chunks_per_launch),
-           "--beam", str(args.beam), "--ctc-weight", str(args.ctc_weight), "--reverse-weight", str(args.reverse_weight),
-           "--cpu-baseline-chunks", "0", "--no-profile", "--traffic", "off", "--no-diarization", "--no-pcie"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RVB_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     got = {}
@@ -159,7 +156,7 @@ def measure_traffic(args):
             tot, ids = 0.0, set()
             with open(path) as fh:
                 for row in csv.DictReader(fh):
-                    if "gemm" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if any(m in row["Kernel_Name"] for m in match) and row["Counter_Name"] == counter:
                         tot += float(row["Counter_Value"])
                         ids.add(row["Dispatch_Id"])
             if not ids:
@@ -172,8 +169,17 @@ def measure_traffic(args):
     (f, nf), (w, nw) = got["FETCH_SIZE"], got["WRITE_SIZE"]
     return {"bytes_per_launch": round((2.0 * f) / nf + w / nw, 1), "read_bytes_per_launch": round(2.0 * f / nf, 1),
             "write_bytes_per_launch": round(w / nw, 1), "launches": nf,
-            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over one step of this command, nested "
+            "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over one step of {what}, nested "
                       "in this run; FETCH_SIZE x2 (gfx950 wide-read correction), units of 1024 B"}
+
+
+def measure_traffic(args):
+    """HBM bytes per GEMM launch of this workload (one step of this same command under the two PMC passes)."""
+    sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--model", args.model,
+           "--dtype", args.dtype, "--hours", str(args.hours), "--chunks-per-launch", str(args.chunks_per_launch),
+           "--beam", str(args.beam), "--ctc-weight", str(args.ctc_weight), "--reverse-weight", str(args.reverse_weight),
+           "--cpu-baseline-chunks", "0", "--no-profile", "--traffic", "off", "--no-diarization", "--no-pcie"]
+    return pmc_traffic(sub, ("gemm",), "this command")
 
 
 # ------------------------------------------------------------------------------------------------ stub (CPU test hook)
@@ -196,13 +202,13 @@ class _StubEngine:
 
 
 # ------------------------------------------------------------------------------------------------ diarization sub-record
-def diarization_record(device, steps=2, warmup=1, hours=1.0, dtype="bf16", cpu_windows=2):
+def diarization_record(device, steps=2, warmup=1, hours=1.0, dtype="bf16", cpu_windows=16, traffic="auto"):
     """BASELINE configs[3] on this GPU, measured exactly as bench_diar.py does (one step = one `pipeline(audio)` call
     on `hours` of audio held in host memory); returned as a sub-record of the main line so that the driver's run
     carries it."""
     import bench_diar
     return bench_diar.run(device, rank=0, world=1, dist=None, steps=steps, warmup=warmup, hours=hours, dtype=dtype,
-                          cpu_windows=cpu_windows)
+                          cpu_windows=cpu_windows, traffic=traffic)
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -396,7 +402,7 @@ def main():
                 out["roofline"]["traffic_detail"] = t
         if not args.no_diarization:
             try:
-                out["diarization"] = diarization_record(device)
+                out["diarization"] = diarization_record(device, traffic=args.traffic)
             except Exception as ex:        # the headline line must not die with the second workload
                 out["diarization"] = {"error": f"{type(ex).__name__}: {ex}"}
             try:                           # BASELINE configs[4]: joint pipeline, ASR encoder GEMMs in fp8

@@ -35,8 +35,10 @@ STAGE_KEYS = ("h2d", "sinc_conv", "window_stats", "pool_norm", "sincnet_conv", "
 
 def cpu_baseline(cfg, seg_sd, emb_sd, pcm, n_windows):
     """The oracle (oracle/diar_ref.py: torch restatement of PyanNet + WeSpeaker ResNet34, i.e. what pyannote runs on
-    CPU) on the first windows, the ResNet once per (window, local speaker) as pyannote does."""
+    CPU) on the first windows -- the ResNet once per (window, ACTIVE local speaker) as pyannote does -- followed by the
+    clustering pyannote runs on those embeddings (scipy centroid linkage + fcluster)."""
     import torch
+    from scipy.cluster.hierarchy import fcluster, linkage
     from oracle import diar_ref as R
     cores = min(os.cpu_count() or 1, 32)      # more threads than that only slows the small convolutions down
     torch.set_num_threads(cores)
@@ -45,19 +47,44 @@ def cpu_baseline(cfg, seg_sd, emb_sd, pcm, n_windows):
     x = torch.stack([wav[w * step:w * step + win] for w in range(n_windows)])[:, None]
     ssd, esd = R.to_torch_sd(seg_sd), R.to_torch_sd(emb_sd)
     t0 = time.perf_counter()
+    embs, passes = [], 0
     with torch.no_grad():
         logp = R.pyannet(ssd, x)
         ml = torch.from_numpy(R.powerset_to_multilabel(logp))
         for w in range(n_windows):
-            feats = torch.from_numpy(R.hamming_fbank(x[w, 0].numpy()))[None].repeat(3, 1, 1)
-            R.wespeaker_embed(esd, feats, ml[w].T.contiguous())
-    dt = time.perf_counter() - t0
+            active = [k for k in range(ml.shape[2]) if float(ml[w, :, k].sum()) > 0]
+            if not active:
+                continue
+            feats = torch.from_numpy(R.hamming_fbank(x[w, 0].numpy()))[None].repeat(len(active), 1, 1)
+            e = R.wespeaker_embed(esd, feats, ml[w].T[active].contiguous())
+            embs.append(np.asarray(e, np.float64).reshape(len(active), -1))
+            passes += len(active)
+    t1 = time.perf_counter()
+    n_emb = 0
+    if embs:
+        X = np.concatenate(embs)
+        X = X / np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1e-12)
+        n_emb = len(X)
+        if n_emb > 1:
+            fcluster(linkage(X, method="centroid", metric="euclidean"), 0.7045654963945799, criterion="distance")
+    t2 = time.perf_counter()
+    dt = t2 - t0
     return {"value": round(n_windows * (step / cfg["sample_rate"]) / dt, 3), "unit": "audio-sec/wall-sec", "cores": cores,
-            "kind": "port", "sample": f"{n_windows} windows of 10 s (1 s hop = {n_windows} s of new audio): segmentation + 3 ResNet34 "
-                                      f"passes per window, torch fp32, {dt:.1f} s; clustering not included"}
+            "kind": "port", "sample": f"{n_windows} windows of 10 s (1 s hop = {n_windows} s of new audio): segmentation + {passes} "
+                                      f"ResNet34 passes (one per active local speaker), torch fp32, {t1 - t0:.1f} s; scipy centroid "
+                                      f"linkage + fcluster of the {n_emb} embeddings {1e3 * (t2 - t1):.1f} ms"}
 
 
-def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype="bf16", cpu_windows=3):
+def conv_traffic(hours, dtype):
+    """HBM bytes per convolution launch (ResNet34 trunk: conv_kernel / conv_igemm_kernel / conv_pair32_kernel) from two nested
+    rocprofv3 --pmc passes over one step of this command (see bench.pmc_traffic)."""
+    import bench
+    sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--hours", str(hours),
+           "--dtype", dtype, "--cpu-baseline-windows", "0", "--traffic", "off"]
+    return bench.pmc_traffic(sub, ("conv_kernel", "conv_igemm", "conv_pair32"), "bench_diar.py")
+
+
+def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype="bf16", cpu_windows=16, traffic="off"):
     """Time `steps` diarization passes on `device`; returns the JSON record on rank 0 (None elsewhere).  bench.py calls
     this for its `diarization` sub-record, main() below for the stand-alone line."""
     import torch
@@ -122,6 +149,11 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
         out["cpu_baseline"] = cpu_baseline(cfg, seg_sd, emb_sd, pcm, cpu_windows) if (world == 1 and cpu_windows > 0) else None
     eng.close()
     pipe._engine = None
+    if out is not None and world == 1 and traffic == "auto":      # the GPU is idle now: nested PMC passes of the same workload
+        t = conv_traffic(hours, dtype)
+        if t is not None:
+            out["roofline"]["traffic"] = t["bytes_per_launch"]
+            out["roofline"]["traffic_detail"] = t
     return out
 
 
@@ -132,7 +164,9 @@ def main():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--hours", type=float, default=1.0)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    p.add_argument("--cpu-baseline-windows", type=int, default=3)
+    p.add_argument("--cpu-baseline-windows", type=int, default=16)
+    p.add_argument("--traffic", default="auto", choices=["auto", "off"],
+                   help="auto: at N = 1 measure the convolutions' HBM traffic with two nested rocprofv3 --pmc passes")
     args = p.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # same self-launch as bench.py
         import bench
@@ -153,7 +187,7 @@ def main():
         raise SystemExit("bench_diar.py needs an MI355X: the networks have no CPU fallback")
     device = torch.device("cuda", local_rank)
     out = run(device, rank, world, dist if use_dist else None, args.steps, args.warmup, args.hours, args.dtype,
-              args.cpu_baseline_windows)
+              args.cpu_baseline_windows, args.traffic)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

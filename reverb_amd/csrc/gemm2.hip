@@ -644,6 +644,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 //   phases after the phase whose lgkmcnt(0) retired its last read.
 // The ring takes 112 KiB; the 34 KiB above it are the epilogue's transposition slabs (and the residual prologue's), so
 // neither ever shares a buffer with the operand stream.
+extern int g_gemm2_flags;
 static constexpr int P_NSLOT = 7, P_HT = 128 * ROW2, P_LEAD = P_NSLOT - 2, P_DEPTH = P_LEAD - 2;
 static constexpr int P_SROW = 64 * 4 + 16;                        // padded fp32 slab row (bytes)
 static constexpr int GEMM2P_LDS = P_NSLOT * P_HT + 8 * 16 * P_SROW;
@@ -678,8 +679,14 @@ __device__ inline const char* uniform_ptr(const char* q) {
 // with twice the K per 128-byte row and v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales on 32x32 accumulator blocks
 // -- a phase is then four 64-cycle MFMAs (a 64x32 quadrant = 2 x 1 blocks x two k64 slices), the same 256 matrix-pipe
 // cycles and the same 8 / 4 fragment reads; scaling as in gemm2_kernel (a_scale per tensor, w_scale per output channel).
-template <typename T, typename OutT, bool CONV>
+// PERSIST (full tiles, no convolution gather): one workgroup per CU walks the tiles of its XCD's contiguous run, and the
+// operand stream does not stop at a tile's edge -- the last five phases of a tile request the first five half-tiles of the
+// NEXT tile (same per-lane offsets, the next tile's scalar bases), so they land underneath the epilogue's stores and the
+// next tile starts multiplying after one barrier: the 2 us first-stage wait and the 0.5-2 us dispatch gap of every tile
+// (scripts/gemm_timeline.py) are gone.  The epilogue's slabs have their own LDS, so nothing waits for anything else.
+template <typename T, typename OutT, bool CONV, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
+  static_assert(!(PERSIST && CONV), "the persistent form reuses the per-lane DMA offsets from tile to tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
   constexpr int BKE = ROW2 / (int)sizeof(T);
@@ -687,34 +694,50 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  if (p.dbg && tid == 0) {
-    p.dbg[blockIdx.x * 6 + 0] = wall_clock64();
-    p.dbg[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
-    p.dbg[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
-  }
-  const int tiles_n = (p.N + B2N - 1) / B2N;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
+  const int tiles_n = (p.N + B2N - 1) / B2N, tiles_m = (p.M + B2M - 1) / B2M;
+  // tile order: each XCD (workgroup id mod 8) owns a contiguous run of the linear tile ids, so that its L2 serves tiles that
+  // share operand panels.  One tile per workgroup: id -> the idx-th tile of the run.  PERSIST: workgroup idx of the XCD
+  // takes tiles idx, idx + G/8, ... of the run (G = gridDim.x, a multiple of 8).
+  int lin, lin_end, lin_step;
   {
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntile = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
+    const int q = ntile >> 3, r = ntile & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    lin = start + idx;
+    lin_end = PERSIST ? start + q + (xcd < r ? 1 : 0) : lin + 1;
+    lin_step = PERSIST ? (int)(gridDim.x >> 3) : 1;
+  }
+  auto tile_of = [&](int bid, int& tm, int& tn) __attribute__((always_inline)) {
+    if (p.group_m > 1) {
+      const int per_group = p.group_m * tiles_n;
+      const int g = bid / per_group;
+      const int first_m = g * p.group_m;
+      const int gsz = min(tiles_m - first_m, p.group_m);
+      const int in_g = bid - g * per_group;
+      tm = first_m + in_g % gsz;
+      tn = in_g / gsz;
+    } else {
+      tm = bid / tiles_n; tn = bid - tm * tiles_n;
+    }
+  };
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // ring state: lives across the tiles of a persistent workgroup
+  int s_cur = 0;                    // slot of half-tile ph
+  int s_rd = 1;                     // slot of half-tile ph+1
+  int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
+  bool first_tile = true;
+  for (;;) {
+  const int dbg_i = PERSIST ? lin : (int)blockIdx.x;
+  if (p.dbg && tid == 0) {
+    p.dbg[dbg_i * 6 + 0] = wall_clock64();
+    p.dbg[dbg_i * 6 + 4] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+    p.dbg[dbg_i * 6 + 5] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
   }
   int tm, tn;
-  if (p.group_m > 1) {
-    const int tiles_m = (p.M + B2M - 1) / B2M;
-    const int per_group = p.group_m * tiles_n;
-    const int g = bid / per_group;
-    const int first_m = g * p.group_m;
-    const int gsz = min(tiles_m - first_m, p.group_m);
-    const int in_g = bid - g * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-  } else {
-    tm = bid / tiles_n; tn = bid - tm * tiles_n;
-  }
+  tile_of(lin, tm, tn);
   const int m0 = tm * B2M, n0 = tn * B2N;
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const bool has_next = PERSIST && lin + lin_step < lin_end;
 
   // ---- DMA sources: every wave stages rows [16 wave, +16) of each half-tile = two 1-KiB pieces; 32-bit byte offsets
   // from the tile's first row (rows past M / N are clamped, never stored), the K position goes into the scalar base
@@ -745,6 +768,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   }
   const char* a_base = uniform_ptr((const char*)((const T*)p.A + a_row0));
   const char* w_base = uniform_ptr((const char*)((const T*)p.W + (size_t)n0 * p.ldw));
+  const char* a_next = a_base;      // PERSIST: the scalar bases of this workgroup's next tile
+  const char* w_next = w_base;
+  if (has_next) {
+    int tm2, tn2;
+    tile_of(lin + lin_step, tm2, tn2);
+    a_next = uniform_ptr((const char*)((const T*)p.A + (size_t)tm2 * B2M * p.lda));
+    w_next = uniform_ptr((const char*)((const T*)p.W + (size_t)tn2 * B2N * p.ldw));
+  }
   const int nk = p.K / BKE, nh = 4 * nk;
   const unsigned lds_wave = lds_base + wave * 2048;
   // byte offset of K step u in an A row, kept incrementally (no division in the loop): +128 per step; the implicit
@@ -769,6 +800,15 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     else if constexpr (ty == 1) dma2(offW[0][0], offW[0][1], uniform_ptr(w_base + (size_t)t * ROW2), dst);
     else if constexpr (ty == 2) dma2(offW[1][0], offW[1][1], uniform_ptr(w_base + (size_t)t * ROW2), dst);
     else dma2(offA[1][0], offA[1][1], uniform_ptr(a_base + ak), dst);
+  };
+  // the same for K step t2 (0 or 1) of the NEXT tile (PERSIST; no convolution: K step t2 sits at byte t2 * 128 of a row)
+  auto stage_next = [&](auto tyc, int t2, int slot) __attribute__((always_inline)) {
+    constexpr int ty = decltype(tyc)::value;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + slot * P_HT);
+    if constexpr (ty == 0) dma2(offA[0][0], offA[0][1], uniform_ptr(a_next + (size_t)t2 * ROW2), dst);
+    else if constexpr (ty == 1) dma2(offW[0][0], offW[0][1], uniform_ptr(w_next + (size_t)t2 * ROW2), dst);
+    else if constexpr (ty == 2) dma2(offW[1][0], offW[1][1], uniform_ptr(w_next + (size_t)t2 * ROW2), dst);
+    else dma2(offA[1][0], offA[1][1], uniform_ptr(a_next + (size_t)t2 * ROW2), dst);
   };
   auto stage = [&](int h, int slot) __attribute__((always_inline)) {       // prologue only: K steps 0 and 1
     const int t = h >> 2, ty = h & 3;
@@ -798,7 +838,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
                        ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
   // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
   // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
-  for (int h = 0; h < P_LEAD && h < nh; ++h) stage(h, h);
+  if (first_tile) {       // a later tile of a persistent workgroup found its first half-tiles requested by the tile before it
+    for (int h = 0; h < P_LEAD && h < nh; ++h) stage(h, h);
+  }
   if (res_acc) {
     const float inv_alpha = 1.0f / p.alpha;
     const int lr4 = lane >> 4, lc4 = (lane & 15) * 4;
@@ -866,12 +908,12 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  {
-    const int infl = (nh < P_LEAD ? nh : P_LEAD) - 2;     // half-tiles 0 and 1 have landed
+  if (first_tile) {       // half-tiles 0 and 1 have landed (later tiles: the previous tile's last two phases waited for them)
+    const int infl = (nh < P_LEAD ? nh : P_LEAD) - 2;
     if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>(); else wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 1] = wall_clock64();
+  if (p.dbg && tid == 0) p.dbg[dbg_i * 6 + 1] = wall_clock64();
 
   // fragment addressing (as gemm2_kernel).  bf16: lane = (row 0..15, 16-byte column group 0..3 of the 64-byte k32 slice), a
   // fragment set is [16-row fragment][k32 slice].  fp8: lane = (row 0..31, half g); the lane's 32 bytes of a k64 slice are
@@ -948,26 +990,34 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 
   std::integral_constant<int, 0> h0;
   std::integral_constant<int, 1> h1;
-  read_a_half(h0, fh, 0);
+  read_a_half(h0, fh, s_cur);
   if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind the first from here on
-  int ph = 0;                       // phase counter
-  int s_cur = 0;                    // slot of half-tile ph
-  int s_rd = 1;                     // slot of half-tile ph+1
-  int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
+  int ph = 0;                       // phase counter (of this tile)
   auto adv = [&]() __attribute__((always_inline)) {
     ++ph;
     s_cur = s_rd;
     s_rd = s_rd + 1 == P_NSLOT ? 0 : s_rd + 1;
     s_st = s_st + 1 == P_NSLOT ? 0 : s_st + 1;
   };
-  // one K step = four phases.  TAIL = the last K steps, where the ring runs dry: requests and waits become conditional
-  auto kstep = [&](auto tailc, int t) __attribute__((always_inline)) {
-    constexpr bool TAIL = decltype(tailc)::value;
+  // one K step = four phases.  MODE 0: steady state.  MODE 1: the last K steps of a workgroup's last tile, where the ring
+  // runs dry: requests and waits become conditional.  MODE 2 (PERSIST): the last K steps of a tile that has a successor --
+  // requests past this tile's K go to the next tile, the counted wait stays the steady one.
+  auto kstep = [&](auto modec, int t) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
+    constexpr bool TAIL = MODE == 1;
     auto ph_head = [&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       constexpr int dt = (j + P_LEAD) / 4;           // 1 or 2 K steps ahead
       static_assert(dt == 1 || dt == 2, "ring depth");
-      if (!TAIL || ph + P_LEAD < nh) stage_ty(std::integral_constant<int, (j + P_LEAD) & 3>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
+      constexpr int ty = (j + P_LEAD) & 3;
+      if constexpr (MODE == 2) {          // K step nk-2 of a persistent tile: its last phase requests the next tile's first half-tile
+        if constexpr (dt == 1) stage_ty(std::integral_constant<int, ty>(), t + 1, (size_t)(t + 1) * ROW2, s_st);
+        else stage_next(std::integral_constant<int, ty>(), 0, s_st);
+      } else if constexpr (MODE == 3) {   // K step nk-1: everything requested belongs to the next tile
+        stage_next(std::integral_constant<int, ty>(), dt - 1, s_st);
+      } else {
+        if (!TAIL || ph + P_LEAD < nh) stage_ty(std::integral_constant<int, ty>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
+      }
     };
     auto ph_wait = [&]() __attribute__((always_inline)) {
       if (TAIL) wait_tail(ph); else wait_vm<2 * P_DEPTH>();
@@ -978,17 +1028,26 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     mid(); mma_q(c0, c1, fh, fa_hi, fb1); end(); adv();
     ph_head(std::integral_constant<int, 2>()); read_a_half(h0, fa_lo, s_rd); read_a_half(h1, fa_hi, s_rd); ph_wait();
     mid(); mma_q(c1, c1, fa_lo, fa_hi, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 3>()); if (!TAIL || t + 1 < nk) read_a_half(h0, fh, s_rd); ph_wait();
+    ph_head(std::integral_constant<int, 3>()); if (MODE == 0 || MODE == 2 || (MODE == 1 && t + 1 < nk)) read_a_half(h0, fh, s_rd); ph_wait();
     mid(); mma_q(c1, c0, fa_lo, fa_hi, fb0); end(); adv();
     ak1 = ak2; ac1 = ac2;
     advance(ak2, ac2);
   };
   constexpr int NTAIL = (P_LEAD + 3) / 4 + 1;        // K steps whose phases may find nothing left to request / wait for
   int t = 0;
-  for (; t < nk - NTAIL; ++t) kstep(std::false_type(), t);
-  for (; t < nk; ++t) kstep(std::true_type(), t);
+  if constexpr (PERSIST) {
+    // one loop shape for every tile (nk >= 4, host-checked): the workgroup's last tile "prefetches" its own first half-tiles
+    // again (a_next = a_base: 80 KiB of harmless reads, drained before the workgroup ends) instead of a third form of the loop
+    for (; t < nk - 2; ++t) kstep(std::integral_constant<int, 0>(), t);
+    kstep(std::integral_constant<int, 2>(), nk - 2);
+    kstep(std::integral_constant<int, 3>(), nk - 1);
+  } else {
+    for (; t < nk - NTAIL; ++t) kstep(std::integral_constant<int, 0>(), t);
+    for (; t < nk; ++t) kstep(std::integral_constant<int, 1>(), t);
+  }
   if (wr == 0) __builtin_amdgcn_s_barrier();       // balances the stagger: every wave has executed the same number of barriers
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 6 + 2] = wall_clock64();
+  if (p.dbg && tid == 0) p.dbg[dbg_i * 6 + 2] = wall_clock64();
+  auto epilogue = [&]() __attribute__((always_inline)) {
 
   // ---- epilogue (as gemm2_kernel's 16x16 path; the slabs have their own LDS above the ring)
   OutT* __restrict__ C = (OutT*)p.C;
@@ -1092,7 +1151,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     if (p.act == ACT_SILU) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
     else if (p.act == ACT_RELU) finish_v([](float x) { return fmaxf(x, 0.0f); });
     else finish_v([](float x) { return x; });
-    if (p.dbg && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[blockIdx.x * 6 + 3] = wall_clock64(); }
+    if (p.dbg && tid == 0) { if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[dbg_i * 6 + 3] = wall_clock64(); }
     return;
   }
   // unaligned output / residual rows: element-wise stores
@@ -1151,17 +1210,42 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   else if (p.act == ACT_RELU) finish([](float v) { return fmaxf(v, 0.0f); });
   else finish([](float v) { return v; });
   }
+  };     // epilogue
+  epilogue();
+  if (!has_next) {
+    if (PERSIST) wait_vm<0>();        // the ring's last (unused) requests must not outlive the workgroup's LDS
+    break;
+  }
+  lin += lin_step;
+  first_tile = false;
+  }      // tiles of this workgroup
 }
 
 template <typename T, typename OutT, bool CONV>
 static int launch2p(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
-  auto kern = gemm2p_kernel<T, OutT, CONV>;
+  static int ncu = 0;
+  auto kern = gemm2p_kernel<T, OutT, CONV, false>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    if constexpr (!CONV && std::is_same<T, bf16_t>::value)
+      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    int dev = 0;
+    hipDeviceProp_t pr;
+    RVB_HIP_CHECK(hipGetDevice(&dev));
+    RVB_HIP_CHECK(hipGetDeviceProperties(&pr, dev));
+    ncu = pr.multiProcessorCount & ~7;
     attr_set = true;
   }
   const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
+  if constexpr (!CONV && std::is_same<T, bf16_t>::value) {
+    // persistent form: full tiles only, and at least two tiles per CU (otherwise there is nothing to prefetch across)
+    if ((g_gemm2_flags & 16) && ncu >= 8 && p.M % B2M == 0 && p.N % B2N == 0 && tiles >= 2 * ncu && p.K >= 4 * (ROW2 / 2)) {
+      hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, true>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
+      RVB_HIP_CHECK(hipGetLastError());
+      return OK;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), GEMM2P_LDS, s, p);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
@@ -1194,6 +1278,12 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 // tuning switches (tests / scripts/gemm_bench.py / environment; none changes results beyond fp32 summation order):
 //   bit 0  32x32x16 MFMAs        bit 1  s_setprio 1 for waves 4-7 in the K loop        group_m: tile order (0/1 = row-major)
 //   bit 2  bf16: the round-2 register-pipelined loop (one 64-KiB stage per K step) instead of the phase-interleaved one
+//   bit 4  bf16: the persistent form of the phase-interleaved loop (cross-tile prefetch) where it applies.  Opt-in: exact
+//          (bit-identical), removes the dispatch gap (2.1 -> 0.1 us per tile) and the first-stage wait, but the epilogue of a
+//          tile then sits on the next tile's critical path -- its stores share the in-order vmcnt queue with the operand
+//          stream, so the next tile's first counted wait also waits for them (epilogue 7.0 -> 10.0 us for ffn1, 7.5 -> 13.5 us
+//          for out-proj; one tile per workgroup just ends the wave with its stores in flight): GEMM time 108.2 -> 113.1 ms
+//          per hour (gpurun_out/s6, profiles/r03_gemm_timeline_persistent.txt)
 //   bit 3  fp8: the phase-interleaved loop (gemm2p_kernel<fp8_t>) instead of gemm2_kernel's plain loop.  Exact, but slower on
 //          the engine's shapes (1 h r640: fp8 GEMMs 58.6 vs 49.7 ms, step 141.4 vs 132.4 ms, gpurun_out/s5): K = 1024 is only 8
 //          fp8 K steps, so 3 of them run the tail form of the loop, and next to 16-register accumulator blocks the allocator

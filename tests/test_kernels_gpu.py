@@ -163,6 +163,48 @@ def test_conv1_cmvn(lib, dtype, d):
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 4)
 
 
+@pytest.mark.parametrize("flags", [0, 16])
+@pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32,group_m", [
+    (8192, 4096, 320, 1, 1.0, False, 0, -2),     # 512 tiles >= 2 per CU: the persistent form (cross-tile prefetch), SiLU, bf16 out
+    (16384, 2048, 256, 0, 0.5, True, 1, 8),      # residual preloaded into the accumulators tile after tile, grouped order, nk = 4
+    (12288, 3072, 1024, 0, 1.0, False, 0, 0),    # row-major order, 3 tiles per CU (the last round partial)
+])
+def test_gemm2_persistent_tiles(lib, flags, M, N, K, act, alpha, use_res, out_f32, group_m):
+    """The persistent form of the phase-interleaved loop (flags 16, opt-in: one workgroup per CU walks the tiles of its XCD's
+    run, the ring keeps streaming across tile edges) against fp64 -- every tile of a large problem, and bit-identical to one
+    tile per workgroup (flags 0), which runs the same arithmetic in the same order."""
+    rng = np.random.default_rng(M + N + K)
+    A = rnd(BF16, rng.standard_normal((M, K)))
+    W = rnd(BF16, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    res = f32(rng.standard_normal((M, N))) if use_res else None
+    C = np.full((M, N), np.nan, np.float32)
+    lib.rvb_test_set_gemm2_opts(flags, group_m)
+    try:
+        _lib.check(lib.rvb_test_gemm(BF16, fptr(A), fptr(W), fptr(bias), fptr(res), fptr(C), M, N, K, alpha, act, out_f32,
+                                     0, 0, 0, 0, 0))
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+    v = A.astype(np.float32) @ W.astype(np.float32).T           # bf16 products are exact in fp32; the sum order differs
+    v = v.astype(np.float64) + bias
+    if act == 1:
+        v = v / (1 + np.exp(-v))
+    v = v * alpha + (res if use_res else 0)
+    assert np.isfinite(C).all()
+    if out_f32:
+        np.testing.assert_allclose(C, v, rtol=2e-4, atol=1e-3)
+    else:
+        np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)
+    key = (M, N, K)
+    if flags == 0:
+        _PERSIST_RESULTS[key] = C.copy()
+    elif key in _PERSIST_RESULTS:
+        np.testing.assert_array_equal(C, _PERSIST_RESULTS.pop(key))
+
+
+_PERSIST_RESULTS = {}
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("K,d,T", [(15, 32, 70), (31, 200, 130)])
 def test_glu_dwconv(lib, dtype, K, d, T):
