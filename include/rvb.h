@@ -29,7 +29,7 @@ extern "C" {
 
 #define RVB_F32 0  /* parity mode: v_mfma_f32_16x16x4_f32, exact f32 fma chains */
 #define RVB_BF16 1 /* throughput mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate/residual */
-#define RVB_FP8 2  /* BASELINE configs[4]: the bf16 engine with the encoder's feed-forward, qkv and pointwise-conv GEMMs on
+#define RVB_FP8 2  /* BASELINE configs[4]: the bf16 engine with the encoder's feed-forward GEMMs (rvb_set_fp8_policy: also qkv / pointwise-conv) on
                       v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 operands: weights scaled per output channel, activations per
                       tensor, scales calibrated by the FIRST rvb_encode call, which itself runs in bf16) */
 
@@ -100,6 +100,13 @@ int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int6
  * select in BaseEncoder.forward via add_optional_chunk_mask (encoder.py:140-145, utils/mask.py:86-197) for models
  * trained with use_dynamic_chunk / static_chunk_size.  chunk_size <= 0: full context (default); left < 0: all. */
 int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks);
+
+/* RVB_FP8 engines: which GEMM groups of which conformer blocks run on the fp8 MFMA path -- `groups` is a bit mask (1 macaron
+ * feed-forward, 2 qkv projection, 4 pointwise conv 1, 8 pointwise conv 2, 16 feed-forward) applied to the blocks
+ * first_block .. last_block (last_block < 0: the last one); everything else stays bf16.  groups < 0 restores the default: the
+ * feed-forward modules of every block (17), the policy whose token error rate against the reference stays at the level of the
+ * reference's own bf16 autocast (tests/test_fp8_gpu.py).  Takes effect with the next rvb_encode; call after rvb_finalize. */
+int rvb_set_fp8_policy(rvb_engine* e, int groups, int first_block, int last_block);
 
 /* ASRModel._forward_encoder + ctc_logprobs + per-frame top-`beam` (asr_model.py:288-329,378-389,
  * search.py:155): encode a batch of B chunks of T0 frames.  feats: host fp32 [B,T0,80], or NULL

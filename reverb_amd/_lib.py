@@ -48,6 +48,7 @@ SIGNATURES = {
     "rvb_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "rvb_host_free": (C.c_int, [C.c_void_p]),
     "rvb_set_decoding_chunk": (C.c_int, [_eng, C.c_int, C.c_int]),
+    "rvb_set_fp8_policy": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int]),
     "rvb_upload_pcm_rate": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int]),
     "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),

@@ -73,6 +73,7 @@ struct rvb_engine {
   bool fp8 = false;              // RVB_FP8: dtype stays DT_BF16, the encoder's feed-forward / qkv / pointwise GEMMs run in fp8
   int f8_state = 0;              // 0 not calibrated, 1 calibrating (bf16 pass collecting max |.|), 2 fp8 GEMMs active
   std::vector<rvb::F8Scales> f8;
+  std::vector<unsigned> f8_groups;   // per block: which GEMM groups run in fp8 (bit 0 ffm, 1 qkv, 2 pw1, 3 pw2, 4 ff)
   rvb::DevBuf d_amax;            // fp32 [blocks][8]
   hipStream_t stream = nullptr;
   bool finalized = false;

@@ -436,6 +436,26 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
   return OK;
 }
 
+// Which GEMM groups of which conformer blocks run in fp8 (rvb_set_fp8_policy).  Default: the two feed-forward modules
+// (groups 1 | 16) of every block.  Measured on the bench hour against the unmodified reference (profiles/r03_fp8_policy_sweep.txt):
+// all five groups 16.2 % greedy / 13.5 % rescored token errors at 123.4 ms; feed-forward only 9.3 % / 10.9 % at 130.8 ms
+// (bf16: 4.7 % / 8.9 % at 143.3 ms; the reference's own bf16 autocast: 8.9 % / 9.1 %); qkv + pointwise only 16.4 % / 14.0 %:
+// the operands of the softmax (qkv) and of the GLU gate / depthwise path (pointwise 1, 2) are where a 3-bit mantissa hurts.
+static int set_fp8_policy_impl(rvb_engine* e, int groups, int first_block, int last_block) {
+  const int nb = (int)e->enc.size();
+  if (nb == 0) { set_error("rvb_set_fp8_policy before rvb_finalize"); return E_STATE; }
+  unsigned mask = groups < 0 ? (getenv("RVB_FP8_GROUPS") ? (unsigned)atoi(getenv("RVB_FP8_GROUPS")) : 17u) : (unsigned)groups;
+  if (groups < 0) {
+    if (getenv("RVB_FP8_FIRST")) first_block = atoi(getenv("RVB_FP8_FIRST"));
+    if (getenv("RVB_FP8_LAST")) last_block = atoi(getenv("RVB_FP8_LAST"));
+  }
+  if (last_block < 0) last_block = nb - 1;
+  e->f8_groups.assign(nb, 0u);
+  for (int l = 0; l < nb; ++l)
+    if (l >= first_block && l <= last_block) e->f8_groups[l] = mask & 31u;
+  return OK;
+}
+
 // ------------------------------------------------------------------------------------ encoder
 // One conformer block.  On entry e->xn already holds norm_ff_macaron(x) (written by the previous block's fused final
 // norm, or by encode_impl for the first block); on exit the block has written `next`(x) to next_out the same way.
@@ -450,12 +470,16 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   float* x = e->x.as<float>();
   const bool f8 = e->fp8 && e->f8_state == 2 && li < 0;
   const bool cal = e->fp8 && e->f8_state == 1 && li < 0;
+  // which GEMM groups of this block run in fp8 (rvb_engine::f8_groups: bit 0 macaron feed-forward, 1 qkv, 2 pointwise conv 1,
+  // 3 pointwise conv 2, 4 feed-forward); the others stay on the bf16 path, LayerNorm output included
+  const unsigned grp = f8 ? e->f8_groups[lidx] : 0u;
+  const bool f8_ffm = grp & 1u, f8_qkv = grp & 2u, f8_pw1 = grp & 4u, f8_pw2 = grp & 8u, f8_ff = (grp & 16u) && !L.is_lsl;
   const F8Scales sc8 = f8 ? e->f8[lidx] : F8Scales();
   auto note = [&](int slot, const void* t, size_t n) -> int {
     return cal ? amax_abs(e->stream, e->dtype, t, n, e->d_amax.as<float>() + (size_t)lidx * 8 + slot) : OK;
   };
   // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
-  if (f8) {
+  if (f8_ffm) {
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, sc8.in_ffm1, 2, sc8.h_ffm, 1.f, ACT_SILU));
     RVB_TRY(run_gemm8(e, e->h.p, ff, L.ffm2, x, d, M, sc8.h_ffm, 1, 1.f, 0.5f, ACT_NONE, x, d));
   } else {
@@ -465,7 +489,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     RVB_TRY(run_gemm(e, e->h.p, ff, L.ffm2, x, d, M, true, 0.5f, ACT_NONE, x, d));
   }
   // rel-pos self attention: x += MHSA(LN(x))              encoder_layer.py:208-216
-  if (f8) {
+  if (f8_qkv) {
     RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_qkv));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, sc8.in_qkv, 0));
   } else {
@@ -506,7 +530,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   }
   RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
   // convolution module: x += Conv(LN(x))                   encoder_layer.py:218-229, convolution.py:89-144
-  if (f8) {
+  if (f8_pw1) {
     RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_pw1));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, sc8.in_pw1, 0));
   } else {
@@ -544,7 +568,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     }
   }
   const int cmode = e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE;
-  if (f8) {
+  if (f8_pw2) {
     RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw2, x, d, M, sc8.in_pw2, 1, 1.f, 1.f, ACT_NONE, x, d));
   } else {
@@ -553,7 +577,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     RVB_TRY(run_gemm(e, e->xn.p, d, L.pw2, x, d, M, true, 1.f, ACT_NONE, x, d));
   }
   // feed-forward (+ language-specific mix), final norm     encoder_layer.py:231-244 / :372-402
-  if (f8 && !L.is_lsl) {
+  if (f8_ff) {
     RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_ff1));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.ff1, e->h.p, ff, M, sc8.in_ff1, 2, sc8.h_ff, 1.f, ACT_SILU));
     RVB_TRY(run_gemm8(e, e->h.p, ff, L.ff2, x, d, M, sc8.h_ff, 1, 1.f, 0.5f, ACT_NONE, x, d));
@@ -685,11 +709,11 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     void* eo = (char*)e->enc_out.p + (size_t)row0 * d * es;
     const bool f8 = e->fp8 && e->f8_state == 2;
     RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, m, d, NORM_LN, 0, nullptr, nullptr, nullptr,
-                     f8 ? e->f8[0].in_ffm1 : 0.f));
+                     (f8 && (e->f8_groups[0] & 1u)) ? e->f8[0].in_ffm1 : 0.f));
     for (size_t li = 0; li < e->enc.size(); ++li) {
       const bool last = li + 1 == e->enc.size();
       RVB_TRY(encoder_layer(e, e->enc[li], (int)li, m, nb, T2, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p,
-                            (f8 && !last) ? e->f8[li + 1].in_ffm1 : 0.f));
+                            (f8 && !last && (e->f8_groups[li + 1] & 1u)) ? e->f8[li + 1].in_ffm1 : 0.f));
     }
     // CTC head + log-softmax + per-frame top-k (ctc.py:106-114, search.py:155)
     for (int r0 = 0; r0 < m; r0 += LOGIT_SLAB) {
@@ -719,6 +743,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
       const float* a = am.data() + l * 8;
       e->f8[l] = {sc(a[0]), sc(a[1]), sc(a[2]), sc(a[3]), sc(a[4]), sc(a[5]), sc(a[6])};
     }
+    if (e->f8_groups.size() != e->enc.size()) RVB_TRY(set_fp8_policy_impl(e, -1, 0, -1));     // default policy (or RVB_FP8_*)
     e->f8_state = 2;
   }
   return OK;
@@ -1500,6 +1525,13 @@ int rvb_host_alloc(void** out, int64_t bytes) {
 int rvb_host_free(void* p) {
   if (p) RVB_HIP_CHECK(hipHostFree(p));
   return OK;
+}
+
+int rvb_set_fp8_policy(rvb_engine* e, int groups, int first_block, int last_block) {
+  if (!e) { set_error("rvb_set_fp8_policy: null engine"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_set_fp8_policy: not an RVB_FP8 engine"); return E_STATE; }
+  if (groups > 31 || first_block < 0) { set_error("rvb_set_fp8_policy: groups is a 5-bit mask, first_block >= 0"); return E_ARG; }
+  return set_fp8_policy_impl(e, groups, first_block, last_block);
 }
 
 int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks) {

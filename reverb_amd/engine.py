@@ -163,6 +163,19 @@ class Engine:
         """Chunk mask of the encoder self-attention for the next encode() calls (<= 0: full context)."""
         check(self.lib.rvb_set_decoding_chunk(self.handle, int(chunk_size), int(num_left_chunks)), "rvb_set_decoding_chunk")
 
+    FP8_GROUPS = {"ffn_macaron": 1, "qkv": 2, "pointwise_conv1": 4, "pointwise_conv2": 8, "ffn": 16}
+
+    def set_fp8_policy(self, groups=None, first_block: int = 0, last_block: int = -1):
+        """fp8 engines: the GEMM groups (names of FP8_GROUPS, or a bit mask) of blocks first_block..last_block that run on
+        the fp8 MFMA path; None = the default (both feed-forward modules of every block)."""
+        if groups is None:
+            mask = -1
+        elif isinstance(groups, int):
+            mask = groups
+        else:
+            mask = sum(self.FP8_GROUPS[g] for g in set(groups))
+        check(self.lib.rvb_set_fp8_policy(self.handle, int(mask), int(first_block), int(last_block)), "rvb_set_fp8_policy")
+
     def apply_decoding_chunk(self, decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1):
         """What BaseEncoder.forward does with these two arguments (encoder.py:140-145 -> add_optional_chunk_mask,
         utils/mask.py:126-197): they select a chunk mask only for models configured with use_dynamic_chunk, a

@@ -103,18 +103,20 @@ def test_layernorm_to_fp8(lib):
     np.testing.assert_allclose(o2, ln2, rtol=0.07, atol=scale2 * 2.0 ** -9 * 1.01)
 
 
-# measured round 2 (profiles/r02_parity_metrics.jsonl): token error rates of the fp8 mode against the unmodified reference
-# small_66: greedy 9.5 % / rescored 9.8 % of 4 666 tokens (bf16: 1.5 % / 3.4 %), encoder cos-sim 0.9995; r640_chunk: 9/66 and
-# 9/84 tokens (bf16 4/66, 6/84), cos-sim 0.9975.  Random-weight models have tiny CTC margins, so these are
-# upper bounds on what calibrated fp8 costs a trained model.  Bound = measured + margin.
-FP8_TER_BOUND = {"small_66": 0.14, "r640_chunk": 0.24}
+# fp8 is held to the reference's own reduced-precision behaviour (test_longform_gpu.RefBf16: the unmodified reference under
+# torch.autocast(cpu, bfloat16) against its fp32 run), with a slack of 1.5: token error rate <= 1.5 x (reference-bf16 TER +
+# margin), frame decisions on confident frames likewise.  Measured round 3 on the bench hour (profiles/r03_fp8_policy_sweep.txt):
+# default policy (feed-forward GEMMs in fp8) 9.3 % greedy / 10.9 % rescored, reference bf16 8.9 % / 9.1 %, engine bf16 4.7 % /
+# 8.9 %; all five GEMM groups in fp8 (round 2's mode, still selectable) 16.2 % / 13.5 %.  Random-weight models have tiny CTC
+# margins, so these bound what calibrated fp8 costs a trained model from above.
+FP8_SLACK = 1.5
 
 
 @pytest.mark.parametrize("name", ["small_66", "r640_chunk"])
 def test_fp8_engine_against_reference(name):
     from golden_util import LongCase
     from reverb_amd.engine import Engine
-    from test_longform_gpu import MODES, _record, _tap_metrics, _ter
+    from test_longform_gpu import MODES, RefBf16, _assert_reduced_precision, _record, _tap_metrics, _ter
     case = LongCase(name)
     n = len(case.js["lens"]) if name == "small_66" else 2
     x = np.concatenate([case.chunk_feats(c)[0] for c in range(n)])
@@ -126,12 +128,13 @@ def test_fp8_engine_against_reference(name):
     eng.encode(x, lens, case.beam)                      # fp8 GEMMs
     assert eng.timing("gemm_fp8")["launches"] > 0, "the fp8 GEMM path did not run"
     m0 = _tap_metrics(eng, case, 0, 0)
+    ref = RefBf16(name)
+    fm = ref.frame_disagreement(eng)
     ter = _ter(eng.search(MODES, case.ctc_weight, case.reverse_weight), case)
     _record(case=name, dtype="fp8", ter={m: list(v) for m, v in ter.items()}, bf16_calibration_pass_ter={m: list(v) for m, v in cal.items()},
-            chunk0=m0)
-    assert m0["cos"] > 0.99, m0
-    for m in MODES:
-        assert ter[m][0] <= FP8_TER_BOUND[name] * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+            chunk0=m0, frames=fm, reference_bf16_ter=ref.ter)
+    assert m0["cos"] > 0.995, m0
+    _assert_reduced_precision(name, "fp8", ter, fm, ref, slack=FP8_SLACK)
     eng.close()
 
 
@@ -145,21 +148,49 @@ def test_fp8_needs_dims_of_128():
 
 
 def test_fp8_bench_workload_against_reference():
-    """bench.py --dtype fp8, checked: the hour of audio bench.py decodes, from PCM, against the reference's tokens."""
+    """bench.py --dtype fp8, checked: the hour of audio bench.py decodes, from PCM, against the reference's tokens -- the
+    default policy (feed-forward GEMMs in fp8) within 1.5 x the reference's own bf16 behaviour; then every GEMM group in fp8
+    (rvb_set_fp8_policy(31), round 2's mode): measured and recorded, bounded at 2.5 x."""
     from golden_util import LongCase
     from reverb_amd.engine import Engine
-    from test_longform_gpu import MODES, _record, _tap_metrics, _ter
+    from test_longform_gpu import MODES, RefBf16, _assert_reduced_precision, _record, _tap_metrics, _ter
     case = LongCase("r640_1h")
     n = len(case.js["lens"])
+    ref = RefBf16("r640_1h")
     eng = Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=n, chunk_frames=case.chunk, cat_embs=case.cat)
     eng.upload_pcm(case.pcm)
     nf = eng.fbank()
     eng.decode_resident(nf, ["ctc_greedy_search"], case.chunk, case.beam, case.ctc_weight, case.reverse_weight)     # calibration (bf16)
-    res = eng.decode_resident(nf, MODES, case.chunk, case.beam, case.ctc_weight, case.reverse_weight)
-    ter = _ter(res, case)
-    m_last = _tap_metrics(eng, case, n - 1, n - 1)
-    _record(case="r640_1h", dtype="fp8", chunks=n, ter={m: list(v) for m, v in ter.items()}, last_chunk=m_last)
-    assert m_last["cos"] > 0.99, m_last
+    got = {}
+    for policy in ("feed-forward", "all groups"):
+        if policy == "all groups":
+            eng.set_fp8_policy(31)
+        res = eng.decode_resident(nf, MODES, case.chunk, case.beam, case.ctc_weight, case.reverse_weight)
+        ter = _ter(res, case)
+        m_last = _tap_metrics(eng, case, n - 1, n - 1)
+        fm = ref.frame_disagreement(eng)
+        _record(case="r640_1h", dtype="fp8", policy=policy, chunks=n, ter={m: list(v) for m, v in ter.items()}, last_chunk=m_last,
+                frames=fm, reference_bf16_ter=ref.ter)
+        assert m_last["cos"] > 0.99, m_last
+        got[policy] = (ter, fm)
+    _assert_reduced_precision("r640_1h", "fp8 feed-forward", *got["feed-forward"], ref, slack=FP8_SLACK)
+    # every group in fp8 does NOT meet that bar (measured: 16.2 % / 13.5 % token errors, 1 603 confident frames flipped against the
+    # reference-bf16's 314) -- which is why it is not the default; it must at least stay a usable approximation, and be worse
+    # than the default on both measures (otherwise the default should change)
+    ter_all, fm_all = got["all groups"]
     for m in MODES:
-        assert ter[m][0] <= 0.30 * ter[m][1], f"{m}: TER {ter[m][0]}/{ter[m][1]}"
+        assert ter_all[m][0] <= 0.25 * ter_all[m][1], (m, ter_all[m])
+        assert ter_all[m][0] >= got["feed-forward"][0][m][0]
+    assert fm_all["engine_confident"] >= got["feed-forward"][1]["engine_confident"]
+    eng.close()
+
+
+def test_fp8_policy_is_validated():
+    from golden_util import LongCase
+    from reverb_amd._lib import RvbError
+    from reverb_amd.engine import Engine
+    case = LongCase("r640_chunk")
+    eng = Engine(case.cfg, case.sd, dtype="bf16", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
+    with pytest.raises(RvbError, match="RVB_FP8"):
+        eng.set_fp8_policy(["ffn"])
     eng.close()

@@ -105,11 +105,11 @@ class RefBf16:
 def _assert_reduced_precision(name, dtype, ter, fm, ref, slack=1.0):
     """The engine's reduced-precision mode is held to the reference's own bf16 behaviour: token error rate against the fp32
     reference no worse than the reference-under-autocast's (+ margin; x `slack` for fp8), and on frames where the fp32
-    reference decides with a margin > 0.1 it disagrees no more often than the reference-bf16 does (+ 0.05 % of the frames)."""
+    reference decides with a margin > 0.1 it disagrees no more often than the reference-bf16 does (+ 0.05 % of the frames + 4)."""
     for m in MODES:
         bound = slack * ref.ter_bound(m)
         assert ter[m][0] <= bound * ter[m][1], f"{name} {dtype} {m}: TER {ter[m][0]}/{ter[m][1]} > {bound:.4f} (reference bf16 {ref.ter[m]:.4f})"
-    lim = slack * (fm["ref_bf16_confident"] + 0.0005 * fm["confident"])
+    lim = slack * (fm["ref_bf16_confident"] + 0.0005 * fm["confident"]) + 4      # + 4 frames: two-chunk cases have ~500 frames
     assert fm["engine_confident"] <= lim, f"{name} {dtype}: {fm}"
 
 
