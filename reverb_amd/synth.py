@@ -28,6 +28,9 @@ MODEL_DIMS = {
     # name: d, heads, ff, enc blocks, dec-ff, dec blocks (each direction), cnn kernel, vocab
     "tiny":  dict(d=32,   h=2,  ff=64,   blocks=4,  dff=64,   dblocks=3, K=15, vocab=48),
     "small": dict(d=128,  h=4,  ff=256,  blocks=4,  dff=256,  dblocks=3, K=15, vocab=500),
+    # the Reverb vocabulary size on small bodies: `joint_decoding` hard-codes sos = 10000 (search.py:479)
+    "tiny_v10k":  dict(d=32,  h=2, ff=64,  blocks=4, dff=64,  dblocks=3, K=15, vocab=10001),
+    "small_v10k": dict(d=128, h=4, ff=256, blocks=4, dff=256, dblocks=3, K=15, vocab=10001),
     "r268":  dict(d=640,  h=8,  ff=2560, blocks=18, dff=2048, dblocks=3, K=31, vocab=10001),
     "r640":  dict(d=1024, h=16, ff=4096, blocks=18, dff=4096, dblocks=3, K=31, vocab=10001),
 }

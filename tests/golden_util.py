@@ -116,3 +116,24 @@ class CausalCase:
             self.x[i, :len(part)] = part
             self.lens[i] = len(part)
         assert self.lens.tolist() == self.js["lens"]
+
+
+class JointCase:
+    """Golden of `joint_decoding` (oracle/gen_golden_joint.py: the reference's BeamSearchTimeSync class on (1, len, d) memories)."""
+
+    def __init__(self, name):
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.js = json.load(f)
+        c = self.c = self.js["case"]
+        self.cfg = synth.make_config(c["dims"], c["norm"])
+        self.sd = synth.make_state_dict(self.cfg, c["seed"], self.js["gamma"], self.js["beta"])
+        feats = fbank_ref.fbank(synth.synth_audio(c["seconds"], seed=1234 + c["seed"]))
+        self.chunk, self.cat = c["chunk"], c["cat"]
+        nch = -(-feats.shape[0] // self.chunk)
+        self.x = np.zeros((nch, self.chunk, 80), np.float32)
+        self.lens = np.zeros(nch, np.int32)
+        for i in range(nch):
+            part = feats[i * self.chunk:(i + 1) * self.chunk]
+            self.x[i, :len(part)] = part
+            self.lens[i] = len(part)
+        assert self.lens.tolist() == self.js["lens"]

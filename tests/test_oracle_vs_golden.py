@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, MODES, Case, CausalCase, GOLDEN, LongCase
+from golden_util import CASES, MODES, Case, CausalCase, GOLDEN, JointCase, LongCase
 from oracle import fbank_ref, model_ref as M, search_ref as S
 
 
@@ -222,3 +222,28 @@ def test_causal_plain_model_oracle_matches_reference_golden():
                 assert [list(h) for h in pref[0].nbest] == want["nbest"], (cs, left, b)
                 r = S.attention_rescoring(sd, case.cfg, pref, ys, n, case.ctc_weight, case.reverse_weight, None)[0]
                 assert list(r.tokens) == want["rescoring"] and abs(float(r.score) - want["rescoring_score"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["joint_tiny", "joint_small"])
+def test_joint_decoding_oracle_matches_reference_class(name):
+    """`joint_decoding` (search.py:450-496; espnet/beam_search_timesync.py): the oracle's restatement against the reference's
+    own BeamSearchTimeSync class driven with (1, len, d) memories (oracle/gen_golden_joint.py) -- winner, start / end frames,
+    per-token confidences, joint score.  The golden also records that the reference's entry point itself raises."""
+    case = JointCase(name)
+    assert case.js["reference_entry_point"].startswith("RuntimeError")
+    sd = M.to_torch_sd(case.sd)
+    cat = torch.tensor(case.cat)
+    with torch.no_grad():
+        enc, mask = M.encoder_forward(sd, case.cfg, torch.from_numpy(case.x), torch.from_numpy(case.lens), cat)
+        probs = M.ctc_logprobs(sd, enc)
+    lens = mask.squeeze(1).sum(1)
+    assert lens.tolist() == case.js["encoder_lens"]
+    for run in case.js["runs"]:
+        got = S.joint_decoding(sd, case.cfg, enc, lens, probs, run["ctc_weight"], run["beam"], run["pre_beam_ratio"],
+                               run["length_bonus"], cat)
+        for b, want in enumerate(run["chunks"]):
+            g = got[b]
+            assert list(g.tokens) == want["tokens"], (run, b)
+            assert list(g.times) == want["times"] and list(g.end_times) == want["end_times"], (run, b)
+            assert abs(g.score - want["score"]) < 2e-3 * max(1.0, abs(want["score"])), (run, b, g.score, want["score"])
+            np.testing.assert_allclose(g.tokens_confidence, want["tokens_confidence"], rtol=2e-3, atol=1e-6)
