@@ -208,6 +208,15 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
                      int silu, const float* add, float* out, int out_f32, int M, int d);
 int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
                    const float* b, float* out, int B, int T0, int F0, int d);
+/* host only: the `joint_decoding` state machine of one chunk (csrc/search.cpp JointSearch: transformer/search.py:450-496,
+ * espnet/beam_search_timesync.py), driven frame by frame; the caller supplies the attention log-probs it asks for */
+void* rvb_test_joint_new(int beam, int pre_beam, int blank, int sos, double w_ctc, double w_dec, double bonus);
+void rvb_test_joint_free(void* h);
+int rvb_test_joint_begin(void* h, int t, const float* tv, const int32_t* ti, int K, float p_tok0, float p_blank, int32_t* decode,
+                         int32_t* n_decode, int32_t* pair_node, int32_t* pair_tok, int32_t* n_pairs, int cap);
+int rvb_test_joint_finish(void* h, const float* vals);
+int rvb_test_joint_prefix(void* h, int node, int32_t* toks, int32_t* n);
+int rvb_test_joint_result(void* h, int32_t* tokens, int32_t* times, int32_t* end_times, double* conf, int32_t* n, double* score);
 int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
                         const int32_t* lens, float* out, int B, int T, int d, int K, int causal,
                         const float* hist /* nullable [K-1][2d] */, int hist_rows);

@@ -228,4 +228,181 @@ void edit_counts(const int32_t* ref, int64_t n, const int32_t* hyp, int64_t m, i
   counts[0] = prev[m].c; counts[1] = prev[m].s; counts[2] = prev[m].d; counts[3] = prev[m].i;
 }
 
+// ================================================================================================
+// joint_decoding: BeamSearchTimeSync (espnet/beam_search_timesync.py) for one chunk, see search.h
+// ================================================================================================
+namespace {
+// beam_search_timesync.py:29-37, python floats: max + log(sum(exp(a - max)))
+inline double lse2(double a, double b) {
+  if (a == NEG_INF && b == NEG_INF) return NEG_INF;
+  const double m = a > b ? a : b;
+  return m + std::log(std::exp(a - m) + std::exp(b - m));
+}
+}  // namespace
+
+JointSearch::JointSearch(const JointParams& p) : p_(p) {
+  Node root;
+  root.parent = -1; root.tok = p.sos; root.len = 1;
+  root.has_times = root.has_conf = true;
+  root.st.assign(1, 0); root.en.assign(1, 0);
+  root.conf.assign(1, {NEG_INF, NEG_INF});
+  root.dp_stamp = 0; root.dp_nb = NEG_INF; root.dp_b = 0.0;          // ctc_score_dp[[sos]] = (-inf, 0.0)
+  root.in_hyps = 1;
+  root.decoded = true; root.log_sum = 0.0;                           // reset() runs the decoder on <sos>
+  nodes_.push_back(root);
+  child_.emplace_back();
+  hyps_.assign(1, 0);
+}
+
+int JointSearch::child(int node, int tok) {
+  for (const auto& c : child_[node]) if (c.first == tok) return c.second;
+  Node n;
+  n.parent = node; n.tok = tok; n.len = nodes_[node].len + 1;
+  nodes_.push_back(n);
+  child_.emplace_back();
+  const int id = (int)nodes_.size() - 1;
+  child_[node].push_back({tok, id});
+  return id;
+}
+
+void JointSearch::prefix(int node, std::vector<int>* toks) const {
+  toks->assign(nodes_[node].len, 0);
+  for (int n = node, i = nodes_[node].len - 1; n >= 0; n = nodes_[n].parent, --i) (*toks)[i] = nodes_[n].tok;
+}
+
+bool JointSearch::begin_frame(int t, const float* tv, const int* ti, int K, float p_tok0, float p_blank, std::vector<int>* decode,
+                              std::vector<int>* pair_node, std::vector<int>* pair_tok) {
+  // :271-274 -- `torch.argmax(p_ctc[0])` is the argmax of a 0-d tensor, i.e. always token 0
+  if (0 == p_.blank && (double)p_tok0 >= p_.log_thr) return false;
+  frame_ = t;
+  const int cur = dp_frame_, nxt = t + 1;                    // stamps: dp entries carry `cur`, next-frame entries `nxt`
+  // candidates: everything >= the pre_beam-th largest log-prob, in token order (nonzero())
+  const int pb = p_.pre_beam < K ? p_.pre_beam : K;
+  const float thr = tv[pb - 1];
+  std::vector<std::pair<int, double>> cands;
+  for (int k = 0; k < K; ++k) if (tv[k] >= thr) cands.push_back({ti[k], (double)tv[k]});
+  std::sort(cands.begin(), cands.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+  new_hyps_.clear();
+  auto nxt_get = [&](Node& n, double& nb, double& b) { if (n.nxt_stamp == nxt) { nb = n.nxt_nb; b = n.nxt_b; } else { nb = NEG_INF; b = NEG_INF; } };
+  touched_.clear();
+  auto nxt_set = [&](Node& n, double nb, double b) {
+    if (n.nxt_stamp != nxt) touched_.push_back((int)(&n - nodes_.data()));
+    n.nxt_stamp = nxt; n.nxt_nb = nb; n.nxt_b = b;
+  };
+  auto add_new = [&](int id) { if (nodes_[id].new_stamp != nxt) { nodes_[id].new_stamp = nxt; new_hyps_.push_back(id); } };
+  const std::vector<int> hyps = hyps_;
+  for (int h : hyps) {
+    const double prev = lse2(nodes_[h].dp_nb, nodes_[h].dp_b);         // nodes in the beam always have a dp entry
+    for (const auto& cd : cands) {
+      const int c = cd.first;
+      const double pc = cd.second;
+      if (c == p_.blank) {
+        double nb, bl;
+        nxt_get(nodes_[h], nb, bl);
+        nxt_set(nodes_[h], nb, lse2(bl, pc + prev));
+        add_new(h);
+        continue;
+      }
+      const int g = child(h, c);                 // may grow nodes_: take references afterwards
+      Node& G = nodes_[g];
+      Node& H = nodes_[h];
+      double nb, bl;
+      nxt_get(G, nb, bl);
+      if (!G.has_times) {
+        G.st = H.st; G.st.push_back(t);
+        G.en = H.en; G.en.push_back(t + 1);
+        G.has_times = true;
+      } else {
+        G.en.back() = t + 1;
+      }
+      if (!G.has_conf) { G.conf = H.conf; G.conf.push_back({NEG_INF, NEG_INF}); G.has_conf = true; }
+      G.conf.back().first = G.conf.back().first > pc ? G.conf.back().first : pc;
+      if (c == H.tok) {                          // repeated token: only through a blank; h itself keeps growing
+        const double nb_prev = H.dp_nb, b_prev = H.dp_b;
+        nb = lse2(nb, pc + b_prev);
+        double hn, hb;
+        nxt_get(H, hn, hb);
+        nxt_set(H, lse2(hn, pc + nb_prev), hb);
+        H.en.back() = t + 1;
+        H.conf.back().first = H.conf.back().first > pc ? H.conf.back().first : pc;
+      } else {
+        nb = lse2(nb, pc + prev);
+      }
+      if (!G.in_hyps && G.dp_stamp == cur) {     // seen before but pruned: its old mass comes back in
+        bl = lse2(bl, (double)p_blank + lse2(G.dp_nb, G.dp_b));
+        nb = lse2(nb, pc + G.dp_nb);
+      }
+      nxt_set(G, nb, bl);
+      add_new(g);
+    }
+  }
+  // attention scores needed for the joint score of every candidate (:226-255, cached_score :185-224)
+  pend_decode_.clear(); pend_node_.clear(); pend_tok_.clear();
+  if (p_.w_dec > 0) {
+    for (int h : new_hyps_) {
+      Node& H = nodes_[h];
+      if (H.len <= 1 || H.att_known) continue;
+      Node& R = nodes_[H.parent];
+      if (!R.decoded) {
+        R.decoded = true;                        // its row exists once the caller has run the decoder step
+        R.log_sum = R.parent >= 0 ? nodes_[R.parent].log_sum + R.att_tok : 0.0;
+        pend_decode_.push_back(H.parent);
+      }
+      pend_node_.push_back(H.parent);
+      pend_tok_.push_back(H.tok);
+    }
+  }
+  decode->insert(decode->end(), pend_decode_.begin(), pend_decode_.end());
+  pair_node->insert(pair_node->end(), pend_node_.begin(), pend_node_.end());
+  pair_tok->insert(pair_tok->end(), pend_tok_.begin(), pend_tok_.end());
+  return true;
+}
+
+void JointSearch::finish_frame(const float* vals) {
+  const int nxt = frame_ + 1;
+  size_t vi = 0;
+  std::vector<std::pair<double, int>> order;     // (score, node) in scoring order
+  for (int h : new_hyps_) {
+    Node& H = nodes_[h];
+    double sc = p_.w_ctc * lse2(H.nxt_nb, H.nxt_b);
+    if (H.len > 1 && p_.w_dec > 0) {
+      if (!H.att_known) { H.att_tok = (double)vals[vi++]; H.att_known = true; }
+      sc += (nodes_[H.parent].log_sum + H.att_tok) * p_.w_dec;
+      H.conf.back().second = H.att_tok;
+    }
+    sc += p_.bonus * (H.len - 1);
+    H.score = sc;
+    order.push_back({sc, h});
+  }
+  // `reverse_dict[score] = hyp` for every scored hypothesis in order (equal scores: the later one wins), descending, top beam
+  std::vector<std::pair<double, int>> uniq;
+  for (const auto& o : order) {
+    bool found = false;
+    for (auto& u : uniq) if (u.first == o.first) { u.second = o.second; found = true; break; }
+    if (!found) uniq.push_back(o);
+  }
+  std::stable_sort(uniq.begin(), uniq.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+  for (int h : hyps_) nodes_[h].in_hyps = 0;
+  hyps_.clear();
+  for (size_t i = 0; i < uniq.size() && (int)i < p_.beam; ++i) { hyps_.push_back(uniq[i].second); nodes_[uniq[i].second].in_hyps = 1; }
+  // ctc_score_dp = ctc_score_dp_next.copy(): exactly the entries written this frame (a repeated token also writes the
+  // entry of the un-extended hypothesis without putting it among the candidates)
+  for (int h : touched_) { Node& H = nodes_[h]; H.dp_stamp = nxt; H.dp_nb = H.nxt_nb; H.dp_b = H.nxt_b; }
+  dp_frame_ = nxt;
+  scored_ = new_hyps_;
+  any_scores_ = true;
+}
+
+void JointSearch::result(JointResult* out) const {
+  const Node& B = nodes_[hyps_[0]];
+  std::vector<int> toks;
+  prefix(hyps_[0], &toks);
+  out->tokens.assign(toks.begin() + 1, toks.end());
+  out->times.assign(B.st.begin() + 1, B.st.end());
+  out->end_times.assign(B.en.begin() + 1, B.en.end());
+  out->tokens_confidence.clear();
+  for (size_t i = 1; i < B.conf.size(); ++i) out->tokens_confidence.push_back(std::exp(B.conf[i].first > B.conf[i].second ? B.conf[i].first : B.conf[i].second));
+  out->score = any_scores_ ? B.score : 0.0;
+}
+
 }  // namespace rvb

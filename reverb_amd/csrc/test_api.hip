@@ -336,6 +336,48 @@ int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_
   return OK;
 }
 
+// host only: the joint_decoding state machine (search.cpp: JointSearch), driven frame by frame by a caller that supplies the
+// attention log-probs -- the CPU tests do that with the oracle's decoder, the engine with its own (rvb_joint_decode)
+void* rvb_test_joint_new(int beam, int pre_beam, int blank, int sos, double w_ctc, double w_dec, double bonus) {
+  JointParams p;
+  p.beam = beam; p.pre_beam = pre_beam; p.blank = blank; p.sos = sos; p.w_ctc = w_ctc; p.w_dec = w_dec; p.bonus = bonus;
+  return new JointSearch(p);
+}
+void rvb_test_joint_free(void* h) { delete (JointSearch*)h; }
+// -> 0 frame skipped, 1 processed.  decode[n_decode] = nodes whose decoder row is needed, pairs (pair_node[i], pair_tok[i])
+int rvb_test_joint_begin(void* h, int t, const float* tv, const int32_t* ti, int K, float p_tok0, float p_blank, int32_t* decode,
+                         int32_t* n_decode, int32_t* pair_node, int32_t* pair_tok, int32_t* n_pairs, int cap) {
+  if (!h || !tv || !ti || !n_decode || !n_pairs) { set_error("rvb_test_joint_begin: bad argument"); return E_ARG; }
+  std::vector<int> d, pn, pt;
+  const bool ran = ((JointSearch*)h)->begin_frame(t, tv, (const int*)ti, K, p_tok0, p_blank, &d, &pn, &pt);
+  if ((int)d.size() > cap || (int)pn.size() > cap) { set_error("rvb_test_joint_begin: capacity"); return E_ARG; }
+  *n_decode = (int32_t)d.size(); *n_pairs = (int32_t)pn.size();
+  for (size_t i = 0; i < d.size(); ++i) decode[i] = d[i];
+  for (size_t i = 0; i < pn.size(); ++i) { pair_node[i] = pn[i]; pair_tok[i] = pt[i]; }
+  return ran ? 1 : 0;
+}
+int rvb_test_joint_finish(void* h, const float* vals) {
+  if (!h) { set_error("rvb_test_joint_finish: bad argument"); return E_ARG; }
+  ((JointSearch*)h)->finish_frame(vals);
+  return OK;
+}
+int rvb_test_joint_prefix(void* h, int node, int32_t* toks, int32_t* n) {
+  if (!h || !toks || !n) { set_error("rvb_test_joint_prefix: bad argument"); return E_ARG; }
+  std::vector<int> t;
+  ((JointSearch*)h)->prefix(node, &t);
+  *n = (int32_t)t.size();
+  for (size_t i = 0; i < t.size(); ++i) toks[i] = t[i];
+  return OK;
+}
+int rvb_test_joint_result(void* h, int32_t* tokens, int32_t* times, int32_t* end_times, double* conf, int32_t* n, double* score) {
+  if (!h || !n || !score) { set_error("rvb_test_joint_result: bad argument"); return E_ARG; }
+  JointResult r;
+  ((JointSearch*)h)->result(&r);
+  *n = (int32_t)r.tokens.size(); *score = r.score;
+  for (size_t i = 0; i < r.tokens.size(); ++i) { tokens[i] = r.tokens[i]; times[i] = r.times[i]; end_times[i] = r.end_times[i]; conf[i] = r.tokens_confidence[i]; }
+  return OK;
+}
+
 int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank, int32_t* n_hyps,
                          int32_t* tokens, int32_t* lens, int32_t* times, int32_t* times_lens, double* scores) {
   if (!topk_val || !topk_idx || !n_hyps || T < 0 || beam < 1) { set_error("rvb_test_prefix_beam: bad argument"); return E_ARG; }

@@ -172,3 +172,80 @@ def test_rescoring_trie_against_a_python_trie(reversed_):
         p += len(s) + 1
     assert len(set(row_of.values())) == R and out["tgt_ptr"][R] == P and sorted(out["pair_slot"].tolist()) == list(range(P))
     assert n_work.value == sum(-(-int(n) // 16) for n in out["hq_len"])
+
+
+# ------------------------------------------------------------------------------------------------ joint_decoding
+def native_joint(sd, cfg, mem, lpz, run, cat, K=None):
+    """Drive the native JointSearch state machine (search.cpp) for one chunk; the attention log-probs it asks for come from the
+    oracle's decoder (model_ref.decoder_step) -- on the GPU the engine's batched decoder step takes that place."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from oracle import model_ref as M
+    lib = _lib.load()
+    V = cfg["output_dim"]
+    sos, beam = V - 1, run["beam"]
+    pre_beam = int(run["pre_beam_ratio"] * beam)
+    K = K or pre_beam
+    h = C.c_void_p(lib.rvb_test_joint_new(beam, pre_beam, 0, sos, run["ctc_weight"], 1.0 - run["ctc_weight"], run["length_bonus"]))
+    n = mem.shape[1]
+    mask = torch.ones(1, 1, n, dtype=torch.bool)
+    rows, caches = {}, {}
+
+    def decode(node):
+        toks = np.zeros(4096, np.int32); ln = np.zeros(1, np.int32)
+        _lib.check(lib.rvb_test_joint_prefix(h, node, iptr(toks), iptr(ln)))
+        prefix = toks[:ln[0]].tolist()
+        parent_cache = None if len(prefix) == 1 else caches[tuple(prefix[:-1])]
+        out, cache = M.decoder_step(sd, cfg, "left_decoder", mem, mask, torch.tensor([prefix[-1]]), len(prefix) - 1, parent_cache, cat)
+        caches[tuple(prefix)] = cache
+        rows[node] = F.log_softmax(out, dim=-1)[0].numpy()
+
+    with torch.no_grad():
+        decode(0)
+        cap = 256
+        dec = np.zeros(cap, np.int32); pn = np.zeros(cap, np.int32); pt = np.zeros(cap, np.int32)
+        nd = np.zeros(1, np.int32); npairs = np.zeros(1, np.int32)
+        tv_all, ti_all = lpz.topk(K, dim=-1)
+        for t in range(n):
+            tv = np.ascontiguousarray(tv_all[t].numpy(), np.float32); ti = np.ascontiguousarray(ti_all[t].numpy(), np.int32)
+            rc = lib.rvb_test_joint_begin(h, t, fptr(tv), iptr(ti), K, float(lpz[t, 0]), float(lpz[t, 0]), iptr(dec), iptr(nd), iptr(pn),
+                                          iptr(pt), iptr(npairs), cap)
+            assert rc >= 0, lib.rvb_last_error()
+            if rc == 0:
+                continue
+            for node in dec[:nd[0]]:
+                decode(int(node))
+            vals = np.array([rows[int(a)][int(b)] for a, b in zip(pn[:npairs[0]], pt[:npairs[0]])], np.float32)
+            _lib.check(lib.rvb_test_joint_finish(h, fptr(vals)))
+    toks = np.zeros(4096, np.int32); st = np.zeros(4096, np.int32); en = np.zeros(4096, np.int32); conf = np.zeros(4096, np.float64)
+    ln = np.zeros(1, np.int32); score = np.zeros(1, np.float64)
+    _lib.check(lib.rvb_test_joint_result(h, iptr(toks), iptr(st), iptr(en), dptr(conf), iptr(ln), dptr(score)))
+    lib.rvb_test_joint_free(h)
+    k = int(ln[0])
+    return toks[:k].tolist(), st[:k].tolist(), en[:k].tolist(), conf[:k].tolist(), float(score[0])
+
+
+@pytest.mark.parametrize("name", ["joint_tiny", "joint_small"])
+def test_joint_decoding_native_state_machine_matches_reference_class(name):
+    """search.cpp's JointSearch against the goldens of the reference's own BeamSearchTimeSync class (oracle/gen_golden_joint.py),
+    with the oracle's decoder supplying the attention log-probs: tokens, start / end frames, confidences, joint score."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import JointCase
+    from oracle import model_ref as M
+    case = JointCase(name)
+    sd = M.to_torch_sd(case.sd)
+    cat = torch.tensor(case.cat)
+    with torch.no_grad():
+        enc, mask = M.encoder_forward(sd, case.cfg, torch.from_numpy(case.x), torch.from_numpy(case.lens), cat)
+        probs = M.ctc_logprobs(sd, enc)
+    lens = mask.squeeze(1).sum(1)
+    for run in case.js["runs"]:
+        for b, want in enumerate(run["chunks"]):
+            n = int(lens[b])
+            for K in (None, 16):            # the engine hands over its top-16; ties aside the candidates are the same
+                toks, st, en, conf, score = native_joint(sd, case.cfg, enc[b:b + 1, :n], probs[b, :n], run, cat, K)
+                assert toks == want["tokens"], (run, b, K)
+                assert st == want["times"] and en == want["end_times"], (run, b, K)
+                assert abs(score - want["score"]) < 2e-3 * max(1.0, abs(want["score"]))
+                np.testing.assert_allclose(conf, want["tokens_confidence"], rtol=2e-3, atol=1e-6)
