@@ -158,6 +158,18 @@ int rvb_attention_decode(rvb_engine* e, int beam, float length_penalty);
 /* best hypothesis of one chunk without <sos>/<eos>; `tokens` needs room for rvb_encoder_frames() entries */
 int rvb_get_attention_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* n_tokens, float* score);
 
+/* `joint_decoding` mode (asr/wenet/transformer/search.py:450-496 -> espnet/beam_search_timesync.py:86-508): time-synchronous
+ * joint CTC / attention beam search on the chunks of the last rvb_encode, which must have kept at least
+ * int(pre_beam_ratio * beam) log-probs per frame.  Every chunk advances one encoder frame per iteration; the prefixes of all
+ * chunks that need the attention decoder form one batched decoder step.  The decoder's memory is the chunk's
+ * valid frames as a (1, len, d) tensor -- the shape BeamSearchTimeSync.reset expects; the reference's own call passes a 2-D
+ * tensor and raises there.  length_bonus is what ASRModel.decode passes as `length_penalty` (asr_model.py:427-431).
+ * Result per chunk: winner without <sos>, start / end frame and confidence (max of CTC and attention) per token, joint score. */
+int rvb_joint_decode(rvb_engine* e, int beam, double ctc_weight, double pre_beam_ratio, double length_bonus);
+int rvb_get_joint_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* times, int32_t* end_times, double* tokens_confidence,
+                         int32_t* n_tokens, double* score);
+int rvb_get_joint_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* steps);
+
 int rvb_get_rescored(rvb_engine* e, int chunk, int32_t* best_index, float* score, double* confidence,
                      double* tokens_confidence /* [len of best] */);
 /* all chunks of the batch at once: the winning hypothesis of each chunk, arrays padded to [B][T]

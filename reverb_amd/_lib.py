@@ -49,6 +49,9 @@ SIGNATURES = {
     "rvb_host_free": (C.c_int, [C.c_void_p]),
     "rvb_set_decoding_chunk": (C.c_int, [_eng, C.c_int, C.c_int]),
     "rvb_set_fp8_policy": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int]),
+    "rvb_joint_decode": (C.c_int, [_eng, C.c_int, C.c_double, C.c_double, C.c_double]),
+    "rvb_get_joint_result": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _i32p, _f64p, _i32p, _f64p]),
+    "rvb_get_joint_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_upload_pcm_rate": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int]),
     "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),

@@ -113,6 +113,11 @@ struct rvb_engine {
   const int* cur_lens = nullptr;   // device pointer: valid encoder frames of the slice being encoded
   std::vector<rvb::PrefixResult> nbest;
   std::vector<rvb::RescoreResult> rescored;
+  std::vector<rvb::JointResult> joint;           // rvb_joint_decode: winner per chunk
+  std::vector<rvb::DevBuf> jkv;                   // joint_decoding: per decoder layer T [rows][2d], key | value of every decoded prefix
+  rvb::DevBuf jlogp, jpair_row, jpair_tok, jpair_out;     // fp32 [rows][V] log-softmax after each decoded prefix; pair gather buffers
+  int64_t joint_rows = 0, joint_steps = 0;       // decoder rows computed / batched decoder steps of the last rvb_joint_decode
+  float last_blank_penalty = 0.f;                // of the last rvb_encode / rvb_stream_finish
   std::vector<std::vector<int>> attn_tokens;     // rvb_attention_decode: best hypothesis per chunk
   std::vector<float> attn_scores;
   rvb::DevBuf atopv, atopi;                       // per-step top-k of the decoder output

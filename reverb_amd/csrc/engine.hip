@@ -620,6 +620,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   const int M = B * T2;
   const size_t es = dt_size(e->dtype);
   e->B = B; e->T0 = T0; e->T1 = T1; e->F1 = F1; e->T2 = T2; e->F2 = F2; e->beam = beam;
+  e->last_blank_penalty = blank_penalty;
   e->in_lens.assign(lens, lens + B);
   e->enc_lens.resize(B);
   std::vector<int32_t> starts(B), qlens(B, T2);
@@ -887,6 +888,7 @@ static int stream_finish_impl(rvb_engine* e, int beam, float blank_penalty) {
   const size_t es = dt_size(e->dtype);
   if (M <= 0) { set_error("rvb_stream_finish: the stream produced no encoder frame"); return E_STATE; }
   e->B = 1; e->T2 = M; e->beam = beam; e->T0 = 0;
+  e->last_blank_penalty = blank_penalty;
   e->in_lens.assign(1, 0); e->enc_lens.assign(1, M);
   e->nbest.clear(); e->rescored.clear();
   const int Vld = (V + 3) & ~3;
@@ -936,8 +938,10 @@ static unsigned search_threads() {
 
 static int prefix_beam_impl(rvb_engine* e, int beam) {
   if (e->B <= 0) { set_error("rvb_ctc_prefix_beam before rvb_encode"); return E_STATE; }
-  if (beam != e->beam) { set_error("rvb_ctc_prefix_beam: beam differs from the one given to rvb_encode"); return E_ARG; }
-  const int B = e->B, T = e->T2;
+  // the search beam may be narrower than the top-k rvb_encode kept per frame (joint_decoding's pre-beam needs more): the first
+  // `beam` entries of a frame's descending top-k ARE its top-`beam` (search.py:155 `logp.topk(beam_size)`)
+  if (beam < 1 || beam > e->beam) { set_error("rvb_ctc_prefix_beam: beam exceeds the top-k kept by rvb_encode"); return E_ARG; }
+  const int B = e->B, T = e->T2, K = e->beam;
   e->nbest.assign(B, PrefixResult());
   const unsigned hw = search_threads();
   double busy_ms = 0.0;
@@ -952,7 +956,7 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
     std::vector<std::thread> pool;
     auto work = [&, c0, nb]() {
       for (int b = next_chunk.fetch_add(1); b < c0 + nb; b = next_chunk.fetch_add(1))
-        prefix_beam_search(e->h_topv + (size_t)b * T * beam, e->h_topi + (size_t)b * T * beam, e->enc_lens[b], beam,
+        prefix_beam_search(e->h_topv + (size_t)b * T * K, e->h_topi + (size_t)b * T * K, e->enc_lens[b], K,
                            beam, e->cfg.blank_id, &e->nbest[b]);
     };
     for (unsigned w = 1; w < nthr; ++w) pool.emplace_back(work);
@@ -1406,6 +1410,245 @@ static int attention_decode_impl(rvb_engine* e, int N, float length_penalty) {
   return OK;
 }
 
+
+// ------------------------------------------------------------------------------------ joint_decoding
+// `joint_decoding` (transformer/search.py:450-496 -> espnet/beam_search_timesync.py:86-508): time-synchronous joint CTC /
+// attention beam search.  The reference runs one BeamSearchTimeSync per chunk and, inside it, the attention decoder on ONE
+// new prefix at a time, re-feeding the whole prefix with the cached layer outputs of its parent (cached_score :185-224).
+// Here every chunk of the batch advances in lockstep, one encoder frame per iteration:
+//   * the CTC half of the frame and the joint scoring run on the host, per chunk (search.cpp JointSearch: the reference's
+//     float64 arithmetic and dict semantics on a prefix trie);
+//   * the prefixes whose decoder output is needed for the first time -- of ALL chunks -- form one batched decoder step:
+//     one row per prefix (its last token), self-attention over the key / value rows of its ancestors (kept per decoder
+//     layer for every decoded prefix, addressed through AttnArgs::kv_index), cross-attention against the chunk's memory
+//     keys / values (projected once), output layer, log-softmax row kept on the device;
+//   * the (prefix, next token) log-probs the joint scores need are gathered from those rows and copied back: a few
+//     floats per chunk and frame.
+// The memory is the chunk's valid frames, as the class's own `reset` expects ((1, len, d); the reference's call passes a
+// 2-D tensor and fails there -- DESIGN.md, oracle/gen_golden_joint.py).
+static int grow_rows(rvb_engine* e, DevBuf& b, size_t row_bytes, int64_t have, int64_t need) {
+  if ((size_t)need * row_bytes <= b.bytes) return OK;
+  DevBuf nb;
+  const int64_t cap = std::max<int64_t>(need, (int64_t)(b.bytes / row_bytes) * 2);
+  RVB_TRY(nb.ensure((size_t)cap * row_bytes));
+  if (have > 0) RVB_HIP_CHECK(hipMemcpyAsync(nb.p, b.p, (size_t)have * row_bytes, hipMemcpyDeviceToDevice, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  b.release();
+  b = nb;
+  nb.p = nullptr; nb.bytes = 0;
+  return OK;
+}
+
+static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double pre_beam_ratio, double length_bonus) {
+  const rvb_model_cfg& c = e->cfg;
+  if (e->B <= 0) { set_error("rvb_joint_decode before rvb_encode"); return E_STATE; }
+  if (!e->dec_l.present) { set_error("model has no attention decoder"); return E_STATE; }
+  const int pre_beam = (int)(pre_beam_ratio * beam);
+  if (beam < 1 || pre_beam < 1) { set_error("rvb_joint_decode: beam and pre_beam_ratio * beam must be >= 1"); return E_ARG; }
+  if (pre_beam > e->beam) {
+    set_error("rvb_joint_decode: rvb_encode kept the top " + std::to_string(e->beam) + " CTC log-probs per frame, the pre-beam needs " +
+              std::to_string(pre_beam));
+    return E_ARG;
+  }
+  if (e->last_blank_penalty != 0.f) { set_error("rvb_joint_decode: blank_penalty is not supported in this mode"); return E_UNSUPPORTED; }
+  RVB_TRY(wait_slices(e, -1));
+  Decoder& D = e->dec_l;
+  const int B = e->B, T2 = e->T2, d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
+  const int M = B * T2, NL = (int)D.layers.size(), K = e->beam;
+  const size_t es = dt_size(e->dtype);
+  const int Vld = (V + 3) & ~3;
+  if (T2 + 1 > e->pe_rows) { set_error("rvb_joint_decode: more positions than positional-table rows"); return E_UNSUPPORTED; }
+
+  // ---- per-frame log-prob of token 0 (the reference's blank-skip test reads p_ctc[0]) and of the blank
+  std::vector<float> p0(M), pbl(M);
+  {
+    RVB_TRY(e->logits.ensure((size_t)LOGIT_SLAB * Vld * 4));
+    RVB_TRY(e->d_tgt.ensure((size_t)LOGIT_SLAB * 4));
+    RVB_TRY(e->d_logp.ensure((size_t)LOGIT_SLAB * 4));
+    std::vector<int32_t> tgt(LOGIT_SLAB);
+    for (int pass = 0; pass < (c.blank_id == 0 ? 1 : 2); ++pass) {
+      std::fill(tgt.begin(), tgt.end(), pass == 0 ? 0 : c.blank_id);
+      RVB_TRY(upload_i32(e, e->d_tgt, tgt.data(), LOGIT_SLAB));
+      std::vector<float>& dst = pass == 0 ? p0 : pbl;
+      for (int r0 = 0; r0 < M; r0 += LOGIT_SLAB) {
+        const int rows = std::min(LOGIT_SLAB, M - r0);
+        RVB_TRY(run_gemm(e, (const char*)e->enc_out.p + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
+        RVB_TRY(lse_gather(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt.as<int>(), e->d_logp.as<float>()));
+        RVB_HIP_CHECK(hipMemcpyAsync(dst.data() + r0, e->d_logp.p, (size_t)rows * 4, hipMemcpyDeviceToHost, e->stream));
+        RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+      }
+    }
+    if (c.blank_id == 0) pbl = p0;
+  }
+
+  // ---- memory keys / values of every chunk, once per decoder layer
+  e->memkv.resize(NL); e->jkv.resize(NL);
+  for (int l = 0; l < NL; ++l) {
+    RVB_TRY(e->memkv[l].ensure((size_t)M * 2 * d * es));
+    RVB_TRY(run_gemm(e, e->enc_out.p, d, D.layers[l].src_kv, e->memkv[l].p, 2 * d, M, false));
+  }
+  const int Rmax = B * std::max(beam, 1);
+  RVB_TRY(e->dx.ensure((size_t)Rmax * d * 4));
+  RVB_TRY(e->dxn.ensure((size_t)Rmax * d * es));
+  RVB_TRY(e->dy.ensure((size_t)Rmax * d * es));
+  RVB_TRY(e->dao.ensure((size_t)Rmax * d * es));
+  RVB_TRY(e->dq.ensure((size_t)Rmax * d * es));
+  RVB_TRY(e->dqkv.ensure((size_t)Rmax * 3 * d * es));
+  RVB_TRY(e->dh.ensure((size_t)Rmax * ff * es));
+  RVB_TRY(e->logits.ensure((size_t)std::max(Rmax, LOGIT_SLAB) * Vld * 4));
+  RVB_TRY(e->atopv.ensure((size_t)Rmax * 4));
+  RVB_TRY(e->atopi.ensure((size_t)Rmax * 4));
+
+  JointParams jp;
+  jp.beam = beam; jp.pre_beam = pre_beam; jp.blank = c.blank_id; jp.sos = c.sos_id;
+  jp.w_ctc = ctc_weight; jp.w_dec = 1.0 - ctc_weight; jp.bonus = length_bonus; jp.log_thr = 0.0;
+  std::vector<JointSearch> js;
+  js.reserve(B);
+  for (int b = 0; b < B; ++b) js.emplace_back(jp);
+  int64_t next_row = 0;
+  e->joint_rows = 0; e->joint_steps = 0;
+  float* x = e->dx.as<float>();
+
+  // one batched decoder step for the prefixes (chunk, node) in `req` (grouped by chunk, in order)
+  struct Req { int chunk, node; };
+  std::vector<int32_t> tok, pos, q1, one, pstart, plen, path, xq0, xqn, xkv;
+  auto step = [&](const std::vector<Req>& req) -> int {
+    const int R = (int)req.size();
+    if (R == 0) return OK;
+    if (R > Rmax) { set_error("rvb_joint_decode: more new prefixes in one frame than beam x chunks"); return E_STATE; }
+    const int64_t row0 = next_row;
+    for (int l = 0; l < NL; ++l) RVB_TRY(grow_rows(e, e->jkv[l], (size_t)2 * d * es, row0, row0 + R));
+    RVB_TRY(grow_rows(e, e->jlogp, (size_t)V * 4, row0, row0 + R));
+    tok.resize(R); pos.resize(R); q1.resize(R); one.assign(R, 1); pstart.resize(R); plen.resize(R);
+    path.clear(); xq0.clear(); xqn.clear(); xkv.clear();
+    std::vector<int32_t> xk0, xkn;
+    int max_xq = 0;
+    std::vector<int> pf;
+    for (int r = 0; r < R; ++r) {
+      JointSearch& J = js[req[r].chunk];
+      const int node = req[r].node;
+      J.set_tag(node, (int)(row0 + r));
+      J.prefix(node, &pf);
+      tok[r] = pf.back(); pos[r] = (int)pf.size() - 1; q1[r] = r;
+      pstart[r] = (int)path.size(); plen[r] = (int)pf.size();
+      const size_t at = path.size();
+      path.resize(at + pf.size());
+      for (int n = node, i = (int)pf.size() - 1; n >= 0; n = J.parent(n), --i) path[at + i] = J.tag(n);   // ancestors are decoded
+      if (r == 0 || req[r].chunk != req[r - 1].chunk) { xq0.push_back(r); xqn.push_back(0); xk0.push_back(req[r].chunk * T2); xkn.push_back(e->enc_lens[req[r].chunk]); }
+      max_xq = std::max(max_xq, ++xqn.back());
+    }
+    const int nx = (int)xq0.size();
+    xkv = xk0; xkv.insert(xkv.end(), xkn.begin(), xkn.end());
+    RVB_TRY(upload_i32(e, e->d_tok, tok.data(), R));
+    RVB_TRY(upload_i32(e, e->d_pos, pos.data(), R));
+    RVB_TRY(upload_i32(e, e->d_hq_start, q1.data(), R));
+    RVB_TRY(upload_i32(e, e->d_hq_len, one.data(), R));
+    RVB_TRY(upload_i32(e, e->d_hpath_start, pstart.data(), R));
+    RVB_TRY(upload_i32(e, e->d_hpath_len, plen.data(), R));
+    RVB_TRY(upload_i32(e, e->d_path, path.data(), path.size()));
+    RVB_TRY(upload_i32(e, e->d_hkv_start, xq0.data(), nx));
+    RVB_TRY(upload_i32(e, e->d_hkv_len, xqn.data(), nx));
+    RVB_TRY(upload_i32(e, e->d_aux_i32, xkv.data(), xkv.size()));
+    {
+      Scope sc(e, "embed");
+      RVB_TRY(embed_tokens(e->stream, D.embed.as<float>(), e->pe_f32.as<float>(), e->d_tok.as<int>(), e->d_pos.as<int>(), x, R, d,
+                           std::sqrt((float)d)));
+    }
+    for (int l = 0; l < NL; ++l) {
+      DecLayer& Ly = D.layers[l];
+      RVB_TRY(run_norm(e, x, Ly.n1, e->dxn.p, false, R, d));
+      RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.self_qkv, e->dqkv.p, 3 * d, R, false));
+      // the new prefixes' key | value rows join the per-layer store (k and v are adjacent in the fused projection)
+      RVB_HIP_CHECK(hipMemcpy2DAsync((char*)e->jkv[l].p + (size_t)row0 * 2 * d * es, (size_t)2 * d * es, (const char*)e->dqkv.p + (size_t)d * es,
+                                     (size_t)3 * d * es, (size_t)2 * d * es, R, hipMemcpyDeviceToDevice, e->stream));
+      AttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.q = e->dqkv.p; a.k = e->jkv[l].p; a.v = (const char*)e->jkv[l].p + (size_t)d * es;
+      a.q_stride = 3 * d; a.k_stride = a.v_stride = 2 * d; a.o_stride = d; a.out = e->dao.p;
+      a.q_start = e->d_hq_start.as<int>(); a.q_len = e->d_hq_len.as<int>();
+      a.kv_start = e->d_hpath_start.as<int>(); a.kv_len = e->d_hpath_len.as<int>(); a.kv_index = e->d_path.as<int>();
+      a.nseq = R; a.heads = heads; a.dk = dk; a.max_q = 1; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
+      { Scope sc(e, "attention"); RVB_TRY(attention(e->stream, e->dtype, a)); }
+      RVB_TRY(run_gemm(e, e->dao.p, d, Ly.self_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+      RVB_TRY(run_norm(e, x, Ly.n2, e->dxn.p, false, R, d));
+      RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.src_q, e->dq.p, d, R, false));
+      memset(&a, 0, sizeof(a));
+      a.q = e->dq.p; a.k = e->memkv[l].p; a.v = (const char*)e->memkv[l].p + (size_t)d * es;
+      a.q_stride = d; a.k_stride = a.v_stride = 2 * d; a.o_stride = d; a.out = e->dao.p;
+      a.q_start = e->d_hkv_start.as<int>(); a.q_len = e->d_hkv_len.as<int>();
+      a.kv_start = e->d_aux_i32.as<int>(); a.kv_len = e->d_aux_i32.as<int>() + nx;
+      a.nseq = nx; a.heads = heads; a.dk = dk; a.max_q = max_xq; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
+      { Scope sc(e, "attention"); RVB_TRY(attention(e->stream, e->dtype, a)); }
+      RVB_TRY(run_gemm(e, e->dao.p, d, Ly.src_out, x, d, R, true, 1.f, ACT_NONE, x, d));
+      RVB_TRY(run_norm(e, x, Ly.n3, e->dxn.p, false, R, d));
+      const void* ffin = e->dxn.p;
+      if (Ly.is_lsl) { RVB_TRY(run_gemm(e, e->dxn.p, d, Ly.lsl, e->dy.p, d, R, false)); ffin = e->dy.p; }
+      RVB_TRY(run_gemm(e, ffin, d, Ly.ff1, e->dh.p, ff, R, false, 1.f, ACT_RELU));
+      RVB_TRY(run_gemm(e, e->dh.p, ff, Ly.ff2, x, d, R, true, 1.f, ACT_NONE, x, d));
+    }
+    RVB_TRY(run_norm(e, x, D.after, e->dxn.p, false, R, d));
+    RVB_TRY(run_gemm(e, e->dxn.p, d, D.out, e->logits.p, Vld, R, true));
+    {
+      Scope sc(e, "ctc_topk");
+      RVB_TRY(logsoftmax_topk(e->stream, e->logits.as<float>(), R, V, Vld, 1, 0.f, 0, e->atopv.as<float>(), e->atopi.as<int>(),
+                              e->jlogp.as<float>() + (size_t)row0 * V));
+    }
+    next_row += R;
+    e->joint_rows += R; e->joint_steps += 1;
+    return OK;
+  };
+
+  // reset(): the decoder on <sos> for every chunk
+  std::vector<Req> req;
+  for (int b = 0; b < B; ++b) req.push_back({b, 0});
+  RVB_TRY(step(req));
+
+  int Tmax = 0;
+  for (int b = 0; b < B; ++b) Tmax = std::max(Tmax, e->enc_lens[b]);
+  std::vector<int> dec, pn, pt, npairs(B), ran(B);
+  std::vector<int32_t> prow, ptok;
+  std::vector<float> vals;
+  for (int t = 0; t < Tmax; ++t) {
+    req.clear(); prow.clear(); ptok.clear();
+    for (int b = 0; b < B; ++b) {
+      npairs[b] = 0; ran[b] = 0;
+      if (t >= e->enc_lens[b]) continue;
+      const size_t f = (size_t)b * T2 + t;
+      dec.clear(); pn.clear(); pt.clear();
+      ran[b] = js[b].begin_frame(t, e->h_topv + f * K, e->h_topi + f * K, K, p0[f], pbl[f], &dec, &pn, &pt) ? 1 : 0;
+      if (!ran[b]) continue;
+      for (int n : dec) req.push_back({b, n});
+      npairs[b] = (int)pn.size();
+      for (size_t i = 0; i < pn.size(); ++i) { prow.push_back(-1 - pn[i]); ptok.push_back(pt[i]); }      // rows resolved after the step
+    }
+    RVB_TRY(step(req));
+    {   // pair rows: the node's tag is known now
+      size_t at = 0;
+      for (int b = 0; b < B; ++b)
+        for (int i = 0; i < npairs[b]; ++i, ++at) prow[at] = js[b].tag(-1 - prow[at]);
+    }
+    const int NP = (int)prow.size();
+    vals.resize(std::max(NP, 1));
+    if (NP > 0) {
+      RVB_TRY(e->jpair_row.ensure((size_t)NP * 4)); RVB_TRY(e->jpair_tok.ensure((size_t)NP * 4)); RVB_TRY(e->jpair_out.ensure((size_t)NP * 4));
+      RVB_TRY(upload_i32(e, e->jpair_row, prow.data(), NP));
+      RVB_TRY(upload_i32(e, e->jpair_tok, ptok.data(), NP));
+      RVB_TRY(gather_pairs(e->stream, e->jlogp.as<float>(), (size_t)V, e->jpair_row.as<int>(), e->jpair_tok.as<int>(), NP, e->jpair_out.as<float>()));
+      RVB_HIP_CHECK(hipMemcpyAsync(vals.data(), e->jpair_out.p, (size_t)NP * 4, hipMemcpyDeviceToHost, e->stream));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    size_t at = 0;
+    for (int b = 0; b < B; ++b) {
+      if (ran[b]) js[b].finish_frame(vals.data() + at);
+      at += npairs[b];
+    }
+  }
+  e->joint.assign(B, JointResult());
+  for (int b = 0; b < B; ++b) js[b].result(&e->joint[b]);
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  return OK;
+}
+
 }  // namespace rvb
 
 // ================================================================================================
@@ -1461,6 +1704,8 @@ void rvb_destroy(rvb_engine* e) {
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
   e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
+  e->jlogp.release(); e->jpair_row.release(); e->jpair_tok.release(); e->jpair_out.release();
+  for (auto& b : e->jkv) b.release();
   for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2, &e->stream_st.cnn, &e->stream_st.cnn2}) for (auto& b : *v) b.release();
   for (auto* v : {&e->kcache, &e->vcache, &e->kcache2, &e->vcache2, &e->memkv}) for (auto& b : *v) b.release();
   auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); l.w8.release(); l.wscale.release(); };
@@ -1749,6 +1994,32 @@ int rvb_attention_decode(rvb_engine* e, int beam, float length_penalty) {
   if (!e) { set_error("rvb_attention_decode: null engine"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   return attention_decode_impl(e, beam, length_penalty);
+}
+int rvb_joint_decode(rvb_engine* e, int beam, double ctc_weight, double pre_beam_ratio, double length_bonus) {
+  if (!e) { set_error("rvb_joint_decode: null engine"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return joint_decode_impl(e, beam, ctc_weight, pre_beam_ratio, length_bonus);
+}
+int rvb_get_joint_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* times, int32_t* end_times, double* tokens_confidence,
+                         int32_t* n_tokens, double* score) {
+  if (!e || !n_tokens) { set_error("rvb_get_joint_result: null argument"); return E_ARG; }
+  if (chunk < 0 || chunk >= (int)e->joint.size()) { set_error("rvb_get_joint_result: no joint_decoding result for this chunk"); return E_STATE; }
+  const JointResult& r = e->joint[chunk];
+  for (size_t i = 0; i < r.tokens.size(); ++i) {      // capacity: rvb_encoder_frames() entries each
+    if (tokens) tokens[i] = r.tokens[i];
+    if (times) times[i] = r.times[i];
+    if (end_times) end_times[i] = r.end_times[i];
+    if (tokens_confidence) tokens_confidence[i] = r.tokens_confidence[i];
+  }
+  *n_tokens = (int32_t)r.tokens.size();
+  if (score) *score = r.score;
+  return OK;
+}
+int rvb_get_joint_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* steps) {
+  if (!e) { set_error("rvb_get_joint_stats: null engine"); return E_ARG; }
+  if (decoder_rows) *decoder_rows = e->joint_rows;
+  if (steps) *steps = e->joint_steps;
+  return OK;
 }
 int rvb_get_attention_result(rvb_engine* e, int chunk, int32_t* tokens, int32_t* n_tokens, float* score) {
   if (!e || !n_tokens) { set_error("rvb_get_attention_result: null argument"); return E_ARG; }

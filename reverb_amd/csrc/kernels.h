@@ -118,6 +118,9 @@ int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const i
 // CSR form for rows with several targets: out[p] = logits[r][target[p]] - lse(r) for p in [ptr[r], ptr[r+1])
 int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, const int* ptr, const int* target, float* out);
 
+// out[i] = table[row[i]][col[i]], fp32 table with ld entries per row
+int gather_pairs(hipStream_t s, const float* table, size_t ld, const int* row, const int* col, int n, float* out);
+
 // dst[r][t][:] = src[parent[r]][t][:], t < rows: caches [R][L][row_bytes]
 int gather_cache(hipStream_t s, const void* src, void* dst, const int* parent, int R, int L, int rows, int row_bytes);
 

@@ -218,4 +218,19 @@ int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, c
   return OK;
 }
 
+// out[i] = table[row[i]][col[i]] (fp32 table with `ld` entries per row): the attention log-probs joint_decoding asks for,
+// read out of the stored log-softmax rows of the decoded prefixes
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const float* __restrict__ table, size_t ld, const int* __restrict__ row,
+                                                           const int* __restrict__ col, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = table[(size_t)row[i] * ld + col[i]];
+}
+
+int gather_pairs(hipStream_t s, const float* table, size_t ld, const int* row, const int* col, int n, float* out) {
+  if (n <= 0) return OK;
+  hipLaunchKernelGGL(gather_pairs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, table, ld, row, col, n, out);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 }  // namespace rvb

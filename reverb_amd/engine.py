@@ -15,7 +15,8 @@ from .search import DecodeResult
 
 DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32,
           "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16, "fp8": _lib.RVB_FP8}
-SUPPORTED_MODES = ("attention", "ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring")
+SUPPORTED_MODES = ("attention", "ctc_greedy_search", "ctc_prefix_beam_search", "attention_rescoring", "joint_decoding")
+JOINT_PRE_BEAM_RATIO = 1.5      # transformer/search.py:458
 
 
 def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_frames: int) -> ModelCfg:
@@ -60,6 +61,11 @@ def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_fra
     cfg.max_chunks = int(max_chunks)
     cfg.chunk_frames = int(chunk_frames)
     return cfg
+
+
+def joint_topk(methods, beam_size: int) -> Optional[int]:
+    """CTC log-probs to keep per frame when `joint_decoding` is among the modes (its pre-beam), else None."""
+    return int(JOINT_PRE_BEAM_RATIO * beam_size) if "joint_decoding" in methods else None
 
 
 def _as_numpy_f32(v) -> Optional[np.ndarray]:
@@ -211,7 +217,9 @@ class Engine:
 
     # -------------------------------------------------------------------------------- decode
     def encode(self, feats: Optional[np.ndarray], lens, beam: int, blank_penalty: float = 0.0, first_chunk: int = 0,
-               T0: Optional[int] = None):
+               T0: Optional[int] = None, topk: Optional[int] = None):
+        """`beam`: the search beam of the modes that follow; `topk` (>= beam): CTC log-probs kept per frame, when a mode needs
+        more than the beam (joint_decoding's pre-beam = int(1.5 * beam))."""
         lens = np.ascontiguousarray(np.asarray(lens, dtype=np.int32).reshape(-1))
         B = len(lens)
         if feats is not None:
@@ -220,11 +228,12 @@ class Engine:
             T0 = feats.shape[1]
         elif T0 is None:
             T0 = self.cfg.chunk_frames
-        check(self.lib.rvb_encode(self.handle, fptr(feats), int(first_chunk), iptr(lens), B, int(T0), int(beam),
+        k = max(int(beam), int(topk or 0))
+        check(self.lib.rvb_encode(self.handle, fptr(feats), int(first_chunk), iptr(lens), B, int(T0), k,
                                   float(blank_penalty)), "rvb_encode")
         t = C.c_int32(0)
         check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
-        self.batch, self.enc_frames, self.beam = B, int(t.value), int(beam)
+        self.batch, self.enc_frames, self.beam, self.topk = B, int(t.value), int(beam), k
 
     # -------------------------------------------------------------------------------- streaming encoder
     def stream_begin(self):
@@ -269,13 +278,14 @@ class Engine:
             return None
         return np.concatenate(outs) if outs else np.zeros((0, self.cfg.d_model), np.float32)
 
-    def stream_finish(self, beam: int, blank_penalty: float = 0.0):
+    def stream_finish(self, beam: int, blank_penalty: float = 0.0, topk: Optional[int] = None):
         """CTC head + top-k over the streamed frames; greedy() / prefix_beam() / rescore() / encoder_out() then see the
         stream as one chunk."""
-        check(self.lib.rvb_stream_finish(self.handle, int(beam), float(blank_penalty)), "rvb_stream_finish")
+        k = max(int(beam), int(topk or 0))
+        check(self.lib.rvb_stream_finish(self.handle, k, float(blank_penalty)), "rvb_stream_finish")
         t = C.c_int32(0)
         check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
-        self.batch, self.enc_frames, self.beam = 1, int(t.value), int(beam)
+        self.batch, self.enc_frames, self.beam, self.topk = 1, int(t.value), int(beam), k
 
     def encoder_lens(self) -> np.ndarray:
         out = np.empty(self.batch, np.int32)
@@ -293,8 +303,9 @@ class Engine:
         return out
 
     def ctc_topk(self):
-        v = np.empty((self.batch, self.enc_frames, self.beam), np.float32)
-        i = np.empty((self.batch, self.enc_frames, self.beam), np.int32)
+        k = getattr(self, "topk", self.beam)
+        v = np.empty((self.batch, self.enc_frames, k), np.float32)
+        i = np.empty((self.batch, self.enc_frames, k), np.int32)
         check(self.lib.rvb_get_ctc_topk(self.handle, fptr(v), iptr(i)))
         return v, i
 
@@ -376,18 +387,43 @@ class Engine:
             res.append(DecodeResult(tok[:n.value].tolist()))
         return res
 
+    def joint_decode(self, ctc_weight: float, length_bonus: float = 0.0, pre_beam_ratio: float = JOINT_PRE_BEAM_RATIO
+                     ) -> List[DecodeResult]:
+        """`joint_decoding` (search.py:450-496): time-synchronous joint CTC / attention beam search of the last encoded batch
+        (encode(..., topk=int(pre_beam_ratio * beam)) first).  DecodeResult: tokens, joint score, start frame and confidence
+        per token -- the fields the reference fills -- plus `end_times`."""
+        check(self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus)),
+              "rvb_joint_decode")
+        T = max(self.enc_frames, 1)
+        tok = np.empty(T, np.int32); st = np.empty(T, np.int32); en = np.empty(T, np.int32); cf = np.empty(T, np.float64)
+        res = []
+        for b in range(self.batch):
+            n, sc = C.c_int32(0), C.c_double(0)
+            check(self.lib.rvb_get_joint_result(self.handle, b, iptr(tok), iptr(st), iptr(en), dptr(cf), C.byref(n), C.byref(sc)),
+                  "rvb_get_joint_result")
+            k = n.value
+            r = DecodeResult(tok[:k].tolist(), float(sc.value), times=st[:k].tolist(), tokens_confidence=cf[:k].tolist())
+            r.end_times = en[:k].tolist()
+            res.append(r)
+        return res
+
+    def joint_stats(self):
+        """(decoder rows computed, batched decoder steps) of the last joint_decode."""
+        r, p = C.c_int64(0), C.c_int64(0)
+        check(self.lib.rvb_get_joint_stats(self.handle, C.byref(r), C.byref(p)))
+        return int(r.value), int(p.value)
+
     def search(self, methods: Sequence[str], ctc_weight: float, reverse_weight: float, length_penalty: float = 0.0
                ) -> Dict[str, List[DecodeResult]]:
-        """Search stages of ASRModel.decode (asr_model.py:391-425) on the last encoded batch."""
+        """Search stages of ASRModel.decode (asr_model.py:391-432) on the last encoded batch."""
         results: Dict[str, List[DecodeResult]] = {}
         for m in methods:
-            if m == "joint_decoding":
-                raise RvbError("joint_decoding is not built: the reference's own decode(['joint_decoding']) raises a mask size "
-                               "mismatch for every model (search.py:474-489 / beam_search_timesync.py:150-154), see DESIGN.md section 7")
             if m not in SUPPORTED_MODES:
                 raise RvbError(f"decoding mode {m!r} is not built yet (supported: {', '.join(SUPPORTED_MODES)})")
         if "attention" in methods:
             results["attention"] = self.attention_beam(length_penalty)
+        if "joint_decoding" in methods:          # asr_model.py:427-431: length_bonus = length_penalty
+            results["joint_decoding"] = self.joint_decode(ctc_weight, length_penalty)
         if "ctc_greedy_search" in methods:
             results["ctc_greedy_search"] = self.greedy()
         if "attention_rescoring" in methods and "ctc_prefix_beam_search" not in methods:
@@ -418,7 +454,7 @@ class Engine:
         out: Dict[str, List[DecodeResult]] = {m: [] for m in modes}
         for s in range(0, n_chunks, self.cfg.max_chunks):
             e = min(n_chunks, s + self.cfg.max_chunks)
-            self.encode(None, lens[s:e], beam_size, blank_penalty, first_chunk=s, T0=chunk_size)
+            self.encode(None, lens[s:e], beam_size, blank_penalty, first_chunk=s, T0=chunk_size, topk=joint_topk(modes, beam_size))
             part = self.search(modes, ctc_weight, reverse_weight, length_penalty)
             for m in modes:
                 out[m].extend(part[m])

@@ -23,7 +23,7 @@ from typing import Generator, List, Tuple
 import numpy as np
 
 from .ctc_align import adjust_model_time_offset, ctc_align, hyps_to_ctm, hyps_to_txt
-from .engine import Engine, SUPPORTED_MODES
+from .engine import Engine, SUPPORTED_MODES, joint_topk
 from .search import DecodeResult
 from .tokenizer import RevBpeTokenizer
 from .wav import read_wav
@@ -80,7 +80,7 @@ class RvbASRModel:
             # the engine apply, and each item of the batch is its own stream (the reference asserts batch 1).
             for b in range(feats.shape[0]):
                 self.engine.forward_chunk_by_chunk(feats[b], decoding_chunk_size, num_decoding_left_chunks, return_output=False)
-                self.engine.stream_finish(beam_size, blank_penalty)
+                self.engine.stream_finish(beam_size, blank_penalty, topk=joint_topk(methods, beam_size))
                 part = self.engine.search(methods, ctc_weight, reverse_weight, length_penalty)
                 for k, v in part.items():
                     results.setdefault(k, []).extend(v)
@@ -88,7 +88,7 @@ class RvbASRModel:
         self.engine.apply_decoding_chunk(decoding_chunk_size, num_decoding_left_chunks)
         mc = self.engine.cfg.max_chunks
         for s in range(0, feats.shape[0], mc):
-            self.engine.encode(feats[s:s + mc], lens[s:s + mc], beam_size, blank_penalty)
+            self.engine.encode(feats[s:s + mc], lens[s:s + mc], beam_size, blank_penalty, topk=joint_topk(methods, beam_size))
             part = self.engine.search(methods, ctc_weight, reverse_weight, length_penalty)
             for k, v in part.items():
                 results.setdefault(k, []).extend(v)

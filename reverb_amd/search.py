@@ -9,7 +9,7 @@ from typing import List, Optional
 
 class DecodeResult:
     __slots__ = ("tokens", "score", "confidence", "tokens_confidence", "times", "nbest", "nbest_scores",
-                 "nbest_times", "ctc_frames")
+                 "nbest_times", "ctc_frames", "end_times")
 
     def __init__(self, tokens: List[int], score: float = 0.0, confidence: float = 0.0,
                  tokens_confidence: Optional[List[float]] = None, times: Optional[List[int]] = None,
@@ -26,6 +26,9 @@ class DecodeResult:
         # extension: frame of each greedy token's first emission (the reference leaves greedy
         # results without times, which makes its own CTM formatter raise)
         self.ctc_frames = None
+        # extension: end frame per token of a joint_decoding result (BeamSearchTimeSync computes them, search.py:490-494
+        # keeps the start frames only)
+        self.end_times = None
 
     def __repr__(self):
         return (f"DecodeResult(tokens={list(self.tokens)!r}, score={self.score!r}, "

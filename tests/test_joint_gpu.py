@@ -1,0 +1,69 @@
+"""`joint_decoding` on the GPU (rvb_joint_decode: every chunk of the batch advances one encoder frame per iteration, one
+batched decoder step for the new prefixes of all chunks) against goldens of the reference's own BeamSearchTimeSync class
+(oracle/gen_golden_joint.py; asr/wenet/transformer/search.py:450-496, espnet/beam_search_timesync.py)."""
+import numpy as np
+import pytest
+
+from golden_util import JointCase
+from reverb_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["joint_tiny", "joint_small"])
+def test_joint_decoding_f32_matches_reference_class(name):
+    case = JointCase(name)
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    for run in case.js["runs"]:
+        beam = run["beam"]
+        eng.encode(case.x, case.lens, beam, topk=int(run["pre_beam_ratio"] * beam))
+        assert eng.encoder_lens().tolist() == case.js["encoder_lens"]
+        got = eng.joint_decode(run["ctc_weight"], run["length_bonus"], run["pre_beam_ratio"])
+        rows, steps = eng.joint_stats()
+        assert steps <= 1 + max(case.js["encoder_lens"]) and rows >= len(case.lens)      # one batched decoder step per frame at most
+        for b, want in enumerate(run["chunks"]):
+            g = got[b]
+            assert list(g.tokens) == want["tokens"], (run, b)
+            assert list(g.times) == want["times"] and list(g.end_times) == want["end_times"], (run, b)
+            assert abs(g.score - want["score"]) <= 2e-2 + 1e-3 * abs(want["score"]), (run, b, g.score, want["score"])
+            np.testing.assert_allclose(g.tokens_confidence, want["tokens_confidence"], rtol=2e-2, atol=1e-5)
+    eng.close()
+
+
+def test_joint_decoding_through_decode_seam_and_with_other_modes():
+    """ASRModel.decode(['joint_decoding', ...]): the mode next to the prefix beam and rescoring in one call (the encoder keeps
+    int(1.5 * beam) log-probs per frame for the pre-beam, the other modes use the first `beam` of them) -- results equal to
+    the modes run alone."""
+    import torch
+    from reverb_amd.reverb import RvbASRModel
+    case = JointCase("joint_tiny")
+    run = case.js["runs"][0]
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    model = RvbASRModel(eng)
+    x, lens = torch.from_numpy(case.x), torch.from_numpy(case.lens)
+    both = model.decode(["joint_decoding", "ctc_prefix_beam_search", "attention_rescoring"], x, lens, run["beam"], ctc_weight=run["ctc_weight"],
+                        length_penalty=run["length_bonus"])
+    alone = model.decode(["ctc_prefix_beam_search", "attention_rescoring"], x, lens, run["beam"], ctc_weight=run["ctc_weight"])
+    for b, want in enumerate(run["chunks"]):
+        assert list(both["joint_decoding"][b].tokens) == want["tokens"]
+        for m in ("ctc_prefix_beam_search", "attention_rescoring"):
+            assert list(both[m][b].tokens) == list(alone[m][b].tokens) and both[m][b].times == alone[m][b].times
+    # a bf16 run decodes something of the same kind (no exactness claim: near-tied hypotheses)
+    eng.close()
+    eng = Engine(case.cfg, case.sd, dtype="bf16", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    run = case.js["runs"][2]
+    eng.encode(case.x, case.lens, run["beam"], topk=int(run["pre_beam_ratio"] * run["beam"]))
+    got = eng.joint_decode(run["ctc_weight"], run["length_bonus"], run["pre_beam_ratio"])
+    for b, want in enumerate(run["chunks"]):
+        assert abs(len(got[b].tokens) - len(want["tokens"])) <= max(4, len(want["tokens"]) // 4)
+    eng.close()
+
+
+def test_joint_decoding_needs_enough_topk():
+    from reverb_amd._lib import RvbError
+    case = JointCase("joint_tiny")
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    eng.encode(case.x, case.lens, 4)
+    with pytest.raises(RvbError, match="pre-beam"):
+        eng.joint_decode(0.3, 0.5)
+    eng.close()
