@@ -33,3 +33,24 @@ run("attention_rescoring (full context)", ["attention_rescoring"])
 run("attention_rescoring, decoding_chunk 16 / left 4", ["attention_rescoring"], 16, 4)
 run("attention_rescoring, decoding_chunk 16 / all left", ["attention_rescoring"], 16, -1)
 run("attention (autoregressive beam 10)", ["attention"])
+
+
+def run_joint(beam, ctc_weight, bonus):
+    for rep in range(2):
+        t0 = time.time()
+        nf = eng.fbank()
+        lens = np.full(n_chunks, chunk, np.int32); lens[-1] = nf - (n_chunks - 1) * chunk
+        eng.encode(None, lens, beam, first_chunk=0, T0=chunk, topk=int(1.5 * beam))
+        t1 = time.time()
+        res = eng.joint_decode(ctc_weight, bonus)
+        dt = time.time() - t0
+    rows, steps = eng.joint_stats()
+    ntok = sum(len(r.tokens) for r in res)
+    print(f"joint_decoding beam {beam} ctc {ctc_weight} bonus {bonus:4.1f}            {dt*1e3:9.1f} ms  RTFx {hours*3600/dt:8.0f}  tokens {ntok}  "
+          f"search {1e3*(time.time()-t1):.1f} ms, {rows} decoder rows in {steps} batched steps")
+
+
+eng.apply_decoding_chunk(-1, -1)
+run_joint(4, 0.3, 0.5)
+run_joint(4, 0.3, 8.0)
+run_joint(10, 0.5, 8.0)
