@@ -834,7 +834,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // 32x32 blocks (fp8): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
   f32x4_t acc[F8 ? 1 : 8][F8 ? 1 : 4];
   f32x16_t acc32[F8 ? 4 : 1][F8 ? 2 : 1];
-  const bool res_acc = p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
+  const bool res_acc = !p.res_epilogue && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
                        ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
   // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
   // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
@@ -1073,6 +1073,27 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
       for (int e = 0; e < CPL; ++e) scv[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
     }
     const bool seg_full = col0 + CPL <= p.N;
+    // The residual of a tile whose residual is added HERE (p.res_epilogue, or whenever it cannot start out in the
+    // accumulators): a ring of RING slabs' worth of 16-byte vectors per lane, requested that far ahead of the slab that
+    // consumes them -- the K loop's fragment registers are dead by now, so 16 vectors (64 registers) fit next to the
+    // accumulators, and a slab's residual rows are in flight while the slabs before it are transposed and stored.
+    constexpr int RING = sizeof(OutT) == 4 ? 3 : 2, RV = NQ * (CPL / 4);       // slabs ahead, vectors per slab and lane
+    float4 rring[RING][RV];
+    const bool res_pre = p.res != nullptr && !res_acc && seg_full;
+    const int colc = min(col0, p.N - CPL);
+    auto res_issue = [&](int i, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int row = min(m0 + wr * 128 + i * 16 + q * RPP + orow, p.M - 1);
+        const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + colc);
+#pragma unroll
+        for (int c4 = 0; c4 < CPL / 4; ++c4) rring[slot][q * (CPL / 4) + c4] = rp[c4];
+      }
+    };
+    if (res_pre) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) res_issue(i, i);
+    }
     auto finish_v = [&](auto actf) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1115,11 +1136,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
           for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
           OutT* cp = C + (size_t)row * p.ldc + col0;
           if (seg_full) {
-            if (p.res && !res_acc) {
-              const float4* rp = (const float4*)(p.res + (size_t)row * p.ldres + col0);
+            if (res_pre) {
 #pragma unroll
               for (int c4 = 0; c4 < CPL / 4; ++c4) {
-                const float4 tt = rp[c4];
+                const float4 tt = rring[i % RING][q * (CPL / 4) + c4];
                 v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
               }
             }
@@ -1146,6 +1166,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
             }
           }
         }
+        if (res_pre && i + RING < 8) res_issue(i + RING, i % RING);
       }
     };
     if (p.act == ACT_SILU) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
@@ -1284,6 +1305,10 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          stream, so the next tile's first counted wait also waits for them (epilogue 7.0 -> 10.0 us for ffn1, 7.5 -> 13.5 us
 //          for out-proj; one tile per workgroup just ends the wave with its stores in flight): GEMM time 108.2 -> 113.1 ms
 //          per hour (gpurun_out/s6, profiles/r03_gemm_timeline_persistent.txt)
+//   bit 5  bf16: start the accumulators from the fp32 residual (round 2's prologue) instead of adding it in the epilogue from a
+//          ring of prefetched vectors (3 slabs ahead for fp32 output).  The ring is the default since round 3: the K loop's
+//          fragment registers are dead in the epilogue, so the prefetch fits where round 2's spilled; ffn2 941 -> 1040 TFLOP/s,
+//          GEMM time 103.1 -> 101.5 ms per hour (gpurun_out/s10), and the sum is formed as the reference forms it, x + alpha * (.)
 //   bit 3  fp8: the phase-interleaved loop (gemm2p_kernel<fp8_t>) instead of gemm2_kernel's plain loop.  Exact, but slower on
 //          the engine's shapes (1 h r640: fp8 GEMMs 58.6 vs 49.7 ms, step 141.4 vs 132.4 ms, gpurun_out/s5): K = 1024 is only 8
 //          fp8 K steps, so 3 of them run the tail form of the loop, and next to 16-register accumulator blocks the allocator
@@ -1299,6 +1324,7 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   GemmArgs p = p0;
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
+  p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);
