@@ -113,6 +113,21 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
     }
   }
   auto load_row = [&](int row, float4* v) {
+    if (a.x_bf16) {      // the depthwise convolution's output of the bf16 engine
+      const bf16_t* x = (const bf16_t*)a.x + (size_t)row * d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = COL(i);
+        if (row < a.M && c < d) {
+          const uint2 u = *(const uint2*)(x + c);
+          v[i] = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffffu)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                             bf16_to_f32((bf16_t)(u.y & 0xffffu)), bf16_to_f32((bf16_t)(u.y >> 16)));
+        } else {
+          v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      return;
+    }
     const float* x = a.x + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -239,6 +254,7 @@ static void launch_rownorm(hipStream_t s, const NormArgs& a) {
 int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
   if (a.M <= 0) return OK;
   if (a.d % 8 || a.d > 2048) { set_error("rownorm: d must be a multiple of 8 and <= 2048"); return E_ARG; }
+  if (a.x_bf16 && dtype != DT_BF16) { set_error("rownorm: bf16 input belongs to the bf16 engine"); return E_ARG; }
   if (a.out2 && (a.mode != NORM_LN || !(a.out_f32 || dtype == DT_F32))) {
     set_error("rownorm: the fused second LayerNorm follows a LayerNorm with fp32 output"); return E_ARG;
   }
@@ -365,7 +381,10 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
 #pragma unroll
   for (int i = 0; i < OPT; ++i) {
     const int t = t0 + rbase + i;
-    if (t < a.T) *(float2*)(a.out + ((size_t)b * a.T + t) * a.d + ch) = make_float2(acc[i].x, acc[i].y);
+    if (t < a.T) {
+      if (a.out_bf16) *(uint32_t*)((bf16_t*)a.out + ((size_t)b * a.T + t) * a.d + ch) = pack2_bf16(acc[i].x, acc[i].y);
+      else *(float2*)(a.out + ((size_t)b * a.T + t) * a.d + ch) = make_float2(acc[i].x, acc[i].y);
+    }
   }
 }
 

@@ -238,8 +238,9 @@ static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void
 // out8 / out2_8 > 0: that output is fp8 bytes of value / scale (the calibrated per-tensor scale of the GEMM that reads it)
 static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bool out_f32, int M, int d,
                     int mode = NORM_LN, int silu = 0, const void* add = nullptr, const LNorm* second = nullptr,
-                    void* out2 = nullptr, float out8 = 0.f, float out2_8 = 0.f) {
+                    void* out2 = nullptr, float out8 = 0.f, float out2_8 = 0.f, bool x_bf16 = false) {
   NormArgs a;
+  a.x_bf16 = x_bf16 ? 1 : 0;
   a.x = x; a.gamma = n.g.as<float>(); a.beta = n.b.as<float>(); a.eps = n.eps; a.mode = mode; a.silu = silu;
   a.add = add; a.out = out; a.out_f32 = out_f32 ? 1 : 0; a.M = M; a.d = d;
   if (second) { a.gamma2 = second->g.as<float>(); a.beta2 = second->b.as<float>(); a.eps2 = second->eps; a.out2 = out2; }
@@ -543,6 +544,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
     g.lens = e->cur_lens; g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
     g.causal = e->cfg.cnn_causal ? 1 : 0;
+    g.out_bf16 = e->dtype == DT_BF16 ? 1 : 0;     // half the bytes to the norm that reads it next (the reference's bf16 autocast rounds here too)
     const int lorder = g.K - 1;
     const bool cached = li >= 0 && g.causal && lorder > 0;
     if (cached) { g.hist = e->stream_st.cnn[li].p; g.hist_rows = e->stream_st.cnn_rows; }
@@ -568,11 +570,12 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     }
   }
   const int cmode = e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE;
+  const bool dw16 = e->dtype == DT_BF16;
   if (f8_pw2) {
-    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2));
+    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2, 0.f, dw16));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw2, x, d, M, sc8.in_pw2, 1, 1.f, 1.f, ACT_NONE, x, d));
   } else {
-    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1));
+    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, 0.f, 0.f, dw16));
     RVB_TRY(note(4, e->xn.p, (size_t)M * d));
     RVB_TRY(run_gemm(e, e->xn.p, d, L.pw2, x, d, M, true, 1.f, ACT_NONE, x, d));
   }

@@ -63,7 +63,8 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 
 enum { NORM_LN = 0, NORM_AFFINE = 1 };
 struct NormArgs {
-  const float* x;      // fp32 [M, d]
+  const float* x;      // fp32 [M, d] (bf16 when x_bf16)
+  int x_bf16 = 0;
   const float* gamma;  // [d]
   const float* beta;   // [d]
   float eps;
@@ -97,8 +98,9 @@ struct GluDwArgs {
   const float* dw_w;      // [d][K]
   const float* dw_b;      // [d]
   const int* lens;        // [B] valid rows per chunk
-  float* out;             // fp32 [B*T, d]
+  float* out;             // fp32 [B*T, d] (or bf16 when out_bf16)
   int B, T, d, K;
+  int out_bf16 = 0;       // bf16 engine: the convolution-module norm that follows reads bf16 (NormArgs::x_bf16)
   int causal = 0;
   const void* hist = nullptr;   // T [K-1][2d], row K-2 = the frame just before this chunk (causal, B = 1)
   int hist_rows = 0;            // real frames in hist (its last hist_rows rows)

@@ -82,7 +82,9 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
                      const float* add, float* out, int out_f32, int M, int d) {
   T_TRY(need_gpu());
   Dev dx, dg, db, da, dout;
-  T_TRY(up_raw(dx, x, (size_t)M * d * 4));
+  const bool x16 = (mode & 256) != 0;            // bit 8 of `mode`: x is handed to the kernel as bf16 (bf16 engine, conv-module norm)
+  mode &= 255;
+  if (x16) T_TRY(up_T(dx, DT_BF16, x, (size_t)M * d)); else T_TRY(up_raw(dx, x, (size_t)M * d * 4));
   T_TRY(up_raw(dg, gamma, (size_t)d * 4));
   T_TRY(up_raw(db, beta, (size_t)d * 4));
   T_TRY(up_T(da, dtype, add, (size_t)M * d));
@@ -91,6 +93,7 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
   NormArgs a;
   a.x = (const float*)dx.p; a.gamma = (const float*)dg.p; a.beta = (const float*)db.p; a.eps = eps; a.mode = mode;
   a.silu = silu; a.add = da.p; a.out = dout.p; a.out_f32 = out_f32; a.M = M; a.d = d;
+  a.x_bf16 = x16 ? 1 : 0;
   T_TRY(rownorm(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());
   return down_T(dout, dtype, f32out, out, (size_t)M * d);
@@ -124,8 +127,11 @@ int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const 
   T_TRY(up_raw(dw, dw_w, (size_t)d * K * 4));
   T_TRY(up_raw(db, dw_b, (size_t)d * 4));
   T_TRY(up_raw(dl, lens, (size_t)B * 4));
+  const bool o16 = (causal & 2) != 0;            // bit 1 of `causal`: bf16 output (bf16 engine)
+  causal &= 1;
   T_TRY(dout.alloc((size_t)B * T * d * 4));
   GluDwArgs a;
+  a.out_bf16 = o16 ? 1 : 0;
   a.G = dG.p; a.pw1_bias = (const float*)dpb.p; a.dw_w = (const float*)dw.p; a.dw_b = (const float*)db.p;
   a.lens = (const int*)dl.p; a.out = (float*)dout.p; a.B = B; a.T = T; a.d = d; a.K = K;
   a.causal = causal;
@@ -135,6 +141,7 @@ int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const 
   }
   T_TRY(glu_dwconv(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());
+  if (o16) return down_T(dout, DT_BF16, false, out, (size_t)B * T * d);
   RVB_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)B * T * d * 4, hipMemcpyDeviceToHost));
   return OK;
 }

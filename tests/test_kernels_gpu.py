@@ -254,6 +254,27 @@ def test_glu_dwconv_causal(lib, dtype, K, d, T, hist_rows):
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-4)
 
 
+def test_bf16_engine_dwconv_output_and_norm_input(lib):
+    """bf16 engine: the depthwise convolution writes bf16 and the convolution-module norm reads bf16 (half the bytes of the
+    fp32 round trip) -- the same values up to that one rounding."""
+    rng = np.random.default_rng(5)
+    B, T, d, K = 2, 70, 64, 15
+    lens = i32([T, T - 9])
+    G = rnd(BF16, rng.standard_normal((B, T, 2 * d)))
+    pb = f32(rng.standard_normal(2 * d)); w = f32(rng.standard_normal((d, K)) / math.sqrt(K)); b = f32(rng.standard_normal(d))
+    o32 = np.empty((B, T, d), np.float32); o16 = np.empty((B, T, d), np.float32)
+    _lib.check(lib.rvb_test_glu_dwconv(BF16, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(o32), B, T, d, K, 0, None, 0))
+    _lib.check(lib.rvb_test_glu_dwconv(BF16, fptr(G), fptr(pb), fptr(w), fptr(b), iptr(lens), fptr(o16), B, T, d, K, 2, None, 0))
+    np.testing.assert_array_equal(o16, bf16_round(o32))
+    M, d = 37, 256
+    x = bf16_round(rng.standard_normal((M, d)) * 3 + 1)
+    g = f32(1 + 0.1 * rng.standard_normal(d)); be = f32(0.1 * rng.standard_normal(d))
+    a = np.empty((M, d), np.float32); c = np.empty((M, d), np.float32)
+    _lib.check(lib.rvb_test_rownorm(BF16, fptr(x), fptr(g), fptr(be), 1e-5, 0, 1, None, fptr(a), 0, M, d))
+    _lib.check(lib.rvb_test_rownorm(BF16, fptr(x), fptr(g), fptr(be), 1e-5, 256, 1, None, fptr(c), 0, M, d))
+    np.testing.assert_array_equal(a, c)          # x is exactly representable in bf16: both input forms give the same output
+
+
 def _ref_attention(q, k, v, p, bu, bv, heads, dk, q_start, q_len, kv_start, kv_len, causal):
     d = heads * dk
     out = np.zeros((q.shape[0], d))
