@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -1442,6 +1445,49 @@ static int grow_rows(rvb_engine* e, DevBuf& b, size_t row_bytes, int64_t have, i
   return OK;
 }
 
+// a few persistent host threads for the per-chunk halves of a joint_decoding frame (512 frames per batch: starting threads
+// per frame would cost more than the work)
+namespace {
+class FramePool {
+ public:
+  explicit FramePool(unsigned n) {
+    for (unsigned i = 1; i < n; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~FramePool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  template <typename F> void run(int n, F&& fn) {          // fn(i) for i in [0, n), the caller works too
+    if (th_.empty() || n < 8) { for (int i = 0; i < n; ++i) fn(i); return; }
+    job_ = [&fn](int i) { fn(i); };
+    { std::lock_guard<std::mutex> g(m_); n_ = n; next_.store(0); busy_ = (int)th_.size(); ++gen_; }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return busy_ == 0; });
+  }
+
+ private:
+  void work() { for (int i = next_.fetch_add(1); i < n_; i = next_.fetch_add(1)) job_(i); }
+  void loop() {
+    int seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      work();
+      { std::lock_guard<std::mutex> g(m_); if (--busy_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)> job_;
+  std::atomic<int> next_{0};
+  int n_ = 0, busy_ = 0, gen_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double pre_beam_ratio, double length_bonus) {
   const rvb_model_cfg& c = e->cfg;
   if (e->B <= 0) { set_error("rvb_joint_decode before rvb_encode"); return E_STATE; }
@@ -1608,21 +1654,26 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
 
   int Tmax = 0;
   for (int b = 0; b < B; ++b) Tmax = std::max(Tmax, e->enc_lens[b]);
-  std::vector<int> dec, pn, pt, npairs(B), ran(B);
+  std::vector<int> npairs(B), ran(B);
+  std::vector<std::vector<int>> cdec(B), cpn(B), cpt(B);
+  std::vector<size_t> pair_at(B + 1);
+  FramePool pool(std::min<unsigned>(search_threads(), 16u));
   std::vector<int32_t> prow, ptok;
   std::vector<float> vals;
   for (int t = 0; t < Tmax; ++t) {
     req.clear(); prow.clear(); ptok.clear();
-    for (int b = 0; b < B; ++b) {
-      npairs[b] = 0; ran[b] = 0;
-      if (t >= e->enc_lens[b]) continue;
+    pool.run(B, [&](int b) {                     // CTC half of the frame, chunk by chunk on the host threads
+      ran[b] = 0; cdec[b].clear(); cpn[b].clear(); cpt[b].clear();
+      if (t >= e->enc_lens[b]) return;
       const size_t f = (size_t)b * T2 + t;
-      dec.clear(); pn.clear(); pt.clear();
-      ran[b] = js[b].begin_frame(t, e->h_topv + f * K, e->h_topi + f * K, K, p0[f], pbl[f], &dec, &pn, &pt) ? 1 : 0;
+      ran[b] = js[b].begin_frame(t, e->h_topv + f * K, e->h_topi + f * K, K, p0[f], pbl[f], &cdec[b], &cpn[b], &cpt[b]) ? 1 : 0;
+    });
+    for (int b = 0; b < B; ++b) {
+      npairs[b] = 0;
       if (!ran[b]) continue;
-      for (int n : dec) req.push_back({b, n});
-      npairs[b] = (int)pn.size();
-      for (size_t i = 0; i < pn.size(); ++i) { prow.push_back(-1 - pn[i]); ptok.push_back(pt[i]); }      // rows resolved after the step
+      for (int n : cdec[b]) req.push_back({b, n});
+      npairs[b] = (int)cpn[b].size();
+      for (size_t i = 0; i < cpn[b].size(); ++i) { prow.push_back(-1 - cpn[b][i]); ptok.push_back(cpt[b][i]); }      // rows resolved after the step
     }
     RVB_TRY(step(req));
     {   // pair rows: the node's tag is known now
@@ -1640,11 +1691,9 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
       RVB_HIP_CHECK(hipMemcpyAsync(vals.data(), e->jpair_out.p, (size_t)NP * 4, hipMemcpyDeviceToHost, e->stream));
       RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
-    size_t at = 0;
-    for (int b = 0; b < B; ++b) {
-      if (ran[b]) js[b].finish_frame(vals.data() + at);
-      at += npairs[b];
-    }
+    pair_at[0] = 0;
+    for (int b = 0; b < B; ++b) pair_at[b + 1] = pair_at[b] + (size_t)npairs[b];
+    pool.run(B, [&](int b) { if (ran[b]) js[b].finish_frame(vals.data() + pair_at[b]); });
   }
   e->joint.assign(B, JointResult());
   for (int b = 0; b < B; ++b) js[b].result(&e->joint[b]);

@@ -16,4 +16,7 @@ cp $O/gemm_traffic.json $P/${R}_gemm_traffic_r640_1h_bf16.json
 cp $O/pmc_by_kernel.csv $P/${R}_pmc_by_kernel.csv
 cp $O/parity_metrics.jsonl $P/${R}_parity_metrics.jsonl
 grep -a "passed" $O/pytest_gpu.log | tail -1 > $P/${R}_pytest_gpu_summary.txt
+grep '^{' $O/bench_r640_forced_dist.log | tail -1 > $P/${R}_bench_r640_1h_forced_dist.json.log
+cp $O/gemm_bench.txt $P/${R}_gemm_bench_switches.txt
+cp $O/gemm_timeline.txt $P/${R}_gemm_timeline.txt
 ls -la $P | grep " ${R}_" | awk '{print $5, $9}'

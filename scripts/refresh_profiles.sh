@@ -14,11 +14,14 @@ cp $R/gpurun_out/parity_metrics.jsonl $O/parity_metrics.jsonl 2>/dev/null
 timeout 900 python bench.py --steps 3 --warmup 1 > $O/bench_r640.log 2> $O/bench_r640.err
 timeout 300 python bench.py --steps 3 --warmup 1 --dtype fp8 --no-diarization --no-pcie --cpu-baseline-chunks 0 > $O/bench_r640_fp8.log 2>&1
 timeout 300 python bench.py --steps 3 --warmup 1 --model r268 --no-diarization --no-pcie --traffic off > $O/bench_r268.log 2>&1
-timeout 300 python bench_diar.py --steps 3 --warmup 1 > $O/bench_diar.log 2>&1
+timeout 400 python bench_diar.py --steps 3 --warmup 1 > $O/bench_diar.log 2>&1
+RVB_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-diarization --no-pcie --traffic off --cpu-baseline-chunks 0 > $O/bench_r640_forced_dist.log 2>&1
+timeout 200 python scripts/gemm_bench.py 0,-2 4,8 > $O/gemm_bench.txt 2>&1
+timeout 200 python scripts/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 cd /tmp
 N="--no-diarization --no-pcie --traffic off --cpu-baseline-chunks 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_asr -- python $R/bench.py --steps 2 --warmup 1 $N > $O/prof_asr_stdout.log 2>&1 < /dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_diar -- python $R/bench_diar.py --steps 2 --warmup 1 --cpu-baseline-windows 0 > $O/prof_diar_stdout.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_diar -- python $R/bench_diar.py --steps 2 --warmup 1 --cpu-baseline-windows 0 --traffic off > $O/prof_diar_stdout.log 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 1 --warmup 0 $N --no-profile > $O/pmc_fetch_stdout.log 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 0 $N --no-profile > $O/pmc_write_stdout.log 2>&1 < /dev/null
 cd $R

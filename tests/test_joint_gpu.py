@@ -59,6 +59,23 @@ def test_joint_decoding_through_decode_seam_and_with_other_modes():
     eng.close()
 
 
+def test_joint_decoding_many_chunks_in_lockstep():
+    """Ten chunks (the two golden chunks five times over) in one batch: the host halves of a frame run on the engine's thread
+    pool (>= 8 chunks), the decoder steps carry rows of every chunk -- each copy must still give the golden answer."""
+    case = JointCase("joint_tiny")
+    run = case.js["runs"][2]
+    x, lens = np.tile(case.x, (5, 1, 1)), np.tile(case.lens, 5)
+    eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=16, chunk_frames=case.chunk, cat_embs=case.cat)
+    eng.encode(x, lens, run["beam"], topk=int(run["pre_beam_ratio"] * run["beam"]))
+    got = eng.joint_decode(run["ctc_weight"], run["length_bonus"], run["pre_beam_ratio"])
+    assert len(got) == 10
+    for b, g in enumerate(got):
+        want = run["chunks"][b % 2]
+        assert list(g.tokens) == want["tokens"] and list(g.times) == want["times"], b
+        assert abs(g.score - want["score"]) <= 2e-2 + 1e-3 * abs(want["score"])
+    eng.close()
+
+
 def test_joint_decoding_needs_enough_topk():
     from reverb_amd._lib import RvbError
     case = JointCase("joint_tiny")
