@@ -1451,30 +1451,32 @@ namespace {
 class FramePool {
  public:
   explicit FramePool(unsigned n) {
-    for (unsigned i = 1; i < n; ++i) th_.emplace_back([this] { loop(); });
+    for (unsigned i = 1; i < n; ++i) th_.emplace_back([this, i] { loop((int)i); });
   }
   ~FramePool() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  template <typename F> void run(int n, F&& fn) {          // fn(i) for i in [0, n), the caller works too
+  // fn(i) for i in [0, n); item i always runs on participant i mod P (the caller is participant 0), so that a chunk's
+  // search state is touched -- and its vectors are grown and freed -- by one thread only
+  template <typename F> void run(int n, F&& fn) {
     if (th_.empty() || n < 8) { for (int i = 0; i < n; ++i) fn(i); return; }
     job_ = [&fn](int i) { fn(i); };
-    { std::lock_guard<std::mutex> g(m_); n_ = n; next_.store(0); busy_ = (int)th_.size(); ++gen_; }
+    { std::lock_guard<std::mutex> g(m_); n_ = n; busy_ = (int)th_.size(); ++gen_; }
     cv_.notify_all();
-    work();
+    work(0);
     std::unique_lock<std::mutex> lk(m_);
     done_.wait(lk, [this] { return busy_ == 0; });
   }
 
  private:
-  void work() { for (int i = next_.fetch_add(1); i < n_; i = next_.fetch_add(1)) job_(i); }
-  void loop() {
+  void work(int id) { const int P = (int)th_.size() + 1; for (int i = id; i < n_; i += P) job_(i); }
+  void loop(int id) {
     int seen = 0;
     for (;;) {
       { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
-      work();
+      work(id);
       { std::lock_guard<std::mutex> g(m_); if (--busy_ == 0) done_.notify_one(); }
     }
   }
@@ -1482,7 +1484,6 @@ class FramePool {
   std::mutex m_;
   std::condition_variable cv_, done_;
   std::function<void(int)> job_;
-  std::atomic<int> next_{0};
   int n_ = 0, busy_ = 0, gen_ = 0;
   bool stop_ = false;
 };
@@ -1572,17 +1573,16 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
     path.clear(); xq0.clear(); xqn.clear(); xkv.clear();
     std::vector<int32_t> xk0, xkn;
     int max_xq = 0;
-    std::vector<int> pf;
     for (int r = 0; r < R; ++r) {
       JointSearch& J = js[req[r].chunk];
       const int node = req[r].node;
       J.set_tag(node, (int)(row0 + r));
-      J.prefix(node, &pf);
-      tok[r] = pf.back(); pos[r] = (int)pf.size() - 1; q1[r] = r;
-      pstart[r] = (int)path.size(); plen[r] = (int)pf.size();
+      const int len = J.length(node);
+      tok[r] = J.token(node); pos[r] = len - 1; q1[r] = r;
+      pstart[r] = (int)path.size(); plen[r] = len;
       const size_t at = path.size();
-      path.resize(at + pf.size());
-      for (int n = node, i = (int)pf.size() - 1; n >= 0; n = J.parent(n), --i) path[at + i] = J.tag(n);   // ancestors are decoded
+      path.resize(at + len);
+      for (int n = node, i = len - 1; n >= 0; n = J.parent(n), --i) path[at + i] = J.tag(n);   // ancestors are decoded
       if (r == 0 || req[r].chunk != req[r - 1].chunk) { xq0.push_back(r); xqn.push_back(0); xk0.push_back(req[r].chunk * T2); xkn.push_back(e->enc_lens[req[r].chunk]); }
       max_xq = std::max(max_xq, ++xqn.back());
     }

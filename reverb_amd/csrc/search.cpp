@@ -244,12 +244,13 @@ JointSearch::JointSearch(const JointParams& p) : p_(p) {
   Node root;
   root.parent = -1; root.tok = p.sos; root.len = 1;
   root.has_times = root.has_conf = true;
-  root.st.assign(1, 0); root.en.assign(1, 0);
-  root.conf.assign(1, {NEG_INF, NEG_INF});
+  root.st = 0; root.en = 0;
+  root.conf_ctc = NEG_INF; root.conf_att = NEG_INF;
   root.dp_stamp = 0; root.dp_nb = NEG_INF; root.dp_b = 0.0;          // ctc_score_dp[[sos]] = (-inf, 0.0)
   root.in_hyps = 1;
   root.decoded = true; root.log_sum = 0.0;                           // reset() runs the decoder on <sos>
   nodes_.push_back(root);
+  par_.push_back(-1); tok_.push_back(p.sos); tag_.push_back(-1);
   child_.emplace_back();
   hyps_.assign(1, 0);
 }
@@ -259,6 +260,7 @@ int JointSearch::child(int node, int tok) {
   Node n;
   n.parent = node; n.tok = tok; n.len = nodes_[node].len + 1;
   nodes_.push_back(n);
+  par_.push_back(node); tok_.push_back(tok); tag_.push_back(-1);
   child_.emplace_back();
   const int id = (int)nodes_.size() - 1;
   child_[node].push_back({tok, id});
@@ -267,7 +269,7 @@ int JointSearch::child(int node, int tok) {
 
 void JointSearch::prefix(int node, std::vector<int>* toks) const {
   toks->assign(nodes_[node].len, 0);
-  for (int n = node, i = nodes_[node].len - 1; n >= 0; n = nodes_[n].parent, --i) (*toks)[i] = nodes_[n].tok;
+  for (int n = node, i = nodes_[node].len - 1; n >= 0; n = par_[n], --i) (*toks)[i] = tok_[n];
 }
 
 bool JointSearch::begin_frame(int t, const float* tv, const int* ti, int K, float p_tok0, float p_blank, std::vector<int>* decode,
@@ -309,22 +311,26 @@ bool JointSearch::begin_frame(int t, const float* tv, const int* ti, int K, floa
       double nb, bl;
       nxt_get(G, nb, bl);
       if (!G.has_times) {
-        G.st = H.st; G.st.push_back(t);
-        G.en = H.en; G.en.push_back(t + 1);
+        G.st_inh = H.st; G.en_inh = H.en;          // times[h][0] + [t], times[h][1] + [t + 1]: h's lists as they are now
+        G.st = t; G.en = t + 1;
         G.has_times = true;
       } else {
-        G.en.back() = t + 1;
+        G.en = t + 1;
       }
-      if (!G.has_conf) { G.conf = H.conf; G.conf.push_back({NEG_INF, NEG_INF}); G.has_conf = true; }
-      G.conf.back().first = G.conf.back().first > pc ? G.conf.back().first : pc;
+      if (!G.has_conf) {
+        G.conf_ctc_inh = H.conf_ctc; G.conf_att_inh = H.conf_att;
+        G.conf_ctc = NEG_INF; G.conf_att = NEG_INF;
+        G.has_conf = true;
+      }
+      G.conf_ctc = G.conf_ctc > pc ? G.conf_ctc : pc;
       if (c == H.tok) {                          // repeated token: only through a blank; h itself keeps growing
         const double nb_prev = H.dp_nb, b_prev = H.dp_b;
         nb = lse2(nb, pc + b_prev);
         double hn, hb;
         nxt_get(H, hn, hb);
         nxt_set(H, lse2(hn, pc + nb_prev), hb);
-        H.en.back() = t + 1;
-        H.conf.back().first = H.conf.back().first > pc ? H.conf.back().first : pc;
+        H.en = t + 1;
+        H.conf_ctc = H.conf_ctc > pc ? H.conf_ctc : pc;
       } else {
         nb = lse2(nb, pc + prev);
       }
@@ -368,7 +374,7 @@ void JointSearch::finish_frame(const float* vals) {
     if (H.len > 1 && p_.w_dec > 0) {
       if (!H.att_known) { H.att_tok = (double)vals[vi++]; H.att_known = true; }
       sc += (nodes_[H.parent].log_sum + H.att_tok) * p_.w_dec;
-      H.conf.back().second = H.att_tok;
+      H.conf_att = H.att_tok;
     }
     sc += p_.bonus * (H.len - 1);
     H.score = sc;
@@ -394,14 +400,25 @@ void JointSearch::finish_frame(const float* vals) {
 }
 
 void JointSearch::result(JointResult* out) const {
-  const Node& B = nodes_[hyps_[0]];
-  std::vector<int> toks;
-  prefix(hyps_[0], &toks);
+  const int best = hyps_[0];
+  const Node& B = nodes_[best];
+  const int L = B.len;                       // list elements: <sos> + tokens
+  std::vector<int> toks, st(L), en(L);
+  std::vector<double> cf(L);
+  prefix(best, &toks);
+  // element L-1 is the node's own entry, element i < L-1 the snapshot kept by the ancestor at depth i+1
+  st[L - 1] = B.st; en[L - 1] = B.en;
+  cf[L - 1] = B.conf_ctc > B.conf_att ? B.conf_ctc : B.conf_att;
+  for (int n = best, i = L - 2; i >= 0; n = nodes_[n].parent, --i) {
+    const Node& N = nodes_[n];
+    st[i] = N.st_inh; en[i] = N.en_inh;
+    cf[i] = N.conf_ctc_inh > N.conf_att_inh ? N.conf_ctc_inh : N.conf_att_inh;
+  }
   out->tokens.assign(toks.begin() + 1, toks.end());
-  out->times.assign(B.st.begin() + 1, B.st.end());
-  out->end_times.assign(B.en.begin() + 1, B.en.end());
+  out->times.assign(st.begin() + 1, st.end());
+  out->end_times.assign(en.begin() + 1, en.end());
   out->tokens_confidence.clear();
-  for (size_t i = 1; i < B.conf.size(); ++i) out->tokens_confidence.push_back(std::exp(B.conf[i].first > B.conf[i].second ? B.conf[i].first : B.conf[i].second));
+  for (int i = 1; i < L; ++i) out->tokens_confidence.push_back(std::exp(cf[i]));
   out->score = any_scores_ ? B.score : 0.0;
 }
 

@@ -46,18 +46,18 @@ class JointSearch {
   // vals[i] = log p(pair_tok[i] | prefix pair_node[i]) for the pairs of the matching begin_frame, in order
   void finish_frame(const float* vals);
   void prefix(int node, std::vector<int>* toks) const;     // tokens of a node's prefix, <sos> first
-  int parent(int node) const { return nodes_[node].parent; }
+  int parent(int node) const { return par_[node]; }
   int length(int node) const { return nodes_[node].len; }
+  int token(int node) const { return tok_[node]; }
   int n_nodes() const { return (int)nodes_.size(); }
   void result(JointResult* out) const;
   // engine-side tag of a node (device row of its decoder state), -1 = not decoded
-  int tag(int node) const { return nodes_[node].tag; }
-  void set_tag(int node, int tag) { nodes_[node].tag = tag; }
+  int tag(int node) const { return tag_[node]; }
+  void set_tag(int node, int tag) { tag_[node] = tag; }
 
  private:
   struct Node {
     int parent, tok, len;
-    int tag = -1;
     bool has_times = false, has_conf = false, decoded = false, att_known = false;
     int in_hyps = 0;             // 1 while the node is in the beam
     int new_stamp = -1;          // frame in which the node entered new_hyps
@@ -66,12 +66,18 @@ class JointSearch {
     double att_tok = 0.0;        // log p_att(tok | parent prefix)
     double log_sum = 0.0;        // log p_att(prefix) (set when the node is decoded)
     double score = 0.0;
-    std::vector<int> st, en;     // start / end frame per token (incl. <sos>)
-    std::vector<std::pair<double, double>> conf;   // (ctc, attention) confidence per token
+    // The reference copies a prefix's start / end / confidence LISTS when it extends the prefix (times[h][0] + [t], ...) and
+    // later mutates only the last element of a list (end frame, confidences of the prefix's own last token).  So a
+    // prefix's list = a snapshot of its parent's list at the moment of the extension + its own entry: the node keeps its
+    // own (mutable) entry and the snapshot of the parent's own entry; older elements are the ancestors' snapshots.  O(1) per
+    // extension instead of an O(length) copy, same values.
+    int st = 0, en = 0, st_inh = 0, en_inh = 0;
+    double conf_ctc = 0, conf_att = 0, conf_ctc_inh = 0, conf_att_inh = 0;
   };
   int child(int node, int tok);
   JointParams p_;
   std::vector<Node> nodes_;
+  std::vector<int> par_, tok_, tag_;     // compact copies for the engine's path walks (a Node is ~150 bytes)
   std::vector<std::vector<std::pair<int, int>>> child_;     // per node: (token, child id)
   std::vector<int> hyps_, new_hyps_, scored_, touched_;
   std::vector<int> pend_decode_, pend_node_, pend_tok_;
