@@ -178,6 +178,13 @@ int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_
                            float* scores, double* confidences, double* tokens_confidence);
 /* fp8 engines: forget the activation scales; the next rvb_encode calibrates again (in bf16) on its batch */
 int rvb_fp8_recalibrate(rvb_engine* e);
+/* fp8 engines: the calibrated per-tensor activation scales, 7 per conformer block (inputs of macaron FFN 1 / its hidden /
+ * qkv / pointwise conv 1 / pointwise conv 2 / FFN 1 / its hidden; powers of two, value = fp8 * scale).  get: *n = 0 while the
+ * engine is not calibrated; `scales` may be NULL to query n.  set: installs scales and ends calibration, so that the very next
+ * rvb_encode already runs in fp8 -- how the ranks of a sharded run agree on one set (element-wise maximum of what each rank
+ * calibrated on its own slice, reverb_amd/dist.py), and how a deployment pins scales measured once. */
+int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n);
+int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n);
 /* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's
  * padded [N, L] decoder batch computes (search.py:391-412); `decoder_rows` = rows actually computed: one per DISTINCT
  * hypothesis prefix of a chunk (the decoder is causal, so hypotheses of one beam share the rows of their common prefix). */

@@ -75,6 +75,8 @@ SIGNATURES = {
     "rvb_get_rescored": (C.c_int, [_eng, C.c_int, _i32p, _f32p, _f64p, _f64p]),
     "rvb_get_rescored_batch": (C.c_int, [_eng, _i32p, _i32p, _i32p, _i32p, _f32p, _f64p, _f64p]),
     "rvb_fp8_recalibrate": (C.c_int, [_eng]),
+    "rvb_get_fp8_scales": (C.c_int, [_eng, _f32p, _i32p]),
+    "rvb_set_fp8_scales": (C.c_int, [_eng, _f32p, C.c_int32]),
     "rvb_get_rescore_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
     "rvb_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -2119,6 +2119,33 @@ int rvb_fp8_recalibrate(rvb_engine* e) {
   e->f8_state = 0;
   return OK;
 }
+int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n) {
+  if (!e || !n) { set_error("rvb_get_fp8_scales: null argument"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_get_fp8_scales: not an RVB_FP8 engine"); return E_STATE; }
+  if (e->f8_state != 2) { *n = 0; return OK; }                       // not calibrated yet
+  *n = (int32_t)(e->f8.size() * 7);
+  if (scales)
+    for (size_t l = 0; l < e->f8.size(); ++l) {
+      const F8Scales& f = e->f8[l];
+      const float v[7] = {f.in_ffm1, f.h_ffm, f.in_qkv, f.in_pw1, f.in_pw2, f.in_ff1, f.h_ff};
+      for (int k = 0; k < 7; ++k) scales[l * 7 + k] = v[k];
+    }
+  return OK;
+}
+int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n) {
+  if (!e || !scales) { set_error("rvb_set_fp8_scales: null argument"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_set_fp8_scales: not an RVB_FP8 engine"); return E_STATE; }
+  if (!e->finalized || n != (int32_t)(e->enc.size() * 7)) { set_error("rvb_set_fp8_scales: need 7 scales per conformer block of a finalized engine"); return E_ARG; }
+  for (int i = 0; i < n; ++i) if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) { set_error("rvb_set_fp8_scales: scales must be positive and finite"); return E_ARG; }
+  e->f8.resize(e->enc.size());
+  for (size_t l = 0; l < e->enc.size(); ++l) {
+    const float* v = scales + l * 7;
+    e->f8[l] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+  }
+  if (e->f8_groups.size() != e->enc.size()) RVB_TRY(set_fp8_policy_impl(e, -1, 0, -1));
+  e->f8_state = 2;
+  return OK;
+}
 int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs) {
   if (!e) { set_error("rvb_get_rescore_stats: null engine"); return E_ARG; }
   if (decoder_rows) *decoder_rows = e->rescore_rows;

@@ -303,6 +303,29 @@ def all_gather_results(hyps: Sequence[DecodeResult], device, max_count: int = No
     return GatheredResults([host[r, :_HDR + int(host[r, 2]) + 2 * int(host[r, 3])] for r in range(world)])
 
 
+def share_fp8_scales(engine, n_frames: int, chunk_size: int, beam_size: int, device) -> None:
+    """fp8 engines calibrate their activation scales on the first batch they encode; the ranks of a sharded run would each
+    do so on their own slice and quantise the same recording differently.  Here every rank that is not calibrated
+    yet runs one calibration pass over its slice, the scales (powers of two) are all-gathered, and every rank installs the
+    element-wise maximum -- what a single GPU calibrating on the whole recording measures.  No-op for other engines and for
+    engines that are calibrated already (scales stick to an engine across recordings)."""
+    if getattr(engine, "dtype", None) != "fp8" or not hasattr(engine, "fp8_scales"):
+        return
+    mine = engine.fp8_scales()
+    if mine is None and n_frames > 0:
+        engine.decode_resident(n_frames, ["ctc_greedy_search"], chunk_size, beam_size, 0.0, 0.0)      # bf16 pass, records max |.|
+        mine = engine.fp8_scales()
+    nb = int(engine.cfg.num_blocks)
+    send = np.zeros(1 + nb * 7, np.float32)
+    if mine is not None:
+        send[0] = 1.0
+        send[1:] = mine.reshape(-1)
+    host = gather_words(send.view(np.int32), device, default_comm(engine)).view(np.float32)
+    have = host[:, 0] > 0
+    if have.any():
+        engine.set_fp8_scales(host[have, 1:].max(axis=0))
+
+
 def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: int, ctc_weight: float,
                    reverse_weight: float, device, blank_penalty: float = 0.0):
     """Decode one long recording with every rank of the default process group taking a contiguous
@@ -313,9 +336,12 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
     c0, c1 = chunk_ranges(n_chunks, world)[rank]
     s0, s1 = sample_range(len(pcm), chunk_size, c0, c1)
     local = {m: [] for m in modes}
+    nf = 0
     if s1 > s0:
         engine.upload_pcm(pcm[s0:s1])
         nf = engine.fbank()
+    share_fp8_scales(engine, nf, chunk_size, beam_size, device)
+    if s1 > s0:
         local = engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
     # every mode's rows travel in the same single all-gather: rank block = [mode 0 rows | mode 1 rows | ...]
     kmax = max(b - a for a, b in chunk_ranges(n_chunks, world))

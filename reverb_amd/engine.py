@@ -182,6 +182,22 @@ class Engine:
             mask = sum(self.FP8_GROUPS[g] for g in set(groups))
         check(self.lib.rvb_set_fp8_policy(self.handle, int(mask), int(first_block), int(last_block)), "rvb_set_fp8_policy")
 
+    def fp8_scales(self) -> Optional[np.ndarray]:
+        """fp8 engines: the calibrated activation scales [blocks, 7], or None before the calibration batch."""
+        n = C.c_int32(0)
+        check(self.lib.rvb_get_fp8_scales(self.handle, None, C.byref(n)), "rvb_get_fp8_scales")
+        if n.value == 0:
+            return None
+        out = np.empty(n.value, np.float32)
+        check(self.lib.rvb_get_fp8_scales(self.handle, fptr(out), C.byref(n)), "rvb_get_fp8_scales")
+        return out.reshape(-1, 7)
+
+    def set_fp8_scales(self, scales):
+        """Install activation scales (e.g. the element-wise maximum over the ranks of a sharded run, or scales measured
+        once): the engine counts as calibrated, the next encode runs in fp8."""
+        a = np.ascontiguousarray(scales, dtype=np.float32).reshape(-1)
+        check(self.lib.rvb_set_fp8_scales(self.handle, fptr(a), len(a)), "rvb_set_fp8_scales")
+
     def apply_decoding_chunk(self, decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1):
         """What BaseEncoder.forward does with these two arguments (encoder.py:140-145 -> add_optional_chunk_mask,
         utils/mask.py:126-197): they select a chunk mask only for models configured with use_dynamic_chunk, a

@@ -194,3 +194,35 @@ def test_fp8_policy_is_validated():
     with pytest.raises(RvbError, match="RVB_FP8"):
         eng.set_fp8_policy(["ffn"])
     eng.close()
+
+
+def test_fp8_scales_can_be_shared_between_engines():
+    """rvb_get_fp8_scales / rvb_set_fp8_scales (the ranks of a sharded run must not calibrate independently): the
+    element-wise maximum of what two engines calibrate on the two halves of a recording equals what one engine calibrates on
+    the whole (max |.| over a union), and an engine that has the scales installed runs its FIRST batch in fp8."""
+    from golden_util import LongCase
+    from reverb_amd.engine import Engine
+    case = LongCase("small_66")
+    n = 8
+    x = np.concatenate([case.chunk_feats(c)[0] for c in range(n)])
+    lens = np.array(case.js["lens"][:n], np.int32)
+    mk = lambda: Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=n, chunk_frames=case.chunk, cat_embs=case.cat)
+    whole, a, b = mk(), mk(), mk()
+    assert whole.fp8_scales() is None
+    whole.encode(x, lens, case.beam)
+    a.encode(x[:4], lens[:4], case.beam)
+    b.encode(x[4:], lens[4:], case.beam)
+    sw, sa, sb = whole.fp8_scales(), a.fp8_scales(), b.fp8_scales()
+    assert sw.shape == (case.cfg["encoder_conf"]["num_blocks"], 7) and (sw > 0).all()
+    np.testing.assert_array_equal(np.maximum(sa, sb), sw)
+    c = mk()
+    c.set_fp8_scales(np.maximum(sa, sb))
+    c.reset_timings(); c.set_profiling(True)
+    c.encode(x, lens, case.beam)                         # no calibration pass: fp8 GEMMs on the very first batch
+    assert c.timing("gemm_fp8")["launches"] > 0
+    whole.encode(x, lens, case.beam)                     # second batch of `whole`: fp8 with the same scales
+    got = [list(r.tokens) for r in c.search(["ctc_greedy_search"], 0.0, 0.0)["ctc_greedy_search"]]
+    want = [list(r.tokens) for r in whole.search(["ctc_greedy_search"], 0.0, 0.0)["ctc_greedy_search"]]
+    assert got == want
+    for e in (whole, a, b, c):
+        e.close()
