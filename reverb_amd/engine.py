@@ -245,6 +245,9 @@ class Engine:
         elif T0 is None:
             T0 = self.cfg.chunk_frames
         k = max(int(beam), int(topk or 0))
+        if k > 16:
+            raise RvbError(f"the CTC kernel keeps at most 16 log-probs per frame; beam {beam}" +
+                           (f" with joint_decoding's pre-beam {topk}" if topk else "") + " needs more")
         check(self.lib.rvb_encode(self.handle, fptr(feats), int(first_chunk), iptr(lens), B, int(T0), k,
                                   float(blank_penalty)), "rvb_encode")
         t = C.c_int32(0)
