@@ -324,6 +324,40 @@ def test_attention_encoder_form(lib, dtype, heads, dk, T, pos):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_late_maximum_forces_a_rescale(lib, dtype):
+    """bf16 mode defers the rescaling of the online softmax while no query's maximum grows by more than 2^8: random scores
+    never take the rescale branch after the first tile, so keys are spiked against chosen queries in LATER tiles (tile 2 for
+    some queries, tile 5 for others, both for a third group, and a small growth below the threshold for a fourth) -- every
+    row against fp64."""
+    heads, dk, T = 2, 64, 400
+    d = heads * dk
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((T, d)); k = rng.standard_normal((T, d)); v = rng.standard_normal((T, d))
+    for h in range(heads):
+        sl = slice(h * dk, (h + 1) * dk)
+        # group A (queries 0, 3, 6, ..): key 150 (tile 2) lies along their common direction, ~20 nats above their other
+        # scores; group B (queries 1, 4, ..): the same with key 330 (tile 5)
+        qa = q[0:T:3, sl].mean(0); ua = qa / np.linalg.norm(qa)
+        qb = q[1:T:3, sl].mean(0); ub = qb / np.linalg.norm(qb)
+        k[150, sl] = ua * 6.0 * math.sqrt(dk) / np.linalg.norm(qa)
+        k[330, sl] = ub * 6.0 * math.sqrt(dk) / np.linalg.norm(qb)
+        q[0:T:3, sl] += 2.0 * ua
+        q[1:T:3, sl] += 2.0 * ub
+        k[200, sl] = 0.4 * k[200, sl] + 0.3 * q[2, sl]      # group C: a mild growth that stays under the threshold
+    q, k, v = rnd(dtype, q), rnd(dtype, k), rnd(dtype, v)
+    starts = i32([0]); lens = i32([T])
+    out = np.empty((T, d), np.float32)
+    _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), None, None, None, fptr(out), T, T, 0, heads, dk,
+                                      iptr(starts), iptr(lens), iptr(starts), iptr(lens), 1, 0))
+    ref = _ref_attention(q, k, v, None, None, None, heads, dk, starts, lens, starts, lens, False)
+    # the spikes really are late maxima far above the threshold (8 in the log2 domain = 5.5 nats)
+    sc = q[:, :dk].astype(np.float64) @ k[:, :dk].astype(np.float64).T / math.sqrt(dk)
+    assert (sc[0::3, 150] - np.delete(sc[0::3], [150, 330], axis=1)[:, :128].max(1) > 6).mean() > 0.9
+    tol = 2e-5 if dtype == F32 else 3e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 def test_attention_decoder_forms(lib, dtype):
     """causal ragged self attention and cross attention over a chunk memory (decoder.py:150-156)."""
     heads, dk = 4, 32
