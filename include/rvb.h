@@ -95,6 +95,42 @@ int rvb_host_alloc(void** out, int64_t bytes);
 int rvb_host_free(void* p);
 int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int64_t* n_frames);
 
+/* The audio reader itself -- `torchaudio.load(audio_file, normalize=False)` followed by `.to(torch.float)`
+ * (asr/wenet/cli/reverb.py:128-130) -- for the lossless containers, decoded on the host from a file image in memory
+ * (csrc/audio.cpp).  normalize=False keeps the decoder's native sample format, so the VALUES depend on the container:
+ *   RIFF/WAVE  PCM 16 (int16), PCM 8 (uint8, 0..255 as stored), PCM 24 / 32 (int32; 24-bit left-justified = value << 8),
+ *              IEEE float 32 / 64 (as stored), A-law / mu-law (expanded to int16); WAVE_FORMAT_EXTENSIBLE of the same
+ *   FLAC       (RFC 9639) <= 16 bits per sample: int16, left-justified; wider: int32, left-justified; frame CRC-8 / CRC-16
+ *              and the STREAMINFO MD5 of the decoded PCM are verified (md5_checked = 1 when the file carries a signature)
+ * MP3 / Ogg / AIFF / RF64 are refused by name (RVB_E_UNSUPPORTED); corrupt data is -6.
+ * rvb_audio_probe fills `info` only.  The decode calls write channel `channel` (or, with channel = -1, all channels
+ * planar [channels][frames]) into `out` of `capacity` samples and return the frames per channel (< 0: error code).
+ * flags: RVB_AUDIO_NO_MD5 skips the FLAC signature check (the loader of the reference does not check it either); bits 8..15 =
+ * host threads for FLAC (0 = one per 512 KiB of stream, at most 16: frames decode independently, a 1 h file in ~0.1 s).
+ * rvb_audio_decode_i16 serves the files whose native format is int16 (sample_format == RVB_SAMPLE_I16): the PCM can go
+ * straight into a page-locked buffer for rvb_upload_pcm_rate; everything else goes through rvb_audio_decode_f32 and
+ * rvb_upload_wave_f32. */
+enum { RVB_AUDIO_WAVE = 1, RVB_AUDIO_FLAC = 2 };
+enum { RVB_AUDIO_NO_MD5 = 1 };
+enum { RVB_SAMPLE_U8 = 1, RVB_SAMPLE_I16 = 2, RVB_SAMPLE_I32 = 3, RVB_SAMPLE_F32 = 4, RVB_SAMPLE_F64 = 5 };
+typedef struct rvb_audio_info {
+  int32_t container;        /* RVB_AUDIO_* */
+  int32_t sample_format;    /* RVB_SAMPLE_*: the dtype of the tensor torchaudio would return */
+  int32_t channels;
+  int32_t sample_rate;
+  int32_t bits_per_sample;  /* as the file declares it */
+  int32_t md5_checked;
+  int64_t frames;           /* samples per channel */
+  int32_t decode_threads;   /* host threads the decode used (FLAC: runs of frames) */
+  int32_t reserved;
+} rvb_audio_info;
+int rvb_audio_probe(const void* data, int64_t nbytes, rvb_audio_info* info);
+int64_t rvb_audio_decode_f32(const void* data, int64_t nbytes, int channel, float* out, int64_t capacity, int flags, rvb_audio_info* info);
+int64_t rvb_audio_decode_i16(const void* data, int64_t nbytes, int channel, int16_t* out, int64_t capacity, int flags, rvb_audio_info* info);
+/* rvb_upload_pcm_rate for a float waveform (`waveform.to(torch.float)` of a non-int16 source, cli/reverb.py:130-134):
+ * resampled on the device when sample_rate != 16000; the fbank reads the float values as they are. */
+int rvb_upload_wave_f32(rvb_engine* e, const float* wave, int64_t n_samples, int sample_rate);
+
 /* Chunk-masked encoder attention for the following rvb_encode calls: query frame i attends the encoder frames
  * [max((i/chunk - left)*chunk, 0), (i/chunk + 1)*chunk) -- what `decoding_chunk_size` / `num_decoding_left_chunks`
  * select in BaseEncoder.forward via add_optional_chunk_mask (encoder.py:140-145, utils/mask.py:86-197) for models

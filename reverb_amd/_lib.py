@@ -21,6 +21,13 @@ class RvbError(RuntimeError):
     pass
 
 
+class AudioInfo(C.Structure):
+    """rvb_audio_info (include/rvb.h)."""
+    _fields_ = [("container", C.c_int32), ("sample_format", C.c_int32), ("channels", C.c_int32), ("sample_rate", C.c_int32),
+                ("bits_per_sample", C.c_int32), ("md5_checked", C.c_int32), ("frames", C.c_int64), ("decode_threads", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "input_dim", "vocab", "d_model", "heads", "ffn_dim", "num_blocks", "cnn_kernel",
@@ -54,6 +61,10 @@ SIGNATURES = {
     "rvb_get_joint_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_upload_pcm_rate": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int]),
     "rvb_get_waveform": (C.c_int, [_eng, _f32p, _i64p]),
+    "rvb_upload_wave_f32": (C.c_int, [_eng, _f32p, C.c_int64, C.c_int]),
+    "rvb_audio_probe": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(AudioInfo)]),
+    "rvb_audio_decode_f32": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_int, C.POINTER(AudioInfo)]),
+    "rvb_audio_decode_i16": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int, _i16p, C.c_int64, C.c_int, C.POINTER(AudioInfo)]),
     "rvb_fbank": (C.c_int, [_eng, _f32p, _i64p]),
     "rvb_encode": (C.c_int, [_eng, _f32p, C.c_int64, _i32p, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rvb_stream_begin": (C.c_int, [_eng]),

@@ -22,14 +22,14 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
     the GIL inside librvb)."""
     from reverb_amd.bin.assign_words2speakers import make_turns, speakers_for_words
     from reverb_amd.reverb import get_output
-    from reverb_amd.wav import read_wav
+    from reverb_amd import audio as audio_reader
     if isinstance(audio, tuple):        # (name, int16 mono PCM at 16 kHz) already in memory
         stem, pcm16 = audio
         wave, rate = np.ascontiguousarray(pcm16, np.int16).reshape(1, -1), 16000
         audio = {"waveform": wave[0], "sample_rate": 16000, "uri": stem}
     else:
         stem = os.path.splitext(os.path.basename(audio))[0]
-        wave, rate = read_wav(audio)
+        wave, rate = audio_reader.load(audio, channel=0)
     timings = {}
     t0 = time.perf_counter()
     chunk = asr.engine.cfg.chunk_frames

@@ -93,7 +93,8 @@ struct rvb_engine {
 
   // ---- audio / features ----
   rvb::DevBuf pcm, feats;        // int16 [n], fp32 [chunks*T0pad][80]
-  rvb::DevBuf wave_f32, rs_kernel; // resampled waveform (fp32, int16 scale) when the input rate is not 16 kHz
+  rvb::DevBuf wave_f32, rs_kernel; // the waveform the fbank reads when it is not int16 PCM at 16 kHz: resampled and / or uploaded as float
+  rvb::DevBuf wave_in;             // a float waveform at another rate, before resampling (rvb_upload_wave_f32)
   bool pcm_is_float = false;
   int dec_chunk = 0, dec_left = -1;   // encoder chunk mask (decoding_chunk_size / num_decoding_left_chunks), 0 = full context
   int64_t n_samples = 0, n_frames = 0, feat_rows = 0;

@@ -1756,6 +1756,7 @@ void rvb_destroy(rvb_engine* e) {
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
   e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
+  e->wave_f32.release(); e->wave_in.release(); e->rs_kernel.release();
   e->jlogp.release(); e->jpair_row.release(); e->jpair_tok.release(); e->jpair_out.release();
   for (auto& b : e->jkv) b.release();
   for (auto* v : {&e->stream_st.kv, &e->stream_st.kv2, &e->stream_st.cnn, &e->stream_st.cnn2}) for (auto& b : *v) b.release();
@@ -1839,11 +1840,10 @@ int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks) {
   return OK;
 }
 
-int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample_rate) {
+// torchaudio.transforms.Resample(sample_rate, 16000) of the uploaded samples (int16 in e->pcm or float in e->wave_in)
+// into e->wave_f32 (cli/reverb.py:131-134)
+static int resample_uploaded(rvb_engine* e, bool src_float, int64_t n, int sample_rate) {
   const int target = 16000;
-  if (sample_rate == target) return rvb_upload_pcm(e, pcm, n);
-  if (!e || (!pcm && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_pcm_rate: bad argument"); return E_ARG; }
-  RVB_HIP_CHECK(hipSetDevice(e->device));
   // torchaudio.functional.resample kernel (sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99), built in fp64
   int a = sample_rate, b = target;
   while (b) { const int t = a % b; a = b; b = t; }
@@ -1865,17 +1865,38 @@ int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample
       ker[(size_t)p * K + k] = (float)(sinc * window * (base_freq / orig));
     }
   const int64_t n_out = (nw * n + orig - 1) / orig;          // ceil(new * length / orig)
-  RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
   RVB_TRY(e->rs_kernel.ensure(ker.size() * 4));
   RVB_TRY(e->wave_f32.ensure((size_t)std::max<int64_t>(n_out, 1) * 4));
-  if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
   RVB_HIP_CHECK(hipMemcpyAsync(e->rs_kernel.p, ker.data(), ker.size() * 4, hipMemcpyHostToDevice, e->stream));
   {
     Scope sc(e, "resample");
-    RVB_TRY(resample(e->stream, e->pcm.as<int16_t>(), n, e->rs_kernel.as<float>(), orig, nw, width, K, e->wave_f32.as<float>(), n_out));
+    if (src_float) RVB_TRY(resample_f32(e->stream, e->wave_in.as<float>(), n, e->rs_kernel.as<float>(), orig, nw, width, K, e->wave_f32.as<float>(), n_out));
+    else RVB_TRY(resample(e->stream, e->pcm.as<int16_t>(), n, e->rs_kernel.as<float>(), orig, nw, width, K, e->wave_f32.as<float>(), n_out));
   }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   e->n_samples = n_out;
+  e->pcm_is_float = true;
+  return OK;
+}
+
+int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample_rate) {
+  if (sample_rate == 16000) return rvb_upload_pcm(e, pcm, n);
+  if (!e || (!pcm && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_pcm_rate: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+  return resample_uploaded(e, false, n, sample_rate);
+}
+
+int rvb_upload_wave_f32(rvb_engine* e, const float* wave, int64_t n, int sample_rate) {
+  if (!e || (!wave && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_wave_f32: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  rvb::DevBuf& dst = sample_rate == 16000 ? e->wave_f32 : e->wave_in;
+  RVB_TRY(dst.ensure((size_t)std::max<int64_t>(n, 1) * 4));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(dst.p, wave, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  if (sample_rate != 16000) return resample_uploaded(e, true, n, sample_rate);
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->n_samples = n;
   e->pcm_is_float = true;
   return OK;
 }

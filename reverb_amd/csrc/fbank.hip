@@ -136,7 +136,8 @@ int fbank_f32(hipStream_t s, const float* wave, int64_t n_frames, float* feats, 
 // torchaudio.transforms.Resample(orig, new) (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) as a
 // polyphase FIR: out[j*new + p] = sum_k ker[p][k] * x[j*orig + k - width], x zero outside [0, n_in).
 // One thread per output sample; the K-tap windows of neighbouring outputs overlap almost entirely (L1/L2).
-__global__ __launch_bounds__(256) void resample_kernel(const int16_t* __restrict__ pcm, int64_t n_in, const float* __restrict__ ker,
+template <typename In>
+__global__ __launch_bounds__(256) void resample_kernel(const In* __restrict__ pcm, int64_t n_in, const float* __restrict__ ker,
                                                        int orig, int new_, int width, int K, float* __restrict__ out,
                                                        int64_t n_out) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -155,7 +156,15 @@ __global__ __launch_bounds__(256) void resample_kernel(const int16_t* __restrict
 int resample(hipStream_t s, const int16_t* pcm, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
              int64_t n_out) {
   if (n_out <= 0) return OK;
-  hipLaunchKernelGGL(resample_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pcm, n_in, ker, orig, new_, width, K, out, n_out);
+  hipLaunchKernelGGL(resample_kernel<int16_t>, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pcm, n_in, ker, orig, new_, width, K, out, n_out);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+int resample_f32(hipStream_t s, const float* pcm, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
+             int64_t n_out) {
+  if (n_out <= 0) return OK;
+  hipLaunchKernelGGL(resample_kernel<float>, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pcm, n_in, ker, orig, new_, width, K, out, n_out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -54,6 +54,8 @@ int fbank_f32(hipStream_t s, const float* wave, int64_t n_frames, float* feats, 
 // polyphase sinc resampler: ker fp32 [new][K] (K = 2*width + orig), out fp32 [n_out] at int16 scale
 int resample(hipStream_t s, const int16_t* pcm, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
              int64_t n_out);
+int resample_f32(hipStream_t s, const float* wave, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
+             int64_t n_out);
 
 // ---------------------------------------------------------------- elementwise.hip
 // CMVN + Conv2d(1,d,3,stride 2) + ReLU; feats fp32 [B,T0,F0] -> out T [B,T1,F1,d] (NHWC)

@@ -532,7 +532,7 @@ class SpeakerDiarization:
 
     @staticmethod
     def _load(file) -> Tuple[np.ndarray, str]:
-        from . import wav as W
+        from . import audio as A
         if isinstance(file, dict):
             uri = file.get("uri")
             if "waveform" in file:
@@ -545,11 +545,14 @@ class SpeakerDiarization:
                 return pcm, uri or "waveform"
             file = file["audio"]
         path = os.fspath(file)
-        pcm, sr = W.read_wav(path)
-        if sr != 16000:
-            raise ValueError(f"{path}: sample rate {sr}; only 16 kHz audio is supported")
-        if pcm.ndim == 2:                                          # (channels, samples) -> mono mean like pyannote Audio
-            pcm = np.clip(np.rint(pcm.astype(np.float32).mean(axis=0)), -32768, 32767).astype(np.int16)
+        pcm, info = A.load_with_info(path)                         # WAVE / FLAC, decoded by librvb on the host
+        if info.sample_rate != 16000:
+            raise ValueError(f"{path}: sample rate {info.sample_rate}; only 16 kHz audio is supported")
+        if info.sample_format != "int16" or pcm.shape[0] > 1:     # (channels, samples) -> mono mean like pyannote Audio
+            mono = A.normalized(pcm, info).mean(axis=0) * np.float32(32768.0)
+            pcm = np.clip(np.rint(mono), -32768, 32767).astype(np.int16)
+        else:
+            pcm = pcm[0]
         return pcm, os.path.splitext(os.path.basename(path))[0]
 
     def _runs(self, classes: np.ndarray) -> ClassRuns:

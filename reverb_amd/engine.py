@@ -153,7 +153,16 @@ class Engine:
         return np.ctypeslib.as_array(buf)[:int(n_samples)]
 
     def upload_pcm(self, pcm: np.ndarray, sample_rate: int = 16000):
-        """int16 mono PCM -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134)."""
+        """Mono waveform -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134).  int16 PCM stays
+        int16; a float32 array (the `.to(torch.float)` of a source whose native format is not int16) is uploaded as it is."""
+        if isinstance(pcm, np.ndarray) and pcm.dtype.kind == "f":
+            wave = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
+            check(self.lib.rvb_upload_wave_f32(self.handle, wave.ctypes.data_as(_lib._f32p), len(wave), int(sample_rate)),
+                  "rvb_upload_wave_f32")
+            n = C.c_int64(0)
+            check(self.lib.rvb_get_waveform(self.handle, None, C.byref(n)), "rvb_get_waveform")
+            self._n_samples = int(n.value)
+            return
         pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
         if sample_rate == 16000:
             check(self.lib.rvb_upload_pcm(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm)), "rvb_upload_pcm")

@@ -26,7 +26,7 @@ from .ctc_align import adjust_model_time_offset, ctc_align, hyps_to_ctm, hyps_to
 from .engine import Engine, SUPPORTED_MODES, joint_topk
 from .search import DecodeResult
 from .tokenizer import RevBpeTokenizer
-from .wav import read_wav
+from . import audio
 
 _FRAME_DOWNSAMPLING_FACTOR = {"linear": 1, "conv2d": 4, "conv2d6": 6, "conv2d8": 8}
 CACHED_MODELS_DIR = Path.home() / ".cache/reverb"
@@ -160,8 +160,9 @@ class ReverbASR:
 
     # ------------------------------------------------------------------ front end
     def _load_pcm(self, audio_file: str, resample_rate: int):
-        """-> (int16 channel 0, its sample rate); the engine resamples to 16 kHz on the device when needed."""
-        wave, rate = read_wav(audio_file)
+        """-> (channel 0 in the native sample format -- int16, or float32 holding `.to(torch.float)` of anything else --, its
+        sample rate); WAVE and FLAC are decoded by librvb on the host, the engine resamples to 16 kHz on the device."""
+        wave, rate = audio.load(audio_file, channel=0)
         logging.info(f"detected sample rate: {rate}")
         if resample_rate != 16000:
             raise NotImplementedError("the device front end is built for a 16 kHz model (resample_rate=16000)")
