@@ -62,6 +62,11 @@ def parse(argv=None):
     p.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     p.add_argument("--traffic", default="auto", choices=["auto", "off"],
                    help="auto: at N = 1 measure the GEMMs' HBM traffic with two nested rocprofv3 --pmc passes")
+    p.add_argument("--gather", default="results", choices=["results", "posteriors"],
+                   help="what the ranks exchange per step: the decoded results (1.3 KB per chunk, the product path) or ALSO the "
+                        "top-beam CTC posteriors (int32 id + fp32 log-prob x beam per encoder frame, 41 KB per chunk) -- the "
+                        "alternative exchange of SURVEY 8(e), inside the timed region; either way a device-to-device "
+                        "all-gather of that posterior payload is timed once outside it (`xgmi_allgather` in the line)")
     p.add_argument("--no-diarization", action="store_true", help="skip the diarization sub-record (N = 1 only)")
     p.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (N = 1 only)")
     return p.parse_args(argv)
@@ -281,6 +286,11 @@ def main():
         if use_dist:      # ONE all-gather of the per-chunk results over RCCL/xGMI; the other ranks'
             hyps = all_gather_results(hyps, device, comm=comm)     # rows stay packed until somebody reads them (dist.GatheredResults)
             ntok = hyps.total_tokens()
+            if args.gather == "posteriors" and comm is not None:
+                # the top-beam posteriors of this rank's last launch, host-staged through the same collective
+                v, i = eng.ctc_topk()
+                packed = np.concatenate([v.reshape(-1).view(np.uint8), i.reshape(-1).view(np.uint8)])
+                stats["posterior_bytes_gathered"] = int(comm.all_gather(packed).nbytes)
         return hyps, ntok
 
     def sync():
@@ -329,6 +339,20 @@ def main():
             pcie = {"value": round(seconds * args.steps / dp, 2), "ms_per_step": round(dp / args.steps * 1e3, 2),
                     "h2d_bytes_per_step": int(n_samples * 2), "host_memory": "page-locked (rvb_host_alloc)"}
 
+    xgmi = None
+    if comm is not None:
+        # SURVEY 8(e)'s bandwidth datapoint, outside the timed region: the posterior exchange of one hour per rank as ONE
+        # all-gather between device buffers (every rank calls it; rank 0 reports)
+        enc_frames = ((chunk - 3) // 2 - 3) // 2 + 1 if chunk >= 7 else 0
+        payload = n_chunks * enc_frames * args.beam * 8
+        ms = comm.time_all_gather(payload, iters=10)
+        xgmi = {"what": "all-gather of the top-beam CTC posteriors of one hour per rank (int32 id + fp32 log-prob, "
+                        f"{enc_frames} frames x beam {args.beam} = {enc_frames * args.beam * 8 / 1e3:.1f} KB per chunk), device to device, "
+                        "HIP events, 10 calls after one warm-up; not part of `value`",
+                "bytes_per_rank": payload, "ms": round(ms, 4),
+                "algbw_GBps": round(payload * world / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                "busbw_GBps": round(payload * (world - 1) / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+
     out = None
     if rank == 0:
         audio_total = seconds * world * args.steps
@@ -368,12 +392,15 @@ def main():
                        "chunks_per_launch": per_launch, "parallelism": f"chunk-shard x{world}",
                        "world_size_reported_by_process_group": world if use_dist else 1,
                        "backend": (("librvb rvb_comm_allgather (RCCL)" if comm else dist.get_backend()) if use_dist else None),
+                       "gather": args.gather if use_dist else None,
+                       "posterior_bytes_gathered_per_step": stats.get("posterior_bytes_gathered"),
                        "results_gathered": len(hyps), "tokens_per_step": int(ntok),
                        # rescoring: (hypothesis, position) log-probs served vs decoder rows computed (one per distinct prefix)
                        "decoder_pairs_per_step": stats.get("decoder_pairs"), "decoder_rows_per_step": stats.get("decoder_rows")},
             "roofline": roof,
             "stage_ms_per_step": {k: round(v["ms"], 3) for k, v in stages.items()} if stages else None,
             "pcie_inclusive": pcie,
+            "xgmi_allgather": xgmi,
         }
         if not STUB and world == 1 and args.cpu_baseline_chunks > 0:
             nb = min(args.cpu_baseline_chunks, n_chunks)

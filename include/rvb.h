@@ -241,6 +241,9 @@ typedef struct rvb_comm rvb_comm;
 int rvb_comm_unique_id(void* id128 /* out: 128 bytes */);
 int rvb_comm_create(int device, int world, int rank, const void* id128, rvb_comm** out);
 int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv);
+/* The collective alone (device to device, HIP events on the communicator's stream, checked): average milliseconds of one
+ * all-gather of `bytes` bytes per rank -- the xGMI datapoint of SURVEY 8(e) for the top-beam posterior exchange. */
+int rvb_comm_time_allgather(rvb_comm* c, int64_t bytes, int iters, double* avg_ms);
 int rvb_comm_free(rvb_comm* c);
 int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128);
 int rvb_allgather_results(rvb_engine* e, const void* send, int64_t bytes, void* recv);

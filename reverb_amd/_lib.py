@@ -94,6 +94,7 @@ SIGNATURES = {
     "rvb_comm_init": (C.c_int, [_eng, C.c_int, C.c_int, C.c_void_p]),
     "rvb_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rvb_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rvb_comm_time_allgather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "rvb_comm_free": (C.c_int, [C.c_void_p]),
     "rvb_allgather_results": (C.c_int, [_eng, C.c_void_p, C.c_int64, C.c_void_p]),
     "rvb_comm_destroy": (C.c_int, [_eng]),

@@ -119,6 +119,48 @@ int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv)
   return OK;
 }
 
+// The collective alone, device buffer to device buffer: `iters` all-gathers of `bytes` bytes per rank between two HIP
+// events on the communicator's stream (after one untimed call).  The send buffer holds the rank number in every byte and the
+// last gather is checked on the host, so a figure is never reported for an exchange that did not happen.
+int rvb_comm_time_allgather(rvb_comm* c, int64_t bytes, int iters, double* avg_ms) {
+  if (!c || bytes <= 0 || iters < 1 || !avg_ms) { set_error("rvb_comm_time_allgather: bad argument"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(c->device));
+  int r = c->send.ensure((size_t)bytes);
+  if (r != OK) return r;
+  r = c->recv.ensure((size_t)bytes * c->world);
+  if (r != OK) return r;
+  RVB_HIP_CHECK(hipMemsetAsync(c->send.p, c->rank & 0xff, (size_t)bytes, c->stream));
+  RVB_HIP_CHECK(hipMemsetAsync(c->recv.p, 0xee, (size_t)bytes * c->world, c->stream));
+  hipEvent_t t0, t1;
+  RVB_HIP_CHECK(hipEventCreate(&t0));
+  RVB_HIP_CHECK(hipEventCreate(&t1));
+  int rc = g_rccl.all_gather(c->send.p, c->recv.p, (size_t)bytes, 0 /* ncclInt8 */, c->nccl, c->stream);
+  if (rc == 0) {
+    (void)hipEventRecord(t0, c->stream);
+    for (int i = 0; i < iters && rc == 0; ++i) rc = g_rccl.all_gather(c->send.p, c->recv.p, (size_t)bytes, 0, c->nccl, c->stream);
+    (void)hipEventRecord(t1, c->stream);
+  }
+  const hipError_t he = hipStreamSynchronize(c->stream);
+  float ms = 0.f;
+  if (rc == 0 && he == hipSuccess) (void)hipEventElapsedTime(&ms, t0, t1);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  if (rc != 0) return nccl_fail("ncclAllGather", rc);
+  RVB_HIP_CHECK(he);
+  // first and last byte of every rank's slot
+  for (int k = 0; k < c->world; ++k) {
+    unsigned char probe[2] = {0, 0};
+    RVB_HIP_CHECK(hipMemcpy(&probe[0], (const char*)c->recv.p + (size_t)k * bytes, 1, hipMemcpyDeviceToHost));
+    RVB_HIP_CHECK(hipMemcpy(&probe[1], (const char*)c->recv.p + (size_t)(k + 1) * bytes - 1, 1, hipMemcpyDeviceToHost));
+    if (probe[0] != (k & 0xff) || probe[1] != (k & 0xff)) {
+      set_error("rvb_comm_time_allgather: slot " + std::to_string(k) + " does not hold rank " + std::to_string(k) + "'s bytes");
+      return E_STATE;
+    }
+  }
+  *avg_ms = (double)ms / iters;
+  return OK;
+}
+
 int rvb_comm_free(rvb_comm* c) {
   if (!c) return OK;
   (void)hipSetDevice(c->device);

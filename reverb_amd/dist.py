@@ -231,6 +231,15 @@ class RvbComm:
         check(self.lib.rvb_comm_allgather(self.handle, send.ctypes.data, send.nbytes, recv.ctypes.data), "rvb_comm_allgather")
         return recv
 
+    def time_all_gather(self, nbytes: int, iters: int = 10) -> float:
+        """Milliseconds of ONE all-gather of `nbytes` bytes per rank, device buffer to device buffer (HIP events on the
+        communicator's stream, contents checked): the collective without the host staging all_gather() adds."""
+        import ctypes as C
+        from ._lib import check
+        ms = C.c_double(0.0)
+        check(self.lib.rvb_comm_time_allgather(self.handle, int(nbytes), int(iters), C.byref(ms)), "rvb_comm_time_allgather")
+        return float(ms.value)
+
     def close(self):
         if self.handle:
             self.lib.rvb_comm_free(self.handle)
