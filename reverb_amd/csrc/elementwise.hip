@@ -271,30 +271,33 @@ int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// GLU + depthwise conv along time (per chunk), LDS halo tile of 64 time steps x 64 channels
+// GLU + depthwise conv along time (per chunk), LDS halo tile of 128 time steps x 128 channels
 // ------------------------------------------------------------------------------------------------
-static constexpr int DW_TT = 64, DW_CT = 128, DW_KMAX = 31;
+static constexpr int DW_TT = 128, DW_CT = 128, DW_KMAX = 31, DW_THREADS = 512;
 
-template <typename T> struct Pair;
-template <> struct Pair<bf16_t> {
-  __device__ static inline void load(const bf16_t* p, float& x, float& y) {
-    const uint32_t u = *(const uint32_t*)p;
-    x = bf16_to_f32((bf16_t)(u & 0xffffu)); y = bf16_to_f32((bf16_t)(u >> 16));
-  }
+// the gated value as it sits in LDS: fp32 in the f32 engine; bf16 in the bf16 engine (F.glu under autocast returns bf16 as
+// well, and half the LDS bytes let four waves per SIMD stay resident)
+template <typename T> struct Gate;
+template <> struct Gate<float> {
+  typedef float2 pair_t;
+  __device__ static inline float put(float v) { return v; }
+  __device__ static inline void get(pair_t p, float& x, float& y) { x = p.x; y = p.y; }
 };
-template <> struct Pair<float> {
-  __device__ static inline void load(const float* p, float& x, float& y) {
-    const float2 u = *(const float2*)p;
-    x = u.x; y = u.y;
-  }
+template <> struct Gate<bf16_t> {
+  typedef uint32_t pair_t;
+  __device__ static inline bf16_t put(float v) { return f32_to_bf16(v); }
+  __device__ static inline void get(pair_t p, float& x, float& y) { x = __uint_as_float(p << 16); y = __uint_as_float(p & 0xffff0000u); }
 };
 
-// block = 64 time steps x 128 channels.  Staging: one thread per (row, 16-byte channel group) -- the two GLU halves
-// are read as 16-byte vectors (many bytes in flight per lane), gated, and written to LDS as fp32.  Compute: a lane
-// owns 2 adjacent channels and 16 consecutive frames (8-byte stores).
+// block = 128 time steps x 128 channels, 8 waves.  Staging: one thread per (row, 16-byte channel group) -- the two GLU halves
+// are read as 16-byte vectors (many bytes in flight per lane), gated, and written to LDS.  Compute: a lane owns 2 adjacent
+// channels and 16 consecutive frames (4- or 8-byte stores); its 31 taps (tap-major in memory: one coalesced 512-byte load per
+// wave and tap) are loaded before the staging so that their latency hides under it.
 template <typename T>
-__global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
-  __shared__ __attribute__((aligned(16))) float2 s_g[DW_TT + DW_KMAX - 1][DW_CT / 2];
+__global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
+  typedef decltype(Gate<T>::put(0.f)) S;
+  constexpr int rows = DW_TT + DW_KMAX - 1;        // always the full window: rows past DW_TT + K - 1 are zero-filled
+  __shared__ __attribute__((aligned(16))) S s_g[rows][DW_CT];
   const int c = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
   const int ch = c0 + 2 * c;
@@ -303,12 +306,17 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
   const int len = a.lens[b];
   const int lorder = K - 1;
   const T* G = (const T*)a.G;
+  // the two channels of a lane as one 2-wide vector: v_pk_fma_f32 does both FMAs of a tap in one instruction
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t wk[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k)
+    wk[k] = (k < K && cok) ? *(const f32x2_t*)(a.dw_w + (size_t)k * a.d + ch) : (f32x2_t){0.f, 0.f};
   constexpr int VE = 16 / (int)sizeof(T);          // channels per 16-byte vector
   constexpr int NG = DW_CT / VE;                   // vector groups per row
-  constexpr int rows = DW_TT + DW_KMAX - 1;        // always the full window: rows past DW_TT + K - 1 are zero-filled
   const bool vec_ok = (a.d % VE) == 0;
 #pragma unroll 4
-  for (int v = threadIdx.x; v < rows * NG; v += 256) {
+  for (int v = threadIdx.x; v < rows * NG; v += DW_THREADS) {
     const int r = v / NG, grp = v - r * NG;
     const int t = t0 - pad + r;
     const int cg = c0 + grp * VE;                  // first channel of the group
@@ -346,23 +354,19 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
           if (cg + e < a.d) g[e] = a.pw1_bias[cg + e] / (1.0f + expf(-a.pw1_bias[a.d + cg + e]));
       }
     }
-    float* dst = (float*)&s_g[r][0] + grp * VE;
+    S sv[VE];
 #pragma unroll
-    for (int q = 0; q < VE / 4; ++q) ((float4*)dst)[q] = make_float4(g[q * 4], g[q * 4 + 1], g[q * 4 + 2], g[q * 4 + 3]);
+    for (int e = 0; e < VE; ++e) sv[e] = Gate<T>::put(g[e]);
+    uint4* dst = (uint4*)&s_g[r][grp * VE];        // 16 bytes (bf16) or 2 x 16 bytes (fp32) per group
+#pragma unroll
+    for (int q = 0; q < (int)(VE * sizeof(S)) / 16; ++q) dst[q] = ((const uint4*)sv)[q];
   }
   __syncthreads();
   if (!cok) return;
   // Each thread owns 16 CONSECUTIVE output frames of its channel pair: the 46 input rows they touch are read from
   // LDS once each and fanned out to the (up to 16) outputs they contribute to, taps in registers -- 46 LDS reads
   // per thread instead of one per FMA pair (the strided version was LDS-bandwidth bound).
-  constexpr int OPT = DW_TT / 4;                 // outputs per thread
-  // the two channels of a lane as one 2-wide vector: v_pk_fma_f32 does both FMAs of a tap in one instruction (the kernel
-  // spends a third of its time in this loop: 1.9 -> 1.2 ms for a quarter hour with the taps removed)
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  f32x2_t wk[DW_KMAX];
-#pragma unroll
-  for (int k = 0; k < DW_KMAX; ++k)
-    wk[k] = k < K ? (f32x2_t){a.dw_w[(size_t)ch * K + k], a.dw_w[(size_t)(ch + 1) * K + k]} : (f32x2_t){0.f, 0.f};
+  constexpr int OPT = DW_TT / (DW_THREADS / 64);   // outputs per thread
   f32x2_t acc[OPT];
   const f32x2_t bv = {a.dw_b[ch], a.dw_b[ch + 1]};
 #pragma unroll
@@ -370,8 +374,9 @@ __global__ __launch_bounds__(256) void glu_dw_kernel(GluDwArgs a) {
   const int rbase = slot * OPT;
 #pragma unroll
   for (int r = 0; r < OPT + DW_KMAX - 1; ++r) {
-    const float2 g2 = s_g[rbase + r][c];
-    const f32x2_t g = {g2.x, g2.y};
+    float gx, gy;
+    Gate<T>::get(*(const typename Gate<T>::pair_t*)&s_g[rbase + r][2 * c], gx, gy);
+    const f32x2_t g = {gx, gy};
 #pragma unroll
     for (int i = 0; i < OPT; ++i) {
       const int k = r - i;                        // compile-time after unrolling
@@ -397,8 +402,8 @@ int glu_dwconv(hipStream_t s, int dtype, const GluDwArgs& a) {
     set_error("glu_dwconv: a left-context history belongs to one causal stream"); return E_ARG;
   }
   dim3 grid(cdiv(a.T, DW_TT), cdiv(a.d, DW_CT), a.B);
-  if (dtype == DT_BF16) hipLaunchKernelGGL(glu_dw_kernel<bf16_t>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(256), 0, s, a);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(glu_dw_kernel<bf16_t>, grid, dim3(DW_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(glu_dw_kernel<float>, grid, dim3(DW_THREADS), 0, s, a);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -38,7 +38,7 @@ struct EncLayer {
   DevBuf pos_keys;            // T [Tpos, d] = linear_pos(pe[:Tpos])
   DevBuf bias_u, bias_v;      // fp32 [h*dk]
   LNorm n_ffm, n_mha, n_conv, n_ff, n_final, n_cnn;
-  DevBuf dw_w, dw_b;          // fp32 [d][K], [d]
+  DevBuf dw_w, dw_b;          // fp32 [K][d] (tap-major), [d]
   bool is_lsl = false;
 };
 struct DecLayer {

@@ -369,7 +369,12 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
       RVB_TRY(need(e, p + ".self_attn.pos_bias_v", d, &t));
       RVB_TRY(upload_f32(e, L.bias_v, t->data.data(), d));
       RVB_TRY(need(e, p + ".conv_module.depthwise_conv.weight", (size_t)d * K, &t));
-      RVB_TRY(upload_f32(e, L.dw_w, t->data.data(), (size_t)d * K));
+      {   // tap-major [K][d] on the device: the lanes of glu_dw_kernel own adjacent channels, so a tap is one coalesced load
+        std::vector<float> wt((size_t)d * K);
+        for (int c = 0; c < d; ++c)
+          for (int k = 0; k < K; ++k) wt[(size_t)k * d + c] = t->data[(size_t)c * K + k];
+        RVB_TRY(upload_f32(e, L.dw_w, wt.data(), (size_t)d * K));
+      }
       RVB_TRY(need(e, p + ".conv_module.depthwise_conv.bias", d, &t));
       RVB_TRY(upload_f32(e, L.dw_b, t->data.data(), d));
       RVB_TRY(pack_norm(e, L.n_ffm, p + ".norm_ff_macaron", d, 1e-5f));

@@ -97,7 +97,7 @@ int rownorm(hipStream_t s, int dtype, const NormArgs& a);
 struct GluDwArgs {
   const void* G;          // T [B*T, 2d]
   const float* pw1_bias;  // [2d]
-  const float* dw_w;      // [d][K]
+  const float* dw_w;      // [K][d]: tap-major (depthwise_conv.weight [d,1,K] transposed at load)
   const float* dw_b;      // [d]
   const int* lens;        // [B] valid rows per chunk
   float* out;             // fp32 [B*T, d] (or bf16 when out_bf16)

@@ -124,7 +124,10 @@ int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const 
   Dev dG, dpb, dw, db, dl, dout, dh;
   T_TRY(up_T(dG, dtype, G, (size_t)B * T * 2 * d));
   T_TRY(up_raw(dpb, pw1_bias, (size_t)2 * d * 4));
-  T_TRY(up_raw(dw, dw_w, (size_t)d * K * 4));
+  std::vector<float> wt((size_t)d * K);            // the caller passes depthwise_conv.weight as the reference stores it, [d][K]
+  for (int c = 0; c < d; ++c)
+    for (int k = 0; k < K; ++k) wt[(size_t)k * d + c] = dw_w[(size_t)c * K + k];
+  T_TRY(up_raw(dw, wt.data(), (size_t)d * K * 4));
   T_TRY(up_raw(db, dw_b, (size_t)d * 4));
   T_TRY(up_raw(dl, lens, (size_t)B * 4));
   const bool o16 = (causal & 2) != 0;            // bit 1 of `causal`: bf16 output (bf16 engine)
