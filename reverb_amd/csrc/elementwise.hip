@@ -18,16 +18,19 @@ namespace rvb {
 // ------------------------------------------------------------------------------------------------
 // CMVN + conv1 (1 -> d channels, 3x3, stride 2) + ReLU, NHWC output
 // ------------------------------------------------------------------------------------------------
+static constexpr int CONV1_ROWS = 4;      // output time rows per workgroup: the 72 weights of a thread are loaded once for all of them
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ feats, const float* __restrict__ mean,
                                                     const float* __restrict__ istd, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, int T0,
                                                     int F0, int T1, int F1, int d) {
-  extern __shared__ float s_in[];  // [3][F0]
-  const int t1 = blockIdx.x, b = blockIdx.y;
-  for (int i = threadIdx.x; i < 3 * F0; i += 256) {
+  extern __shared__ float s_in[];  // [2 * CONV1_ROWS + 1][F0]: the input rows of CONV1_ROWS output rows (stride 2, 3 taps)
+  const int t1_0 = blockIdx.x * CONV1_ROWS, b = blockIdx.y;
+  const int nrow = min(CONV1_ROWS, T1 - t1_0);
+  for (int i = threadIdx.x; i < (2 * nrow + 1) * F0; i += 256) {
     const int kh = i / F0, f = i - kh * F0;
-    s_in[i] = (feats[((size_t)b * T0 + 2 * t1 + kh) * F0 + f] - mean[f]) * istd[f];
+    s_in[i] = (feats[((size_t)b * T0 + 2 * t1_0 + kh) * F0 + f] - mean[f]) * istd[f];
   }
   __syncthreads();
   // a thread owns 8 adjacent output channels (one 16-byte bf16 store, two for f32): full-width stores -- 8-byte
@@ -37,35 +40,41 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
   const int nslots = 256 / per;                 // f1 slots sharing the block
   const int cgl = threadIdx.x % per, fslot = threadIdx.x / per;
   if (fslot >= nslots) return;
-  T* orow = out + ((size_t)b * T1 + t1) * F1 * d;
   for (int cg = cgl; cg < ncg; cg += per) {
     float wr[8][9], br[8];
+    // weights tap-major [9][d]: the 8 channels of a thread are 32 contiguous bytes, the threads of a wave contiguous
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      br[c] = bias[cg * 8 + c];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) wr[c][k] = w[(cg * 8 + c) * 9 + k];
+    for (int k = 0; k < 9; ++k) {
+      const float4 lo = *(const float4*)(w + (size_t)k * d + cg * 8), hi = *(const float4*)(w + (size_t)k * d + cg * 8 + 4);
+      wr[0][k] = lo.x; wr[1][k] = lo.y; wr[2][k] = lo.z; wr[3][k] = lo.w;
+      wr[4][k] = hi.x; wr[5][k] = hi.y; wr[6][k] = hi.z; wr[7][k] = hi.w;
     }
-    for (int f1 = fslot; f1 < F1; f1 += nslots) {
-      float xin[9];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int c = 0; c < 8; ++c) br[c] = bias[cg * 8 + c];
+    for (int row = 0; row < nrow; ++row) {
+      T* orow = out + ((size_t)b * T1 + t1_0 + row) * F1 * d;
+      const float* in = s_in + 2 * row * F0;
+      for (int f1 = fslot; f1 < F1; f1 += nslots) {
+        float xin[9];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) xin[kh * 3 + kw] = s_in[kh * F0 + 2 * f1 + kw];
-      float o[8];
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float acc = br[c];
+          for (int kw = 0; kw < 3; ++kw) xin[kh * 3 + kw] = in[kh * F0 + 2 * f1 + kw];
+        float o[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc += wr[c][k] * xin[k];
-        o[c] = fmaxf(acc, 0.f);
-      }
-      T* dst = orow + (size_t)f1 * d + cg * 8;
-      if constexpr (sizeof(T) == 2) {
-        *(uint4*)dst = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
-      } else {
-        ((float4*)dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
-        ((float4*)dst)[1] = make_float4(o[4], o[5], o[6], o[7]);
+        for (int c = 0; c < 8; ++c) {
+          float acc = br[c];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc += wr[c][k] * xin[k];
+          o[c] = fmaxf(acc, 0.f);
+        }
+        T* dst = orow + (size_t)f1 * d + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+          *(uint4*)dst = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
+        } else {
+          ((float4*)dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
+          ((float4*)dst)[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
       }
     }
   }
@@ -76,8 +85,8 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
   const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1;
   if (B <= 0 || T1 <= 0) return OK;
   if (d % 8) { set_error("subsample_conv1: d must be a multiple of 8"); return E_ARG; }
-  dim3 grid(T1, B);
-  const size_t sh = 3 * F0 * sizeof(float);
+  dim3 grid(cdiv(T1, CONV1_ROWS), B);
+  const size_t sh = (2 * CONV1_ROWS + 1) * F0 * sizeof(float);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(conv1_kernel<bf16_t>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (bf16_t*)out, T0, F0, T1, F1, d);
   else

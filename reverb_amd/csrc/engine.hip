@@ -312,7 +312,12 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
     RVB_TRY(need(e, "encoder.global_cmvn.istd", F0, &t));
     RVB_TRY(upload_f32(e, e->cmvn_istd, t->data.data(), F0));
     RVB_TRY(need(e, "encoder.embed.conv.0.weight", (size_t)d * 9, &t));
-    RVB_TRY(upload_f32(e, e->conv1_w, t->data.data(), (size_t)d * 9));
+    {   // tap-major [9][d]: a thread of conv1_kernel reads its 8 channels of a tap as 32 contiguous bytes
+      std::vector<float> wt((size_t)d * 9);
+      for (int c = 0; c < d; ++c)
+        for (int k = 0; k < 9; ++k) wt[(size_t)k * d + c] = t->data[(size_t)c * 9 + k];
+      RVB_TRY(upload_f32(e, e->conv1_w, wt.data(), (size_t)d * 9));
+    }
     RVB_TRY(need(e, "encoder.embed.conv.0.bias", d, &t));
     RVB_TRY(upload_f32(e, e->conv1_b, t->data.data(), d));
     {  // conv2 [co][ci][kh][kw] -> [co][(kh*3+kw)*d + ci]  (K-contiguous rows for the implicit GEMM)

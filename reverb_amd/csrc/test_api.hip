@@ -107,7 +107,10 @@ int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float
   T_TRY(up_raw(df, feats, (size_t)B * T0 * F0 * 4));
   T_TRY(up_raw(dm, mean, (size_t)F0 * 4));
   T_TRY(up_raw(di, istd, (size_t)F0 * 4));
-  T_TRY(up_raw(dw, w, (size_t)d * 9 * 4));
+  std::vector<float> wt((size_t)d * 9);            // the caller passes conv.0.weight as the reference stores it, [d][1][3][3]
+  for (int c = 0; c < d; ++c)
+    for (int k = 0; k < 9; ++k) wt[(size_t)k * d + c] = w[(size_t)c * 9 + k];
+  T_TRY(up_raw(dw, wt.data(), (size_t)d * 9 * 4));
   T_TRY(up_raw(db, b, (size_t)d * 4));
   const size_t n = (size_t)B * T1 * F1 * d;
   T_TRY(dout.alloc(n * dt_size(dtype)));
