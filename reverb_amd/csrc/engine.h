@@ -1,7 +1,11 @@
 // Engine: weights, workspace and orchestration of the Reverb-ASR hot path on one MI355X.
 #pragma once
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rvb.h"
@@ -64,6 +68,72 @@ struct RescoreResult {
   std::vector<std::vector<float>> logp, rlogp;   // per hyp: len+1 decoder log-probs
 };
 
+
+// Host worker threads kept alive across calls (prefix beam search per slice, trie building): starting 31 threads costs
+// about as much as the work of the last, un-overlapped slice.  run(n, fn): fn is executed by n threads, the caller among them.
+class HostPool {
+ public:
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(unsigned n, const std::function<void()>& fn) {
+    if (n <= 1) { fn(); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      while (th_.size() + 1 < n) th_.emplace_back([this] { loop(); });
+      job_ = &fn; want_ = n - 1; started_ = 0; finished_ = 0; ++gen_;
+    }
+    cv_.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return finished_ == want_; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || (gen_ != seen && started_ < want_); });
+      if (stop_) return;
+      seen = gen_;
+      ++started_;
+      const std::function<void()>* job = job_;
+      lk.unlock();
+      (*job)();
+      lk.lock();
+      if (++finished_ == want_) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void()>* job_ = nullptr;
+  unsigned want_ = 0, started_ = 0, finished_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
+// ---- rescoring: every DISTINCT prefix of a chunk's n-best list is one decoder row (engine.hip, "rescoring")
+struct HypRef { int chunk, idx, len, row0; };      // row0: first of the hypothesis' len+1 (hyp, j) pairs
+
+struct TrieBatch {
+  int R = 0, P = 0, max_chunk_rows = 0;            // unique rows, (hyp, j) pairs, most rows of one chunk
+  std::vector<int32_t> tok, pos;                   // per row: input token, position
+  std::vector<int32_t> path;                       // per hypothesis: the rows of its prefixes 0..len (flat)
+  std::vector<int32_t> hq_start, hq_len, hq_pos0, hkv_start, hkv_len;   // per hypothesis: owned rows / path
+  std::vector<int32_t> crow_start, crow_len;       // per chunk: its rows (contiguous)
+  std::vector<int32_t> tgt_ptr, tgt;               // CSR over rows: the targets asked of a row
+  std::vector<int32_t> pair_slot;                  // (hyp, j) pair -> position in tgt / in the gathered log-probs
+  std::vector<int32_t> work;                       // self-attention blocks: {hypothesis, first owned query}
+};
+
 }  // namespace rvb
 
 struct rvb_engine {
@@ -114,6 +184,8 @@ struct rvb_engine {
   const int* cur_lens = nullptr;   // device pointer: valid encoder frames of the slice being encoded
   std::vector<rvb::PrefixResult> nbest;
   std::vector<rvb::RescoreResult> rescored;
+  std::vector<rvb::TrieBatch> trie_l;   // per chunk, local numbering: built by the prefix-beam workers for the rescoring decoder
+  rvb::HostPool pool;                   // host workers of the CTC search and the trie building
   std::vector<rvb::JointResult> joint;           // rvb_joint_decode: winner per chunk
   std::vector<rvb::DevBuf> jkv;                   // joint_decoding: per decoder layer T [rows][2d], key | value of every decoded prefix
   rvb::DevBuf jlogp, jpair_row, jpair_tok, jpair_out;     // fp32 [rows][V] log-softmax after each decoded prefix; pair gather buffers

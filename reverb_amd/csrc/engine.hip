@@ -952,6 +952,8 @@ static unsigned search_threads() {
   return std::min(hw, 32u);
 }
 
+static void build_chunk_trie(rvb_engine* e, int b, bool reversed, int sos, int eos, TrieBatch* t);   // with the rescoring, below
+
 static int prefix_beam_impl(rvb_engine* e, int beam) {
   if (e->B <= 0) { set_error("rvb_ctc_prefix_beam before rvb_encode"); return E_STATE; }
   // the search beam may be narrower than the top-k rvb_encode kept per frame (joint_decoding's pre-beam needs more): the first
@@ -959,6 +961,8 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
   if (beam < 1 || beam > e->beam) { set_error("rvb_ctc_prefix_beam: beam exceeds the top-k kept by rvb_encode"); return E_ARG; }
   const int B = e->B, T = e->T2, K = e->beam;
   e->nbest.assign(B, PrefixResult());
+  const bool prebuild = e->dec_l.present;
+  e->trie_l.assign(prebuild ? B : 0, TrieBatch());
   const unsigned hw = search_threads();
   double busy_ms = 0.0;
   for (size_t si = 0; si < e->slices.size(); ++si) {
@@ -969,15 +973,17 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
     // out one at a time because their lengths (and so their cost) differ
     const unsigned nthr = std::max(1u, std::min<unsigned>(hw, (unsigned)(nb + 1) / 2));
     std::atomic<int> next_chunk(c0);
-    std::vector<std::thread> pool;
+    const int sos = e->cfg.sos_id, eos = e->cfg.eos_id;
     auto work = [&, c0, nb]() {
-      for (int b = next_chunk.fetch_add(1); b < c0 + nb; b = next_chunk.fetch_add(1))
+      for (int b = next_chunk.fetch_add(1); b < c0 + nb; b = next_chunk.fetch_add(1)) {
         prefix_beam_search(e->h_topv + (size_t)b * T * K, e->h_topi + (size_t)b * T * K, e->enc_lens[b], K,
                            beam, e->cfg.blank_id, &e->nbest[b]);
+        // the chunk's prefix trie for the left-to-right rescoring decoder, while the worker has the n-best list hot: for
+        // every slice but the last this happens underneath the encoder of the next slice (rescore_impl only stitches)
+        if (prebuild) build_chunk_trie(e, b, false, sos, eos, &e->trie_l[b]);
+      }
     };
-    for (unsigned w = 1; w < nthr; ++w) pool.emplace_back(work);
-    work();                                      // the calling thread is worker 0
-    for (auto& t : pool) t.join();
+    e->pool.run(nthr, work);                     // the calling thread is one of the nthr
     busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   auto& pe = e->prof["search_host"];
@@ -994,31 +1000,19 @@ static int prefix_beam_impl(rvb_engine* e, int beam) {
 // right-to-left decoder sees the reversed hypotheses, search.py:427-433).  Row results do not depend on the batch they
 // are computed in (GEMM rows are independent, an attention row walks its own keys in order), so every hypothesis
 // reads exactly the log-probs the padded batch would give it.  On the bench workload 13-35 % of the rows remain.
-struct HypRef { int chunk, idx, len, row0; };      // row0: first of the hypothesis' len+1 (hyp, j) pairs
-
-struct TrieBatch {
-  int R = 0, P = 0, max_chunk_rows = 0;            // unique rows, (hyp, j) pairs, most rows of one chunk
-  std::vector<int32_t> tok, pos;                   // per row: input token, position
-  std::vector<int32_t> path;                       // per hypothesis: the rows of its prefixes 0..len (flat)
-  std::vector<int32_t> hq_start, hq_len, hq_pos0, hkv_start, hkv_len;   // per hypothesis: owned rows / path
-  std::vector<int32_t> crow_start, crow_len;       // per chunk: its rows (contiguous)
-  std::vector<int32_t> tgt_ptr, tgt;               // CSR over rows: the targets asked of a row
-  std::vector<int32_t> pair_slot;                  // (hyp, j) pair -> position in tgt / in the gathered log-probs
-  std::vector<int32_t> work;                       // self-attention blocks: {hypothesis, first owned query}
-};
-
 // seq(h, j) = j-th decoder input token AFTER <sos> of hypothesis h; target of pair (h, j) = seq(h, j) for j < len, else eos
 template <typename SeqFn>
-static void build_trie(const std::vector<HypRef>& hyps, int B, int sos, int eos, SeqFn seq, TrieBatch* t) {
+static void build_trie_range(const HypRef* hb, const HypRef* he, int chunk0, int B, int sos, int eos, SeqFn seq, TrieBatch* t) {
   *t = TrieBatch();
   std::vector<std::pair<int32_t, int32_t>> asks;   // (row, target) in pair order
   std::vector<std::vector<std::pair<int32_t, int32_t>>> kids;   // per row: (token, child row) -- fan-out is tiny
   t->crow_start.assign(B, 0); t->crow_len.assign(B, 0);
   int cur_chunk = -1, root = -1;
-  for (const HypRef& h : hyps) {
-    if (h.chunk != cur_chunk) {
+  for (const HypRef* hp = hb; hp != he; ++hp) {
+    const HypRef& h = *hp;
+    if (h.chunk - chunk0 != cur_chunk) {
       if (cur_chunk >= 0) t->crow_len[cur_chunk] = t->R - t->crow_start[cur_chunk];
-      cur_chunk = h.chunk;
+      cur_chunk = h.chunk - chunk0;
       t->crow_start[cur_chunk] = t->R;
       root = -1;
     }
@@ -1064,6 +1058,65 @@ static void build_trie(const std::vector<HypRef>& hyps, int B, int sos, int eos,
 }
 
 // one decoder over the trie rows; logp[slot] = log p(target | prefix) for every ask (TrieBatch::pair_slot maps pairs)
+// One chunk's trie in local numbering (rows, hypotheses, path entries and pairs counted from 0).
+static void build_chunk_trie(rvb_engine* e, int b, bool reversed, int sos, int eos, TrieBatch* t) {
+  const PrefixResult& pr = e->nbest[b];
+  std::vector<HypRef> hyps(pr.nbest.size());
+  for (size_t i = 0; i < hyps.size(); ++i) hyps[i] = {b, (int)i, (int)pr.nbest[i].size(), 0};
+  if (reversed)
+    build_trie_range(hyps.data(), hyps.data() + hyps.size(), b, 1, sos, eos,
+                     [&](const HypRef& h, int j) { return pr.nbest[h.idx][h.len - 1 - j]; }, t);
+  else
+    build_trie_range(hyps.data(), hyps.data() + hyps.size(), b, 1, sos, eos, [&](const HypRef& h, int j) { return pr.nbest[h.idx][j]; }, t);
+}
+
+// The batch trie from the chunks' tries: the rows of a chunk are contiguous and only that chunk's hypotheses refer to them, so
+// a chunk's local numbering differs from the global one by the running totals of the chunks before it -- rows, hypotheses,
+// path entries, (hypothesis, position) pairs.  Bit-identical to build_trie_range over all hypotheses at once (which took
+// 1.6 ms on one thread for the 176-chunk bench batch, with the device idle).
+static void merge_tries(const std::vector<TrieBatch>& part, TrieBatch* t) {
+  const int B = (int)part.size();
+  *t = TrieBatch();
+  size_t nR = 0, nH = 0, nPath = 0, nP = 0, nW = 0;
+  for (const TrieBatch& c : part) { nR += c.R; nH += c.hq_start.size(); nPath += c.path.size(); nP += c.P; nW += c.work.size(); }
+  t->tok.reserve(nR); t->pos.reserve(nR); t->path.reserve(nPath); t->work.reserve(nW);
+  t->hq_start.reserve(nH); t->hq_len.reserve(nH); t->hq_pos0.reserve(nH); t->hkv_start.reserve(nH); t->hkv_len.reserve(nH);
+  t->tgt.reserve(nP); t->pair_slot.reserve(nP); t->tgt_ptr.reserve(nR + 1);
+  t->crow_start.assign(B, 0); t->crow_len.assign(B, 0);
+  for (int b = 0; b < B; ++b) {
+    const TrieBatch& c = part[b];
+    const int32_t R0 = t->R, H0 = (int32_t)t->hq_start.size(), PATH0 = (int32_t)t->path.size(), P0 = t->P;
+    t->crow_start[b] = c.R ? R0 : 0; t->crow_len[b] = c.R;      // a chunk without hypotheses keeps the zeros of the batch form
+    t->max_chunk_rows = std::max(t->max_chunk_rows, c.R);
+    t->tok.insert(t->tok.end(), c.tok.begin(), c.tok.end());
+    t->pos.insert(t->pos.end(), c.pos.begin(), c.pos.end());
+    for (int32_t v : c.path) t->path.push_back(v + R0);
+    for (int32_t v : c.hq_start) t->hq_start.push_back(v + R0);
+    t->hq_len.insert(t->hq_len.end(), c.hq_len.begin(), c.hq_len.end());
+    t->hq_pos0.insert(t->hq_pos0.end(), c.hq_pos0.begin(), c.hq_pos0.end());
+    for (int32_t v : c.hkv_start) t->hkv_start.push_back(v + PATH0);
+    t->hkv_len.insert(t->hkv_len.end(), c.hkv_len.begin(), c.hkv_len.end());
+    for (size_t k = 0; k + 1 < c.work.size(); k += 2) { t->work.push_back(c.work[k] + H0); t->work.push_back(c.work[k + 1]); }
+    for (int r = 0; r < c.R; ++r) t->tgt_ptr.push_back(c.tgt_ptr[r] + P0);
+    t->tgt.insert(t->tgt.end(), c.tgt.begin(), c.tgt.end());
+    for (int32_t v : c.pair_slot) t->pair_slot.push_back(v + P0);
+    t->R += c.R; t->P += c.P;
+  }
+  t->tgt_ptr.push_back(t->P);
+}
+
+// every chunk's trie on the host pool, then stitched
+static void build_trie_parallel(rvb_engine* e, bool reversed, TrieBatch* t) {
+  const int B = e->B, sos = e->cfg.sos_id, eos = e->cfg.eos_id;
+  std::vector<TrieBatch> part(B);
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) build_chunk_trie(e, b, reversed, sos, eos, &part[b]);
+  };
+  e->pool.run(std::max(1u, std::min<unsigned>(search_threads(), (unsigned)B / 4)), work);
+  merge_tries(part, t);
+}
+
 static int decoder_forward(rvb_engine* e, Decoder& D, const TrieBatch& t, std::vector<float>* logp) {
   const rvb_model_cfg& c = e->cfg;
   const int d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
@@ -1183,61 +1236,79 @@ static int rescore_impl(rvb_engine* e, double ctc_weight, double reverse_weight)
   }
   RVB_TRY(upload_i32(e, e->d_aux_i32, ckv.data(), ckv.size()));
   TrieBatch tl, tr;
-  build_trie(hyps, B, sos, eos, [&](const HypRef& h, int j) { return e->nbest[h.chunk].nbest[h.idx][j]; }, &tl);
+  const auto th0 = std::chrono::steady_clock::now();
+  if ((int)e->trie_l.size() == B) merge_tries(e->trie_l, &tl);      // built by the prefix-beam workers, chunk by chunk
+  else build_trie_parallel(e, false, &tl);
+  {
+    auto& pe = e->prof["rescore_trie_host"];
+    pe.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+    pe.launches += 1;
+  }
   std::vector<float> lslot, rslot;
+  const auto td0 = std::chrono::steady_clock::now();
   RVB_TRY(decoder_forward(e, e->dec_l, tl, &lslot));
+  {
+    auto& pe = e->prof["rescore_decoder_wall"];
+    pe.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
+    pe.launches += 1;
+  }
   e->xattn_max_rows = tl.max_chunk_rows;
   e->rescore_rows = tl.R; e->rescore_pairs = tl.P;
   if (use_r) {   // reversed input and targets, asr_model.py:896-953, search.py:427-433
-    build_trie(hyps, B, sos, eos, [&](const HypRef& h, int j) { return e->nbest[h.chunk].nbest[h.idx][h.len - 1 - j]; }, &tr);
+    build_trie_parallel(e, true, &tr);
     RVB_TRY(decoder_forward(e, e->dec_r, tr, &rslot));
     e->rescore_rows += tr.R; e->rescore_pairs += tr.P;
   }
+  const auto ta0 = std::chrono::steady_clock::now();
   std::vector<float> logp(P), rlogp(use_r ? P : 0);
   for (int p = 0; p < P; ++p) { logp[p] = lslot[tl.pair_slot[p]]; if (use_r) rlogp[p] = rslot[tr.pair_slot[p]]; }
 
-  // score accumulation exactly as search.py:413-441: fp32 running sums (0-dim float32 tensors),
-  // python-float exp() for confidences, strict '>' so the first maximum wins
+  // score accumulation exactly as search.py:413-441: fp32 running sums (0-dim float32 tensors), strict '>' so the first
+  // maximum wins; the python-float exp() of the confidences is evaluated for the winning hypothesis only (the reference
+  // computes them for every hypothesis and keeps the winner's)
   e->rescored.assign(B, RescoreResult());
-  std::vector<std::vector<float>> sc_all(B);
-  std::vector<std::vector<double>> conf_all(B);
-  std::vector<std::vector<std::vector<double>>> tc_all(B);
-  for (const HypRef& hr : hyps) {
+  std::vector<float> att_score(hyps.size());        // decoder score before the CTC term (the confidence is derived from it)
+  std::vector<int> best_hyp(B, -1);
+  for (size_t hi = 0; hi < hyps.size(); ++hi) {
+    const HypRef& hr = hyps[hi];
     const PrefixResult& pr = e->nbest[hr.chunk];
     RescoreResult& rr = e->rescored[hr.chunk];
-    if (rr.logp.empty()) { rr.logp.resize(pr.nbest.size()); rr.rlogp.resize(pr.nbest.size()); }
+    if (rr.logp.empty()) { rr.logp.resize(pr.nbest.size()); rr.rlogp.resize(pr.nbest.size()); rr.score = -INFINITY; }
     const float* lp = logp.data() + hr.row0;
     rr.logp[hr.idx].assign(lp, lp + hr.len + 1);
     float score = 0.f;
-    std::vector<double> tc(hr.len);
-    for (int j = 0; j < hr.len; ++j) { score += lp[j]; tc[j] = std::exp((double)lp[j]); }
+    for (int j = 0; j < hr.len; ++j) score += lp[j];
     score += lp[hr.len];
     if (use_r) {
       const float* rp = rlogp.data() + hr.row0;
       rr.rlogp[hr.idx].assign(rp, rp + hr.len + 1);
       float r_score = 0.f;
-      for (int j = 0; j < hr.len; ++j) {
-        const float s = rp[hr.len - j - 1];
-        r_score += s;
-        tc[j] = (tc[j] + std::exp((double)s)) / 2.0;
-      }
+      for (int j = 0; j < hr.len; ++j) r_score += rp[hr.len - j - 1];
       r_score += rp[hr.len];
       // python: tensor(fp32) * float(1 - rw) + tensor(fp32) * float(rw)
       score = score * (float)(1.0 - reverse_weight) + r_score * (float)reverse_weight;
     }
-    conf_all[hr.chunk].push_back(std::exp((double)(score / (float)(hr.len + 1))));
+    att_score[hi] = score;
     score += (float)(pr.scores[hr.idx] * ctc_weight);
-    sc_all[hr.chunk].push_back(score);
-    tc_all[hr.chunk].push_back(std::move(tc));
+    if (best_hyp[hr.chunk] < 0 || score > rr.score) { rr.score = score; rr.best = hr.idx; best_hyp[hr.chunk] = (int)hi; }
   }
   for (int b = 0; b < B; ++b) {
     RescoreResult& rr = e->rescored[b];
-    float best = -INFINITY;
-    int bi = 0;
-    for (size_t i = 0; i < sc_all[b].size(); ++i)
-      if (sc_all[b][i] > best) { best = sc_all[b][i]; bi = (int)i; }
-    rr.best = bi; rr.score = best;
-    if (!sc_all[b].empty()) { rr.confidence = conf_all[b][bi]; rr.tok_conf = tc_all[b][bi]; }
+    if (best_hyp[b] < 0) { rr.best = 0; rr.score = -INFINITY; continue; }
+    const HypRef& hr = hyps[best_hyp[b]];
+    const float* lp = logp.data() + hr.row0;
+    rr.confidence = std::exp((double)(att_score[best_hyp[b]] / (float)(hr.len + 1)));
+    rr.tok_conf.resize(hr.len);
+    for (int j = 0; j < hr.len; ++j) rr.tok_conf[j] = std::exp((double)lp[j]);
+    if (use_r) {
+      const float* rp = rlogp.data() + hr.row0;
+      for (int j = 0; j < hr.len; ++j) rr.tok_conf[j] = (rr.tok_conf[j] + std::exp((double)rp[hr.len - j - 1])) / 2.0;
+    }
+  }
+  {
+    auto& pe = e->prof["rescore_scores_host"];
+    pe.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
+    pe.launches += 1;
   }
   return OK;
 }
@@ -2217,7 +2288,35 @@ extern "C" int rvb_test_build_trie(const int32_t* tokens, const int32_t* lens, c
   int P = 0, off = 0;
   for (int i = 0; i < n_hyps; ++i) { hyps.push_back({chunk_of[i], i, lens[i], P}); first[i] = off; P += lens[i] + 1; off += lens[i]; }
   TrieBatch t;
-  build_trie(hyps, n_chunks, sos, eos, [&](const HypRef& h, int j) { return tokens[first[h.idx] + (reversed ? h.len - 1 - j : j)]; }, &t);
+  auto seq = [&](const HypRef& h, int j) { return tokens[first[h.idx] + (reversed ? h.len - 1 - j : j)]; };
+  build_trie_range(hyps.data(), hyps.data() + hyps.size(), 0, n_chunks, sos, eos, seq, &t);
+  {   // the engine builds the same trie chunk by chunk and stitches the parts (merge_tries): both forms must agree exactly
+    std::vector<TrieBatch> part(std::max(n_chunks, 0));
+    size_t a = 0;
+    for (int b = 0; b < n_chunks; ++b) {
+      size_t z = a;
+      while (z < hyps.size() && hyps[z].chunk == b) ++z;
+      build_trie_range(hyps.data() + a, hyps.data() + z, b, 1, sos, eos, seq, &part[b]);
+      a = z;
+    }
+    TrieBatch m;
+    merge_tries(part, &m);
+    const bool same = m.R == t.R && m.P == t.P && m.max_chunk_rows == t.max_chunk_rows && m.tok == t.tok && m.pos == t.pos &&
+                      m.path == t.path && m.hq_start == t.hq_start && m.hq_len == t.hq_len && m.hq_pos0 == t.hq_pos0 &&
+                      m.hkv_start == t.hkv_start && m.hkv_len == t.hkv_len && m.crow_start == t.crow_start &&
+                      m.crow_len == t.crow_len && m.tgt_ptr == t.tgt_ptr && m.tgt == t.tgt && m.pair_slot == t.pair_slot &&
+                      m.work == t.work;
+    if (a != hyps.size() || !same) {
+      std::string which;
+#define RVB_DIFF(f) if (!(m.f == t.f)) which += std::string(" ") + #f;
+      RVB_DIFF(R) RVB_DIFF(P) RVB_DIFF(max_chunk_rows) RVB_DIFF(tok) RVB_DIFF(pos) RVB_DIFF(path) RVB_DIFF(hq_start) RVB_DIFF(hq_len)
+      RVB_DIFF(hq_pos0) RVB_DIFF(hkv_start) RVB_DIFF(hkv_len) RVB_DIFF(crow_start) RVB_DIFF(crow_len) RVB_DIFF(tgt_ptr) RVB_DIFF(tgt)
+      RVB_DIFF(pair_slot) RVB_DIFF(work)
+#undef RVB_DIFF
+      set_error("rvb_test_build_trie: the stitched per-chunk tries differ from the batch trie in:" + which);
+      return E_STATE;
+    }
+  }
   *n_rows = t.R;
   if (n_work) *n_work = (int32_t)t.work.size() / 2;
   auto cp = [](int32_t* dst, const std::vector<int32_t>& v) { if (dst) memcpy(dst, v.data(), v.size() * 4); };

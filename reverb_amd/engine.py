@@ -383,6 +383,10 @@ class Engine:
 
     def _rescore_bulk(self, ctc_weight: float, reverse_weight: float) -> List[DecodeResult]:
         check(self.lib.rvb_attention_rescore(self.handle, float(ctc_weight), float(reverse_weight)), "rvb_attention_rescore")
+        return self._rescore_fetch()
+
+    def _rescore_fetch(self) -> List[DecodeResult]:
+        """The winners of the last rvb_attention_rescore in one bulk read."""
         B, T = self.batch, self.enc_frames
         lens = np.empty(B, np.int32); tok = np.empty((B, T), np.int32); tl = np.empty(B, np.int32)
         tim = np.empty((B, T), np.int32); sc = np.empty(B, np.float32); cf = np.empty(B, np.float64)
