@@ -186,6 +186,10 @@ int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int3
 /* attention_rescoring (search.py:363-448) over the stored n-best of every chunk of the batch.
  * Per chunk: index of the winning hypothesis, its score (fp32 accumulation as the reference),
  * confidence, and per-token confidences [max_len] of the winner. */
+/* Optional, between rvb_encode and rvb_ctc_prefix_beam when rvb_attention_rescore will follow: enqueues the decoders' memory
+ * key / value projections (decoder_layer.py:112-119 `src_attn(x, memory, memory)`), which depend on the encoder output alone,
+ * so that the device computes them while the host searches the last slice.  rvb_attention_rescore does it itself otherwise. */
+int rvb_prepare_rescoring(rvb_engine* e, int right_to_left);
 int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight);
 /* `attention` mode (asr/wenet/transformer/search.py:251-360): autoregressive beam search with the left decoder on
  * the chunks of the last rvb_encode; per-hypothesis K/V caches on the device, beam bookkeeping on the host in float32

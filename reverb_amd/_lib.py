@@ -80,6 +80,7 @@ SIGNATURES = {
     "rvb_ctc_prefix_beam": (C.c_int, [_eng, C.c_int]),
     "rvb_get_nbest_count": (C.c_int, [_eng, C.c_int, _i32p, _i32p]),
     "rvb_get_nbest": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "rvb_prepare_rescoring": (C.c_int, [_eng, C.c_int]),
     "rvb_attention_rescore": (C.c_int, [_eng, C.c_double, C.c_double]),
     "rvb_attention_decode": (C.c_int, [_eng, C.c_int, C.c_float]),
     "rvb_get_attention_result": (C.c_int, [_eng, C.c_int, _i32p, _i32p, _f32p]),

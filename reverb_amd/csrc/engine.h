@@ -49,6 +49,7 @@ struct DecLayer {
   Linear self_qkv, self_out, src_q, src_kv, src_out, ff1, ff2, lsl;
   LNorm n1, n2, n3;
   bool is_lsl = false;
+  DevBuf kvmem;               // T [B*T2][2d]: this layer's keys / values of the encoder output (rescoring)
 };
 struct Decoder {
   DevBuf embed;               // fp32 [V][d]
@@ -56,6 +57,7 @@ struct Decoder {
   LNorm after;
   std::vector<DecLayer> layers;
   bool present = false;
+  bool kv_ready = false;      // the layers' kvmem hold the current batch (rvb_prepare_rescoring or the first decoder pass)
 };
 
 struct ProfEntry { double ms = 0, flops = 0; int64_t launches = 0; };

@@ -636,6 +636,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   const int M = B * T2;
   const size_t es = dt_size(e->dtype);
   e->B = B; e->T0 = T0; e->T1 = T1; e->F1 = F1; e->T2 = T2; e->F2 = F2; e->beam = beam;
+  e->dec_l.kv_ready = e->dec_r.kv_ready = false;
   e->last_blank_penalty = blank_penalty;
   e->in_lens.assign(lens, lens + B);
   e->enc_lens.resize(B);
@@ -807,6 +808,7 @@ static int stream_begin_impl(rvb_engine* e) {
   }
   st.active = true; st.offset = 0; st.cache_len = 0; st.cnn_rows = 0;
   e->B = 0; e->nbest.clear(); e->rescored.clear(); e->slices.clear();
+  e->dec_l.kv_ready = e->dec_r.kv_ready = false;
   return OK;
 }
 
@@ -904,6 +906,7 @@ static int stream_finish_impl(rvb_engine* e, int beam, float blank_penalty) {
   const size_t es = dt_size(e->dtype);
   if (M <= 0) { set_error("rvb_stream_finish: the stream produced no encoder frame"); return E_STATE; }
   e->B = 1; e->T2 = M; e->beam = beam; e->T0 = 0;
+  e->dec_l.kv_ready = e->dec_r.kv_ready = false;
   e->last_blank_penalty = blank_penalty;
   e->in_lens.assign(1, 0); e->enc_lens.assign(1, M);
   e->nbest.clear(); e->rescored.clear();
@@ -1117,6 +1120,21 @@ static void build_trie_parallel(rvb_engine* e, bool reversed, TrieBatch* t) {
   merge_tries(part, t);
 }
 
+// Keys / values of the encoder output for every decoder layer (decoder_layer.py:112-119: `src_attn(x, memory, memory)`; the
+// reference projects the memory once per hypothesis, asr_model.py:895): they depend on the encoder output alone, so they can
+// be enqueued before the CTC search of the last slice has produced a single hypothesis (rvb_prepare_rescoring) -- the device
+// computes them while the host searches.
+static int decoder_memory_kv(rvb_engine* e, Decoder& D, int M) {
+  const int d = e->cfg.d_model;
+  const size_t es = dt_size(e->dtype);
+  for (auto& L : D.layers) {
+    RVB_TRY(L.kvmem.ensure((size_t)M * 2 * d * es));
+    RVB_TRY(run_gemm(e, e->enc_out.p, d, L.src_kv, L.kvmem.p, 2 * d, M, false));
+  }
+  D.kv_ready = true;
+  return OK;
+}
+
 static int decoder_forward(rvb_engine* e, Decoder& D, const TrieBatch& t, std::vector<float>* logp) {
   const rvb_model_cfg& c = e->cfg;
   const int d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
@@ -1142,7 +1160,7 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const TrieBatch& t, std::v
   RVB_TRY(e->dq.ensure((size_t)R * d * es));
   RVB_TRY(e->dqkv.ensure((size_t)R * 3 * d * es));
   RVB_TRY(e->dh.ensure((size_t)R * ff * es));
-  RVB_TRY(e->kvmem.ensure((size_t)M * 2 * d * es));
+  if (!D.kv_ready) RVB_TRY(decoder_memory_kv(e, D, M));
   RVB_TRY(e->d_logp.ensure((size_t)t.P * 4));
   float* x = e->dx.as<float>();
   {
@@ -1172,9 +1190,8 @@ static int decoder_forward(rvb_engine* e, Decoder& D, const TrieBatch& t, std::v
     // the reference repeats the memory N times, asr_model.py:895)       decoder_layer.py:112-119
     RVB_TRY(run_norm(e, x, L.n2, e->dxn.p, false, R, d));
     RVB_TRY(run_gemm(e, e->dxn.p, d, L.src_q, e->dq.p, d, R, false));
-    RVB_TRY(run_gemm(e, e->enc_out.p, d, L.src_kv, e->kvmem.p, 2 * d, M, false));
     memset(&a, 0, sizeof(a));
-    a.q = e->dq.p; a.k = e->kvmem.p; a.v = (const char*)e->kvmem.p + (size_t)d * es;
+    a.q = e->dq.p; a.k = L.kvmem.p; a.v = (const char*)L.kvmem.p + (size_t)d * es;
     a.q_stride = d; a.k_stride = a.v_stride = 2 * d; a.o_stride = d; a.out = e->dao.p;
     // all rows of a chunk attend to the same memory and there is no causal mask: they form ONE query sequence per
     // chunk, so the chunk's K/V tiles are staged once per 128 rows
@@ -1854,6 +1871,7 @@ void rvb_destroy(rvb_engine* e) {
     for (auto& L : D->layers) {
       for (Linear* l : {&L.self_qkv, &L.self_out, &L.src_q, &L.src_kv, &L.src_out, &L.ff1, &L.ff2, &L.lsl}) rel_lin(*l);
       for (LNorm* n : {&L.n1, &L.n2, &L.n3}) rel_n(*n);
+      L.kvmem.release();
     }
   }
   if (e->h_topv) (void)hipHostFree(e->h_topv);
@@ -2140,6 +2158,17 @@ int rvb_get_nbest(rvb_engine* e, int chunk, int32_t* tokens, int32_t* lens, int3
   return OK;
 }
 
+int rvb_prepare_rescoring(rvb_engine* e, int right_to_left) {
+  if (!e) { set_error("rvb_prepare_rescoring: null engine"); return E_ARG; }
+  if (e->B <= 0) { set_error("rvb_prepare_rescoring before rvb_encode"); return E_STATE; }
+  if (!e->dec_l.present) { set_error("model has no attention decoder"); return E_STATE; }
+  if (right_to_left && !e->dec_r.present) { set_error("rvb_prepare_rescoring: model has no right-to-left decoder"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  // enqueued behind the encoder slices still in flight; nothing here waits for the device
+  if (!e->dec_l.kv_ready) RVB_TRY(decoder_memory_kv(e, e->dec_l, e->B * e->T2));
+  if (right_to_left && !e->dec_r.kv_ready) RVB_TRY(decoder_memory_kv(e, e->dec_r, e->B * e->T2));
+  return OK;
+}
 int rvb_attention_rescore(rvb_engine* e, double ctc_weight, double reverse_weight) {
   if (!e) { set_error("null engine"); return E_ARG; }
   return rescore_impl(e, ctc_weight, reverse_weight);

@@ -459,7 +459,9 @@ class Engine:
         if "ctc_greedy_search" in methods:
             results["ctc_greedy_search"] = self.greedy()
         if "attention_rescoring" in methods and "ctc_prefix_beam_search" not in methods:
-            # fast path: n-best lists stay in the engine, one bulk read of the winners
+            # fast path: n-best lists stay in the engine, one bulk read of the winners; the decoders' memory keys / values are
+            # enqueued first so that the device has work while the host searches the last slice
+            check(self.lib.rvb_prepare_rescoring(self.handle, 1 if reverse_weight > 0 else 0), "rvb_prepare_rescoring")
             check(self.lib.rvb_ctc_prefix_beam(self.handle, self.beam), "rvb_ctc_prefix_beam")
             results["attention_rescoring"] = self._rescore_bulk(ctc_weight, reverse_weight)
         elif "ctc_prefix_beam_search" in methods or "attention_rescoring" in methods:

@@ -40,6 +40,7 @@ def main():
         t = [time.perf_counter()]
         nf = eng.fbank(); t.append(time.perf_counter())
         eng.encode(None, lens, 10, 0.0, first_chunk=0, T0=chunk); t.append(time.perf_counter())
+        check(eng.lib.rvb_prepare_rescoring(eng.handle, 0), "rvb_prepare_rescoring")
         check(eng.lib.rvb_ctc_prefix_beam(eng.handle, eng.beam), "rvb_ctc_prefix_beam"); t.append(time.perf_counter())
         check(eng.lib.rvb_attention_rescore(eng.handle, 0.1, 0.0), "rvb_attention_rescore"); t.append(time.perf_counter())
         res = eng._rescore_fetch()
