@@ -60,6 +60,10 @@ int rvd_frames_per_window(const rvd_engine* e);
 
 /* 16-bit mono PCM at cfg.sample_rate -> HBM; evaluates the sinc filter bank once for all windows */
 int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n_samples);
+/* pyannote's `Audio` resamples every file to the model's rate (torchaudio.functional.resample with its defaults = the kernel of
+ * the ASR front end, rvb_upload_pcm_rate): int16 mono PCM at `sample_rate` -> int16 at cfg.sample_rate, on the device.
+ * out == NULL: only *n_out is written; otherwise *n_out holds the capacity of `out` on entry, the length on return. */
+int rvd_resample_pcm(rvd_engine* e, const int16_t* pcm, int64_t n_samples, int sample_rate, int16_t* out, int64_t* n_out);
 
 /* segmentation model on windows [first, first+n): logp_out host fp32 [n][frames][num_classes] (NULL: keep the
  * result on the device only) */

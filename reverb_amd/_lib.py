@@ -159,6 +159,7 @@ DIAR_SIGNATURES = {
     "rvd_num_windows": (C.c_int64, [_eng, C.c_int64]),
     "rvd_frames_per_window": (C.c_int, [_eng]),
     "rvd_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvd_resample_pcm": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int, _i16p, _i64p]),
     "rvd_segment": (C.c_int, [_eng, C.c_int64, C.c_int, _f32p]),
     "rvd_get_classes": (C.c_int, [_eng, C.POINTER(C.c_uint8)]),
     "rvd_get_tap": (C.c_int, [_eng, C.c_char_p, _f32p]),

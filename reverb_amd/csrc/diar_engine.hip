@@ -678,20 +678,59 @@ int64_t rvd_num_windows(const rvd_engine* e, int64_t n) {
 }
 int rvd_frames_per_window(const rvd_engine* e) { return e ? e->p3 : 0; }
 
+// the file is in e->pcm (int16, n samples at the model's rate): waveform, SincNet front end, embedding fbank
+static int prepare_audio(rvd_engine* e, int64_t n);
+
 int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n) {
   if (!e || !pcm || n <= 0) { set_error("rvd_upload_pcm: null or empty audio"); return E_ARG; }
   if (!e->finalized) { set_error("rvd_upload_pcm: finalize the model first"); return E_STATE; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVD_TRY(e->pcm.ensure((size_t)n * 2));
+  { DScope sc(e, "h2d");
+    RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream)); }
+  return prepare_audio(e, n);
+}
+
+// pyannote's Audio resamples every file to the model's rate with torchaudio.functional.resample (its defaults: the kernel
+// of the ASR front end, rvb_upload_pcm_rate).  The resampled waveform comes back as int16 -- both networks of this engine start
+// from int16 PCM, and the host shards a recording by samples at the model's rate -- i.e. rounded by at most half an LSB (-96 dB).
+// out == NULL: only *n_out (= ceil(n * rate_out / rate_in)) is written.
+int rvd_resample_pcm(rvd_engine* e, const int16_t* pcm, int64_t n, int sample_rate, int16_t* out, int64_t* n_out) {
+  if (!e || !pcm || n <= 0 || !n_out) { set_error("rvd_resample_pcm: null or empty audio"); return E_ARG; }
+  if (sample_rate < 1000 || sample_rate > 384000) { set_error("rvd_resample_pcm: sample rate out of range"); return E_ARG; }
+  const int target = e->cfg.sample_rate;
+  std::vector<float> ker;
+  int orig, nw, width, K;
+  resample_taps(sample_rate, target, &ker, &orig, &nw, &width, &K);
+  const int64_t m = ((int64_t)nw * n + orig - 1) / orig;
+  if (!out) { *n_out = m; return OK; }
+  if (*n_out < m) { set_error("rvd_resample_pcm: output buffer too small"); return E_ARG; }
+  *n_out = m;
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  DevBuf src, taps, res, dst;
+  int r = src.ensure((size_t)n * 2 + 16);
+  if (r == OK) r = taps.ensure(ker.size() * 4);
+  if (r == OK) r = res.ensure((size_t)m * 4);
+  if (r == OK) r = dst.ensure((size_t)m * 2);
+  if (r == OK && hipMemcpyAsync(src.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream) != hipSuccess) r = E_HIP;
+  if (r == OK && hipMemcpyAsync(taps.p, ker.data(), ker.size() * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess) r = E_HIP;
+  if (r == OK) { DScope sc(e, "resample"); r = resample(e->stream, src.as<int16_t>(), n, taps.as<float>(), orig, nw, width, K, res.as<float>(), m); }
+  if (r == OK) r = round_to_i16(e->stream, res.as<float>(), m, dst.as<int16_t>());
+  if (r == OK && hipMemcpyAsync(out, dst.p, (size_t)m * 2, hipMemcpyDeviceToHost, e->stream) != hipSuccess) r = E_HIP;
+  if (hipStreamSynchronize(e->stream) != hipSuccess && r == OK) r = E_HIP;
+  src.release(); taps.release(); res.release(); dst.release();
+  if (r == E_HIP) set_error("rvd_resample_pcm: device copy or kernel failed");
+  return r;
+}
+
+static int prepare_audio(rvd_engine* e, int64_t n) {
   const rvd_model_cfg& c = e->cfg;
   e->n_samples = n;
   e->n_windows = rvd_num_windows(e, n);
   e->n_pad = (e->n_windows - 1) * c.step_samples + c.window_samples;
   e->craw_frames = (e->n_pad - SINC_K) / SINC_STRIDE + 1;
-  RVD_TRY(e->pcm.ensure((size_t)n * 2));
   RVD_TRY(e->wave.ensure((size_t)e->n_pad * 4));
   RVD_TRY(e->craw.ensure((size_t)e->craw_frames * c.sinc_filters * 4));
-  { DScope sc(e, "h2d");
-    RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream)); }
   { DScope sc(e, "pcm_to_float");
     RVD_TRY(pcm_to_float(e->stream, e->pcm.as<int16_t>(), n, e->wave.as<float>(), e->n_pad)); }
   { DScope sc(e, "sinc_conv", 2.0 * (double)e->craw_frames * c.sinc_filters * SINC_K);

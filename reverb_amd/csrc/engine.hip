@@ -1943,26 +1943,9 @@ int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks) {
 // into e->wave_f32 (cli/reverb.py:131-134)
 static int resample_uploaded(rvb_engine* e, bool src_float, int64_t n, int sample_rate) {
   const int target = 16000;
-  // torchaudio.functional.resample kernel (sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99), built in fp64
-  int a = sample_rate, b = target;
-  while (b) { const int t = a % b; a = b; b = t; }
-  const int orig = sample_rate / a, nw = target / a;
-  const double lpw = 6.0, rolloff = 0.99;
-  const double base_freq = std::min(orig, nw) * rolloff;
-  const int width = (int)std::ceil(lpw * orig / base_freq);
-  const int K = 2 * width + orig;
-  std::vector<float> ker((size_t)nw * K);
-  const double PI = 3.14159265358979323846;
-  for (int p = 0; p < nw; ++p)
-    for (int k = 0; k < K; ++k) {
-      double t = (-(double)p / nw + (double)(k - width) / orig) * base_freq;
-      t = std::max(-lpw, std::min(lpw, t));
-      const double c = std::cos(t * PI / lpw / 2.0);
-      const double window = c * c;
-      t *= PI;
-      const double sinc = t == 0.0 ? 1.0 : std::sin(t) / t;
-      ker[(size_t)p * K + k] = (float)(sinc * window * (base_freq / orig));
-    }
+  std::vector<float> ker;
+  int orig, nw, width, K;
+  resample_taps(sample_rate, target, &ker, &orig, &nw, &width, &K);
   const int64_t n_out = (nw * n + orig - 1) / orig;          // ceil(new * length / orig)
   RVB_TRY(e->rs_kernel.ensure(ker.size() * 4));
   RVB_TRY(e->wave_f32.ensure((size_t)std::max<int64_t>(n_out, 1) * 4));

@@ -9,6 +9,10 @@
 // four frames per workgroup; the 400-sample window is read coalesced, the radix-2 FFT runs
 // in LDS (4 butterflies per lane per stage), the mel projection reads the power spectrum
 // from LDS with each lane owning mel bins {lane, lane+64}.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -165,6 +169,40 @@ int resample_f32(hipStream_t s, const float* pcm, int64_t n_in, const float* ker
              int64_t n_out) {
   if (n_out <= 0) return OK;
   hipLaunchKernelGGL(resample_kernel<float>, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pcm, n_in, ker, orig, new_, width, K, out, n_out);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+void resample_taps(int sample_rate, int target, std::vector<float>* ker, int* orig_out, int* new_out, int* width_out, int* K_out) {
+  int a = sample_rate, b = target;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int orig = sample_rate / a, nw = target / a;
+  const double lpw = 6.0, rolloff = 0.99;
+  const double base_freq = std::min(orig, nw) * rolloff;
+  const int width = (int)std::ceil(lpw * orig / base_freq);
+  const int K = 2 * width + orig;
+  ker->assign((size_t)nw * K, 0.f);
+  const double PI = 3.14159265358979323846;
+  for (int p = 0; p < nw; ++p)
+    for (int k = 0; k < K; ++k) {
+      double t = (-(double)p / nw + (double)(k - width) / orig) * base_freq;
+      t = std::max(-lpw, std::min(lpw, t));
+      const double c = std::cos(t * PI / lpw / 2.0);
+      const double window = c * c;
+      t *= PI;
+      const double sinc = t == 0.0 ? 1.0 : std::sin(t) / t;
+      (*ker)[(size_t)p * K + k] = (float)(sinc * window * (base_freq / orig));
+    }
+  *orig_out = orig; *new_out = nw; *width_out = width; *K_out = K;
+}
+
+__global__ __launch_bounds__(256) void round_i16_kernel(const float* __restrict__ x, int64_t n, int16_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int16_t)__builtin_rintf(fminf(fmaxf(x[i], -32768.f), 32767.f));
+}
+int round_to_i16(hipStream_t s, const float* x, int64_t n, int16_t* out) {
+  if (n <= 0) return OK;
+  hipLaunchKernelGGL(round_i16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, n, out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

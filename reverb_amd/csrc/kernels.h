@@ -1,6 +1,7 @@
 // Internal launcher interface of librvb's HIP kernels (one translation unit per kernel family).
 // All pointers are device pointers; all launches are asynchronous on the given stream.
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace rvb {
@@ -51,6 +52,11 @@ struct FbankTables {
 // pcm: int16 mono (device).  feats: fp32 [n_frames, 80] raw log-mel.
 int fbank(hipStream_t s, const int16_t* pcm, int64_t n_frames, float* feats, const FbankTables& t);
 int fbank_f32(hipStream_t s, const float* wave, int64_t n_frames, float* feats, const FbankTables& t);
+// torchaudio.functional.resample's kernel (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) for sample_rate -> target,
+// built in fp64 on the host: ker [new][K], K = 2 * width + orig, with orig / new the rates divided by their gcd
+void resample_taps(int sample_rate, int target, std::vector<float>* ker, int* orig, int* new_, int* width, int* K);
+// float [n] (int16 scale) -> int16, round to nearest even, saturating
+int round_to_i16(hipStream_t s, const float* x, int64_t n, int16_t* out);
 // polyphase sinc resampler: ker fp32 [new][K] (K = 2*width + orig), out fp32 [n_out] at int16 scale
 int resample(hipStream_t s, const int16_t* pcm, int64_t n_in, const float* ker, int orig, int new_, int width, int K, float* out,
              int64_t n_out);

@@ -75,6 +75,17 @@ class DiarEngine:
     def num_windows(self, n_samples: int) -> int:
         return int(self.lib.rvd_num_windows(self._h, int(n_samples)))
 
+    def resample(self, pcm: np.ndarray, sample_rate: int) -> np.ndarray:
+        """int16 mono PCM at `sample_rate` -> int16 at the model's rate (torchaudio.functional.resample's kernel, on the device)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1)
+        n = C.c_int64(0)
+        _check(self.lib.rvd_resample_pcm(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.shape[0], int(sample_rate), None,
+                                         C.byref(n)), "rvd_resample_pcm")
+        out = np.empty(int(n.value), np.int16)
+        _check(self.lib.rvd_resample_pcm(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.shape[0], int(sample_rate),
+                                         out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(n)), "rvd_resample_pcm")
+        return out[:int(n.value)]
+
     def upload(self, pcm: np.ndarray) -> int:
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         _check(self.lib.rvd_upload_pcm(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.shape[0]), "rvd_upload_pcm")

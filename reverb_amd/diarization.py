@@ -530,29 +530,30 @@ class SpeakerDiarization:
             self._engine = DiarEngine(self.cfg, self._seg_sd, self._emb_sd, dtype=self.dtype, device=self.device_index or 0)
         return self._engine
 
-    @staticmethod
-    def _load(file) -> Tuple[np.ndarray, str]:
+    def _load(self, file) -> Tuple[np.ndarray, str]:
+        """-> (int16 mono PCM at 16 kHz, uri).  pyannote's `Audio`: downmix to mono (mean), resample to the model's rate."""
         from . import audio as A
         if isinstance(file, dict):
             uri = file.get("uri")
             if "waveform" in file:
                 w = file["waveform"]
                 w = w.detach().cpu().numpy() if hasattr(w, "detach") else np.asarray(w)
-                if int(file.get("sample_rate", 16000)) != 16000:
-                    raise ValueError("only 16 kHz audio is supported (resampling is listed under 'next' in DESIGN.md)")
                 w = w.mean(axis=0) if w.ndim == 2 else w          # pyannote Audio: downmix to mono
                 pcm = w if w.dtype == np.int16 else np.clip(np.rint(w * 32768.0), -32768, 32767).astype(np.int16)
+                rate = int(file.get("sample_rate", 16000))
+                if rate != 16000:
+                    pcm = self.engine.resample(pcm, rate)
                 return pcm, uri or "waveform"
             file = file["audio"]
         path = os.fspath(file)
         pcm, info = A.load_with_info(path)                         # WAVE / FLAC, decoded by librvb on the host
-        if info.sample_rate != 16000:
-            raise ValueError(f"{path}: sample rate {info.sample_rate}; only 16 kHz audio is supported")
         if info.sample_format != "int16" or pcm.shape[0] > 1:     # (channels, samples) -> mono mean like pyannote Audio
             mono = A.normalized(pcm, info).mean(axis=0) * np.float32(32768.0)
             pcm = np.clip(np.rint(mono), -32768, 32767).astype(np.int16)
         else:
             pcm = pcm[0]
+        if info.sample_rate != 16000:                             # resampled on the device (rvd_resample_pcm)
+            pcm = self.engine.resample(pcm, info.sample_rate)
         return pcm, os.path.splitext(os.path.basename(path))[0]
 
     def _runs(self, classes: np.ndarray) -> ClassRuns:

@@ -92,3 +92,35 @@ def test_joint_transcribe_diarize_writes_ctm_rttm_stm(setup, tmp_path):
         cp, sp = c.split(" "), s.split(" ")
         assert sp[0] == "talk" and sp[1] == "1" and sp[2] in speakers
         assert abs(float(sp[3]) - float(cp[2])) < 1e-3 and sp[5] == cp[4]
+
+
+def test_pipeline_reads_other_rates_and_flac(setup, tmp_path):
+    """pyannote's Audio resamples to the model's rate and downmixes: a 48 kHz stereo WAV and a 16 kHz FLAC go through the same
+    pipeline.  The FLAC holds the very samples of the WAV fixture (identical RTTM); the device resampler is checked against
+    the torchaudio restatement (oracle/resample_ref.py) up to the int16 rounding."""
+    from oracle import resample_ref
+    from tests import flac_writer as FW
+    from tests.test_audio_decode import wav_bytes
+    model, wav, pcm = setup
+    pipe = D.Pipeline.from_pretrained(model, dtype="f32").to("cuda")
+    want = io.StringIO(); pipe(wav).write_rttm(want)
+    flac = tmp_path / "talk.flac"
+    flac.write_bytes(FW.encode(pcm.astype(np.int64)[None], 16, 16000, block=4096, predictor=("fixed", 2), partition_order=3))
+    got = io.StringIO(); pipe(str(flac)).write_rttm(got)
+    assert got.getvalue() == want.getvalue()
+    # 48 kHz stereo: both channels carry the signal 3x oversampled (linear interpolation is enough here)
+    x48 = np.interp(np.arange(len(pcm) * 3) / 3.0, np.arange(len(pcm)), pcm.astype(np.float64)).astype(np.int16)
+    w48 = tmp_path / "talk48.wav"
+    w48.write_bytes(wav_bytes(1, 2, 48000, 16, np.stack([x48, x48], axis=1).astype("<i2").tobytes()))
+    loaded, uri = pipe._load(str(w48))
+    ref = resample_ref.resample(x48.astype(np.float32), 48000, 16000)
+    assert uri == "talk48" and loaded.dtype == np.int16 and loaded.shape == ref.shape
+    assert np.abs(loaded.astype(np.float32) - ref).max() <= 0.5 + 2e-2         # half an LSB of rounding + fp32 summation order
+    ann = pipe(str(w48))
+    assert ann.uri == "talk48" and len(ann.labels()) >= 1
+    # the in-memory form at another rate
+    import torch
+    ann2 = pipe({"waveform": torch.from_numpy(x48.astype(np.float32) / 32768.0)[None], "sample_rate": 48000, "uri": "talk48"})
+    a, b = io.StringIO(), io.StringIO()
+    ann.write_rttm(a); ann2.write_rttm(b)
+    assert a.getvalue() == b.getvalue()
