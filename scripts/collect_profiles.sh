@@ -12,11 +12,11 @@ grep '^{' $O/bench_r640.log | tail -1 > $P/${R}_bench_r640_1h_bf16.json.log
 grep '^{' $O/bench_r640_fp8.log | tail -1 > $P/${R}_bench_r640_1h_fp8.json.log
 grep '^{' $O/bench_r268.log | tail -1 > $P/${R}_bench_r268_1h_bf16.json.log
 grep '^{' $O/bench_diar.log | tail -1 > $P/${R}_bench_diar_1h_bf16.json.log
-cp $O/gemm_traffic.json $P/${R}_gemm_traffic_r640_1h_bf16.json
-cp $O/pmc_by_kernel.csv $P/${R}_pmc_by_kernel.csv
+[ -f $O/gemm_traffic.json ] && cp $O/gemm_traffic.json $P/${R}_gemm_traffic_r640_1h_bf16.json || true
+[ -f $O/pmc_by_kernel.csv ] && cp $O/pmc_by_kernel.csv $P/${R}_pmc_by_kernel.csv || true
 cp $O/parity_metrics.jsonl $P/${R}_parity_metrics.jsonl
 grep -a "passed" $O/pytest_gpu.log | tail -1 > $P/${R}_pytest_gpu_summary.txt
 grep '^{' $O/bench_r640_forced_dist.log | tail -1 > $P/${R}_bench_r640_1h_forced_dist.json.log
-cp $O/gemm_bench.txt $P/${R}_gemm_bench_switches.txt
-cp $O/gemm_timeline.txt $P/${R}_gemm_timeline.txt
+[ -f $O/gemm_bench.txt ] && cp $O/gemm_bench.txt $P/${R}_gemm_bench_switches.txt || true
+[ -f $O/gemm_timeline.txt ] && cp $O/gemm_timeline.txt $P/${R}_gemm_timeline.txt || true
 ls -la $P | grep " ${R}_" | awk '{print $5, $9}'
