@@ -305,6 +305,9 @@ int rvb_test_lse_gather_multi(const float* logits, int R, int V, const int32_t* 
 int rvb_test_build_trie(const int32_t* tokens, const int32_t* lens, const int32_t* chunk_of, int n_hyps, int n_chunks, int sos, int eos,
                         int reversed, int32_t* n_rows, int32_t* tok, int32_t* pos, int32_t* path, int32_t* hq_start, int32_t* hq_len,
                         int32_t* hq_pos0, int32_t* tgt_ptr, int32_t* tgt, int32_t* pair_slot, int32_t* n_work);
+/* host only: the worker pool of the CTC search / trie building (engine.h HostPool) runs `rounds` jobs on up to n_threads threads;
+ * fails unless every work item of every job was executed exactly once */
+int rvb_test_host_pool(int n_threads, int items, int rounds);
 int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats /* [frames,80] */);
 /* native prefix beam search on host arrays: top-k log-probs/indices [T,beam] of one utterance */
 int rvb_test_prefix_beam(const float* topk_val, const int32_t* topk_idx, int T, int beam, int blank,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "rvb_test_rownorm_fp8": (C.c_int, [_f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, _f32p, _f32p,
                                        C.c_float, C.c_float, _f32p, _f32p]),
     "rvb_test_lse_gather_multi": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p]),
+    "rvb_test_host_pool": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "rvb_test_build_trie": (C.c_int, [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p,
                                       _i32p, _i32p, _i32p, _i32p, _i32p]),
     "rvb_test_fbank": (C.c_int, [_i16p, C.c_int64, _f32p]),

@@ -23,6 +23,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -461,6 +463,9 @@ void decode_run(const uint8_t* d, size_t n, const StreamInfo& si, Run& r, bool k
   } catch (const Fail& e) {
     r.failed = true;
     r.error = e;
+  } catch (const std::exception& e) {        // allocation failure inside a worker thread: reported, not propagated
+    r.failed = true;
+    r.error = Fail{-4, std::string("FLAC: ") + e.what()};
   }
   r.end_pos = off;
   r.end_sample = done;
@@ -771,6 +776,9 @@ int64_t guarded(const char* where, F&& f) {
   } catch (const std::bad_alloc&) {
     rvb::set_error(std::string(where) + ": out of host memory");
     return -4;
+  } catch (const std::exception& e) {
+    rvb::set_error(std::string(where) + ": " + e.what());
+    return E_DATA;
   }
 }
 

@@ -2337,6 +2337,27 @@ extern "C" int rvb_test_build_trie(const int32_t* tokens, const int32_t* lens, c
   return OK;
 }
 
+// host only: HostPool runs `rounds` jobs of `n_threads` threads each; every job hands out `items` work items through an atomic
+// counter (the pattern of the CTC search) and the call checks that each item was executed exactly once in every round.
+extern "C" int rvb_test_host_pool(int n_threads, int items, int rounds) {
+  if (n_threads < 1 || items < 0 || rounds < 1) { set_error("rvb_test_host_pool: bad argument"); return E_ARG; }
+  HostPool pool;
+  std::vector<std::atomic<int>> hits(items);
+  for (int r = 0; r < rounds; ++r) {
+    for (auto& h : hits) h.store(0);
+    std::atomic<int> next(0), entered(0);
+    const unsigned n = (unsigned)std::max(1, n_threads - (r % 3));     // the pool grows and is reused with fewer threads
+    pool.run(n, [&] {
+      entered.fetch_add(1);
+      for (int i = next.fetch_add(1); i < items; i = next.fetch_add(1)) hits[i].fetch_add(1);
+    });
+    if (entered.load() != (int)n) { set_error("rvb_test_host_pool: a job was not run by the requested number of threads"); return E_STATE; }
+    for (int i = 0; i < items; ++i)
+      if (hits[i].load() != 1) { set_error("rvb_test_host_pool: work item executed " + std::to_string(hits[i].load()) + " times"); return E_STATE; }
+  }
+  return OK;
+}
+
 extern "C" int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feats) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: librvb has no CPU fallback"); return E_HIP; }

@@ -249,3 +249,11 @@ def test_joint_decoding_native_state_machine_matches_reference_class(name):
                 assert st == want["times"] and en == want["end_times"], (run, b, K)
                 assert abs(score - want["score"]) < 2e-3 * max(1.0, abs(want["score"]))
                 np.testing.assert_allclose(conf, want["tokens_confidence"], rtol=2e-3, atol=1e-6)
+
+
+def test_host_pool_runs_every_item_once():
+    """The worker pool behind the CTC search and the trie building (csrc/engine.h HostPool): jobs of varying width reuse the
+    same threads; each work item of each job runs exactly once."""
+    lib = _lib.load()
+    for threads, items, rounds in ((1, 10, 3), (4, 1000, 30), (16, 37, 50), (32, 0, 5), (8, 100000, 4)):
+        _lib.check(lib.rvb_test_host_pool(threads, items, rounds), "rvb_test_host_pool")
