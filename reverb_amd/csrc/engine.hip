@@ -647,7 +647,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     e->enc_lens[b] = lens[b] > 6 ? (lens[b] - 7) / 4 + 1 : 0;
     starts[b] = b * T2;
   }
-  e->nbest.clear(); e->rescored.clear();
+  e->nbest.clear(); e->trie_l.clear(); e->rescored.clear();
   RVB_TRY(upload_i32(e, e->d_enc_lens, e->enc_lens.data(), B));
   RVB_TRY(upload_i32(e, e->d_seq_start, starts.data(), B));
   RVB_TRY(upload_i32(e, e->d_seq_len, qlens.data(), B));
@@ -807,7 +807,7 @@ static int stream_begin_impl(rvb_engine* e) {
     }
   }
   st.active = true; st.offset = 0; st.cache_len = 0; st.cnn_rows = 0;
-  e->B = 0; e->nbest.clear(); e->rescored.clear(); e->slices.clear();
+  e->B = 0; e->nbest.clear(); e->trie_l.clear(); e->rescored.clear(); e->slices.clear();
   e->dec_l.kv_ready = e->dec_r.kv_ready = false;
   return OK;
 }
@@ -909,7 +909,7 @@ static int stream_finish_impl(rvb_engine* e, int beam, float blank_penalty) {
   e->dec_l.kv_ready = e->dec_r.kv_ready = false;
   e->last_blank_penalty = blank_penalty;
   e->in_lens.assign(1, 0); e->enc_lens.assign(1, M);
-  e->nbest.clear(); e->rescored.clear();
+  e->nbest.clear(); e->trie_l.clear(); e->rescored.clear();
   const int Vld = (V + 3) & ~3;
   RVB_TRY(e->logits.ensure((size_t)LOGIT_SLAB * Vld * 4));
   RVB_TRY(e->topv.ensure((size_t)M * beam * 4));
