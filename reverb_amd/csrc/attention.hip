@@ -342,6 +342,7 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   if (dk <= D) {                                                                   \
     if (a.q_block == 16) return launch_attn<T, D, false, 1>(s, a);                 \
     if (a.q_block == 64) return pos ? launch_attn<T, D, true, 4>(s, a) : launch_attn<T, D, false, 4>(s, a); \
+    if (a.q_block == 256) return pos ? launch_attn<T, D, true, 16>(s, a) : launch_attn<T, D, false, 16>(s, a); \
     return pos ? launch_attn<T, D, true, 8>(s, a) : launch_attn<T, D, false, 8>(s, a); \
   }
   RVB_ATTN_CASE(32)
@@ -361,7 +362,7 @@ int attention(hipStream_t s, int dtype, const AttnArgs& a) {
     return E_ARG;
   }
   if ((a.bias_u == nullptr) != (a.bias_v == nullptr)) { set_error("attention: bias_u/bias_v must come together"); return E_ARG; }
-  if (a.q_block != 0 && a.q_block != 16 && a.q_block != 64 && a.q_block != 128) { set_error("attention: q_block must be 0 (= 128), 16, 64 or 128"); return E_ARG; }
+  if (a.q_block != 0 && a.q_block != 16 && a.q_block != 64 && a.q_block != 128 && a.q_block != 256) { set_error("attention: q_block must be 0 (= 128), 16, 64, 128 or 256"); return E_ARG; }
   if (a.q_block == 16 && a.p) { set_error("attention: 16-query blocks are built for the decoder forms (no positional keys)"); return E_ARG; }
   return dtype == DT_BF16 ? dispatch_attn<bf16_t>(s, a) : dispatch_attn<float>(s, a);
 }
