@@ -85,7 +85,9 @@ int rvb_get_waveform(rvb_engine* e, float* out, int64_t* n_samples);
 
 /* ReverbASR.compute_feats (cli/reverb.py:119-146): Kaldi fbank of 16 kHz mono int16 PCM.
  * rvb_upload_pcm copies the samples to HBM; rvb_fbank computes [n_frames,80] log-mel on the
- * device (kept resident, zero-padded to whole chunks) and optionally copies it to feats_out. */
+ * device (kept resident, zero-padded to whole chunks) and optionally copies it to feats_out.  With feats_out == NULL the
+ * call only enqueues the kernel (rvb_encode is ordered behind it on the engine's stream); with a host buffer it returns
+ * when the copy has landed. */
 int64_t rvb_num_frames(int64_t n_samples);
 int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
 /* Page-locked host memory for the audio reader (what `torchaudio.load` fills in the reference, cli/reverb.py:128):

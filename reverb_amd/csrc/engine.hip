@@ -2008,15 +2008,19 @@ int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
   // chunk with zeros, cli/reverb.py:165-175): ceil(nf / c) * c < nf + c <= nf + chunk_frames
   const int64_t rows = nf + T0;
   RVB_TRY(e->feats.ensure((size_t)std::max<int64_t>(rows, 1) * 80 * 4));
-  RVB_HIP_CHECK(hipMemsetAsync(e->feats.p, 0, (size_t)std::max<int64_t>(rows, 1) * 80 * 4, e->stream));
+  // only the padding rows: the kernel writes rows [0, nf)
+  RVB_HIP_CHECK(hipMemsetAsync((char*)e->feats.p + (size_t)nf * 80 * 4, 0, (size_t)std::max<int64_t>(rows - nf, 1) * 80 * 4, e->stream));
   FbankTables t{e->fb_window.as<float>(), e->fb_twiddle.as<float>(), e->fb_melw.as<float>(), e->fb_lo.as<int>(), e->fb_hi.as<int>()};
   {
     Scope sc(e, "fbank");
     if (e->pcm_is_float) RVB_TRY(fbank_f32(e->stream, e->wave_f32.as<float>(), nf, e->feats.as<float>(), t));
     else RVB_TRY(fbank(e->stream, e->pcm.as<int16_t>(), nf, e->feats.as<float>(), t));
   }
-  if (feats_out && nf) RVB_HIP_CHECK(hipMemcpyAsync(feats_out, e->feats.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost, e->stream));
-  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (feats_out && nf) {
+    RVB_HIP_CHECK(hipMemcpyAsync(feats_out, e->feats.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  }
+  // features that stay in HBM: nothing to wait for, rvb_encode is ordered behind the kernel on the engine's stream
   e->n_frames = nf; e->feat_rows = rows;
   if (n_frames) *n_frames = nf;
   return OK;
