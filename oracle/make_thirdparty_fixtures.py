@@ -42,8 +42,39 @@ def torchaudio_fixtures():
         x = synth.synth_audio(1.0, seed=7, sample_rate=r)
         y = torchaudio.transforms.Resample(r, 16000)(torch.from_numpy(x.astype(np.float32)).unsqueeze(0))   # cli/reverb.py:131-134
         out[f"resample_{r}"] = y[0].numpy().astype(np.float32)
+    out.update(audio_reader_fixtures(torch, torchaudio))
     np.savez_compressed(os.path.join(GOLDEN, "thirdparty_torchaudio.npz"), **out)
     print("wrote thirdparty_torchaudio.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+AUDIO_FILES = (("wav_s16", "wav", dict(encoding="PCM_S", bits_per_sample=16)), ("wav_u8", "wav", dict(encoding="PCM_U", bits_per_sample=8)),
+               ("wav_s24", "wav", dict(encoding="PCM_S", bits_per_sample=24)), ("wav_s32", "wav", dict(encoding="PCM_S", bits_per_sample=32)),
+               ("wav_f32", "wav", dict(encoding="PCM_F", bits_per_sample=32)), ("wav_ulaw", "wav", dict(encoding="ULAW", bits_per_sample=8)),
+               ("wav_alaw", "wav", dict(encoding="ALAW", bits_per_sample=8)), ("flac_16", "flac", dict(bits_per_sample=16)),
+               ("flac_24", "flac", dict(bits_per_sample=24)))
+
+
+def audio_reader_fixtures(torch, torchaudio):
+    """The VALUE convention of `torchaudio.load(path, normalize=False)` per container (cli/reverb.py:128): every file below is
+    written with torchaudio.save from one seeded stereo signal, its BYTES are stored, and so is what load(normalize=False)
+    returns for it (dtype name + values) -- tests/test_thirdparty_fixtures.py decodes the stored bytes with librvb's reader
+    (reverb_amd/audio.py) and compares."""
+    import tempfile
+    from reverb_amd import synth
+    x = synth.synth_audio(0.5, seed=21).astype(np.float32) / 32768.0
+    wave = torch.from_numpy(np.stack([x, -0.5 * x]))
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, ext, kw in AUDIO_FILES:
+            path = os.path.join(d, name + "." + ext)
+            torchaudio.save(path, wave, 16000, **kw)
+            got, rate = torchaudio.load(path, normalize=False)
+            assert rate == 16000
+            with open(path, "rb") as f:
+                out["audio_bytes_" + name] = np.frombuffer(f.read(), np.uint8)
+            out["audio_dtype_" + name] = np.array(str(got.dtype).replace("torch.", ""))
+            out["audio_float_" + name] = got.to(torch.float).numpy()          # cli/reverb.py:130
+    return out
 
 
 def pyannote_fixtures():

@@ -105,3 +105,20 @@ def test_device_diarization_networks_vs_pyannote():
     emb = eng.embed(np.arange(x.shape[0], dtype=np.int64), masks)
     assert np.abs(emb - z["emb"]).max() < 2e-3 * np.abs(z["emb"]).max()
     eng.close()
+
+
+@need_ta
+def test_audio_reader_vs_torchaudio():
+    """librvb's WAVE / FLAC reader against `torchaudio.load(path, normalize=False).to(torch.float)` on files torchaudio wrote
+    itself: same dtype of the native tensor, same float values."""
+    from oracle.make_thirdparty_fixtures import AUDIO_FILES
+    from reverb_amd import audio
+    z = np.load(TA)
+    for name, _ext, _kw in AUDIO_FILES:
+        if "audio_bytes_" + name not in z:
+            pytest.skip("fixture file predates the audio-reader section: regenerate it")
+        got, info = audio.decode_bytes(z["audio_bytes_" + name].tobytes())
+        assert info.sample_format == str(z["audio_dtype_" + name]), name
+        want = z["audio_float_" + name]
+        assert got.shape == want.shape, name
+        np.testing.assert_array_equal(got.astype(np.float32), want, err_msg=name)
