@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 
-CONTAINERS = {1: "wav", 2: "flac"}
+CONTAINERS = {1: "wav", 2: "flac", 3: "aiff"}
 SAMPLE_FORMATS = {1: "uint8", 2: "int16", 3: "int32", 4: "float32", 5: "float64"}
 
 

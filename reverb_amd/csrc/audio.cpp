@@ -1,5 +1,5 @@
 // Host-side audio file decoding for librvb: what `torchaudio.load(audio_file, normalize=False)` hands to
-// ReverbASR.compute_feats (asr/wenet/cli/reverb.py:128) for the two lossless containers -- RIFF/WAVE and FLAC.
+// ReverbASR.compute_feats (asr/wenet/cli/reverb.py:128) for the lossless containers -- RIFF/WAVE (and RF64), AIFF / AIFF-C, FLAC.
 //
 // The reference keeps the decoder's NATIVE sample format (normalize=False) and then calls `.to(torch.float)`
 // (reverb.py:130), so the numbers the fbank sees depend on the container:
@@ -7,6 +7,8 @@
 //   WAVE 8-bit PCM                   uint8                      -> 0 .. 255 (offset binary, as stored)
 //   WAVE 24-bit / 32-bit PCM         int32 (24-bit left-justified: value << 8)
 //   WAVE IEEE float 32 / 64          float32 / float64          -> as stored (64-bit rounded to float)
+//   AIFF / AIFF-C                    as the WAVE form of the same samples (big-endian or `sowt`); 8-bit AIFF is signed
+//                                    and arrives as uint8 with the offset added (value + 128)
 //   FLAC <= 16 bits per sample       int16, left-justified      -> value << (16 - bps)
 //   FLAC  > 16 bits per sample       int32, left-justified      -> value << (32 - bps)
 // (the FFmpeg-backed loader of the torchaudio the reference pins: s16 / s32 / u8 / flt / dbl planar or packed
@@ -610,9 +612,11 @@ uint32_t le(const uint8_t* p, int n) {
 }
 
 Wave wave_open(const uint8_t* d, size_t n) {
-  if (n < 12 || std::memcmp(d, "RIFF", 4) != 0 || std::memcmp(d + 8, "WAVE", 4) != 0) fail(E_DATA, "not a RIFF/WAVE file");
+  const bool rf64 = n >= 12 && std::memcmp(d, "RF64", 4) == 0;          // EBU Tech 3306: RIFF with 64-bit sizes in a ds64 chunk
+  if (n < 12 || (!rf64 && std::memcmp(d, "RIFF", 4) != 0) || std::memcmp(d + 8, "WAVE", 4) != 0) fail(E_DATA, "not a RIFF/WAVE file");
   Wave w;
   bool fmt = false;
+  uint64_t data64 = 0;
   size_t pos = 12;
   while (n - pos >= 8) {
     const uint8_t* id = d + pos;
@@ -621,10 +625,13 @@ Wave wave_open(const uint8_t* d, size_t n) {
     if (std::memcmp(id, "data", 4) == 0) {
       if (!fmt) fail(E_DATA, "WAVE: data chunk before the fmt chunk");
       w.data = d + pos;
+      if (rf64 && size == 0xffffffffu && data64 != 0) size = (size_t)std::min<uint64_t>(data64, n - pos);
       w.bytes = std::min(size, n - pos);       // streamed writers leave 0 / 0xffffffff here: take what is there
       if (size == 0) w.bytes = n - pos;
       return w;
     }
+    if (rf64 && std::memcmp(id, "ds64", 4) == 0 && size >= 24 && size <= n - pos)
+      data64 = (uint64_t)le(d + pos + 8, 4) | (uint64_t)le(d + pos + 12, 4) << 32;      // riffSize, dataSize, sampleCount
     if (size > n - pos) fail(E_DATA, "WAVE: chunk runs past the end of the file");
     if (std::memcmp(id, "fmt ", 4) == 0) {
       if (size < 16) fail(E_DATA, "WAVE: fmt chunk shorter than 16 bytes");
@@ -643,6 +650,69 @@ Wave wave_open(const uint8_t* d, size_t n) {
     pos += size + (size & 1);
   }
   fail(E_DATA, "WAVE: missing fmt or data chunk");
+}
+
+// AIFF / AIFF-C (Apple, 1989 / 1991): big-endian chunks; COMM = channels, frames, bits, sample rate as an 80-bit extended
+// float (+ a compression id in AIFF-C: NONE / twos big-endian, sowt little-endian, fl32 / FL32, fl64); SSND = offset,
+// block size, samples.  Mapped onto the WAVE decoder's sample formats (endianness handled by a byte-swapped copy).
+struct Aiff {
+  Wave w;
+  bool big_endian = true;
+};
+double ext80(const uint8_t* p) {
+  const int exp = ((p[0] & 0x7f) << 8) | p[1];
+  uint64_t mant = 0;
+  for (int i = 0; i < 8; ++i) mant = (mant << 8) | p[2 + i];
+  if (exp == 0 && mant == 0) return 0.0;
+  const double v = std::ldexp((double)mant, exp - 16383 - 63);
+  return (p[0] & 0x80) ? -v : v;
+}
+Aiff aiff_open(const uint8_t* d, size_t n) {
+  const bool aifc = std::memcmp(d + 8, "AIFC", 4) == 0;
+  Aiff a;
+  bool comm = false;
+  uint32_t frames = 0;
+  size_t pos = 12;
+  while (n - pos >= 8) {
+    const uint8_t* id = d + pos;
+    const size_t size = be(d + pos + 4, 4);
+    pos += 8;
+    if (size > n - pos && std::memcmp(id, "SSND", 4) != 0) fail(E_DATA, "AIFF: chunk runs past the end of the file");
+    if (std::memcmp(id, "COMM", 4) == 0) {
+      if (size < 18) fail(E_DATA, "AIFF: COMM chunk shorter than 18 bytes");
+      const uint8_t* p = d + pos;
+      a.w.channels = (int)be(p, 2);
+      frames = be(p + 2, 4);
+      a.w.bits = (int)be(p + 6, 2);
+      a.w.rate = (int)std::lround(ext80(p + 8));
+      a.w.tag = 1;
+      if (aifc) {
+        if (size < 22) fail(E_DATA, "AIFF-C: COMM chunk without a compression type");
+        const uint8_t* c = p + 18;
+        if (std::memcmp(c, "NONE", 4) == 0 || std::memcmp(c, "twos", 4) == 0) a.big_endian = true;
+        else if (std::memcmp(c, "sowt", 4) == 0) a.big_endian = false;
+        else if (std::memcmp(c, "fl32", 4) == 0 || std::memcmp(c, "FL32", 4) == 0) a.w.tag = 3;
+        else if (std::memcmp(c, "fl64", 4) == 0 || std::memcmp(c, "FL64", 4) == 0) a.w.tag = 3;
+        else if (std::memcmp(c, "alaw", 4) == 0 || std::memcmp(c, "ALAW", 4) == 0) { a.w.tag = 6; a.w.bits = 8; }
+        else if (std::memcmp(c, "ulaw", 4) == 0 || std::memcmp(c, "ULAW", 4) == 0) { a.w.tag = 7; a.w.bits = 8; }
+        else fail(E_UNSUPPORTED, std::string("AIFF-C: compression type '") + std::string((const char*)c, 4) + "' is not decoded here");
+      }
+      a.w.bits = (a.w.bits + 7) / 8 * 8;       // 12-bit samples sit left-justified in 16 bits, 20-bit in 24
+      comm = true;
+    } else if (std::memcmp(id, "SSND", 4) == 0) {
+      if (!comm) fail(E_DATA, "AIFF: SSND chunk before the COMM chunk");
+      if (size < 8 || n - pos < 8) fail(E_DATA, "AIFF: SSND chunk shorter than its header");
+      const size_t off = be(d + pos, 4);
+      const size_t start = pos + 8 + off;
+      if (start > n) fail(E_DATA, "AIFF: sample data offset past the end of the file");
+      a.w.data = d + start;
+      const size_t want = (size_t)frames * (size_t)a.w.channels * (size_t)(a.w.bits / 8);
+      a.w.bytes = std::min(want, n - start);
+      return a;
+    }
+    pos += size + (size & 1);
+  }
+  fail(E_DATA, "AIFF: missing COMM or SSND chunk");
 }
 
 int16_t alaw(uint8_t a) {
@@ -705,24 +775,43 @@ inline double wave_sample(const Wave& w, const WaveFormat& wf, size_t i, int c) 
 }
 
 int sniff(const uint8_t* d, size_t n) {
-  if (n >= 12 && std::memcmp(d, "RIFF", 4) == 0 && std::memcmp(d + 8, "WAVE", 4) == 0) return RVB_AUDIO_WAVE;
+  if (n >= 12 && (std::memcmp(d, "RIFF", 4) == 0 || std::memcmp(d, "RF64", 4) == 0) && std::memcmp(d + 8, "WAVE", 4) == 0) return RVB_AUDIO_WAVE;
+  if (n >= 12 && std::memcmp(d, "FORM", 4) == 0 && (std::memcmp(d + 8, "AIFF", 4) == 0 || std::memcmp(d + 8, "AIFC", 4) == 0)) return RVB_AUDIO_AIFF;
   const size_t off = n >= 10 && std::memcmp(d, "ID3", 3) == 0 ? skip_id3(d, n) : 0;
   if (n - off >= 4 && std::memcmp(d + off, "fLaC", 4) == 0) return RVB_AUDIO_FLAC;
   if (n - off >= 4 && std::memcmp(d + off, "OggS", 4) == 0) fail(E_UNSUPPORTED, "Ogg container (Vorbis / Opus): lossy codecs are not decoded here");
   if (off > 0 || (n >= 2 && d[0] == 0xff && (d[1] & 0xe0) == 0xe0)) fail(E_UNSUPPORTED, "MPEG audio (MP3): lossy codecs are not decoded here");
-  if (n >= 12 && std::memcmp(d, "RF64", 4) == 0) fail(E_UNSUPPORTED, "RF64 container is not decoded here");
-  if (n >= 12 && std::memcmp(d, "FORM", 4) == 0) fail(E_UNSUPPORTED, "AIFF container is not decoded here");
-  fail(E_DATA, "unrecognised audio container (RIFF/WAVE and FLAC are decoded)");
+  if (n >= 12 && std::memcmp(d, "FORM", 4) == 0) fail(E_UNSUPPORTED, "IFF container other than AIFF / AIFF-C is not decoded here");
+  fail(E_DATA, "unrecognised audio container (RIFF/WAVE, RF64, AIFF and FLAC are decoded)");
 }
 
 template <typename Out>
 int64_t decode(const uint8_t* d, size_t n, int channel, Out* out, int64_t capacity, int flags, rvb_audio_info* info, bool i16) {
   const int kind = sniff(d, n);
   const bool want = out != nullptr;
-  if (kind == RVB_AUDIO_WAVE) {
-    const Wave w = wave_open(d, n);
-    const WaveFormat wf = wave_format(w);
-    info->container = RVB_AUDIO_WAVE;
+  if (kind == RVB_AUDIO_WAVE || kind == RVB_AUDIO_AIFF) {
+    Wave w;
+    std::vector<uint8_t> swapped;              // AIFF: big-endian samples, byte-swapped once into the WAVE layout
+    bool signed8 = false;
+    if (kind == RVB_AUDIO_WAVE) {
+      w = wave_open(d, n);
+    } else {
+      const Aiff a = aiff_open(d, n);
+      w = a.w;
+      signed8 = w.tag == 1 && w.bits == 8;
+      const size_t width = (size_t)w.bits / 8;
+      if (want && width > 1 && a.big_endian) {
+        swapped.resize(w.bytes / width * width);
+        for (size_t i = 0; i + width <= swapped.size(); i += width)
+          for (size_t k = 0; k < width; ++k) swapped[i + k] = w.data[i + width - 1 - k];
+        w.data = swapped.data();
+        w.bytes = swapped.size();
+      }
+    }
+    WaveFormat wf = wave_format(w);
+    // 8-bit AIFF is two's complement; FFmpeg's pcm_s8 decoder hands it on as offset binary (uint8, + 128), the same
+    // native format as 8-bit WAVE
+    info->container = kind;
     info->channels = w.channels;
     info->sample_rate = w.rate;
     info->bits_per_sample = w.bits;
@@ -737,7 +826,10 @@ int64_t decode(const uint8_t* d, size_t n, int channel, Out* out, int64_t capaci
     if ((int64_t)(c1 - c0) * info->frames > capacity) fail(E_ARG, "audio decode: output buffer too small");
     for (int c = c0; c < c1; ++c) {
       Out* o = out + (size_t)(c - c0) * (size_t)info->frames;
-      for (size_t i = 0; i < (size_t)info->frames; ++i) o[i] = (Out)wave_sample(w, wf, i, c);
+      if (signed8)
+        for (size_t i = 0; i < (size_t)info->frames; ++i) o[i] = (Out)((int)(int8_t)w.data[i * (size_t)w.channels + (size_t)c] + 128);
+      else
+        for (size_t i = 0; i < (size_t)info->frames; ++i) o[i] = (Out)wave_sample(w, wf, i, c);
     }
     return info->frames;
   }
