@@ -309,11 +309,13 @@ void read_subframe(Bits& br, int64_t* s, int block, int bps) {
     if (order > block) fail(E_DATA, "FLAC: predictor order exceeds the block size");
     for (int i = 0; i < order; ++i) s[i] = br.s(bps);
     read_residual(br, s, block, order);
+    // predictor sums in wrapping (unsigned) arithmetic: a valid stream stays far inside 64 bits, a corrupt one must not
+    // run into undefined behaviour before its CRC-16 is looked at
     const int* c = kFixed[order];
     for (int i = order; i < block; ++i) {
-      int64_t pred = 0;
-      for (int j = 0; j < order; ++j) pred += (int64_t)c[j] * s[i - 1 - j];
-      s[i] += pred;
+      uint64_t pred = 0;
+      for (int j = 0; j < order; ++j) pred += (uint64_t)(int64_t)c[j] * (uint64_t)s[i - 1 - j];
+      s[i] = (int64_t)((uint64_t)s[i] + pred);
     }
   } else if (type >= 32) {
     const int order = type - 31;
@@ -327,9 +329,9 @@ void read_subframe(Bits& br, int64_t* s, int block, int bps) {
     for (int j = 0; j < order; ++j) coef[j] = br.s(prec);
     read_residual(br, s, block, order);
     for (int i = order; i < block; ++i) {
-      int64_t pred = 0;
-      for (int j = 0; j < order; ++j) pred += coef[j] * s[i - 1 - j];
-      s[i] += pred >> shift;
+      uint64_t pred = 0;
+      for (int j = 0; j < order; ++j) pred += (uint64_t)coef[j] * (uint64_t)s[i - 1 - j];
+      s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)pred >> shift));
     }
   } else {
     fail(E_DATA, "FLAC: reserved subframe type");
@@ -401,14 +403,14 @@ size_t read_frame(const uint8_t* d, size_t n, size_t off, const StreamInfo& si, 
   int64_t* a = ch[0].data();
   int64_t* b = f.channels > 1 ? ch[1].data() : nullptr;
   if (f.chan_mode == 1) {
-    for (int i = 0; i < f.block; ++i) b[i] = a[i] - b[i];
+    for (int i = 0; i < f.block; ++i) b[i] = (int64_t)((uint64_t)a[i] - (uint64_t)b[i]);
   } else if (f.chan_mode == 2) {
-    for (int i = 0; i < f.block; ++i) a[i] = a[i] + b[i];
+    for (int i = 0; i < f.block; ++i) a[i] = (int64_t)((uint64_t)a[i] + (uint64_t)b[i]);
   } else if (f.chan_mode == 3) {
     for (int i = 0; i < f.block; ++i) {
-      const int64_t side = b[i], mid = (int64_t)(((uint64_t)a[i] << 1) | (uint64_t)(side & 1));
-      a[i] = (mid + side) >> 1;
-      b[i] = (mid - side) >> 1;
+      const uint64_t side = (uint64_t)b[i], mid = ((uint64_t)a[i] << 1) | (side & 1);
+      a[i] = (int64_t)(mid + side) >> 1;
+      b[i] = (int64_t)(mid - side) >> 1;
     }
   }
   return off + body + 2;

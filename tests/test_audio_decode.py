@@ -375,3 +375,39 @@ def test_rf64():
     got, info = audio.decode_bytes(b"RF64" + struct.pack("<I", 0xFFFFFFFF) + body)
     assert info.container == "wav" and info.frames == len(s16)          # the 64-bit size of ds64, not the rest of the file
     np.testing.assert_array_equal(got[0], s16)
+
+
+def test_flac_threads_on_small_and_odd_streams():
+    """Explicit thread counts on streams too small or too irregular to split: the decoder falls back to the front-to-back walk."""
+    for n, block, th in ((100, 16, 8), (3000, 256, 16), (70000, 1024, 255), (5000, 4096, 4)):
+        x = signal(2, n, 16, n)
+        got, info = audio.decode_bytes(FW.encode(x, 16, 16000, block=block, stereo="mid_side"), threads=th)
+        np.testing.assert_array_equal(got, x.astype(np.int16))
+        assert info.md5_checked and info.decode_threads >= 1
+    sizes = [1000, 16, 2500, 1484] * 8
+    x = signal(1, sum(sizes), 16, 5)
+    got, info = audio.decode_bytes(FW.encode(x, 16, 16000, variable_blocks=sizes), threads=6)
+    np.testing.assert_array_equal(got, x.astype(np.int16))
+    assert info.decode_threads == 6                       # variable block size: runs are placed by their sample numbers
+
+
+def test_mutated_files_are_rejected_or_decoded_never_worse():
+    """A slice of the sanitizer corpus (scripts/fuzz): every mutated file either decodes or raises ValueError /
+    NotImplementedError -- nothing else, for any thread count."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_corpus", os.path.join(os.path.dirname(__file__), "..", "scripts", "fuzz",
+                                                                              "make_corpus.py"))
+    mc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mc)
+    rng, base = np.random.default_rng(7), mc.seeds()
+    decoded = rejected = 0
+    for it in range(1500):
+        data = mc.mutate(base[it % len(base)], rng)
+        try:
+            wave, info = audio.decode_bytes(data, threads=it % 4)
+            assert wave.shape == (info.channels, info.frames)
+            decoded += 1
+        except (ValueError, NotImplementedError, MemoryError):
+            rejected += 1
+    assert decoded > 100 and rejected > 100
