@@ -636,12 +636,17 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 //     half-tile p), waits -- counted `vmcnt`, never 0 in steady state -- until half-tile p+2 has landed, and requests
 //     half-tile p+P_LEAD into the slot whose last reader finished two phases earlier: 3 half-tiles stay in flight ACROSS
 //     the barriers instead of one 64-KiB stage drained to zero at every K step;
-//   * a phase is {DMA issue, reads, vmcnt | s_barrier | lgkmcnt(0), 16 MFMAs | s_barrier}, and the second wave row
-//     runs ONE BARRIER BEHIND the first: on every SIMD one wave multiplies while the other reads and issues.  Without
-//     that stagger the same loop is slower than the old one (846 vs 919 TFLOP/s in the lab).
+//   * a phase is {DMA issue, reads, vmcnt | s_barrier | 16 MFMAs, each behind a counted lgkmcnt wait for just the
+//     fragments it consumes | s_barrier}, and the second wave row runs ONE BARRIER BEHIND the first: on every SIMD one
+//     wave multiplies while the other reads and issues.  Without that stagger the same loop is slower than the old one
+//     (846 vs 919 TFLOP/s in the lab).  (Until late in round 3 a blanket `s_waitcnt lgkmcnt(0)` sat behind the first
+//     barrier: every wave then waited for all 8 of its reads before its first MFMA and the compiler's own counted waits
+//     were dead code; without it the GEMMs of the bench hour take 103.3 instead of ~105.7 ms on the same box class.)
 //   RAW: a wave waits for its own pieces of half-tile h before the first barrier of phase h-2; every reader is past
-//   that barrier (or the one after it, for the staggered row) when it reads in phase h-1.  WAR: a slot is refilled two
-//   phases after the phase whose lgkmcnt(0) retired its last read.
+//   that barrier (or the one after it, for the staggered row) when it reads in phase h-1.  WAR: the reads of a phase have
+//   all been consumed by that phase's MFMAs, i.e. have retired before its closing barrier G (one barrier later for the
+//   staggered row); the slot is requested again in the read section of the phase two phases on, which no wave enters
+//   before barrier G + 2.
 // The ring takes 112 KiB; the 34 KiB above it are the epilogue's transposition slabs (and the residual prologue's), so
 // neither ever shares a buffer with the operand stream.
 extern int g_gemm2_flags;
@@ -979,7 +984,6 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   auto mid = [&]() __attribute__((always_inline)) {          // read section -> MFMA section
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
   auto end = [&]() __attribute__((always_inline)) {
