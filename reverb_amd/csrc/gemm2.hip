@@ -947,14 +947,22 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
       for (int i = 0; i < 4; ++i) f[i] = *(const uint4*)(sp + i * 2048 + (hf ? ro1 : ro0));
     }
   };
+  // bf16: the two k-halves of a B set are read separately, k-half 0 of both fragments first: the first eight MFMAs of a
+  // phase (k-half 0) then wait for two reads, not for the whole set
+  auto read_b_khalf = [&](auto sc, uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
+    constexpr int sk = decltype(sc)::value;
+    const char* sp = smem + slot * P_HT + b_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f[j][sk] = *(const uint4*)(sp + j * 2048 + (sk ? ro1 : ro0));
+  };
   auto read_b = [&](uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
     const char* sp = smem + slot * P_HT + b_off;
     if constexpr (F8) {
       f[0][0] = *(const uint4*)(sp + ro0); f[0][1] = *(const uint4*)(sp + rh0);
       f[1][0] = *(const uint4*)(sp + ro1); f[1][1] = *(const uint4*)(sp + rh1);
     } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { f[j][0] = *(const uint4*)(sp + j * 2048 + ro0); f[j][1] = *(const uint4*)(sp + j * 2048 + ro1); }
+      read_b_khalf(std::integral_constant<int, 0>(), f, slot);
+      read_b_khalf(std::integral_constant<int, 1>(), f, slot);
     }
   };
   // quadrant (ai, bj) of the wave tile += A (k-halves alo, ahi) x B
@@ -1026,7 +1034,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     auto ph_wait = [&]() __attribute__((always_inline)) {
       if (TAIL) wait_tail(ph); else wait_vm<2 * P_DEPTH>();
     };
-    ph_head(std::integral_constant<int, 0>()); read_a_half(h1, fa_hi, s_cur); read_b(fb0, s_rd); ph_wait();
+    ph_head(std::integral_constant<int, 0>());
+    if constexpr (F8) {
+      read_a_half(h1, fa_hi, s_cur); read_b(fb0, s_rd);
+    } else {      // in consumption order: B0's k-half 0 (with the prefetched A0 k-half 0), then the k-half-1 operands
+      read_b_khalf(h0, fb0, s_rd); read_a_half(h1, fa_hi, s_cur); read_b_khalf(h1, fb0, s_rd);
+    }
+    ph_wait();
     mid(); mma_q(c0, c0, fh, fa_hi, fb0); end(); adv();
     ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait();
     mid(); mma_q(c0, c1, fh, fa_hi, fb1); end(); adv();
