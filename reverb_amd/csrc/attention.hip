@@ -342,7 +342,11 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   if (dk <= D) {                                                                   \
     if (a.q_block == 16) return launch_attn<T, D, false, 1>(s, a);                 \
     if (a.q_block == 64) return pos ? launch_attn<T, D, true, 4>(s, a) : launch_attn<T, D, false, 4>(s, a); \
-    if (a.q_block == 256) return pos ? launch_attn<T, D, true, 16>(s, a) : launch_attn<T, D, false, 16>(s, a); \
+    if (a.q_block == 256) {                                                        \
+      if constexpr (sizeof(T) == 2 && D <= 64) return pos ? launch_attn<T, D, true, 16>(s, a) : launch_attn<T, D, false, 16>(s, a); \
+      set_error("attention: 256-query workgroups are built for bf16 with dk <= 64 (128 VGPRs per wave)"); \
+      return E_UNSUPPORTED;                                                        \
+    }                                                                              \
     return pos ? launch_attn<T, D, true, 8>(s, a) : launch_attn<T, D, false, 8>(s, a); \
   }
   RVB_ATTN_CASE(32)
