@@ -101,22 +101,22 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 // out2 = LN2(result) in the compute dtype -- the encoder's `norm_final` is always followed by the next block's first
 // LayerNorm (or `after_norm`), so the pair is one pass over the row (encoder_layer.py:242-244 -> :199-201).
 // ------------------------------------------------------------------------------------------------
-template <typename OutT, typename AddT, int NV>
-__global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
+template <typename OutT, typename AddT, int NV, bool TWO>
+__global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_kernel(NormArgs a) {
   // a lane owns NV/2 runs of 8 consecutive columns (two float4 loads, one 16-byte bf16 / 8-byte fp8 store per run):
   // vector i covers columns COL(i) .. COL(i)+3
   const int lane = threadIdx.x & 63;
   const int d = a.d;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
 #define COL(i) ((((lane) + 64 * ((i) >> 1)) << 3) + (((i) & 1) << 2))
-  float4 g[NV], be[NV], g2[NV], be2[NV];
+  float4 g[NV], be[NV], g2[TWO ? NV : 1], be2[TWO ? NV : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = COL(i);
     const bool ok = c < d;
     g[i] = ok ? *(const float4*)(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     be[i] = ok ? *(const float4*)(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.out2) {
+    if constexpr (TWO) {
       g2[i] = ok ? *(const float4*)(a.gamma2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       be2[i] = ok ? *(const float4*)(a.beta2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
         }
       }
     }
-    if (a.out2) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
+    if constexpr (TWO) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
       const float mean2 = wave_sum(sum2) / (float)d;
       float sq = 0.f;
 #pragma unroll
@@ -255,9 +255,15 @@ template <typename OutT, typename AddT>
 static void launch_rownorm(hipStream_t s, const NormArgs& a) {
   // enough waves to cover the latency of a row's loads, few enough that gamma / beta are fetched once per many rows
   const int blocks = std::min(cdiv(a.M, 4), 256 * 8);
-  if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2>), dim3(blocks), dim3(256), 0, s, a);
-  else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.out2) {
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, true>), dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, false>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, false>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, false>), dim3(blocks), dim3(256), 0, s, a);
+  }
 }
 
 int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
