@@ -101,8 +101,21 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 // out2 = LN2(result) in the compute dtype -- the encoder's `norm_final` is always followed by the next block's first
 // LayerNorm (or `after_norm`), so the pair is one pass over the row (encoder_layer.py:242-244 -> :199-201).
 // ------------------------------------------------------------------------------------------------
-template <typename OutT, typename AddT, int NV, bool TWO>
-__global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_kernel(NormArgs a) {
+// SW >= 0: the mode switches are compile-time (bit 0 bf16 input, bit 1 LayerNorm statistics, bit 2 SiLU, bit 3 `add`, bit 4 fp8
+// second-stage output), so the row loop has no branches and the compiler's waitcnt pass emits COUNTED waits: with the run-time
+// switches (SW = -1) it has to assume that any conditional load may be pending at every join and answers with `s_waitcnt vmcnt(0)`
+// right behind the next row's prefetch and in front of every store -- the loop then runs one memory round trip at a time.
+template <typename OutT, typename AddT, int NV, bool TWO, int SW>
+__global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArgs a) {
+  constexpr bool CT = SW >= 0;
+  // the bf16 engine's statistics use the LDS-free reduction (its summation tree differs in the last bit from __shfl_xor's, which the
+  // f32 engine keeps so that its results do not move)
+  auto wsum = [](float x) __attribute__((always_inline)) { if constexpr (sizeof(AddT) == 2) return wave_sum_dpp(x); else return wave_sum(x); };
+  const bool sw_xb = CT ? (bool)(SW & 1) : (bool)a.x_bf16;
+  const bool sw_ln = CT ? (bool)(SW & 2) : a.mode == NORM_LN;
+  const bool sw_silu = CT ? (bool)(SW & 4) : (bool)a.silu;
+  const bool sw_add = CT ? (bool)(SW & 8) : a.add != nullptr;
+  const bool sw_o2f8 = CT ? (bool)(SW & 16) : (bool)a.out2_fp8;
   // a lane owns NV/2 runs of 8 consecutive columns (two float4 loads, one 16-byte bf16 / 8-byte fp8 store per run):
   // vector i covers columns COL(i) .. COL(i)+3
   const int lane = threadIdx.x & 63;
@@ -121,27 +134,31 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
       be2[i] = ok ? *(const float4*)(a.beta2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  // Loads are UNCONDITIONAL (row and column clamped into the matrix, the value masked afterwards): a predicated load is a branch
+  // around the instruction, and behind a branch the waitcnt pass no longer knows how many loads are in flight -- it then waits
+  // for all of them (`vmcnt(0)`) at the first use, i.e. right behind the prefetch.
   auto load_row = [&](int row, float4* v) {
-    if (a.x_bf16) {      // the depthwise convolution's output of the bf16 engine
-      const bf16_t* x = (const bf16_t*)a.x + (size_t)row * d;
+    const int rr = min(row, a.M - 1);
+    const bool rok = row < a.M;
+    if (sw_xb) {      // the depthwise convolution's output of the bf16 engine
+      const bf16_t* x = (const bf16_t*)a.x + (size_t)rr * d;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = COL(i);
-        if (row < a.M && c < d) {
-          const uint2 u = *(const uint2*)(x + c);
-          v[i] = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffffu)), bf16_to_f32((bf16_t)(u.x >> 16)),
-                             bf16_to_f32((bf16_t)(u.y & 0xffffu)), bf16_to_f32((bf16_t)(u.y >> 16)));
-        } else {
-          v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const uint2 u = *(const uint2*)(x + min(c, d - 4));
+        const bool ok = rok && c < d;
+        v[i] = make_float4(ok ? bf16_to_f32((bf16_t)(u.x & 0xffffu)) : 0.f, ok ? bf16_to_f32((bf16_t)(u.x >> 16)) : 0.f,
+                           ok ? bf16_to_f32((bf16_t)(u.y & 0xffffu)) : 0.f, ok ? bf16_to_f32((bf16_t)(u.y >> 16)) : 0.f);
       }
       return;
     }
-    const float* x = a.x + (size_t)row * d;
+    const float* x = a.x + (size_t)rr * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = COL(i);
-      v[i] = (row < a.M && c < d) ? *(const float4*)(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 u = *(const float4*)(x + min(c, d - 4));
+      const bool ok = rok && c < d;
+      v[i] = make_float4(ok ? u.x : 0.f, ok ? u.y : 0.f, ok ? u.z : 0.f, ok ? u.w : 0.f);
     }
   };
   float4 v[NV], nx[NV];
@@ -149,11 +166,11 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
   for (int row = wave0; row < a.M; row += nwaves) {
     load_row(row + nwaves, nx);                 // next row of this wave: in flight under the reductions below
     float mean = 0.f, rstd = 1.f;
-    if (a.mode == NORM_LN) {
+    if (sw_ln) {
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
-      mean = wave_sum(sum) / (float)d;
+      mean = wsum(sum) / (float)d;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -162,10 +179,17 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
       }
-      rstd = rsqrtf(wave_sum(sq) / (float)d + a.eps);
+      rstd = rsqrtf(wsum(sq) / (float)d + a.eps);
+    }
+    // The next row's values are taken out of the memory pipe HERE, before this row's stores are issued: `vmcnt` counts loads and
+    // stores in one in-order queue, so a wait for the prefetch placed behind the stores would also wait for their round trip.
+    if constexpr (CT) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)      // tied to rstd so that the scheduler cannot lift it above the reductions
+        asm volatile("" : "+v"(nx[i].x), "+v"(nx[i].y), "+v"(nx[i].z), "+v"(nx[i].w), "+v"(rstd));
     }
     OutT* out = (OutT*)a.out + (size_t)row * d;
-    const AddT* add = a.add ? (const AddT*)a.add + (size_t)row * d : nullptr;
+    const AddT* add = sw_add ? (const AddT*)a.add + (size_t)row * d : nullptr;
     float sum2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
       if (c >= d) continue;
       float o[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
                     (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
-      if (a.silu) {
+      if (sw_silu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if constexpr (sizeof(OutT) <= 2) o[e] = o[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * o[e]));
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
       }
     }
     if constexpr (TWO) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
-      const float mean2 = wave_sum(sum2) / (float)d;
+      const float mean2 = wsum(sum2) / (float)d;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
       }
-      const float rstd2 = rsqrtf(wave_sum(sq) / (float)d + a.eps2);
+      const float rstd2 = rsqrtf(wsum(sq) / (float)d + a.eps2);
       AddT* o2 = (AddT*)a.out2 + (size_t)row * d;      // AddT is the compute dtype
 #pragma unroll
       for (int i = 0; i < NV; i += 2) {
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? (TWO ? 4 : 5) : 2)) void rownorm_ke
           q[4 * h + 2] = (v[i + h].z - mean2) * rstd2 * g2[i + h].z + be2[i + h].z;
           q[4 * h + 3] = (v[i + h].w - mean2) * rstd2 * g2[i + h].w + be2[i + h].w;
         }
-        if (a.out2_fp8) {
+        if (sw_o2f8) {
           const float qs = a.out2_inv_scale;
           *(uint2*)((fp8_t*)a.out2 + (size_t)row * d + c) = make_uint2(pack4_fp8(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs),
                                                                        pack4_fp8(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs));
@@ -255,14 +279,31 @@ template <typename OutT, typename AddT>
 static void launch_rownorm(hipStream_t s, const NormArgs& a) {
   // enough waves to cover the latency of a row's loads, few enough that gamma / beta are fetched once per many rows
   const int blocks = std::min(cdiv(a.M, 4), 256 * 8);
+  const int sw = (a.x_bf16 ? 1 : 0) | (a.mode == NORM_LN ? 2 : 0) | (a.silu ? 4 : 0) | (a.add ? 8 : 0) | (a.out2_fp8 ? 16 : 0);
+  // the encoder's shapes (d <= 1024, i.e. NV = 4) and switch combinations get branch-free instantiations; everything else runs
+  // the generic kernel
+  if (a.d > 512 && a.d <= 1024) {
+#define RVB_NORM_CASE(TWO_, SW_) \
+    if ((a.out2 != nullptr) == TWO_ && sw == SW_) { hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, TWO_, SW_>), dim3(blocks), dim3(256), 0, s, a); return; }
+    RVB_NORM_CASE(false, 2)        // LayerNorm in front of a GEMM
+    RVB_NORM_CASE(false, 2 | 4 | 1)   // the convolution module's LayerNorm + SiLU on the bf16 depthwise output
+    RVB_NORM_CASE(false, 4 | 1)       // ... its BatchNorm (affine) form
+    RVB_NORM_CASE(false, 2 | 4)       // the same two on an fp32 depthwise output
+    RVB_NORM_CASE(false, 4)
+    RVB_NORM_CASE(true, 2)         // norm_final + the next block's first LayerNorm
+    RVB_NORM_CASE(true, 2 | 8)     // ... with the language-specific `add`
+    RVB_NORM_CASE(true, 2 | 16)    // ... with an fp8 second output
+    RVB_NORM_CASE(true, 2 | 8 | 16)
+#undef RVB_NORM_CASE
+  }
   if (a.out2) {
-    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, true>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, true>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, true>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, true, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, true, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, true, -1>), dim3(blocks), dim3(256), 0, s, a);
   } else {
-    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, false>), dim3(blocks), dim3(256), 0, s, a);
-    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, false>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, false>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, false, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, false, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, false, -1>), dim3(blocks), dim3(256), 0, s, a);
   }
 }
 
