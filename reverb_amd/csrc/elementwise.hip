@@ -371,6 +371,65 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
   constexpr int VE = 16 / (int)sizeof(T);          // channels per 16-byte vector
   constexpr int NG = DW_CT / VE;                   // vector groups per row
   const bool vec_ok = (a.d % VE) == 0;
+  // Staging in two sweeps when rows are whole 16-byte vectors (every model shape): first ALL of a thread's loads, unconditional
+  // (addresses clamped into the chunk; what lies outside is replaced below), then the gating and the LDS writes.  With the loads
+  // predicated inside one loop the compiler waited for each item's pair of vectors before it issued the next item's: five
+  // memory round trips per workgroup instead of one.
+  if (vec_ok) {
+    constexpr int ITEMS_ALL = (rows * NG + DW_THREADS - 1) / DW_THREADS;
+    constexpr int ITEMS = 3;                       // per sweep: 24 registers of loads in flight (the 31 taps are live as well)
+#pragma unroll
+    for (int it0 = 0; it0 < ITEMS_ALL; it0 += ITEMS) {
+    uint4 ra[ITEMS], rb[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int v = min((int)threadIdx.x + (it0 + it) * DW_THREADS, rows * NG - 1);
+      const int r = v / NG, grp = v - r * NG;
+      const int t = t0 - pad + r;
+      const int cg = min(c0 + grp * VE, a.d - VE);
+      const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
+      const T* gr = from_hist ? (const T*)a.hist + (size_t)(lorder + t) * 2 * a.d
+                              : G + ((size_t)b * a.T + min(max(t, 0), a.T - 1)) * 2 * a.d;
+      ra[it] = *(const uint4*)(gr + cg);
+      rb[it] = *(const uint4*)(gr + a.d + cg);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int v = threadIdx.x + (it0 + it) * DW_THREADS;
+      if (v >= rows * NG) break;
+      const int r = v / NG, grp = v - r * NG;
+      const int t = t0 - pad + r;
+      const int cg = c0 + grp * VE;
+      float g[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = 0.f;
+      const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
+      if (cg < a.d && (t >= 0 || a.causal) && t < a.T && r < DW_TT + K - 1) {
+        if ((t >= 0 && t < len) || from_hist) {
+          T av[VE], bvv[VE];
+          *(uint4*)av = ra[it];
+          *(uint4*)bvv = rb[it];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            const float a0 = Cvt<T>::to_f32(av[e]), b0 = Cvt<T>::to_f32(bvv[e]);
+            if constexpr (sizeof(T) == 2) g[e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b0));
+            else g[e] = a0 / (1.0f + expf(-b0));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e)
+            if (cg + e < a.d) g[e] = a.pw1_bias[cg + e] / (1.0f + expf(-a.pw1_bias[a.d + cg + e]));
+        }
+      }
+      S sv[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) sv[e] = Gate<T>::put(g[e]);
+      uint4* dst = (uint4*)&s_g[r][grp * VE];
+#pragma unroll
+      for (int q = 0; q < (int)(VE * sizeof(S)) / 16; ++q) dst[q] = ((const uint4*)sv)[q];
+    }
+    }
+  } else {
 #pragma unroll 4
   for (int v = threadIdx.x; v < rows * NG; v += DW_THREADS) {
     const int r = v / NG, grp = v - r * NG;
@@ -416,6 +475,7 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
     uint4* dst = (uint4*)&s_g[r][grp * VE];        // 16 bytes (bf16) or 2 x 16 bytes (fp32) per group
 #pragma unroll
     for (int q = 0; q < (int)(VE * sizeof(S)) / 16; ++q) dst[q] = ((const uint4*)sv)[q];
+  }
   }
   __syncthreads();
   if (!cok) return;
