@@ -284,7 +284,7 @@ static void launch_rownorm(hipStream_t s, const NormArgs& a) {
   // the generic kernel
   if (a.d > 512 && a.d <= 1024) {
 #define RVB_NORM_CASE(TWO_, SW_) \
-    if ((a.out2 != nullptr) == TWO_ && sw == SW_) { hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, TWO_, SW_>), dim3(blocks), dim3(256), 0, s, a); return; }
+    if ((a.out2 != nullptr) == (TWO_) && sw == (SW_)) { hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, TWO_, SW_>), dim3(blocks), dim3(256), 0, s, a); return; }
     RVB_NORM_CASE(false, 2)        // LayerNorm in front of a GEMM
     RVB_NORM_CASE(false, 2 | 4 | 1)   // the convolution module's LayerNorm + SiLU on the bf16 depthwise output
     RVB_NORM_CASE(false, 4 | 1)       // ... its BatchNorm (affine) form
