@@ -148,6 +148,20 @@ __device__ inline float rows_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// 64-lane sum without LDS: four DPP steps inside every 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the
+// row swaps above.  About 10 VALU instructions against six ds_bpermute round trips for the __shfl_xor form (wave_sum).  The
+// summation tree differs from wave_sum's, i.e. the result can differ in the last bit: used where that is allowed (bf16 engine).
+template <int CTRL> __device__ inline float dpp_f32(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float wave_sum_dpp(float v) {
+  v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);      // row_half_mirror
+  v += dpp_f32<0x140>(v);      // row_mirror
+  return rows_sum(v);
+}
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ status codes (include/rvb.h)

@@ -101,47 +101,64 @@ int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* m
 // out2 = LN2(result) in the compute dtype -- the encoder's `norm_final` is always followed by the next block's first
 // LayerNorm (or `after_norm`), so the pair is one pass over the row (encoder_layer.py:242-244 -> :199-201).
 // ------------------------------------------------------------------------------------------------
-template <typename OutT, typename AddT, int NV>
-__global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
+// SW >= 0: the mode switches are compile-time (bit 0 bf16 input, bit 1 LayerNorm statistics, bit 2 SiLU, bit 3 `add`, bit 4 fp8
+// second-stage output), so the row loop has no branches and the compiler's waitcnt pass emits COUNTED waits: with the run-time
+// switches (SW = -1) it has to assume that any conditional load may be pending at every join and answers with `s_waitcnt vmcnt(0)`
+// right behind the next row's prefetch and in front of every store -- the loop then runs one memory round trip at a time.
+template <typename OutT, typename AddT, int NV, bool TWO, int SW>
+__global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArgs a) {
+  constexpr bool CT = SW >= 0;
+  // the bf16 engine's statistics use the LDS-free reduction (its summation tree differs in the last bit from __shfl_xor's, which the
+  // f32 engine keeps so that its results do not move)
+  auto wsum = [](float x) __attribute__((always_inline)) { if constexpr (sizeof(AddT) == 2) return wave_sum_dpp(x); else return wave_sum(x); };
+  const bool sw_xb = CT ? (bool)(SW & 1) : (bool)a.x_bf16;
+  const bool sw_ln = CT ? (bool)(SW & 2) : a.mode == NORM_LN;
+  const bool sw_silu = CT ? (bool)(SW & 4) : (bool)a.silu;
+  const bool sw_add = CT ? (bool)(SW & 8) : a.add != nullptr;
+  const bool sw_o2f8 = CT ? (bool)(SW & 16) : (bool)a.out2_fp8;
   // a lane owns NV/2 runs of 8 consecutive columns (two float4 loads, one 16-byte bf16 / 8-byte fp8 store per run):
   // vector i covers columns COL(i) .. COL(i)+3
   const int lane = threadIdx.x & 63;
   const int d = a.d;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
 #define COL(i) ((((lane) + 64 * ((i) >> 1)) << 3) + (((i) & 1) << 2))
-  float4 g[NV], be[NV], g2[NV], be2[NV];
+  float4 g[NV], be[NV], g2[TWO ? NV : 1], be2[TWO ? NV : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = COL(i);
     const bool ok = c < d;
     g[i] = ok ? *(const float4*)(a.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     be[i] = ok ? *(const float4*)(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.out2) {
+    if constexpr (TWO) {
       g2[i] = ok ? *(const float4*)(a.gamma2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       be2[i] = ok ? *(const float4*)(a.beta2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  // Loads are UNCONDITIONAL (row and column clamped into the matrix, the value masked afterwards): a predicated load is a branch
+  // around the instruction, and behind a branch the waitcnt pass no longer knows how many loads are in flight -- it then waits
+  // for all of them (`vmcnt(0)`) at the first use, i.e. right behind the prefetch.
   auto load_row = [&](int row, float4* v) {
-    if (a.x_bf16) {      // the depthwise convolution's output of the bf16 engine
-      const bf16_t* x = (const bf16_t*)a.x + (size_t)row * d;
+    const int rr = min(row, a.M - 1);
+    const bool rok = row < a.M;
+    if (sw_xb) {      // the depthwise convolution's output of the bf16 engine
+      const bf16_t* x = (const bf16_t*)a.x + (size_t)rr * d;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = COL(i);
-        if (row < a.M && c < d) {
-          const uint2 u = *(const uint2*)(x + c);
-          v[i] = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffffu)), bf16_to_f32((bf16_t)(u.x >> 16)),
-                             bf16_to_f32((bf16_t)(u.y & 0xffffu)), bf16_to_f32((bf16_t)(u.y >> 16)));
-        } else {
-          v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const uint2 u = *(const uint2*)(x + min(c, d - 4));
+        const bool ok = rok && c < d;
+        v[i] = make_float4(ok ? bf16_to_f32((bf16_t)(u.x & 0xffffu)) : 0.f, ok ? bf16_to_f32((bf16_t)(u.x >> 16)) : 0.f,
+                           ok ? bf16_to_f32((bf16_t)(u.y & 0xffffu)) : 0.f, ok ? bf16_to_f32((bf16_t)(u.y >> 16)) : 0.f);
       }
       return;
     }
-    const float* x = a.x + (size_t)row * d;
+    const float* x = a.x + (size_t)rr * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = COL(i);
-      v[i] = (row < a.M && c < d) ? *(const float4*)(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 u = *(const float4*)(x + min(c, d - 4));
+      const bool ok = rok && c < d;
+      v[i] = make_float4(ok ? u.x : 0.f, ok ? u.y : 0.f, ok ? u.z : 0.f, ok ? u.w : 0.f);
     }
   };
   float4 v[NV], nx[NV];
@@ -149,11 +166,11 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
   for (int row = wave0; row < a.M; row += nwaves) {
     load_row(row + nwaves, nx);                 // next row of this wave: in flight under the reductions below
     float mean = 0.f, rstd = 1.f;
-    if (a.mode == NORM_LN) {
+    if (sw_ln) {
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
-      mean = wave_sum(sum) / (float)d;
+      mean = wsum(sum) / (float)d;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -162,10 +179,17 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
       }
-      rstd = rsqrtf(wave_sum(sq) / (float)d + a.eps);
+      rstd = rsqrtf(wsum(sq) / (float)d + a.eps);
+    }
+    // The next row's values are taken out of the memory pipe HERE, before this row's stores are issued: `vmcnt` counts loads and
+    // stores in one in-order queue, so a wait for the prefetch placed behind the stores would also wait for their round trip.
+    if constexpr (CT) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)      // tied to rstd so that the scheduler cannot lift it above the reductions
+        asm volatile("" : "+v"(nx[i].x), "+v"(nx[i].y), "+v"(nx[i].z), "+v"(nx[i].w), "+v"(rstd));
     }
     OutT* out = (OutT*)a.out + (size_t)row * d;
-    const AddT* add = a.add ? (const AddT*)a.add + (size_t)row * d : nullptr;
+    const AddT* add = sw_add ? (const AddT*)a.add + (size_t)row * d : nullptr;
     float sum2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
       if (c >= d) continue;
       float o[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
                     (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
-      if (a.silu) {
+      if (sw_silu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if constexpr (sizeof(OutT) <= 2) o[e] = o[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * o[e]));
@@ -209,8 +233,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
         }
       }
     }
-    if (a.out2) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
-      const float mean2 = wave_sum(sum2) / (float)d;
+    if constexpr (TWO) {       // second LayerNorm on the row just produced (fp32 values, exactly what a separate pass would read)
+      const float mean2 = wsum(sum2) / (float)d;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
           sq += dx * dx + dy * dy + dz * dz + dw * dw;
         }
       }
-      const float rstd2 = rsqrtf(wave_sum(sq) / (float)d + a.eps2);
+      const float rstd2 = rsqrtf(wsum(sq) / (float)d + a.eps2);
       AddT* o2 = (AddT*)a.out2 + (size_t)row * d;      // AddT is the compute dtype
 #pragma unroll
       for (int i = 0; i < NV; i += 2) {
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(NormArgs a) {
           q[4 * h + 2] = (v[i + h].z - mean2) * rstd2 * g2[i + h].z + be2[i + h].z;
           q[4 * h + 3] = (v[i + h].w - mean2) * rstd2 * g2[i + h].w + be2[i + h].w;
         }
-        if (a.out2_fp8) {
+        if (sw_o2f8) {
           const float qs = a.out2_inv_scale;
           *(uint2*)((fp8_t*)a.out2 + (size_t)row * d + c) = make_uint2(pack4_fp8(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs),
                                                                        pack4_fp8(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs));
@@ -255,9 +279,32 @@ template <typename OutT, typename AddT>
 static void launch_rownorm(hipStream_t s, const NormArgs& a) {
   // enough waves to cover the latency of a row's loads, few enough that gamma / beta are fetched once per many rows
   const int blocks = std::min(cdiv(a.M, 4), 256 * 8);
-  if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2>), dim3(blocks), dim3(256), 0, s, a);
-  else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8>), dim3(blocks), dim3(256), 0, s, a);
+  const int sw = (a.x_bf16 ? 1 : 0) | (a.mode == NORM_LN ? 2 : 0) | (a.silu ? 4 : 0) | (a.add ? 8 : 0) | (a.out2_fp8 ? 16 : 0);
+  // the encoder's shapes (d <= 1024, i.e. NV = 4) and switch combinations get branch-free instantiations; everything else runs
+  // the generic kernel
+  if (a.d > 512 && a.d <= 1024) {
+#define RVB_NORM_CASE(TWO_, SW_) \
+    if ((a.out2 != nullptr) == (TWO_) && sw == (SW_)) { hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, TWO_, SW_>), dim3(blocks), dim3(256), 0, s, a); return; }
+    RVB_NORM_CASE(false, 2)        // LayerNorm in front of a GEMM
+    RVB_NORM_CASE(false, 2 | 4 | 1)   // the convolution module's LayerNorm + SiLU on the bf16 depthwise output
+    RVB_NORM_CASE(false, 4 | 1)       // ... its BatchNorm (affine) form
+    RVB_NORM_CASE(false, 2 | 4)       // the same two on an fp32 depthwise output
+    RVB_NORM_CASE(false, 4)
+    RVB_NORM_CASE(true, 2)         // norm_final + the next block's first LayerNorm
+    RVB_NORM_CASE(true, 2 | 8)     // ... with the language-specific `add`
+    RVB_NORM_CASE(true, 2 | 16)    // ... with an fp8 second output
+    RVB_NORM_CASE(true, 2 | 8 | 16)
+#undef RVB_NORM_CASE
+  }
+  if (a.out2) {
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, true, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, true, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, true, -1>), dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    if (a.d <= 512) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 2, false, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.d <= 1024) hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 4, false, -1>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rownorm_kernel<OutT, AddT, 8, false, -1>), dim3(blocks), dim3(256), 0, s, a);
+  }
 }
 
 int rownorm(hipStream_t s, int dtype, const NormArgs& a) {
@@ -324,6 +371,65 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
   constexpr int VE = 16 / (int)sizeof(T);          // channels per 16-byte vector
   constexpr int NG = DW_CT / VE;                   // vector groups per row
   const bool vec_ok = (a.d % VE) == 0;
+  // Staging in two sweeps when rows are whole 16-byte vectors (every model shape): first ALL of a thread's loads, unconditional
+  // (addresses clamped into the chunk; what lies outside is replaced below), then the gating and the LDS writes.  With the loads
+  // predicated inside one loop the compiler waited for each item's pair of vectors before it issued the next item's: five
+  // memory round trips per workgroup instead of one.
+  if (vec_ok) {
+    constexpr int ITEMS_ALL = (rows * NG + DW_THREADS - 1) / DW_THREADS;
+    constexpr int ITEMS = 3;                       // per sweep: 24 registers of loads in flight (the 31 taps are live as well)
+#pragma unroll
+    for (int it0 = 0; it0 < ITEMS_ALL; it0 += ITEMS) {
+    uint4 ra[ITEMS], rb[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int v = min((int)threadIdx.x + (it0 + it) * DW_THREADS, rows * NG - 1);
+      const int r = v / NG, grp = v - r * NG;
+      const int t = t0 - pad + r;
+      const int cg = min(c0 + grp * VE, a.d - VE);
+      const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
+      const T* gr = from_hist ? (const T*)a.hist + (size_t)(lorder + t) * 2 * a.d
+                              : G + ((size_t)b * a.T + min(max(t, 0), a.T - 1)) * 2 * a.d;
+      ra[it] = *(const uint4*)(gr + cg);
+      rb[it] = *(const uint4*)(gr + a.d + cg);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int v = threadIdx.x + (it0 + it) * DW_THREADS;
+      if (v >= rows * NG) break;
+      const int r = v / NG, grp = v - r * NG;
+      const int t = t0 - pad + r;
+      const int cg = c0 + grp * VE;
+      float g[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = 0.f;
+      const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
+      if (cg < a.d && (t >= 0 || a.causal) && t < a.T && r < DW_TT + K - 1) {
+        if ((t >= 0 && t < len) || from_hist) {
+          T av[VE], bvv[VE];
+          *(uint4*)av = ra[it];
+          *(uint4*)bvv = rb[it];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            const float a0 = Cvt<T>::to_f32(av[e]), b0 = Cvt<T>::to_f32(bvv[e]);
+            if constexpr (sizeof(T) == 2) g[e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b0));
+            else g[e] = a0 / (1.0f + expf(-b0));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e)
+            if (cg + e < a.d) g[e] = a.pw1_bias[cg + e] / (1.0f + expf(-a.pw1_bias[a.d + cg + e]));
+        }
+      }
+      S sv[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) sv[e] = Gate<T>::put(g[e]);
+      uint4* dst = (uint4*)&s_g[r][grp * VE];
+#pragma unroll
+      for (int q = 0; q < (int)(VE * sizeof(S)) / 16; ++q) dst[q] = ((const uint4*)sv)[q];
+    }
+    }
+  } else {
 #pragma unroll 4
   for (int v = threadIdx.x; v < rows * NG; v += DW_THREADS) {
     const int r = v / NG, grp = v - r * NG;
@@ -369,6 +475,7 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
     uint4* dst = (uint4*)&s_g[r][grp * VE];        // 16 bytes (bf16) or 2 x 16 bytes (fp32) per group
 #pragma unroll
     for (int q = 0; q < (int)(VE * sizeof(S)) / 16; ++q) dst[q] = ((const uint4*)sv)[q];
+  }
   }
   __syncthreads();
   if (!cok) return;

@@ -732,6 +732,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   int s_rd = 1;                     // slot of half-tile ph+1
   int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
   bool first_tile = true;
+  // Candidate (not measured, off by default): the CUs of a launch run their tiles in lockstep, so for the fp32 + residual
+  // shapes (512 KiB of HBM traffic per tile in the epilogue, none in the K loop) the whole chip alternates between an
+  // HBM-bound and a compute-bound phase.  Starting every second CU's first workgroup half a tile late keeps the two halves of
+  // the chip out of phase for the rest of the launch.  `stagger_ticks` = half the expected tile time (host estimate).
+  if (p.stagger_ticks > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    const long long until = wall_clock64() + p.stagger_ticks;
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
   for (;;) {
   const int dbg_i = PERSIST ? lin : (int)blockIdx.x;
   if (p.dbg && tid == 0) {
@@ -1343,6 +1351,12 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
+  p.stagger_ticks = 0;
+  if ((g_gemm2_flags & 64) && p.res != nullptr && p.out_f32) {
+    // half of (K loop at ~1.45 us per 64-wide K step + ~15 us of epilogue), in 10-ns ticks
+    const double tile_us = 1.45 * (double)((p.K + 63) / 64) + 15.0;
+    p.stagger_ticks = (int)(tile_us * 100.0 / 2.0);
+  }
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);

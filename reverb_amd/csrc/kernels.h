@@ -27,6 +27,7 @@ struct GemmArgs {
   int cT1, cF1, cT2, cF2, cC;
   int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
   int res_epilogue;   // gemm2p: add the residual in the epilogue (prefetched) instead of preloading the accumulators; leave 0
+  int stagger_ticks;  // gemm2p tuning (RVB_GEMM2_FLAGS bit 6): every second workgroup of the first wave starts this many 10-ns ticks late; leave 0
   // fp8 (OCP e4m3) operands, gemm2 only: A and W are bytes, the accumulator is multiplied by a_scale * w_scale[n];
   // out_fp8: C is written as fp8 of value * out_inv_scale (saturating)
   int in_fp8, out_fp8;
