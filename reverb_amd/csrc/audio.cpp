@@ -58,12 +58,15 @@ struct Md5 {
     static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,
                               14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
                               4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
-    static uint32_t K[64];
-    static bool init = false;
-    if (!init) {
-      for (int i = 0; i < 64; ++i) K[i] = (uint32_t)(int64_t)std::floor(std::fabs(std::sin((double)(i + 1))) * 4294967296.0);
-      init = true;
-    }
+    // floor(|sin(i + 1)| * 2^32), RFC 1321 section 3.4; a constant table (no lazily filled static: two decoder threads may hash at once)
+    static constexpr uint32_t K[64] = {
+        0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u, 0x698098d8u, 0x8b44f7afu,
+        0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u, 0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau,
+        0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u, 0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u,
+        0x676f02d9u, 0x8d2a4c8au, 0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+        0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u, 0xf4292244u, 0x432aff97u,
+        0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u, 0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u,
+        0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
     uint32_t w[16];
     for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
@@ -620,7 +623,7 @@ Wave wave_open(const uint8_t* d, size_t n) {
   bool fmt = false;
   uint64_t data64 = 0;
   size_t pos = 12;
-  while (n - pos >= 8) {
+  while (pos <= n && n - pos >= 8) {
     const uint8_t* id = d + pos;
     size_t size = le(d + pos + 4, 4);
     pos += 8;
@@ -649,7 +652,8 @@ Wave wave_open(const uint8_t* d, size_t n) {
       }
       fmt = true;
     }
-    pos += size + (size & 1);
+    pos += size;
+    if ((size & 1) && pos < n) ++pos;     // the pad byte of an odd-sized chunk may be missing at the end of the file
   }
   fail(E_DATA, "WAVE: missing fmt or data chunk");
 }
@@ -675,7 +679,7 @@ Aiff aiff_open(const uint8_t* d, size_t n) {
   bool comm = false;
   uint32_t frames = 0;
   size_t pos = 12;
-  while (n - pos >= 8) {
+  while (pos <= n && n - pos >= 8) {
     const uint8_t* id = d + pos;
     const size_t size = be(d + pos + 4, 4);
     pos += 8;
@@ -712,7 +716,8 @@ Aiff aiff_open(const uint8_t* d, size_t n) {
       a.w.bytes = std::min(want, n - start);
       return a;
     }
-    pos += size + (size & 1);
+    pos += size;
+    if ((size & 1) && pos < n) ++pos;     // the pad byte of an odd-sized chunk may be missing at the end of the file
   }
   fail(E_DATA, "AIFF: missing COMM or SSND chunk");
 }
@@ -836,7 +841,15 @@ int64_t decode(const uint8_t* d, size_t n, int channel, Out* out, int64_t capaci
     return info->frames;
   }
   // FLAC: integer samples left-justified in the 16- or 32-bit word of the native sample format
-  StreamInfo si = flac_open(d, n).si;
+  const FlacStream fs = flac_open(d, n);
+  StreamInfo si = fs.si;
+  {
+    // STREAMINFO's 36-bit sample count is attacker-controlled and callers size buffers from it before a single frame is
+    // decoded: a frame is at least 8 bytes (header 5, one subframe byte, CRC-16) and holds at most max_block (<= 65535) samples
+    const int64_t per_frame = si.max_block > 0 ? si.max_block : 65535;
+    const int64_t most = ((int64_t)(n - std::min(n, fs.first_frame)) / 8 + 1) * per_frame;
+    if (si.total > most) fail(E_DATA, "FLAC: STREAMINFO declares more samples than the file can hold");
+  }
   if (want) {
     if (i16 && si.bps > 16) fail(E_UNSUPPORTED, "rvb_audio_decode_i16: the file's native sample format is not int16");
     if (channel >= si.channels) fail(E_ARG, "audio decode: channel index out of range");

@@ -164,7 +164,7 @@ class RvbComm:
         assert len(unique_id) == 128
         self.lib = _lib.load()
         self.world, self.rank = int(world), int(rank)
-        device = engine if isinstance(engine, int) else int(getattr(engine, "device_index", getattr(engine, "device", 0)) or 0)
+        device = _device_of(engine)
         self._id = C.create_string_buffer(unique_id, 128)
         self.handle = C.c_void_p()
         _lib.check(self.lib.rvb_comm_create(device, self.world, self.rank, C.cast(self._id, C.c_void_p), C.byref(self.handle)),
@@ -257,19 +257,39 @@ _DEFAULT_COMM = None
 
 def default_comm(engine):
     """The transport of the result gathers: librvb's own RCCL binding (`rvb_comm_create` / `rvb_comm_allgather`,
-    csrc/comm.hip -- no torch tensor in the loop) whenever the process group runs on GPUs ("nccl" = RCCL) and `engine` is a
-    real librvb engine (ASR or diarization); None = torch.distributed (the gloo CPU tests with stub engines, or
-    RVB_COMM=torch).  The unique id travels once through the existing process group; the communicator is process-wide."""
+    csrc/comm.hip -- no torch tensor in the loop) whenever the process group runs on GPUs ("nccl" = RCCL); None =
+    torch.distributed (the gloo CPU tests with stub engines, or RVB_COMM=torch).  The choice depends on the backend and on
+    RVB_COMM ONLY -- never on what this rank happens to hold (a rank without windows has no diarization engine yet: if it
+    chose differently from its peers the collectives would not match and the job would hang).  `engine`: an Engine /
+    DiarEngine, a device index, a torch device, or None (= LOCAL_RANK).  The unique id travels once through the existing
+    process group; the communicator is process-wide."""
     import os
     import torch.distributed as dist
     global _DEFAULT_COMM
     if os.environ.get("RVB_COMM", "cabi") == "torch" or dist.get_backend() != "nccl":
         return None
-    if engine is None or not hasattr(engine, "lib"):
-        return None
     if _DEFAULT_COMM is None or not _DEFAULT_COMM.handle:
-        _DEFAULT_COMM = RvbComm.from_torch_group(engine)
+        _DEFAULT_COMM = RvbComm.from_torch_group(_device_of(engine))
     return _DEFAULT_COMM
+
+
+def _device_of(engine) -> int:
+    """Device index of an engine / int / torch.device / "cuda:N" string; LOCAL_RANK when nothing says otherwise."""
+    import os
+    if engine is None:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    if isinstance(engine, int):
+        return engine
+    if isinstance(engine, str):
+        return int(engine.split(":")[1]) if ":" in engine else int(os.environ.get("LOCAL_RANK", "0"))
+    idx = getattr(engine, "index", None)            # torch.device
+    if idx is None:
+        idx = getattr(engine, "device_index", None)
+    if idx is None:
+        idx = getattr(engine, "device", None)
+        if not isinstance(idx, int):
+            idx = getattr(idx, "index", None)
+    return int(idx) if idx is not None else int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def gather_words(send: np.ndarray, device, comm: "RvbComm" = None) -> np.ndarray:
@@ -433,7 +453,7 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
         classes, emb = pipeline.networks(pcm[s0:s1])
         assert classes.shape == (w1 - w0, frames), (classes.shape, w0, w1, frames)
     kmax = max(b - a for a, b in ranges)
-    host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, default_comm(getattr(pipeline, "_engine", None)))
+    host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, default_comm(pipeline.device_index if getattr(pipeline, "device_index", None) is not None else device))
     parts = [unpack_diar_shard(host[r], kmax) for r in range(world)]
     for r, (a, b) in enumerate(ranges):
         assert parts[r][0].shape[0] == b - a, (r, parts[r][0].shape, a, b)

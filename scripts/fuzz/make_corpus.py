@@ -20,7 +20,14 @@ def seeds():
             wav_bytes(1, 2, 16000, 16, x.T.astype("<i2").tobytes()), wav_bytes(3, 1, 16000, 32, np.zeros(100, "<f4").tobytes()),
             wav_bytes(6, 1, 8000, 8, bytes(range(256))), wav_bytes(1, 2, 8000, 24, bytes(600), extensible=True),
             aiff_bytes(2, 16000, 16, x.T.astype(">i2").tobytes()), aiff_bytes(1, 8000, 8, bytes(200), compression=b"NONE"),
-            aiff_bytes(1, 22050, 32, np.zeros(50, ">f4").tobytes(), compression=b"fl32")]
+            aiff_bytes(1, 22050, 32, np.zeros(50, ">f4").tobytes(), compression=b"fl32"),
+            # odd-sized trailing chunks without their pad byte (the round-3 walker ran past the buffer on these two)
+            _riff(b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"LIST" + struct.pack("<I", 3) + b"abc"),
+            b"FORM" + struct.pack(">I", 17) + b"AIFF" + b"ANNO" + struct.pack(">I", 5) + b"hello"]
+
+
+def _riff(body):
+    return b"RIFF" + struct.pack("<I", len(body)) + body
 
 
 def mutate(d, rng):

@@ -411,3 +411,60 @@ def test_mutated_files_are_rejected_or_decoded_never_worse():
         except (ValueError, NotImplementedError, MemoryError):
             rejected += 1
     assert decoded > 100 and rejected > 100
+
+
+def test_odd_sized_last_chunk_without_its_pad_byte():
+    """an odd-sized chunk that ends exactly at the end of the file, pad byte missing, with no data / SSND chunk
+    in front of it, moved the walker to n + 1; `n - pos` wrapped and the walk went on through the heap.  Both walkers must
+    stop and name the missing chunk.  (Exact-size heap copies: under ASan these were heap-buffer-overflows.)"""
+    fmt = b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+    body = b"WAVE" + fmt + b"LIST" + struct.pack("<I", 3) + b"abc"
+    riff = b"RIFF" + struct.pack("<I", len(body)) + body
+    assert len(riff) == 47
+    with pytest.raises(ValueError, match="missing fmt or data"):
+        audio.probe_bytes(riff)
+    with pytest.raises(ValueError, match="missing fmt or data"):
+        audio.decode_bytes(riff)
+    form_body = b"AIFF" + b"ANNO" + struct.pack(">I", 5) + b"hello"
+    aiff = b"FORM" + struct.pack(">I", len(form_body)) + form_body
+    with pytest.raises(ValueError, match="missing COMM or SSND"):
+        audio.probe_bytes(aiff)
+    # the same odd chunk followed by real data still decodes (pad byte present)
+    s16 = np.arange(-8, 8, dtype="<i2")
+    body = b"WAVE" + fmt + b"LIST" + struct.pack("<I", 3) + b"abc\0" + b"data" + struct.pack("<I", 32) + s16.tobytes()
+    got, _ = audio.decode_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    np.testing.assert_array_equal(got[0], s16)
+
+
+def test_flac_header_cannot_request_an_absurd_allocation():
+    """STREAMINFO's 36-bit sample count sized the output array before any frame was decoded: a 42-byte header
+    could ask for terabytes.  The probe now bounds it by what the file's bytes can hold."""
+    x = signal(1, 4096, 16, 3)
+    data = bytearray(FW.encode(x, 16, 16000))
+    # STREAMINFO starts at byte 8: min/max block (4), min/max frame (6), rate:20 ch:3 bps:5 total:36 -> the low 32 bits of
+    # total are bytes 22..25, its top 4 bits the low nibble of byte 21
+    data[8 + 13] |= 0x0F
+    data[8 + 14:8 + 18] = b"\xff\xff\xff\xff"
+    with pytest.raises(ValueError, match="more samples than the file can hold"):
+        audio.probe_bytes(bytes(data))
+    with pytest.raises(ValueError, match="more samples than the file can hold"):
+        audio.decode_bytes(bytes(data))
+
+
+def test_md5_from_two_threads_at_once():
+    """the MD5 round constants were a lazily filled static table behind a plain bool."""
+    import threading
+    x = signal(2, 20000, 16, 11)
+    data = FW.encode(x, 16, 16000)
+    want = native(x, 16)
+    bad = []
+
+    def work():
+        for _ in range(5):
+            got, info = audio.decode_bytes(data)
+            if not info.md5_checked or not np.array_equal(got, want):
+                bad.append(1)
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
