@@ -272,13 +272,13 @@ def main():
         from reverb_amd.dist import default_comm
         comm = default_comm(eng)
 
-    def step(upload=False):
+    def step(upload=False, last=False):
         if STUB:
             hyps = eng.decode()
         else:
-            if upload:
-                eng.upload_pcm(pcm)
-            nf = eng.fbank()
+            nf = eng.fbank()                 # upload=True: consumes the pending double-buffered upload (ordered behind it)
+            if upload and not last:
+                eng.upload_pcm_async(pcm)    # the NEXT step's samples go up underneath this step's encoder (copy stream)
             hyps = eng.decode_resident(nf, modes, chunk, args.beam, args.ctc_weight, args.reverse_weight)["attention_rescoring"]
         ntok = sum(len(h.tokens) for h in hyps)
         if not STUB:
@@ -302,8 +302,10 @@ def main():
             dist.barrier()
         sync()
         t0 = time.perf_counter()
-        for _ in range(k):
-            r = step(**kw)
+        if kw.get("upload"):
+            eng.upload_pcm_async(pcm)        # the first step's samples: the one upload nothing can hide
+        for i in range(k):
+            r = step(last=i + 1 == k, **kw)
         sync()
         if use_dist:
             dist.barrier()
@@ -333,11 +335,15 @@ def main():
             stages = {k: eng.timing(k) for k in ("fbank", "subsample", "gemm", "gemm_fp8", "attention", "rownorm", "glu_dwconv",
                                                  "ctc_topk", "embed", "lse_gather", "search_host")}
         if world == 1 and not args.no_pcie:
-            # the same step from PCM in (page-locked) HOST memory: SURVEY.md 8d's end-to-end definition; reported beside
-            # `value`, never as `value` (inputs are HBM-resident there)
+            # the same steps from PCM in (page-locked) HOST memory: SURVEY.md 8d's end-to-end definition.  Every step's
+            # samples cross PCIe inside the timed region (K uploads for K steps); since round 4 they are double-buffered
+            # (rvb_upload_pcm_async): step i+1's samples travel on a copy stream underneath step i's encoder, only the
+            # first upload is exposed.  Reported beside `value` (inputs HBM-resident there, as the bench contract asks).
             dp, _ = timed(args.steps, upload=True)
             pcie = {"value": round(seconds * args.steps / dp, 2), "ms_per_step": round(dp / args.steps * 1e3, 2),
-                    "h2d_bytes_per_step": int(n_samples * 2), "host_memory": "page-locked (rvb_host_alloc)"}
+                    "h2d_bytes_per_step": int(n_samples * 2), "host_memory": "page-locked (rvb_host_alloc)",
+                    "uploads_in_timed_region": args.steps,
+                    "overlap": "double-buffered: upload of step i+1 on a copy stream under step i (rvb_upload_pcm_async)"}
 
     xgmi = None
     if comm is not None:

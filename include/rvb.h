@@ -93,6 +93,14 @@ int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
 /* Page-locked host memory for the audio reader (what `torchaudio.load` fills in the reference, cli/reverb.py:128):
  * PCM decoded straight into such a buffer reaches HBM at the PCIe rate (115 MB per hour of audio in ~2 ms);
  * pageable memory works with rvb_upload_pcm too, several times slower.  Free with rvb_host_free. */
+/* Double-buffered upload for back-to-back recordings (a long-form service decodes file i while file i+1 arrives): the copy
+ * is enqueued on a copy stream of the engine's and the call returns at once; from page-locked memory it runs on a DMA engine
+ * underneath the decoding in progress.  The samples become the engine's audio at the NEXT rvb_fbank, which orders itself
+ * behind the copy on the device; `pcm` must stay valid and unchanged until that rvb_fbank has been called and one more
+ * stream synchronisation (any blocking call) has passed.  One upload may be pending at a time (RVB_E_STATE otherwise).
+ * 16 kHz int16 only.  Replaces: the `torchaudio.load` + `.to(device)` of the NEXT file in cli/reverb.py:128-146, which the
+ * reference runs serially. */
+int rvb_upload_pcm_async(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
 int rvb_host_alloc(void** out, int64_t bytes);
 int rvb_host_free(void* p);
 int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int64_t* n_frames);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "rvb_finalize": (C.c_int, [_eng, _f32p, C.c_int]),
     "rvb_num_frames": (C.c_int64, [C.c_int64]),
     "rvb_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvb_upload_pcm_async": (C.c_int, [_eng, _i16p, C.c_int64]),
     "rvb_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "rvb_host_free": (C.c_int, [C.c_void_p]),
     "rvb_set_decoding_chunk": (C.c_int, [_eng, C.c_int, C.c_int]),

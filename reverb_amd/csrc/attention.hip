@@ -58,9 +58,33 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // block -> (sequence, first query): the grid's (x, z), or one entry of a host-built work list (ragged batches of
   // short sequences: no empty blocks)
-  const int head = blockIdx.y;
-  const int seq = a.work ? a.work[2 * blockIdx.x] : blockIdx.z;
-  const int q0 = a.work ? a.work[2 * blockIdx.x + 1] : blockIdx.x * QT;
+  // Grid form: the query blocks of one (sequence, head) read the same K / P / V rows, and workgroups go to the 8 XCDs round
+  // robin in launch order (x fastest) -- left alone, the four 128-query blocks of an encoder chunk land on four XCDs and
+  // each L2 fetches the chunk's keys and values for itself (round 3: 32 GB fetched per hour of audio against 10 GB
+  // algorithmic).  Remapped so that all gridDim.x blocks of a (sequence, head) run on ONE XCD, back to back: launch-order id
+  // L -> XCD L % 8, slot j = L / 8 on it -> group (j / gx) * 8 + xcd, query block j % gx; the ids past the last whole round of
+  // 8 groups keep the plain order (a bijection either way).
+  int head = blockIdx.y, seq, q0;
+  if (a.work) {
+    seq = a.work[2 * blockIdx.x];
+    q0 = a.work[2 * blockIdx.x + 1];
+  } else {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int total = gx * gy * (int)gridDim.z, full = total / (8 * gx) * (8 * gx);
+    int group, qb;
+    if (L < full && !a.plain_order) {
+      const int xcd = L & 7, j = L >> 3;
+      group = (j / gx) * 8 + xcd;
+      qb = j - (j / gx) * gx;
+    } else {
+      group = L / gx;
+      qb = L - group * gx;
+    }
+    seq = group / gy;
+    head = group - seq * gy;
+    q0 = qb * QT;
+  }
   const int qlen = a.q_len[seq];
   if (q0 >= qlen) return;                       // block-uniform
   const int qs = a.q_start[seq], ks = a.kv_start[seq], kvlen = a.kv_len[seq];
@@ -358,8 +382,11 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   return E_UNSUPPORTED;
 }
 
-int attention(hipStream_t s, int dtype, const AttnArgs& a) {
-  if (a.nseq <= 0 || a.max_q <= 0) return OK;
+int attention(hipStream_t s, int dtype, const AttnArgs& a0) {
+  if (a0.nseq <= 0 || a0.max_q <= 0) return OK;
+  static const int plain = getenv("RVB_ATTN_PLAIN") ? atoi(getenv("RVB_ATTN_PLAIN")) : 0;      // tuning: A/B of the block order
+  AttnArgs a = a0;
+  if (plain) a.plain_order = 1;
   const int ve = dtype == DT_BF16 ? 8 : 4;
   if (a.dk % ve || a.q_stride % ve || a.k_stride % ve || a.v_stride % ve || (a.p && a.p_stride % ve)) {
     set_error("attention: dk and row strides must be multiples of the 16-byte vector width");

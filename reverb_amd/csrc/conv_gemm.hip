@@ -1,8 +1,10 @@
-// 3x3 stride-1 convolution of the ResNet34 trunk as an implicit GEMM on gemm2.hip's pipelined LDS-DMA loop (bf16).
+// 3x3 convolution (stride 1 or 2, pad 1) of the ResNet34 trunk as an implicit GEMM on gemm2.hip's pipelined LDS-DMA loop (bf16).
 //
-//   rows    = output pixels (b, f, t) of the bordered NHWC tensor [B][F+2][T+2][Cin] (zero border = the padding)
-//   K steps = 64 input channels of one tap; the A operand of a step is gathered by LDS-DMA from the pixels shifted
-//             by (kh, kw): one 128-byte run per pixel, no im2col buffer, no register staging
+//   rows    = output pixels (b, f, t); the input is the bordered NHWC tensor [B][Fi+2][Ti+2][Cin] (zero border = the padding)
+//   K steps = 64 input channels of one tap; the A operand of a step is gathered by LDS-DMA from the input pixels
+//             (S f + kh, S t + kw) of the bordered tensor (S = stride): one 128-byte run per pixel, no im2col buffer, no
+//             register staging.  Round 4: the two stride-2 convolutions that open stages 3 and 4 (64 -> 128, 128 -> 256) run
+//             here too -- on the direct kernel they were the 512-VGPR + scratch instantiations (24 ms per hour of audio)
 //   columns = output channels, weights [Cout][9][Cin] (BatchNorm folded), tile 256 pixels x 128 or 256 channels
 //
 // Main loop and gather measured in scripts/micro/gemm_lab.hip ("conv" mode, exact against a naive convolution):
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / NWN, wc = wave % NWN;
   const int F = p.Fo, T = p.To, Cin = p.Cin, Cout = p.Cout;
-  const int TP = T + 2, FP = F + 2;
+  const int TP = T + 2, FP = F + 2;                           // bordered OUTPUT (and residual) geometry
+  const int TPi = p.Ti + 2, FPi = p.Fi + 2, S = p.stride;     // bordered INPUT geometry, stride
   const int M = p.B * F * T;
   const int tiles_n = Cout / BN;
   const int nwg = gridDim.x;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     if (m >= M) m = M - 1;                                     // clamped rows are computed and never stored
     const int b = m / (F * T), rem = m - b * (F * T);
     const int fo = rem / T, to = rem - fo * T;
-    a_src[i] = in + ((size_t)(b * FP + fo) * TP + to) * Cin + (lc ^ ((row >> 1) & 7)) * 8;      // tap (0,0), channel 0
+    a_src[i] = in + ((size_t)(b * FPi + S * fo) * TPi + S * to) * Cin + (lc ^ ((row >> 1) & 7)) * 8;      // tap (0,0), channel 0
   }
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   auto issue = [&](int kt) __attribute__((always_inline)) {
     const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKE;
     const int kh = tap / 3, kw = tap - kh * 3;
-    const size_t aoff = (size_t)(kh * TP + kw) * Cin + c0;
+    const size_t aoff = (size_t)(kh * TPi + kw) * Cin + c0;
     const size_t woff = (size_t)tap * Cin + c0;
     const unsigned dst = lds_base + (kt & 1) * STAGE;
 #pragma unroll
@@ -245,8 +248,10 @@ int launch_igemm(hipStream_t st, const ConvArgs& p) {
 }  // namespace
 
 bool conv_igemm_applicable(int dtype, const ConvArgs& p) {
-  return dtype == DT_BF16 && p.w_ig != nullptr && p.taps == 9 && p.stride == 1 && p.Cin % 64 == 0 && p.Cout % 128 == 0 &&
-         p.Fo == p.Fi && p.To == p.Ti && (int64_t)p.B * p.Fo * p.To < (int64_t)1 << 31;
+  if (!(dtype == DT_BF16 && p.w_ig != nullptr && p.taps == 9 && p.Cin % 64 == 0 && p.Cout % 128 == 0 &&
+        (int64_t)p.B * p.Fo * p.To < (int64_t)1 << 31)) return false;
+  if (p.stride == 1) return p.Fo == p.Fi && p.To == p.Ti;
+  return p.stride == 2 && p.Fo == (p.Fi - 1) / 2 + 1 && p.To == (p.Ti - 1) / 2 + 1;      // Conv2d(k 3, stride 2, pad 1)
 }
 
 int conv_igemm(hipStream_t s, const ConvArgs& p) {

@@ -388,8 +388,10 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   // implicit-GEMM kernel (conv_gemm.hip) for the 128- and 256-channel stride-1 convolutions: second weight layout
   // [cout][tap][cin].  Validated on hardware in round 2 (tests/test_diar_gpu.py: both kernels against the oracle and
   // against each other; 806 / 1150 TFLOP/s vs 555-598 for the direct kernel); RVD_CONV_IGEMM=0 selects the direct kernel.
+  // Round 4: the stride-2 convolutions that open stages 3 and 4 go there too (RVD_CONV_IGEMM=1: stride 1 only, as in round 2).
   const char* ig = getenv("RVD_CONV_IGEMM");
-  if ((!ig || atoi(ig) != 0) && e->dtype == DT_BF16 && k == 3 && stride == 1 && cin % 64 == 0 && cout % 128 == 0) {
+  const int ig_mode = ig ? atoi(ig) : 2;
+  if (ig_mode != 0 && e->dtype == DT_BF16 && k == 3 && (stride == 1 || (stride == 2 && ig_mode >= 2)) && cin % 64 == 0 && cout % 128 == 0) {
     std::vector<float> pg((size_t)cout * taps * cin);
     for (int o = 0; o < cout; ++o) {
       const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f);

@@ -165,6 +165,13 @@ struct rvb_engine {
 
   // ---- audio / features ----
   rvb::DevBuf pcm, feats;        // int16 [n], fp32 [chunks*T0pad][80]
+  // double-buffered upload (rvb_upload_pcm_async): the NEXT recording's samples travel on `copy_stream` into `pcm_next` while
+  // the current one is being decoded; the next rvb_fbank waits for `pcm_ready` on the engine's stream and swaps the buffers
+  rvb::DevBuf pcm_next;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t pcm_ready = nullptr, pcm_free = nullptr;   // pcm_free: the last fbank that read `pcm` has run
+  bool pcm_pending = false;
+  int64_t n_samples_next = 0;
   rvb::DevBuf wave_f32, rs_kernel; // the waveform the fbank reads when it is not int16 PCM at 16 kHz: resampled and / or uploaded as float
   rvb::DevBuf wave_in;             // a float waveform at another rate, before resampling (rvb_upload_wave_f32)
   bool pcm_is_float = false;

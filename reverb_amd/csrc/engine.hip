@@ -1880,6 +1880,10 @@ void rvb_destroy(rvb_engine* e) {
   for (auto ev : e->slice_event_pool) (void)hipEventDestroy(ev);
   for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->pcm_ready) (void)hipEventDestroy(e->pcm_ready);
+  if (e->pcm_free) (void)hipEventDestroy(e->pcm_free);
+  e->pcm_next.release();
   (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1901,14 +1905,46 @@ int rvb_finalize(rvb_engine* e, const float* cat_embs, int n_cat) {
 
 int64_t rvb_num_frames(int64_t n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
 
+// a synchronous upload replaces whatever rvb_upload_pcm_async left pending (the later call wins)
+static int drop_pending_upload(rvb_engine* e) {
+  if (e->pcm_pending) {
+    RVB_HIP_CHECK(hipStreamSynchronize(e->copy_stream));
+    e->pcm_pending = false;
+  }
+  return OK;
+}
+
 int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n) {
   if (!e || (!pcm && n > 0) || n < 0) { set_error("rvb_upload_pcm: bad argument"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(drop_pending_upload(e));
   RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
   if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   e->n_samples = n;
   e->pcm_is_float = false;
+  return OK;
+}
+
+// The double-buffered form: returns as soon as the copy is enqueued on the engine's copy stream (page-locked `pcm`: it then runs
+// on a DMA engine underneath whatever the engine's compute stream is doing -- the decoding of the PREVIOUS recording); the
+// samples become the engine's audio at the next rvb_fbank, which orders itself behind the copy.  `pcm` must stay valid and
+// unchanged until then.  One upload may be pending at a time.
+int rvb_upload_pcm_async(rvb_engine* e, const int16_t* pcm, int64_t n) {
+  if (!e || (!pcm && n > 0) || n < 0) { set_error("rvb_upload_pcm_async: bad argument"); return E_ARG; }
+  if (e->pcm_pending) { set_error("rvb_upload_pcm_async: an upload is already pending (consumed by the next rvb_fbank)"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  if (!e->copy_stream) {
+    RVB_HIP_CHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    RVB_HIP_CHECK(hipEventCreateWithFlags(&e->pcm_ready, hipEventDisableTiming));
+    RVB_HIP_CHECK(hipEventCreateWithFlags(&e->pcm_free, hipEventDisableTiming));
+  }
+  else RVB_HIP_CHECK(hipStreamWaitEvent(e->copy_stream, e->pcm_free, 0));        // WAR: the last fbank may still read a PCM buffer
+  RVB_TRY(e->pcm_next.ensure((size_t)n * 2 + 16));
+  if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm_next.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->copy_stream));
+  RVB_HIP_CHECK(hipEventRecord(e->pcm_ready, e->copy_stream));
+  e->n_samples_next = n;
+  e->pcm_pending = true;
   return OK;
 }
 
@@ -1965,6 +2001,7 @@ int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample
   if (sample_rate == 16000) return rvb_upload_pcm(e, pcm, n);
   if (!e || (!pcm && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_pcm_rate: bad argument"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(drop_pending_upload(e));
   RVB_TRY(e->pcm.ensure((size_t)n * 2 + 16));
   if (n) RVB_HIP_CHECK(hipMemcpyAsync(e->pcm.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
   return resample_uploaded(e, false, n, sample_rate);
@@ -1973,6 +2010,7 @@ int rvb_upload_pcm_rate(rvb_engine* e, const int16_t* pcm, int64_t n, int sample
 int rvb_upload_wave_f32(rvb_engine* e, const float* wave, int64_t n, int sample_rate) {
   if (!e || (!wave && n > 0) || n < 0 || sample_rate < 1000 || sample_rate > 384000) { set_error("rvb_upload_wave_f32: bad argument"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(drop_pending_upload(e));
   rvb::DevBuf& dst = sample_rate == 16000 ? e->wave_f32 : e->wave_in;
   RVB_TRY(dst.ensure((size_t)std::max<int64_t>(n, 1) * 4));
   if (n) RVB_HIP_CHECK(hipMemcpyAsync(dst.p, wave, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
@@ -2002,6 +2040,13 @@ int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
   if (!e) { set_error("rvb_fbank: null engine"); return E_ARG; }
   if (!e->fb_window.p) { set_error("rvb_fbank before rvb_finalize"); return E_STATE; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
+  if (e->pcm_pending) {          // rvb_upload_pcm_async: the samples that went up underneath the previous decode become the audio
+    RVB_HIP_CHECK(hipStreamWaitEvent(e->stream, e->pcm_ready, 0));
+    std::swap(e->pcm, e->pcm_next);
+    e->n_samples = e->n_samples_next;
+    e->pcm_is_float = false;
+    e->pcm_pending = false;
+  }
   const int64_t nf = rvb_num_frames(e->n_samples);
   const int64_t T0 = e->cfg.chunk_frames;
   // zero padded so that ANY chunking with chunk_size <= chunk_frames finds whole chunks (feats_batcher pads the last
@@ -2016,6 +2061,7 @@ int rvb_fbank(rvb_engine* e, float* feats_out, int64_t* n_frames) {
     if (e->pcm_is_float) RVB_TRY(fbank_f32(e->stream, e->wave_f32.as<float>(), nf, e->feats.as<float>(), t));
     else RVB_TRY(fbank(e->stream, e->pcm.as<int16_t>(), nf, e->feats.as<float>(), t));
   }
+  if (e->copy_stream) RVB_HIP_CHECK(hipEventRecord(e->pcm_free, e->stream));     // the PCM buffers are idle from here on
   if (feats_out && nf) {
     RVB_HIP_CHECK(hipMemcpyAsync(feats_out, e->feats.p, (size_t)nf * 80 * 4, hipMemcpyDeviceToHost, e->stream));
     RVB_HIP_CHECK(hipStreamSynchronize(e->stream));

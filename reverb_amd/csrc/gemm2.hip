@@ -732,14 +732,6 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   int s_rd = 1;                     // slot of half-tile ph+1
   int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
   bool first_tile = true;
-  // Candidate (not measured, off by default): the CUs of a launch run their tiles in lockstep, so for the fp32 + residual
-  // shapes (512 KiB of HBM traffic per tile in the epilogue, none in the K loop) the whole chip alternates between an
-  // HBM-bound and a compute-bound phase.  Starting every second CU's first workgroup half a tile late keeps the two halves of
-  // the chip out of phase for the rest of the launch.  `stagger_ticks` = half the expected tile time (host estimate).
-  if (p.stagger_ticks > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    const long long until = wall_clock64() + p.stagger_ticks;
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-  }
   for (;;) {
   const int dbg_i = PERSIST ? lin : (int)blockIdx.x;
   if (p.dbg && tid == 0) {
@@ -790,6 +782,12 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     w_next = uniform_ptr((const char*)((const T*)p.W + (size_t)tn2 * B2N * p.ldw));
   }
   const int nk = p.K / BKE, nh = 4 * nk;
+  // K serpentine (RVB_GEMM2_FLAGS bit 7): the 32 CUs of an XCD run 32 consecutive tiles of its run in lockstep -- one "wave" of
+  // tiles = an 8 x 4 block of the tile grid whose 12 operand panels stream through the XCD's 4-MiB L2 once, front to back --
+  // and the next wave shares 8 (A) or 4 (W) of those panels but starts again at K = 0, whose lines the L2 dropped first.
+  // Odd waves walk K from the far end instead, so they begin with the lines the wave before them touched last.  The fp32
+  // summation order of those tiles is reversed (bf16 engine only; the f32 parity engine runs gemm.hip).
+  const bool k_rev = !CONV && !PERSIST && p.k_serp && ((blockIdx.x >> 8) & 1);
   const unsigned lds_wave = lds_base + wave * 2048;
   // byte offset of K step u in an A row, kept incrementally (no division in the loop): +128 per step; the implicit
   // convolution walks the 3x3 taps, whose (kh, kw .. kw+2) channels are contiguous in NHWC -- only a new kernel row kh
@@ -808,6 +806,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // half-tile ty = {0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1} of K step t (whose A offset is ak) into ring slot `slot`
   auto stage_ty = [&](auto tyc, int t, size_t ak, int slot) __attribute__((always_inline)) {
     constexpr int ty = decltype(tyc)::value;
+    if constexpr (!CONV && !PERSIST) {
+      if (k_rev) { t = nk - 1 - t; ak = (size_t)t * ROW2; }      // this tile walks K downwards (see k_rev)
+    }
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + slot * P_HT);
     if constexpr (ty == 0) dma2(offA[0][0], offA[0][1], uniform_ptr(a_base + ak), dst);
     else if constexpr (ty == 1) dma2(offW[0][0], offW[0][1], uniform_ptr(w_base + (size_t)t * ROW2), dst);
@@ -832,16 +833,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     else stage_ty(std::integral_constant<int, 3>(), t, ak, slot);
   };
   static_assert(P_LEAD - 1 < 8, "the prologue requests half-tiles of K steps 0 and 1 only");
-  // half-tile p+2 (read in the next phase) has landed: everything but the newest min(P_DEPTH, nh-3-p) half-tiles
-  auto wait_tail = [&](int pp) __attribute__((always_inline)) {
-    const int infl = nh - 3 - pp;
-    if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>();
-    else if (infl < 0) {}
-    else if (infl == 0) wait_vm<0>();
-    else if (infl == 1) wait_vm<2>();
-    else wait_vm<4>();
-  };
-  static_assert(P_DEPTH == 3, "wait_tail enumerates the counts below P_DEPTH");
+  static_assert(P_DEPTH == 3, "the tail's counted waits enumerate the counts below P_DEPTH");
 
   // 16x16 fragments: acc[i][j] = rows 16i.., cols 16j.. of the wave's 128x64 tile (C/D: col = lane&15, row = 4*(lane>>4)+r).
   // 32x32 blocks (fp8): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
@@ -1022,8 +1014,12 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // one K step = four phases.  MODE 0: steady state.  MODE 1: the last K steps of a workgroup's last tile, where the ring
   // runs dry: requests and waits become conditional.  MODE 2 (PERSIST): the last K steps of a tile that has a successor --
   // requests past this tile's K go to the next tile, the counted wait stays the steady one.
-  auto kstep = [&](auto modec, int t) __attribute__((always_inline)) {
+  // R (tail form only) = K steps left including this one, a compile-time constant: with it every "is there anything left to
+  // request / to wait for" decision of the tail folds away (round 3 chose them by chains of scalar branches on the phase
+  // counter -- 3 of the 16 K steps of a K = 1024 tile ran that way).
+  auto kstep = [&](auto modec, auto leftc, int t) __attribute__((always_inline)) {
     constexpr int MODE = decltype(modec)::value;
+    constexpr int R = decltype(leftc)::value;
     constexpr bool TAIL = MODE == 1;
     auto ph_head = [&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
@@ -1036,11 +1032,20 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
       } else if constexpr (MODE == 3) {   // K step nk-1: everything requested belongs to the next tile
         stage_next(std::integral_constant<int, ty>(), dt - 1, s_st);
       } else {
-        if (!TAIL || ph + P_LEAD < nh) stage_ty(std::integral_constant<int, ty>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
+        // tail: half-tile ph + P_LEAD exists iff 4 t + j + P_LEAD < 4 nk, i.e. j + P_LEAD < 4 R
+        if constexpr (!TAIL || j + P_LEAD < 4 * R) stage_ty(std::integral_constant<int, ty>(), t + dt, dt == 1 ? ak1 : ak2, s_st);
       }
     };
-    auto ph_wait = [&]() __attribute__((always_inline)) {
-      if (TAIL) wait_tail(ph); else wait_vm<2 * P_DEPTH>();
+    // half-tile ph + 2 (read in the next phase) has landed: everything but the newest min(P_DEPTH, nh - 3 - ph) half-tiles
+    auto ph_wait = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (TAIL) {
+        constexpr int infl = 4 * R - 3 - j;          // = nh - 3 - ph
+        if constexpr (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>();
+        else if constexpr (infl >= 0) wait_vm<2 * (infl < 0 ? 0 : infl)>();
+      } else {
+        wait_vm<2 * P_DEPTH>();
+      }
     };
     ph_head(std::integral_constant<int, 0>());
     if constexpr (F8) {
@@ -1048,13 +1053,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     } else {      // in consumption order: B0's k-half 0 (with the prefetched A0 k-half 0), then the k-half-1 operands
       read_b_khalf(h0, fb0, s_rd); read_a_half(h1, fa_hi, s_cur); read_b_khalf(h1, fb0, s_rd);
     }
-    ph_wait();
+    ph_wait(std::integral_constant<int, 0>());
     mid(); mma_q(c0, c0, fh, fa_hi, fb0); end(); adv();
-    ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait();
+    ph_head(std::integral_constant<int, 1>()); read_b(fb1, s_rd); ph_wait(std::integral_constant<int, 1>());
     mid(); mma_q(c0, c1, fh, fa_hi, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 2>()); read_a_half(h0, fa_lo, s_rd); read_a_half(h1, fa_hi, s_rd); ph_wait();
+    ph_head(std::integral_constant<int, 2>()); read_a_half(h0, fa_lo, s_rd); read_a_half(h1, fa_hi, s_rd); ph_wait(std::integral_constant<int, 2>());
     mid(); mma_q(c1, c1, fa_lo, fa_hi, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 3>()); if (MODE == 0 || MODE == 2 || (MODE == 1 && t + 1 < nk)) read_a_half(h0, fh, s_rd); ph_wait();
+    ph_head(std::integral_constant<int, 3>()); if constexpr (MODE == 0 || MODE == 2 || (MODE == 1 && R > 1)) read_a_half(h0, fh, s_rd); ph_wait(std::integral_constant<int, 3>());
     mid(); mma_q(c1, c0, fa_lo, fa_hi, fb0); end(); adv();
     ak1 = ak2; ac1 = ac2;
     advance(ak2, ac2);
@@ -1064,12 +1069,15 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   if constexpr (PERSIST) {
     // one loop shape for every tile (nk >= 4, host-checked): the workgroup's last tile "prefetches" its own first half-tiles
     // again (a_next = a_base: 80 KiB of harmless reads, drained before the workgroup ends) instead of a third form of the loop
-    for (; t < nk - 2; ++t) kstep(std::integral_constant<int, 0>(), t);
-    kstep(std::integral_constant<int, 2>(), nk - 2);
-    kstep(std::integral_constant<int, 3>(), nk - 1);
+    for (; t < nk - 2; ++t) kstep(std::integral_constant<int, 0>(), c0, t);
+    kstep(std::integral_constant<int, 2>(), c0, nk - 2);
+    kstep(std::integral_constant<int, 3>(), c0, nk - 1);
   } else {
-    for (; t < nk - NTAIL; ++t) kstep(std::integral_constant<int, 0>(), t);
-    for (; t < nk; ++t) kstep(std::integral_constant<int, 1>(), t);
+    static_assert(NTAIL == 3, "the tail is unrolled by hand: K steps with 3, 2 and 1 steps left");
+    for (; t < nk - NTAIL; ++t) kstep(std::integral_constant<int, 0>(), c0, t);
+    if (nk >= 3) kstep(c1, std::integral_constant<int, 3>(), nk - 3);
+    if (nk >= 2) kstep(c1, std::integral_constant<int, 2>(), nk - 2);
+    kstep(c1, c1, nk - 1);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();       // balances the stagger: every wave has executed the same number of barriers
   if (p.dbg && tid == 0) p.dbg[dbg_i * 6 + 2] = wall_clock64();
@@ -1339,6 +1347,9 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          the engine's shapes (1 h r640: fp8 GEMMs 58.6 vs 49.7 ms, step 141.4 vs 132.4 ms, gpurun_out/s5): K = 1024 is only 8
 //          fp8 K steps, so 3 of them run the tail form of the loop, and next to 16-register accumulator blocks the allocator
 //          spills (4-8 scratch accesses per K step in two of the three output variants)
+//   bit 6  (round 4, removed) half-tile start stagger of every second CU for the fp32 + residual shapes: measured +3.4 % GEMM time
+//          (profiles/r04_candidates.txt) -- the epilogue is not burst-bound, the delayed CUs just finish half a tile later
+//   bit 7  K serpentine: odd waves of tiles walk K downwards (see k_rev in gemm2p_kernel)
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -1351,12 +1362,7 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
-  p.stagger_ticks = 0;
-  if ((g_gemm2_flags & 64) && p.res != nullptr && p.out_f32) {
-    // half of (K loop at ~1.45 us per 64-wide K step + ~15 us of epilogue), in 10-ns ticks
-    const double tile_us = 1.45 * (double)((p.K + 63) / 64) + 15.0;
-    p.stagger_ticks = (int)(tile_us * 100.0 / 2.0);
-  }
+  p.k_serp = (g_gemm2_flags >> 7) & 1;
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);

@@ -27,7 +27,7 @@ struct GemmArgs {
   int cT1, cF1, cT2, cF2, cC;
   int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
   int res_epilogue;   // gemm2p: add the residual in the epilogue (prefetched) instead of preloading the accumulators; leave 0
-  int stagger_ticks;  // gemm2p tuning (RVB_GEMM2_FLAGS bit 6): every second workgroup of the first wave starts this many 10-ns ticks late; leave 0
+  int k_serp;         // gemm2p tuning (RVB_GEMM2_FLAGS bit 7): odd waves of tiles walk K downwards (L2 reuse across waves); leave 0
   // fp8 (OCP e4m3) operands, gemm2 only: A and W are bytes, the accumulator is multiplied by a_scale * w_scale[n];
   // out_fp8: C is written as fp8 of value * out_inv_scale (saturating)
   int in_fp8, out_fp8;
@@ -161,6 +161,7 @@ struct AttnArgs {
   const int* work;       // [n_work][2] = {sequence, first query} per block instead of the (max_q / q_block, nseq) grid
   int n_work;
   int q_block;           // queries per workgroup: 0 / 128 (8 waves) or 16 (1 wave; decoder forms only)
+  int plain_order;       // tuning (RVB_ATTN_PLAIN=1): keep the launch order instead of the XCD-aware (sequence, head) grouping
 };
 int attention(hipStream_t s, int dtype, const AttnArgs& a);
 

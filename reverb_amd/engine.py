@@ -155,6 +155,7 @@ class Engine:
     def upload_pcm(self, pcm: np.ndarray, sample_rate: int = 16000):
         """Mono waveform -> HBM; other rates than 16 kHz are resampled on the device (reverb.py:128-134).  int16 PCM stays
         int16; a float32 array (the `.to(torch.float)` of a source whose native format is not int16) is uploaded as it is."""
+        self._n_samples_next = None             # a synchronous upload replaces a pending upload_pcm_async
         if isinstance(pcm, np.ndarray) and pcm.dtype.kind == "f":
             wave = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
             check(self.lib.rvb_upload_wave_f32(self.handle, wave.ctypes.data_as(_lib._f32p), len(wave), int(sample_rate)),
@@ -173,6 +174,16 @@ class Engine:
             n = C.c_int64(0)
             check(self.lib.rvb_get_waveform(self.handle, None, C.byref(n)), "rvb_get_waveform")
             self._n_samples = int(n.value)
+
+    def upload_pcm_async(self, pcm: np.ndarray):
+        """Double-buffered upload of the NEXT recording (16 kHz int16, ideally a pinned_pcm() array): returns at once, the copy
+        runs underneath the decoding in progress, and the samples become the engine's audio at the next fbank().  `pcm` must
+        not change until then."""
+        assert isinstance(pcm, np.ndarray) and pcm.dtype == np.int16 and pcm.flags["C_CONTIGUOUS"]
+        pcm = pcm.reshape(-1)
+        check(self.lib.rvb_upload_pcm_async(self.handle, pcm.ctypes.data_as(_lib._i16p), len(pcm)), "rvb_upload_pcm_async")
+        self._pending_pcm = pcm                 # keeps the host buffer alive until the copy has been consumed
+        self._n_samples_next = len(pcm)
 
     def set_decoding_chunk(self, chunk_size: int = -1, num_left_chunks: int = -1):
         """Chunk mask of the encoder self-attention for the next encode() calls (<= 0: full context)."""
@@ -234,6 +245,8 @@ class Engine:
         (and the (n_frames, 80) float32 array when asked)."""
         n = C.c_int64(0)
         out = None
+        if getattr(self, "_n_samples_next", None) is not None:      # upload_pcm_async: this call makes those samples the audio
+            self._n_samples, self._n_samples_next = self._n_samples_next, None
         if return_feats:
             out = np.empty((int(self.lib.rvb_num_frames(self._n_samples)), 80), np.float32)
         check(self.lib.rvb_fbank(self.handle, fptr(out), C.byref(n)), "rvb_fbank")

@@ -186,25 +186,27 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
     either does with the fp32 oracle; the timing keys prove that both kernels really ran."""
     from reverb_amd.diar_engine import DiarEngine
     out, flops, ig = {}, {}, {}
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):            # 2 = the default since round 4: the stride-2 convolutions of stages 3-4 as well
         monkeypatch.setenv("RVD_CONV_IGEMM", flag)
         eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
         eng.upload(case["pcm"])
         eng.reset_timings(); eng.set_profiling(True)
         out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
         eng.set_profiling(False)
-        flops[flag] = eng.timing("emb_conv_128")[1] + eng.timing("emb_conv_256")[1]
+        flops[flag] = sum(eng.timing(k)[1] for k in ("emb_conv_128", "emb_conv_256", "emb_conv_s2_128", "emb_conv_s2_256"))
         ig[flag] = eng.timing("emb_conv_igemm")[2]
         eng.close()
-    assert flops["0"] == flops["1"] > 0
+    assert flops["0"] == flops["1"] == flops["2"] > 0
     assert ig["0"] == 0 and ig["1"] >= 16          # 11 + 5 stride-1 3x3 convolutions of stages 3-4 per trunk pass
+    assert ig["2"] == ig["1"] // 16 * 18           # + the two stride-2 convolutions that open those stages
     active = emb_case["masks"].sum(1) > 0
-    a, b = out["0"][active], out["1"][active]
-    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-    assert cos.min() > 0.9995, cos
     want = emb_case["want"][active]
-    cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
-    assert cosw.min() > 0.995, cosw
+    for flag in ("1", "2"):
+        a, b = out["0"][active], out[flag][active]
+        cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        assert cos.min() > 0.9995, (flag, cos)
+        cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
+        assert cosw.min() > 0.995, (flag, cosw)
 
 
 def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):

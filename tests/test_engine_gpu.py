@@ -262,6 +262,38 @@ def test_slice_pipeline_and_bulk_results_equal_plain_path():
     eng.close()
 
 
+def test_double_buffered_upload_gives_the_same_features():
+    """rvb_upload_pcm_async (round 4: the next recording's samples travel on a copy stream underneath the decoding in
+    progress and become the audio at the next rvb_fbank): three recordings of different lengths back to back, each
+    uploaded while the one before it is the engine's audio -- features bit-identical to the synchronous upload, a second
+    pending upload is refused, and the buffers alternate without mixing recordings."""
+    case = Case("tiny_ln")
+    eng = _engine(case, "f32")
+    recs = [synth.synth_audio(3.0 + 1.7 * i, seed=20 + i) for i in range(3)]
+    want = []
+    for r in recs:
+        eng.upload_pcm(r)
+        want.append(eng.fbank(return_feats=True)[1].copy())
+    pins = []
+    for r in recs:
+        b = eng.pinned_pcm(len(r)); b[:] = r; pins.append(b)
+    eng.upload_pcm_async(pins[0])
+    with pytest.raises(Exception, match="already pending"):
+        eng.upload_pcm_async(pins[1])
+    for i in range(3):
+        nf, got = eng.fbank(return_feats=True)           # consumes upload i
+        if i + 1 < 3:
+            eng.upload_pcm_async(pins[i + 1])            # goes up while recording i is the engine's audio
+        assert nf == want[i].shape[0]
+        np.testing.assert_array_equal(got, want[i])
+    np.testing.assert_array_equal(eng.fbank(return_feats=True)[1], want[2])     # nothing pending: the same audio again
+    eng.upload_pcm(recs[0])                              # the synchronous form still works afterwards
+    np.testing.assert_array_equal(eng.fbank(return_feats=True)[1], want[0])
+    eng.upload_pcm_async(pins[1])                        # and an upload over a synchronously uploaded recording
+    np.testing.assert_array_equal(eng.fbank(return_feats=True)[1], want[1])
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------ `attention` mode
 @pytest.mark.parametrize("name", ["tiny_ln", "tiny_ln_r2l", "tiny_bn", "small_ln"])
 def test_attention_mode_f32_matches_reference_golden(name):
