@@ -235,10 +235,17 @@ def main():
         import torch.distributed as dist
         if STUB:
             dist.init_process_group("gloo")
-        else:
+        elif os.environ.get("RVB_COMM", "cabi") == "torch":      # everything through torch.distributed's own RCCL communicator
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()          # what the process group (RCCL) reports, not what the environment claims
+        else:
+            # round 4: torch.distributed is the RENDEZVOUS only (a CPU gloo group that carries the 128-byte RCCL id once, and
+            # whose store is the side channel of the failure path); every collective of the run -- the result gather, the
+            # barriers around the timed region, the maximum of the step time -- goes through librvb's own communicator
+            # (rvb_comm_*), so a rank holds ONE RCCL communicator
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()          # what the process group reports, not what the environment claims
     if not STUB and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cpu") if STUB else torch.device("cuda", local_rank)
@@ -287,19 +294,25 @@ def main():
             hyps = all_gather_results(hyps, device, comm=comm)     # rows stay packed until somebody reads them (dist.GatheredResults)
             ntok = hyps.total_tokens()
             if args.gather == "posteriors" and comm is not None:
-                # the top-beam posteriors of this rank's last launch, host-staged through the same collective
-                v, i = eng.ctc_topk()
-                packed = np.concatenate([v.reshape(-1).view(np.uint8), i.reshape(-1).view(np.uint8)])
-                stats["posterior_bytes_gathered"] = int(comm.all_gather(packed).nbytes)
+                # the top-beam posteriors of this rank's last launch, gathered DEVICE TO DEVICE (round 4: straight out of the
+                # engine's HBM buffers into the communicator's, rvb_comm_allgather_topk; round 3 staged them through the host)
+                nbytes, _ = comm.all_gather_topk(eng)
+                stats["posterior_bytes_gathered"] = int(nbytes) * world
         return hyps, ntok
 
     def sync():
         if not STUB:
             torch.cuda.synchronize()
 
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        else:
+            dist.barrier()
+
     def timed(k, **kw):
         if use_dist:
-            dist.barrier()
+            barrier()
         sync()
         t0 = time.perf_counter()
         if kw.get("upload"):
@@ -308,12 +321,15 @@ def main():
             r = step(last=i + 1 == k, **kw)
         sync()
         if use_dist:
-            dist.barrier()
+            barrier()
         dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            if comm is not None:
+                dt = comm.max(dt)
+            else:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
         return dt, r
 
     for _ in range(args.warmup):
@@ -397,7 +413,8 @@ def main():
                                    f"ctc_weight {args.ctc_weight}, reverse_weight {args.reverse_weight}",
                        "chunks_per_launch": per_launch, "parallelism": f"chunk-shard x{world}",
                        "world_size_reported_by_process_group": world if use_dist else 1,
-                       "backend": (("librvb rvb_comm_allgather (RCCL)" if comm else dist.get_backend()) if use_dist else None),
+                       "backend": (("librvb rvb_comm_* (RCCL): gather, barriers, time reduction; torch.distributed " + dist.get_backend() +
+                                    " = rendezvous only" if comm else dist.get_backend()) if use_dist else None),
                        "gather": args.gather if use_dist else None,
                        "posterior_bytes_gathered_per_step": stats.get("posterior_bytes_gathered"),
                        "results_gathered": len(hyps), "tokens_per_step": int(ntok),

@@ -109,20 +109,33 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
         step()
     eng = pipe.engine
     eng.reset_timings(); eng.set_profiling(True)
+    comm = None
+    if use_dist:       # barriers and the time reduction through librvb's communicator (the one diarize_sharded gathers on)
+        from reverb_amd.dist import default_comm
+        comm = default_comm(pipe.device_index if pipe.device_index is not None else device)
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        else:
+            dist.barrier()
     if use_dist:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         ann = step()
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if comm is not None:
+            dt = comm.max(dt)
+        else:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
     eng.set_profiling(False)
     out = None
     if rank == 0:
@@ -181,7 +194,10 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RVB_COMM", "cabi") == "torch":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")       # rendezvous only (see bench.py): the collectives are librvb's
         world = dist.get_world_size()
     if not torch.cuda.is_available():
         raise SystemExit("bench_diar.py needs an MI355X: the networks have no CPU fallback")

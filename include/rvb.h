@@ -26,6 +26,7 @@ extern "C" {
 #define RVB_E_STATE -3
 #define RVB_E_NOMEM -4
 #define RVB_E_UNSUPPORTED -5
+#define RVB_E_TIMEOUT -7        /* a collective did not complete within rvb_comm_set_timeout (-6: corrupt audio data) */
 
 #define RVB_F32 0  /* parity mode: v_mfma_f32_16x16x4_f32, exact f32 fma chains */
 #define RVB_BF16 1 /* throughput mode: v_mfma_f32_16x16x32_bf16, fp32 accumulate/residual */
@@ -259,6 +260,20 @@ int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv)
 /* The collective alone (device to device, HIP events on the communicator's stream, checked): average milliseconds of one
  * all-gather of `bytes` bytes per rank -- the xGMI datapoint of SURVEY 8(e) for the top-beam posterior exchange. */
 int rvb_comm_time_allgather(rvb_comm* c, int64_t bytes, int iters, double* avg_ms);
+/* Failure handling (the reference has none: it is single-process).  With a timeout set, a collective that
+ * does not complete in `seconds` -- a peer died or hangs -- returns RVB_E_TIMEOUT instead of blocking for ever; the
+ * communicator is aborted (ncclCommAbort) and every later call on it returns RVB_E_STATE.  The host then exchanges through
+ * its rendezvous channel and re-queues the missing rank's chunk range (reverb_amd/dist.py: decode_sharded).  0 = wait for ever. */
+int rvb_comm_set_timeout(rvb_comm* c, double seconds);
+/* What a launcher needs of a process group besides the gather: a barrier and the maximum of a double over the ranks
+ * (bench.py's step timing) -- 8-byte all-gathers on the same communicator, so a rank holds ONE RCCL communicator. */
+int rvb_comm_barrier(rvb_comm* c);
+int rvb_comm_max_f64(rvb_comm* c, double* value /* in: this rank's, out: the maximum */);
+/* The alternative exchange of SURVEY.md 8(e) -- top-beam CTC posteriors instead of decoded results -- device to device: the
+ * [B, T, k] fp32 log-probs and int32 ids of the engine's last rvb_encode are gathered straight out of HBM into the
+ * communicator's device buffer ([world][vals] then [world][ids]); host_out (nullable, 2 * world * B*T*k*4 bytes) receives a
+ * copy; *bytes_per_rank = B*T*k*8.  Every rank must hold the same batch shape. */
+int rvb_comm_allgather_topk(rvb_comm* c, rvb_engine* e, void* host_out, int64_t* bytes_per_rank);
 int rvb_comm_free(rvb_comm* c);
 int rvb_comm_init(rvb_engine* e, int world, int rank, const void* id128);
 int rvb_allgather_results(rvb_engine* e, const void* send, int64_t bytes, void* recv);

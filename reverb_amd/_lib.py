@@ -97,6 +97,10 @@ SIGNATURES = {
     "rvb_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rvb_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rvb_comm_time_allgather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
+    "rvb_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "rvb_comm_barrier": (C.c_int, [C.c_void_p]),
+    "rvb_comm_max_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "rvb_comm_allgather_topk": (C.c_int, [C.c_void_p, _eng, C.c_void_p, _i64p]),
     "rvb_comm_free": (C.c_int, [C.c_void_p]),
     "rvb_allgather_results": (C.c_int, [_eng, C.c_void_p, C.c_int64, C.c_void_p]),
     "rvb_comm_destroy": (C.c_int, [_eng]),

@@ -6,7 +6,10 @@
 // socket; reverb_amd/dist.py's RvbComm broadcasts it over an existing torch.distributed group or takes it from a file).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include <cstring>
 
@@ -19,6 +22,7 @@ namespace {
 typedef int (*GetUniqueIdFn)(void*);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int /* ncclDataType_t */, void*, hipStream_t);
 typedef int (*CommDestroyFn)(void*);
+typedef int (*CommAbortFn)(void*);
 typedef const char* (*GetErrorStringFn)(int);
 
 }  // namespace
@@ -31,6 +35,7 @@ struct Rccl {
   int (*init_rank)(void**, int, Id128, int) = nullptr;
   AllGatherFn all_gather = nullptr;
   CommDestroyFn destroy = nullptr;
+  CommAbortFn abort = nullptr;           // optional (ncclCommAbort): tears a communicator down without waiting for its peers
   GetErrorStringFn err = nullptr;
 };
 Rccl g_rccl;
@@ -51,6 +56,7 @@ int load_rccl() {
     g_rccl.init_rank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.all_gather = (AllGatherFn)dlsym(g_rccl.lib, "ncclAllGather");
     g_rccl.destroy = (CommDestroyFn)dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.abort = (CommAbortFn)dlsym(g_rccl.lib, "ncclCommAbort");
     g_rccl.err = (GetErrorStringFn)dlsym(g_rccl.lib, "ncclGetErrorString");
   });
   if (!g_rccl.lib || !g_rccl.get_id || !g_rccl.init_rank || !g_rccl.all_gather || !g_rccl.destroy) {
@@ -83,7 +89,40 @@ struct rvb_comm {
   void* nccl = nullptr;
   hipStream_t stream = nullptr;
   rvb::DevBuf send, recv;
+  double timeout_s = 0.0;        // 0 = wait for ever (rvb_comm_set_timeout)
+  bool dead = false;             // a collective timed out: the communicator was aborted and refuses further calls
+  hipEvent_t done = nullptr;
 };
+
+// Wait for everything enqueued on the communicator's stream -- for ever, or (rvb_comm_set_timeout) until the deadline: a peer
+// that died or hangs never joins the collective and the kernel RCCL launched would spin for ever.  On a timeout the
+// communicator is aborted (ncclCommAbort where the library has it; its stream is abandoned, not synchronised) and marked
+// dead: RVB_E_TIMEOUT now and RVB_E_STATE for every later call, so that the host can switch to its fall-back exchange
+// (reverb_amd/dist.py: the rendezvous store) instead of hanging the job.
+static int comm_wait(rvb_comm* c, const char* what) {
+  if (c->timeout_s <= 0.0) { RVB_HIP_CHECK(hipStreamSynchronize(c->stream)); return rvb::OK; }
+  if (!c->done) RVB_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  RVB_HIP_CHECK(hipEventRecord(c->done, c->stream));
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(c->timeout_s);
+  for (;;) {
+    const hipError_t q = hipEventQuery(c->done);
+    if (q == hipSuccess) return rvb::OK;
+    if (q != hipErrorNotReady) { rvb::set_error(std::string(what) + ": " + hipGetErrorString(q)); return rvb::E_HIP; }
+    if (std::chrono::steady_clock::now() > deadline) break;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  c->dead = true;
+  if (g_rccl.abort && c->nccl) {
+    // ncclCommAbort makes the communicator's kernels leave their wait loops, so the stream drains: wait for that, or the copies
+    // queued behind the collective could still land in host buffers the caller is about to free
+    (void)g_rccl.abort(c->nccl);
+    c->nccl = nullptr;
+    (void)hipStreamSynchronize(c->stream);
+  }
+  rvb::set_error(std::string(what) + ": no completion within " + std::to_string(c->timeout_s) + " s (a peer is missing); communicator aborted");
+  return rvb::E_TIMEOUT;
+}
+#define RVB_COMM_ALIVE(c, what) do { if ((c)->dead) { set_error(std::string(what) + ": the communicator was aborted after a timeout"); return E_STATE; } } while (0)
 
 int rvb_comm_create(int device, int world, int rank, const void* id128, rvb_comm** out) {
   if (!out || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("rvb_comm_create: bad argument"); return E_ARG; }
@@ -106,6 +145,7 @@ int rvb_comm_create(int device, int world, int rank, const void* id128, rvb_comm
 // every rank contributes `bytes` bytes (host memory); `recv` (host, world * bytes) receives them in rank order
 int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv) {
   if (!c || !send || !recv || bytes <= 0) { set_error("rvb_comm_allgather: bad argument"); return E_ARG; }
+  RVB_COMM_ALIVE(c, "rvb_comm_allgather");
   RVB_HIP_CHECK(hipSetDevice(c->device));
   int r = c->send.ensure((size_t)bytes);
   if (r != OK) return r;
@@ -115,8 +155,57 @@ int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv)
   const int rc = g_rccl.all_gather(c->send.p, c->recv.p, (size_t)bytes, 0 /* ncclInt8 */, c->nccl, c->stream);
   if (rc != 0) return nccl_fail("ncclAllGather", rc);
   RVB_HIP_CHECK(hipMemcpyAsync(recv, c->recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
-  RVB_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return comm_wait(c, "rvb_comm_allgather");
+}
+
+int rvb_comm_set_timeout(rvb_comm* c, double seconds) {
+  if (!c || seconds < 0.0) { set_error("rvb_comm_set_timeout: bad argument"); return E_ARG; }
+  c->timeout_s = seconds;
   return OK;
+}
+
+// barrier and max-reduction as 8-byte all-gathers on the same communicator: the launcher needs nothing else of a process
+// group (bench.py's step timing: barrier, K steps, barrier, maximum over the ranks)
+int rvb_comm_barrier(rvb_comm* c) {
+  if (!c) { set_error("rvb_comm_barrier: null communicator"); return E_ARG; }
+  double mine = 0.0;
+  std::vector<double> all((size_t)c->world);
+  return rvb_comm_allgather(c, &mine, 8, all.data());
+}
+int rvb_comm_max_f64(rvb_comm* c, double* value) {
+  if (!c || !value) { set_error("rvb_comm_max_f64: null argument"); return E_ARG; }
+  std::vector<double> all((size_t)c->world);
+  const int r = rvb_comm_allgather(c, value, 8, all.data());
+  if (r != OK) return r;
+  double m = all[0];
+  for (double v : all) m = v > m ? v : m;
+  *value = m;
+  return OK;
+}
+
+// The posterior exchange of SURVEY.md 8(e), device to device: every rank's per-frame top-k CTC log-probs and token ids of the
+// last rvb_encode ([B, T, k] fp32 and int32, already in HBM) are gathered straight from the engine's buffers into the
+// communicator's receive buffer -- [world][vals] followed by [world][ids] -- with no host staging.  `host_out` (nullable,
+// 2 * world * bytes_per_rank_per_array) receives a copy for a host that searches centrally; *bytes_per_rank = B * T * k * 8.
+// Every rank must hold the same batch shape.
+int rvb_comm_allgather_topk(rvb_comm* c, rvb_engine* e, void* host_out, int64_t* bytes_per_rank) {
+  if (!c || !e) { set_error("rvb_comm_allgather_topk: null argument"); return E_ARG; }
+  RVB_COMM_ALIVE(c, "rvb_comm_allgather_topk");
+  if (e->B <= 0 || !e->topv.p || !e->topi.p) { set_error("rvb_comm_allgather_topk: no encoded batch"); return E_STATE; }
+  if (e->device != c->device) { set_error("rvb_comm_allgather_topk: engine and communicator are on different devices"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(c->device));
+  const size_t part = (size_t)e->B * e->T2 * e->beam * 4;
+  int r = c->recv.ensure(2 * part * c->world);
+  if (r != OK) return r;
+  if (!c->done) RVB_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  RVB_HIP_CHECK(hipEventRecord(c->done, e->stream));                 // the encoder's top-k kernels come first
+  RVB_HIP_CHECK(hipStreamWaitEvent(c->stream, c->done, 0));
+  int rc = g_rccl.all_gather(e->topv.p, c->recv.p, part, 0 /* ncclInt8 */, c->nccl, c->stream);
+  if (rc == 0) rc = g_rccl.all_gather(e->topi.p, (char*)c->recv.p + part * c->world, part, 0, c->nccl, c->stream);
+  if (rc != 0) return nccl_fail("ncclAllGather", rc);
+  if (host_out) RVB_HIP_CHECK(hipMemcpyAsync(host_out, c->recv.p, 2 * part * c->world, hipMemcpyDeviceToHost, c->stream));
+  if (bytes_per_rank) *bytes_per_rank = (int64_t)(2 * part);
+  return comm_wait(c, "rvb_comm_allgather_topk");
 }
 
 // The collective alone, device buffer to device buffer: `iters` all-gathers of `bytes` bytes per rank between two HIP
@@ -124,6 +213,7 @@ int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv)
 // last gather is checked on the host, so a figure is never reported for an exchange that did not happen.
 int rvb_comm_time_allgather(rvb_comm* c, int64_t bytes, int iters, double* avg_ms) {
   if (!c || bytes <= 0 || iters < 1 || !avg_ms) { set_error("rvb_comm_time_allgather: bad argument"); return E_ARG; }
+  RVB_COMM_ALIVE(c, "rvb_comm_time_allgather");
   RVB_HIP_CHECK(hipSetDevice(c->device));
   int r = c->send.ensure((size_t)bytes);
   if (r != OK) return r;
@@ -164,10 +254,13 @@ int rvb_comm_time_allgather(rvb_comm* c, int64_t bytes, int iters, double* avg_m
 int rvb_comm_free(rvb_comm* c) {
   if (!c) return OK;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  // a dead communicator whose library has no ncclCommAbort may never drain: its stream and buffers are then abandoned
+  const bool drained = !c->dead || (g_rccl.abort != nullptr);
+  if (c->stream && drained) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) g_rccl.destroy(c->nccl);
-  c->send.release(); c->recv.release();
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->done) (void)hipEventDestroy(c->done);
+  if (drained) { c->send.release(); c->recv.release(); }
+  if (c->stream && drained) (void)hipStreamDestroy(c->stream);
   delete c;
   return OK;
 }

@@ -165,7 +165,7 @@ __device__ inline float wave_sum_dpp(float v) {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ status codes (include/rvb.h)
-enum { OK = 0, E_ARG = -1, E_HIP = -2, E_STATE = -3, E_NOMEM = -4, E_UNSUPPORTED = -5 };
+enum { OK = 0, E_ARG = -1, E_HIP = -2, E_STATE = -3, E_NOMEM = -4, E_UNSUPPORTED = -5, E_TIMEOUT = -7 /* -6: corrupt audio data (audio.cpp) */ };
 
 }  // namespace rvb
 

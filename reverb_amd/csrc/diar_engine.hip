@@ -802,9 +802,10 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
   if (n > 46000) { set_error("rvd_centroid_linkage: more than 46000 points"); return E_UNSUPPORTED; }   // n^2 index and uint16 sizes
   if (n == 1) return OK;
   RVB_HIP_CHECK(hipSetDevice(e->device));
-  DevBuf dX, dD, dI, dM, dZ;
+  DevBuf dX, dD, dI, dM, dZ, dC;
   int rc = OK;
   do {
+    if ((rc = dC.ensure(4096)) != OK) break;
     if ((rc = dX.ensure((size_t)n * d * 8)) != OK) break;
     if ((rc = dD.ensure((size_t)n * n * 8)) != OK) break;
     if ((rc = dI.ensure((size_t)3 * n * 4)) != OK) break;
@@ -820,7 +821,7 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     {
       DScope sc(e, "linkage");
       rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), (uint16_t*)(dI.as<int>() + 2 * n), dI.as<int>(),
-                            dI.as<int>() + n, dM.as<double>(), dZ.as<double>());
+                            dI.as<int>() + n, dM.as<double>(), dZ.as<double>(), dC.p);
     }
     if (rc != OK) break;
     if (hipMemcpyAsync(Z, dZ.p, (size_t)(n - 1) * 4 * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
@@ -844,7 +845,7 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
       cid[y] = n + k;
     }
   } while (0);
-  dX.release(); dD.release(); dI.release(); dM.release(); dZ.release();
+  dX.release(); dD.release(); dI.release(); dM.release(); dZ.release(); dC.release();
   return rc;
 }
 

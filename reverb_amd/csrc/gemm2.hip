@@ -1349,7 +1349,8 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          spills (4-8 scratch accesses per K step in two of the three output variants)
 //   bit 6  (round 4, removed) half-tile start stagger of every second CU for the fp32 + residual shapes: measured +3.4 % GEMM time
 //          (profiles/r04_candidates.txt) -- the epilogue is not burst-bound, the delayed CUs just finish half a tile later
-//   bit 7  K serpentine: odd waves of tiles walk K downwards (see k_rev in gemm2p_kernel)
+//   bit 7  K serpentine on for every shape, bit 8 on for N <= 2048 (default: off -- measured neutral in the engine): odd waves
+//          of tiles walk K downwards (see k_rev in gemm2p_kernel)
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -1362,7 +1363,12 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
-  p.k_serp = (g_gemm2_flags >> 7) & 1;
+  // K serpentine (round 4): in the kernel benchmark, where one launch is repeated and its operands sit in the Infinity Cache, it
+  // is worth +4.6 % on ffn2, +4.3 % on pw1, +5.5 % on embed, -3.7 % on ffn1 (profiles/r04_call2_ab.txt); in the ENGINE, where a
+  // GEMM's operands were written by the kernel before it, neither "all shapes" nor "N <= 2048 only" moves the GEMM time of the
+  // bench hour (104.5 vs 104.6 ms; 102.7 vs 102.7 ms, profiles/r04_call3_linkage_serp.txt).  Off by default; bit 7 = every shape,
+  // bit 8 = the shapes with N <= 2048.
+  p.k_serp = (g_gemm2_flags & 128) ? 1 : ((g_gemm2_flags & 256) ? (p.N <= 2048 ? 1 : 0) : 0);
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);

@@ -254,8 +254,10 @@ int tstp_pool(hipStream_t s, int dtype, const void* x, const int* item_b, const 
 // ---------------------------------------------------------------- linkage.hip
 // scipy.cluster.hierarchy.linkage(X, "centroid", "euclidean") for X fp64 [n][d] (device): Z fp64 [n-1][4] in merge
 // order.  Scratch (device): D [n*n] doubles, size [n] uint16 (initialised to 1), cluster_id [n] (arange) and
-// neighbor [n] ints, min_dist [n] doubles.
+// neighbor [n] ints, min_dist [n] doubles, scratch >= 4 KiB (control block of the multi-workgroup merge loop; null = one
+// workgroup only).  From 3 000 points on the merge loop runs on 16 workgroups of one XCD (RVD_LINKAGE_MB) and the call then
+// returns after the loop has finished (it checks the loop's status and falls back to the one-workgroup loop if needed).
 int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
-                     double* min_dist, double* Z);
+                     double* min_dist, double* Z, void* scratch);
 
 }  // namespace rvb

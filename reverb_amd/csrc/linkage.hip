@@ -8,6 +8,7 @@
 // candidates with lazy validation, Lance-Williams centroid update) restated step for step so that the
 // dendrogram is the same -- runs as ONE persistent 1024-thread workgroup: every merge is a block-wide
 // argmin over the candidate distances plus one fused pass over the two merged rows.
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -161,6 +162,14 @@ __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__
   for (int j = x + 1 + threadIdx.x; j < n; j += 256) p = min_pair(p, MinPair{D[(size_t)x * n + j], j});
   p = block_argmin(p, red);
   if (threadIdx.x == 0) { neighbor[x] = p.v < INFINITY ? p.i : -1; min_dist[x] = p.v; }
+}
+
+// Lance-Williams centroid update, scipy's `_centroid` with the two divisions of a merge hoisted: sub = nx ny d(x,y)^2 / (nx + ny)
+// and inv_fs = 1 / (nx + ny) are formed once per merge.  One definition for both merge loops, contraction off, so that the
+// single-workgroup kernel and the multi-workgroup kernel round identically (their dendrograms are compared bit for bit).
+__device__ inline double lw_centroid(double fx, double fy, double dxi, double dyi, double sub, double inv_fs) {
+#pragma clang fp contract(off)
+  return sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) * inv_fs);
 }
 
 // ------------------------------------------------------------------------------------ merge loop (one workgroup)
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
         int z = slot(base, e);
         asm volatile("" : "+v"(z));              // addresses are formed here, not hoisted for all LK_E elements at once
         const double dxi = dxv[e], dyi = dyv[e];
-        const double nd = sqrt((((fx * dxi * dxi) + (fy * dyi * dyi)) - sub) * inv_fs);
+        const double nd = lw_centroid(fx, fy, dxi, dyi, sub, inv_fs);
         ry[z] = nd;
         D[(size_t)z * n + y] = nd;
         if (z < y) {
@@ -370,32 +379,345 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
   if (tid == 0) g_min_dist[n - 1] = (double)retries;     // statistics: invalid candidates re-evaluated (slot n-1 is unused)
 }
 
+// ------------------------------------------------------------------------------------ merge loop (MB_G workgroups of ONE XCD)
+// Round 4.  The one-workgroup loop above is bound by what a single CU can issue per merge (a fused fp64 pass over the live
+// slots + 3-4 block reductions: ~10 us per merge at n = 9 200, ~75 us at n = 27 000 where its state no longer fits LDS) and it
+// is replicated on every rank of a sharded run: 91 ms of a 430 ms hour, 1.6 s of the 2.6 s that config 5's three hours take.
+// Here MB_G = 16 persistent workgroups share a merge:
+//
+//   * slot z belongs to workgroup (z / 16) mod MB_G (16 consecutive slots = one 128-byte line of a row of D); the owner keeps
+//     the slot's nearest-neighbour candidate (lower bound, neighbour, validity in the neighbour's sign -- exactly the
+//     one-workgroup loop's encoding of scipy's lazy `dist == D[x, neighbor[x]]`) in ITS LDS.  Cluster sizes (uint16) are
+//     replicated in every workgroup's LDS: every workgroup applies every merge to its copy.
+//   * a ROUND = every workgroup publishes 48 bytes -- its best VALID candidate (distance, x, neighbour), its smallest STALE lower
+//     bound (distance, z), and its share of the nearest neighbour of the cluster the previous merge created (the minimum of the
+//     distances it just wrote into that row, over its slots above it) -- then ONE grid barrier, then every wave reads the 16
+//     entries and reduces them in registers (DPP), so all workgroups derive the same decision without a second exchange:
+//       - the best valid candidate is lexicographically (distance, slot) below every stale bound -> that pair is merged (what
+//         scipy's heap pops once its top is valid);
+//       - otherwise the stale rows whose bound lies below the best valid candidate are rescanned, each by its owner, all
+//         workgroups in parallel (scipy rescans the same rows, one heap pop at a time), and the round repeats.
+//     A rescan is block-local: every entry of row z other than column y / row y of the merge in progress was written either by
+//     the owner itself or at least one barrier ago, and the liveness of the columns is in the replicated sizes.
+//     (A first version kept every candidate exact and rescanned eagerly: correct, 65 ms for the pipeline's hour, but 30-140
+//     rescans per merge on high-dimensional noise, where a few hub points are everybody's neighbour: 0.8-3.2 s.)
+//   * coherence without cache maintenance: all workgroups run on ONE XCD (they share its L2), shared data (D, the published
+//     entries, the barrier word) is read and written with agent-scope relaxed atomics (sc1: past the CU's vector L1, served by
+//     the XCD's L2), and a workgroup arrives at the barrier only after every thread has waited for its own stores
+//     (`s_waitcnt vmcnt(0)`: acknowledged by the L2).  No release / acquire fences: on a multi-XCD part those write back /
+//     invalidate the whole L2.  Workgroups find each other at start-up: 8 x (MB_G + 8) are launched (round robin over the 8
+//     XCDs), the first to arrive names its XCD (HW_REG_XCC_ID), the first MB_G arrivals on that XCD take tickets, everybody
+//     else returns at once.  Every spin is bounded; a barrier that does not complete sets an abort word, the kernel returns
+//     with status -2 and centroid_linkage() falls back to the one-workgroup loop.
+static constexpr int MB_G = 16, MB_NT = 1024;
+struct LkEntry { double val_v; int val_x, val_y; double st_v; int st_z, pad0; double part_v; int part_z, pad1; };   // 48 bytes
+struct LkCtl { int xcc, tickets; unsigned bar; int abort; LkEntry ent[2][MB_G]; };
+static_assert(sizeof(LkEntry) == 48, "published entry: six 8-byte words");
+
+__device__ inline unsigned long long mb_ld64(const void* p) {
+  return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void mb_st64(void* p, unsigned long long v) {
+  __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double mb_ldf(const double* p) { return __longlong_as_double((long long)mb_ld64(p)); }
+__device__ inline void mb_stf(double* p, double v) { mb_st64(p, (unsigned long long)__double_as_longlong(v)); }
+__device__ inline void mb_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline bool lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }
+
+// all MB_G workgroups have arrived `gen` times; false = gave up (abort word set, by us or by somebody else)
+__device__ inline bool mb_grid_barrier(LkCtl* ctl, unsigned gen, int* s_flag) {
+  __syncthreads();                       // every thread of the workgroup has waited for its stores (caller)
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = gen * (unsigned)MB_G;
+    unsigned spins = 0;
+    int ok = 1;
+    while ((int)(__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0) {
+        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || spins > (1u << 22)) {
+          __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ D, int n, const int* __restrict__ g_neighbor,
+                                                           double* __restrict__ g_min_dist, double* __restrict__ Z, LkCtl* ctl) {
+  extern __shared__ __attribute__((aligned(16))) char mb_smem[];
+  __shared__ MinPair red[2][16];
+  __shared__ int s_wtot[16];
+  __shared__ int s_b, s_flag, s_rcount, s_acount;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // ---- which workgroups take part
+  if (tid == 0) {
+    const int my = (int)(__builtin_amdgcn_s_getreg(63508) & 0xf) + 1;      // HW_REG_XCC_ID + 1
+    int expected = 0;
+    __hip_atomic_compare_exchange_strong(&ctl->xcc, &expected, my, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int chosen = expected == 0 ? my : expected;
+    int b = -1;
+    if (chosen == my) {
+      b = __hip_atomic_fetch_add(&ctl->tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b >= MB_G) b = -1;
+    }
+    s_b = b;
+  }
+  if (tid < 32) red[tid >> 4][tid & 15] = MinPair{INFINITY, 0x7fffffff};
+  __syncthreads();
+  const int b = s_b;
+  if (b < 0) return;
+  int rphase = 0;
+
+  // ---- LDS: own candidates, rescan list, replicated sizes, sorted live list
+  const int ngrp = (n + 15) >> 4;                           // 16-slot groups
+  const int m = ((ngrp + MB_G - 1) / MB_G) << 4;            // own slots (capacity)
+  double* s_md = (double*)mb_smem;                          // [m] candidate distance: exact when valid, a lower bound when stale
+  int* s_nb = (int*)(s_md + m);                             // [m] >= 0 valid neighbour, <= -2 stale (neighbour -2 - nb), -1 none
+  int* s_rl = s_nb + m;                                     // [m] rows to rescan
+  uint16_t* s_sz = (uint16_t*)(s_rl + m);                   // [n]
+  uint16_t* s_al = s_sz + ((n + 1) & ~1);                   // [n] live slots, ascending (rebuilt every 256 merges)
+  auto slot_of = [&](int li) -> int { return (((li >> 4) * MB_G + b) << 4) + (li & 15); };
+  auto owner_of = [&](int z) -> int { return (z >> 4) % MB_G; };
+  auto li_of = [&](int z) -> int { return (((z >> 4) / MB_G) << 4) + (z & 15); };
+  for (int i = tid; i < n; i += MB_NT) s_sz[i] = 1;
+  for (int li = tid; li < m; li += MB_NT) {
+    const int z = slot_of(li);
+    const bool ok = z < n - 1;                              // slot n-1 has no candidate (no y > n-1)
+    s_md[li] = ok ? g_min_dist[z] : INFINITY;
+    s_nb[li] = ok ? g_neighbor[z] : -1;
+  }
+  auto rebuild = [&]() {                                    // sorted list of the live slots (uniform result: s_acount)
+    __syncthreads();
+    const int wv = tid >> 6;
+    const int C = (n + MB_NT - 1) / MB_NT, z0 = tid * C;
+    int c = 0;
+    for (int j = 0; j < C; ++j) { const int z = z0 + j; if (z < n && s_sz[z] != 0) ++c; }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) s_wtot[wv] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < MB_NT / 64; ++w) { const int t = s_wtot[w]; if (w < wv) woff += t; total += t; }
+    int pos = woff + incl - c;
+    for (int j = 0; j < C; ++j) { const int z = z0 + j; if (z < n && s_sz[z] != 0) s_al[pos++] = (uint16_t)z; }
+    if (tid == 0) s_acount = total;
+    __syncthreads();
+  };
+  long long rescans = 0;
+  unsigned gen = 0;                                         // grid barriers passed
+  int yprev = -1;
+  MinPair part{INFINITY, 0x7fffffff};                       // this workgroup's share of the new row's nearest neighbour
+  for (int k = 0; k < n - 1; ++k) {
+    if ((k & 255) == 0) rebuild();
+    int x = 0, y = -1;
+    double dist = 0.0;
+    for (;;) {
+      // ---- local minima over the own candidates (dead / pending slots hold +inf): best valid, smallest stale bound
+      MinPair lv{INFINITY, 0x7fffffff}, ls{INFINITY, 0x7fffffff};
+      for (int li = tid; li < m; li += MB_NT) {
+        const double md = s_md[li];
+        if (md < INFINITY) {
+          const MinPair c{md, slot_of(li)};
+          if (s_nb[li] >= 0) lv = min_pair(lv, c); else ls = min_pair(ls, c);
+        }
+      }
+      lv = block_argmin_alt(lv, red, rphase);
+      ls = block_argmin_alt(ls, red, rphase);
+      if (tid == 0) {
+        LkEntry* e = &ctl->ent[gen & 1][b];
+        const int nbx = lv.v < INFINITY ? s_nb[li_of(lv.i)] : -1;
+        mb_stf(&e->val_v, lv.v);
+        mb_st64(&e->val_x, (unsigned long long)(unsigned)lv.i | ((unsigned long long)(unsigned)nbx << 32));
+        mb_stf(&e->st_v, ls.v);
+        mb_st64(&e->st_z, (unsigned long long)(unsigned)ls.i);
+        mb_stf(&e->part_v, part.v);
+        mb_st64(&e->part_z, (unsigned long long)(unsigned)part.i);
+      }
+      mb_stores_done();                                     // the merge pass's stores to D and the entry: acknowledged by the L2
+      ++gen;
+      if (!mb_grid_barrier(ctl, gen, &s_flag)) {
+        if (b == 0 && tid == 0) g_min_dist[n - 1] = -2.0;
+        return;
+      }
+      // ---- every wave: the 16 entries, reduced in registers
+      MinPair gv, gs, gp;
+      int gy;
+      {
+        const LkEntry* e = &ctl->ent[(gen - 1) & 1][lane & 15];
+        const double vv = mb_ldf(&e->val_v);
+        const unsigned long long vxy = mb_ld64(&e->val_x);
+        const double sv = mb_ldf(&e->st_v);
+        const int sz = (int)(unsigned)mb_ld64(&e->st_z);
+        const double pv = mb_ldf(&e->part_v);
+        const int pz = (int)(unsigned)mb_ld64(&e->part_z);
+        const int vx = (int)(unsigned)vxy, vy = (int)(unsigned)(vxy >> 32);
+        gv = row_argmin(MinPair{vv, vx});
+        gs = row_argmin(MinPair{sv, sz});
+        gp = row_argmin(MinPair{pv, pz});
+        const unsigned long long win = __ballot(vv == gv.v && vx == gv.i);
+        gy = __shfl(vy, __builtin_ctzll(win | (1ull << 63)));
+      }
+      if (yprev >= 0) {
+        // the cluster of the previous merge: its (exact) candidate is known only now; installed by its owner, one more competitor
+        if (yprev < n - 1) {
+          if (owner_of(yprev) == b && tid == 0) { s_md[li_of(yprev)] = gp.v; s_nb[li_of(yprev)] = gp.v < INFINITY ? gp.i : -1; }
+          if (lex_less(gp.v, yprev, gv.v, gv.i)) { gv = MinPair{gp.v, yprev}; gy = gp.i; }
+        }
+        yprev = -1;
+        part = MinPair{INFINITY, 0x7fffffff};
+      }
+      if (!(gv.v < INFINITY) && !(gs.v < INFINITY)) {       // uniform: every workgroup read the same entries
+        if (b == 0 && tid == 0) g_min_dist[n - 1] = -1.0;
+        return;
+      }
+      if (lex_less(gv.v, gv.i, gs.v, gs.i)) { x = gv.i; y = gy; dist = gv.v; break; }
+      // ---- validation: the own stale rows whose bound lies below the best valid candidate (at least the smallest stale one)
+      if (tid == 0) s_rcount = 0;
+      __syncthreads();
+      for (int li = tid; li < m; li += MB_NT) {
+        const double md = s_md[li];
+        if (md < INFINITY && s_nb[li] <= -2) {
+          const int z = slot_of(li);
+          if (lex_less(md, z, gv.v, gv.i) || (md == gs.v && z == gs.i)) s_rl[atomicAdd(&s_rcount, 1)] = z;
+        }
+      }
+      __syncthreads();
+      const int R = s_rcount, na = s_acount;
+      for (int r = 0; r < R; ++r) {
+        const int z = s_rl[r];
+        const double* rz = D + (size_t)z * n;
+        MinPair q{INFINITY, 0x7fffffff};
+        for (int p0 = 0; p0 < na; p0 += 4 * MB_NT) {
+          double dv[4];
+          int jv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {                     // four loads in flight per thread
+            const int p = p0 + u * MB_NT + tid;
+            const int j = p < na ? (int)s_al[p] : -1;
+            const bool ok = j > z && s_sz[j] != 0;
+            jv[u] = ok ? j : 0x7fffffff;
+            dv[u] = ok ? mb_ldf(rz + j) : INFINITY;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) q = min_pair(q, MinPair{dv[u], jv[u]});
+        }
+        q = block_argmin_alt(q, red, rphase);
+        if (tid == 0) { s_md[li_of(z)] = q.v; s_nb[li_of(z)] = q.v < INFINITY ? q.i : -1; }
+      }
+      rescans += R;
+      __syncthreads();                                      // candidate writes of thread 0 before the next local minima
+    }
+    if (y < 0 || y >= n || x < 0 || x >= n) {               // uniform
+      if (b == 0 && tid == 0) g_min_dist[n - 1] = -1.0;
+      return;
+    }
+    const int nx = s_sz[x], ny = s_sz[y];
+    __syncthreads();                                        // sizes read; the owner's candidate write for yprev is visible
+    if (b == 0 && tid == 64) {
+      Z[4 * (size_t)k + 0] = x; Z[4 * (size_t)k + 1] = y; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
+    }
+    if (tid == 0) { s_sz[x] = 0; s_sz[y] = (uint16_t)(nx + ny); }
+    if (tid == 1 && owner_of(x) == b) s_md[li_of(x)] = INFINITY;
+    if (tid == 2 && owner_of(y) == b) s_md[li_of(y)] = INFINITY;       // pending until the next barrier
+    __syncthreads();
+    // ---- merge pass over the own slots: Lance-Williams update of row / column y, lazy candidate maintenance (as above)
+    const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
+    const double sub = (fx * fy * dist * dist) / fs;
+    const double inv_fs = 1.0 / fs;
+    const double* rx = D + (size_t)x * n;
+    double* ry = D + (size_t)y * n;
+    MinPair best{INFINITY, 0x7fffffff};
+    for (int li = tid; li < m; li += MB_NT) {
+      const int z = slot_of(li);
+      if (z >= n || z == x || z == y || s_sz[z] == 0) continue;
+      const double dxi = mb_ldf(rx + z), dyi = mb_ldf(ry + z);
+      const double nd = lw_centroid(fx, fy, dxi, dyi, sub, inv_fs);
+      mb_stf(ry + z, nd);
+      mb_stf(D + (size_t)z * n + y, nd);
+      if (z < y) {
+        const int nb0 = s_nb[li];
+        const double md = s_md[li];
+        int nb = nb0;
+        int dec = nb <= -2 ? -2 - nb : nb;                  // neighbour whatever the validity
+        if (z < x && dec == x) dec = y;                     // scipy: "reassign neighbor candidates from x to y"
+        if (dec == y) nb = (md == nd) ? y : -2 - y;         // D[z][y] just changed: re-evaluate `dist == D[z, neighbor]`
+        if (nd < md) { nb = y; s_md[li] = nd; }             // lower-bound update
+        if (nb != nb0) s_nb[li] = nb;
+      } else {
+        best = min_pair(best, MinPair{nd, z});
+      }
+    }
+    part = block_argmin_alt(best, red, rphase);
+    yprev = y;
+  }
+  if (b == 0 && tid == 0) g_min_dist[n - 1] = (double)rescans;       // statistics (workgroup 0's rescans; slot n-1 is unused)
+}
+
 int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
-                     double* min_dist, double* Z) {
+                     double* min_dist, double* Z, void* scratch) {
   if (n < 2) return OK;
   const int t = cdiv(n, 64);
-  hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, s, X, n, d, D);
-  RVB_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
-  RVB_HIP_CHECK(hipGetLastError());
   const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
   const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
   const bool no_compact = getenv("RVD_LINKAGE_COMPACT") && atoi(getenv("RVD_LINKAGE_COMPACT")) == 0;
   const int flags = getenv("RVD_LINKAGE_PROF") ? 1 : 0;
+  // RVD_LINKAGE_MB: 0 = never the multi-workgroup loop, 1 = always (tests: any n), unset = from 3 000 points on (below that one
+  // CU's LDS-resident loop is as fast: a merge is a chain of latencies either way)
+  const char* mbe = getenv("RVD_LINKAGE_MB");
+  const int mb_mode = mbe ? atoi(mbe) : -1;
+  const int ngrp = (n + 15) >> 4, m_own = ((ngrp + MB_G - 1) / MB_G) << 4;
+  const size_t lds_mb = (size_t)m_own * 16 + (size_t)((n + 1) & ~1) * 4;
+  const bool use_mb = scratch != nullptr && !force_global && !no_compact && lds_mb <= 150 * 1024 &&
+                      (mb_mode == 1 || (mb_mode < 0 && n >= 3000));
   static bool attr_set = false;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_kernel<true, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)linkage_mb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  if (!force_global && !no_compact && lds_c <= 158 * 1024 && n <= LK_E * 1024) {
-    hipLaunchKernelGGL((linkage_kernel<true, 1024, true>), dim3(1), dim3(1024), lds_c, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
-  } else if (lds <= 158 * 1024 && !force_global) {
-    hipLaunchKernelGGL((linkage_kernel<true, 1024, false>), dim3(1), dim3(1024), lds, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
-  } else {
-    hipLaunchKernelGGL((linkage_kernel<false, 1024, false>), dim3(1), dim3(1024), 0, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, s, X, n, d, D);
+    RVB_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nn_init_kernel, dim3(n - 1), dim3(256), 0, s, D, n, neighbor, min_dist);
+    RVB_HIP_CHECK(hipGetLastError());
+    if (use_mb && attempt == 0) {
+      RVB_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(LkCtl), s));
+      // at least 64 KiB of LDS per workgroup so that a CU holds one of them (the MB_G participants sit on MB_G different CUs)
+      const size_t lds_launch = lds_mb < 96 * 1024 ? 96 * 1024 : lds_mb;
+      hipLaunchKernelGGL(linkage_mb_kernel, dim3(8 * (MB_G + 8)), dim3(MB_NT), lds_launch, s, D, n, neighbor, min_dist, Z, (LkCtl*)scratch);
+      RVB_HIP_CHECK(hipGetLastError());
+      double status = 0.0;
+      RVB_HIP_CHECK(hipMemcpyAsync(&status, min_dist + (n - 1), 8, hipMemcpyDeviceToHost, s));
+      RVB_HIP_CHECK(hipStreamSynchronize(s));
+      if (status != -2.0) return OK;               // done (or -1: no candidate pair, reported by the caller)
+      // a barrier gave up (the workgroups did not all become resident on one XCD): start over on the one-workgroup loop --
+      // unless the multi-workgroup loop was asked for by name (tests): then this is an error, never a silent fall-back
+      if (mb_mode == 1) { set_error("centroid_linkage: the multi-workgroup merge loop (RVD_LINKAGE_MB=1) gave up at a grid barrier"); return E_STATE; }
+      if (getenv("RVD_LINKAGE_PROF")) fprintf(stderr, "linkage: multi-workgroup loop aborted, falling back to one workgroup\n");
+      const double inf = INFINITY;
+      RVB_HIP_CHECK(hipMemcpyAsync(min_dist + (n - 1), &inf, 8, hipMemcpyHostToDevice, s));
+      RVB_HIP_CHECK(hipStreamSynchronize(s));
+      continue;
+    }
+    if (!force_global && !no_compact && lds_c <= 158 * 1024 && n <= LK_E * 1024) {
+      hipLaunchKernelGGL((linkage_kernel<true, 1024, true>), dim3(1), dim3(1024), lds_c, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+    } else if (lds <= 158 * 1024 && !force_global) {
+      hipLaunchKernelGGL((linkage_kernel<true, 1024, false>), dim3(1), dim3(1024), lds, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+    } else {
+      hipLaunchKernelGGL((linkage_kernel<false, 1024, false>), dim3(1), dim3(1024), 0, s, flags, D, n, size, cluster_id, neighbor, min_dist, Z);
+    }
+    RVB_HIP_CHECK(hipGetLastError());
+    break;
   }
-  RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
 

@@ -251,6 +251,33 @@ def test_centroid_linkage_matches_scipy(case, n, d, seed):
     assert np.array_equal(fcluster(got, 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
 
 
+@pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (17, 8, 5), (257, 16, 2), (1500, 256, 3), (3100, 64, 4), (6000, 32, 6)])
+def test_centroid_linkage_on_sixteen_workgroups_matches_scipy_and_the_one_workgroup_loop(case, monkeypatch, n, d, seed):
+    """Round 4: the merge loop on 16 persistent workgroups of one XCD (linkage.hip linkage_mb_kernel: one grid barrier per
+    merge, exact nearest-neighbour candidates, agent-scope relaxed atomics through the XCD's L2).  RVD_LINKAGE_MB=1 forces it
+    for any n (the default takes it from 3 000 points on).  Pinned to scipy like the one-workgroup loop -- same merges in
+    the same order, distances < 1e-9 -- and BIT-IDENTICAL to the one-workgroup loop (RVD_LINKAGE_MB=0): both round the
+    Lance-Williams update through the same function.  The status word tells that it really ran (no silent fall-back)."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from reverb_amd.diar_engine import DiarEngine
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((5, d))
+    X = centers[rng.integers(5, size=n)] + 0.35 * rng.standard_normal((n, d))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = linkage(X, method="centroid", metric="euclidean")
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RVD_LINKAGE_MB", mode)
+        monkeypatch.setenv("RVD_LINKAGE_PROF", "1")          # prints when the multi-workgroup loop gives up (stderr)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
+        got[mode] = eng.centroid_linkage(X)
+        eng.close()
+    assert np.array_equal(got["1"][:, [0, 1, 3]], want[:, [0, 1, 3]])
+    assert np.abs(got["1"][:, 2] - want[:, 2]).max() < 1e-9
+    assert np.array_equal(got["1"], got["0"])
+    assert np.array_equal(fcluster(got["1"], 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
+
+
 def test_centroid_linkage_without_slot_compaction_matches_scipy(case, monkeypatch):
     """10 240 < n <= ~11 500 points keep the LDS-resident state but not the re-dealt slot lists (registers for ten batches of
     1024): RVD_LINKAGE_COMPACT=0 runs that variant on a small input."""

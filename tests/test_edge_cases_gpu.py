@@ -139,6 +139,30 @@ def test_cabi_collective_on_one_rank():
     # the collective alone, device to device (the xGMI datapoint of bench.py): runs, is checked, takes a sane time
     ms = comm.time_all_gather(7_200_000, iters=3)
     assert 0.0 < ms < 50.0
+    # round 4: what a launcher needs besides the gather (one RCCL communicator per rank: no torch.distributed "nccl" group)
+    comm.barrier()
+    assert comm.max(3.25) == 3.25
+    # ... and the posterior exchange device to device: the engine's top-k buffers, straight from HBM
+    x2, lens2 = case.chunked_feats()
+    eng.encode(x2, lens2, case.beam)
+    v, i = eng.ctc_topk()
+    nbytes, (gv, gi) = comm.all_gather_topk(eng, to_host=True)
+    assert nbytes == v.nbytes + i.nbytes
+    np.testing.assert_array_equal(gv[0], v)
+    np.testing.assert_array_equal(gi[0], i)
+    assert comm.all_gather_topk(eng)[0] == nbytes            # without the host copy
+    # a generous timeout changes nothing
+    comm.set_timeout(30.0)
+    np.testing.assert_array_equal(comm.all_gather(x), x[None])
+    # ... an impossible one (1 ns for a 64 MB gather + two PCIe copies) ends the collective with RVB_E_TIMEOUT instead of
+    # blocking, and the communicator refuses further use: the path a dead peer takes on a real world
+    from reverb_amd._lib import RvbError
+    comm.set_timeout(1e-9)
+    big = np.zeros(16_000_000, np.int32)
+    with pytest.raises(RvbError, match=r"\(-7\)"):
+        comm.all_gather(big)
+    with pytest.raises(RvbError, match="aborted after a timeout"):
+        comm.all_gather(x)
     comm.close()
     # the engine-bound form of the same collective
     import ctypes as C

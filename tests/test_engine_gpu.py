@@ -106,12 +106,24 @@ def test_bf16_engine_within_tolerance(name):
         tot += len(g)
         r = res["attention_rescoring"][b]
         assert len(r.times) == len(r.tokens) or case.js["outputs"]["attention_rescoring"].get("error")
-    # synthetic random-weight models have tiny CTC margins (79 vs 73 tokens under bf16 autocast); measured on
-    # the long-form goldens (tests/test_longform_gpu.py: 1.5 % on 4 664 tokens for the d=128 model, 4.7 % on 11 417 for
-    # r640); these cases have 66-150 tokens, where one near-tie is 1 %
+    # The bound is the reference's own reduced-precision behaviour (round 4; VERDICT r3 "next" #7): the unmodified reference
+    # decoded the same batch under torch.autocast('cpu', bfloat16) (oracle/gen_golden_bf16ref_short.py ->
+    # tests/golden/short_refbf16.json: 5 / 76, 11 / 95, 7 / 65 greedy token edits against its own fp32 run); the engine may
+    # lose no more than that + 1 % of the tokens (rounded up: these cases have 65-95 tokens, one near-tie is > 1 %).
+    import json
+    import math
     from test_longform_gpu import _record
-    _record(case=name, dtype="bf16", ter={"ctc_greedy_search": [err, tot]})
-    assert err <= 0.12 * max(tot, 1), f"token error rate {err}/{tot}"
+    with open(os.path.join(os.path.dirname(__file__), "golden", "short_refbf16.json")) as f:
+        ref = json.load(f)["cases"][name]["edits"]
+    err_r = 0
+    for b in range(len(lens)):
+        err_r += _edit_distance(res["attention_rescoring"][b].tokens, case.golden("attention_rescoring")[b]["tokens"])
+    tot_r = sum(len(h["tokens"]) for h in case.golden("attention_rescoring"))
+    _record(case=name, dtype="bf16", ter={"ctc_greedy_search": [err, tot], "attention_rescoring": [err_r, tot_r]},
+            reference_bf16_ter=ref)
+    assert ref["ctc_greedy_search"][1] == tot and ref["attention_rescoring"][1] == tot_r
+    assert err <= ref["ctc_greedy_search"][0] + math.ceil(0.01 * tot), f"greedy token edits {err}/{tot}, reference-bf16 {ref['ctc_greedy_search']}"
+    assert err_r <= ref["attention_rescoring"][0] + math.ceil(0.01 * tot_r), f"rescored token edits {err_r}/{tot_r}, reference-bf16 {ref['attention_rescoring']}"
     eng.close()
 
 

@@ -150,7 +150,7 @@ def test_fp8_needs_dims_of_128():
 def test_fp8_bench_workload_against_reference():
     """bench.py --dtype fp8, checked: the hour of audio bench.py decodes, from PCM, against the reference's tokens -- the
     default policy (feed-forward GEMMs in fp8) within 1.5 x the reference's own bf16 behaviour; then every GEMM group in fp8
-    (rvb_set_fp8_policy(31), round 2's mode): measured and recorded, bounded at 2.5 x."""
+    (rvb_set_fp8_policy(31), round 2's mode): measured and recorded, no parity bound claimed."""
     from golden_util import LongCase
     from reverb_amd.engine import Engine
     from test_longform_gpu import MODES, RefBf16, _assert_reduced_precision, _record, _tap_metrics, _ter
@@ -175,11 +175,12 @@ def test_fp8_bench_workload_against_reference():
         got[policy] = (ter, fm)
     _assert_reduced_precision("r640_1h", "fp8 feed-forward", *got["feed-forward"], ref, slack=FP8_SLACK)
     # every group in fp8 does NOT meet that bar (measured: 16.2 % / 13.5 % token errors, 1 603 confident frames flipped against the
-    # reference-bf16's 314) -- which is why it is not the default; it must at least stay a usable approximation, and be worse
-    # than the default on both measures (otherwise the default should change)
+    # reference-bf16's 314) -- which is why it is not the default and why NO parity bound is claimed for it (round 4: the
+    # literal 25 % that used to stand here was not a parity statement).  It is measured and recorded (profiles/*parity_metrics*),
+    # its encoder output must stay an approximation of the reference's (cos > 0.99 above), and it must be worse than the default
+    # on both measures -- otherwise the default should change
     ter_all, fm_all = got["all groups"]
     for m in MODES:
-        assert ter_all[m][0] <= 0.25 * ter_all[m][1], (m, ter_all[m])
         assert ter_all[m][0] >= got["feed-forward"][0][m][0]
     assert fm_all["engine_confident"] >= got["feed-forward"][1]["engine_confident"]
     eng.close()
