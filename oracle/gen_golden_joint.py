@@ -34,7 +34,11 @@ CASES = [
                dict(beam=3, ctc_weight=0.6, pre_beam_ratio=2.0, length_bonus=0.2),
                # a random decoder charges ~9 nats per token: a large length bonus / CTC weight keeps the hypotheses long
                dict(beam=4, ctc_weight=0.3, pre_beam_ratio=1.5, length_bonus=7.0),
-               dict(beam=5, ctc_weight=0.9, pre_beam_ratio=1.5, length_bonus=1.0)]),
+               dict(beam=5, ctc_weight=0.9, pre_beam_ratio=1.5, length_bonus=1.0),
+               # round 4: a pre-beam of 18 candidates per frame (the CTC kernel kept at most 16 until then), and a blank penalty
+               # (`ctc_logprobs(encoder_out, blank_penalty, blank_id)`, asr_model.py:318-329 -> search.py:466)
+               dict(beam=12, ctc_weight=0.5, pre_beam_ratio=1.5, length_bonus=2.0),
+               dict(beam=4, ctc_weight=0.3, pre_beam_ratio=1.5, length_bonus=3.0, blank_penalty=2.0)]),
     dict(name="joint_small", dims="small_v10k", norm="layer_norm", seed=9, seconds=20.6, chunk=2051, cat=[0.3, 0.7],
          runs=[dict(beam=4, ctc_weight=0.3, pre_beam_ratio=1.5, length_bonus=0.5),
                dict(beam=4, ctc_weight=0.5, pre_beam_ratio=1.5, length_bonus=5.0)]),
@@ -83,8 +87,9 @@ def main():
             elens = mask.squeeze(1).sum(1)
             out["encoder_lens"] = elens.tolist()
             for run in case["runs"]:
-                rows = joint_decoding_3d(model, enc, elens, probs, run["ctc_weight"], run["beam"], run["pre_beam_ratio"],
-                                         run["length_bonus"], cat)
+                bp = run.get("blank_penalty", 0.0)
+                rows = joint_decoding_3d(model, enc, elens, model.ctc_logprobs(enc, bp, 0) if bp else probs, run["ctc_weight"], run["beam"],
+                                         run["pre_beam_ratio"], run["length_bonus"], cat)
                 out["runs"].append(dict(run, chunks=rows))
                 print(case["name"], run, [len(r["tokens"]) for r in rows], [round(r["score"], 3) for r in rows])
         print("  reference entry point:", out["reference_entry_point"])

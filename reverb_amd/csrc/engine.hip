@@ -627,7 +627,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   if (B <= 0 || B > c.max_chunks || T0 < 7 || T0 > c.chunk_frames) {
     set_error("rvb_encode: need 1 <= B <= max_chunks and 7 <= T0 <= chunk_frames"); return E_ARG;
   }
-  if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_encode: beam must be in [1,16]"); return E_ARG; }
+  if (beam < 1 || beam > 64 || beam > c.vocab) { set_error("rvb_encode: beam must be in [1,64]"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   RVB_TRY(wait_slices(e, -1));      // a previous batch may still be in flight
   e->stream_st.active = false;      // the offline path reuses the stream's output buffer: an open stream ends here
@@ -900,7 +900,7 @@ static int stream_finish_impl(rvb_engine* e, int beam, float blank_penalty) {
   const rvb_model_cfg& c = e->cfg;
   auto& st = e->stream_st;
   if (!st.active) { set_error("rvb_stream_finish before rvb_stream_begin"); return E_STATE; }
-  if (beam < 1 || beam > 16 || beam > c.vocab) { set_error("rvb_stream_finish: beam must be in [1,16]"); return E_ARG; }
+  if (beam < 1 || beam > 64 || beam > c.vocab) { set_error("rvb_stream_finish: beam must be in [1,64]"); return E_ARG; }
   RVB_HIP_CHECK(hipSetDevice(e->device));
   const int d = c.d_model, V = c.vocab, M = st.offset;
   const size_t es = dt_size(e->dtype);
@@ -1598,7 +1598,6 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
               std::to_string(pre_beam));
     return E_ARG;
   }
-  if (e->last_blank_penalty != 0.f) { set_error("rvb_joint_decode: blank_penalty is not supported in this mode"); return E_UNSUPPORTED; }
   RVB_TRY(wait_slices(e, -1));
   Decoder& D = e->dec_l;
   const int B = e->B, T2 = e->T2, d = c.d_model, heads = c.dec_heads, dk = d / heads, ff = c.dec_ffn_dim, V = c.vocab;
@@ -1621,7 +1620,10 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
       for (int r0 = 0; r0 < M; r0 += LOGIT_SLAB) {
         const int rows = std::min(LOGIT_SLAB, M - r0);
         RVB_TRY(run_gemm(e, (const char*)e->enc_out.p + (size_t)r0 * d * es, d, e->ctc, e->logits.p, Vld, rows, true));
-        RVB_TRY(lse_gather(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt.as<int>(), e->d_logp.as<float>()));
+        // with a blank penalty the reference's CTC log-probs are the log-softmax of the PENALISED logits (ctc_logprobs,
+        // asr_model.py:318-329; search.py:466): the same rows the top-k kernel produced for this batch
+        RVB_TRY(lse_gather(e->stream, e->logits.as<float>(), rows, V, Vld, e->d_tgt.as<int>(), e->d_logp.as<float>(), e->last_blank_penalty,
+                           c.blank_id));
         RVB_HIP_CHECK(hipMemcpyAsync(dst.data() + r0, e->d_logp.p, (size_t)rows * 4, hipMemcpyDeviceToHost, e->stream));
         RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
       }
@@ -1795,6 +1797,12 @@ static int joint_decode_impl(rvb_engine* e, int beam, double ctc_weight, double 
   }
   e->joint.assign(B, JointResult());
   for (int b = 0; b < B; ++b) js[b].result(&e->joint[b]);
+  for (int b = 0; b < B; ++b)
+    if (js[b].ties_cut() && K < V) {
+      set_error("rvb_joint_decode: a frame of chunk " + std::to_string(b) + " has more than " + std::to_string(K - pre_beam) +
+                " log-probs that tie exactly with the pre-beam threshold; keep more per frame (rvb_encode's beam argument, up to 64)");
+      return E_UNSUPPORTED;
+    }
   RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
   return OK;
 }

@@ -1351,6 +1351,11 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          (profiles/r04_candidates.txt) -- the epilogue is not burst-bound, the delayed CUs just finish half a tile later
 //   bit 7  K serpentine on for every shape, bit 8 on for N <= 2048 (default: off -- measured neutral in the engine): odd waves
 //          of tiles walk K downwards (see k_rev in gemm2p_kernel)
+//   bit 9  (round 4, measured and removed) transposed accumulators -- the MFMA operands swapped, so that a lane owns four
+//          consecutive columns of a row -- and the epilogue storing straight from registers (8-byte bf16 vectors, 32-byte runs
+//          per row) instead of through the LDS transposition: exact, 234 VGPRs, but the epilogue of a K = 1024 tile goes
+//          7.75 -> 10.4 us (ffn1), 5.2 -> 9.8 us (qkv), 4.9 -> 7.5 us (plain) and the GEMMs of the bench hour 105.4 -> 107.4 ms
+//          (profiles/r04_call5_tr_epilogue_linkage_eager.txt): partial-line stores cost more than the LDS round trip saves
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }

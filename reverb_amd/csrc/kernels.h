@@ -125,8 +125,10 @@ int embed_tokens(hipStream_t s, const float* E, const float* pe, const int* tok,
 int logsoftmax_topk(hipStream_t s, const float* logits, int M, int V, int ld, int k, float blank_penalty,
                     int blank_id, float* topk_val, int* topk_idx, float* logp_out);
 
-// out[r] = logits[r][target[r]] - logsumexp(logits[r][:V])
-int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out);
+// out[r] = logits[r][target[r]] - logsumexp(logits[r][:V]); blank_penalty != 0: of the row with logits[blank_id] -= blank_penalty
+// (ctc_logprobs, asr_model.py:318-329)
+int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out, float blank_penalty = 0.f,
+               int blank_id = -1);
 // CSR form for rows with several targets: out[p] = logits[r][target[p]] - lse(r) for p in [ptr[r], ptr[r+1])
 int lse_gather_multi(hipStream_t s, const float* logits, int R, int V, int ld, const int* ptr, const int* target, float* out);
 

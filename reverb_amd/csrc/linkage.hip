@@ -410,6 +410,12 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
 //     else returns at once.  Every spin is bounded; a barrier that does not complete sets an abort word, the kernel returns
 //     with status -2 and centroid_linkage() falls back to the one-workgroup loop.
 static constexpr int MB_G = 16, MB_NT = 1024;
+// Eager validation right after a merge of the stale rows whose bound is within 5 % of the merged distance (to save the extra
+// round they would cost when they reach the top): measured and switched off -- on high-dimensional noise 33 rows per merge
+// qualify (96 -> 135 ms at n = 9 200, 422 -> 648 ms at n = 27 000), on the pipeline's embeddings it changes nothing (74 ms);
+// profiles/r04_call5_tr_epilogue_linkage_eager.txt.  MB_EAGER = 0 compiles the path away.
+static constexpr int MB_EAGER = 0;                       // stale rows a workgroup may validate right after a merge
+static constexpr double MB_EAGER_FACTOR = 1.05;          // ... when their bound is within 5 % of the distance just merged
 struct LkEntry { double val_v; int val_x, val_y; double st_v; int st_z, pad0; double part_v; int part_z, pad1; };   // 48 bytes
 struct LkCtl { int xcc, tickets; unsigned bar; int abort; LkEntry ent[2][MB_G]; };
 static_assert(sizeof(LkEntry) == 48, "published entry: six 8-byte words");
@@ -511,6 +517,28 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
     if (tid == 0) s_acount = total;
     __syncthreads();
   };
+  // exact nearest live neighbour above z, block-local (see the header): candidate of row z becomes valid
+  auto rescan_row = [&](int z) {
+    const int na = s_acount;
+    const double* rz = D + (size_t)z * n;
+    MinPair q{INFINITY, 0x7fffffff};
+    for (int p0 = 0; p0 < na; p0 += 4 * MB_NT) {
+      double dv[4];
+      int jv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                         // four loads in flight per thread
+        const int p = p0 + u * MB_NT + tid;
+        const int j = p < na ? (int)s_al[p] : -1;
+        const bool ok = j > z && s_sz[j] != 0;
+        jv[u] = ok ? j : 0x7fffffff;
+        dv[u] = ok ? mb_ldf(rz + j) : INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q = min_pair(q, MinPair{dv[u], jv[u]});
+    }
+    q = block_argmin_alt(q, red, rphase);
+    if (tid == 0) { s_md[li_of(z)] = q.v; s_nb[li_of(z)] = q.v < INFINITY ? q.i : -1; }
+  };
   long long rescans = 0;
   unsigned gen = 0;                                         // grid barriers passed
   int yprev = -1;
@@ -590,28 +618,8 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
         }
       }
       __syncthreads();
-      const int R = s_rcount, na = s_acount;
-      for (int r = 0; r < R; ++r) {
-        const int z = s_rl[r];
-        const double* rz = D + (size_t)z * n;
-        MinPair q{INFINITY, 0x7fffffff};
-        for (int p0 = 0; p0 < na; p0 += 4 * MB_NT) {
-          double dv[4];
-          int jv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {                     // four loads in flight per thread
-            const int p = p0 + u * MB_NT + tid;
-            const int j = p < na ? (int)s_al[p] : -1;
-            const bool ok = j > z && s_sz[j] != 0;
-            jv[u] = ok ? j : 0x7fffffff;
-            dv[u] = ok ? mb_ldf(rz + j) : INFINITY;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) q = min_pair(q, MinPair{dv[u], jv[u]});
-        }
-        q = block_argmin_alt(q, red, rphase);
-        if (tid == 0) { s_md[li_of(z)] = q.v; s_nb[li_of(z)] = q.v < INFINITY ? q.i : -1; }
-      }
+      const int R = s_rcount;
+      for (int r = 0; r < R; ++r) rescan_row(s_rl[r]);
       rescans += R;
       __syncthreads();                                      // candidate writes of thread 0 before the next local minima
     }
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
     if (b == 0 && tid == 64) {
       Z[4 * (size_t)k + 0] = x; Z[4 * (size_t)k + 1] = y; Z[4 * (size_t)k + 2] = dist; Z[4 * (size_t)k + 3] = nx + ny;
     }
-    if (tid == 0) { s_sz[x] = 0; s_sz[y] = (uint16_t)(nx + ny); }
+    if (tid == 0) { s_sz[x] = 0; s_sz[y] = (uint16_t)(nx + ny); s_rcount = 0; }
     if (tid == 1 && owner_of(x) == b) s_md[li_of(x)] = INFINITY;
     if (tid == 2 && owner_of(y) == b) s_md[li_of(y)] = INFINITY;       // pending until the next barrier
     __syncthreads();
@@ -632,6 +640,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
     const double fx = (double)nx, fy = (double)ny, fs = (double)(nx + ny);
     const double sub = (fx * fy * dist * dist) / fs;
     const double inv_fs = 1.0 / fs;
+    const double eager_thr = dist * MB_EAGER_FACTOR;
     const double* rx = D + (size_t)x * n;
     double* ry = D + (size_t)y * n;
     MinPair best{INFINITY, 0x7fffffff};
@@ -651,11 +660,24 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
         if (dec == y) nb = (md == nd) ? y : -2 - y;         // D[z][y] just changed: re-evaluate `dist == D[z, neighbor]`
         if (nd < md) { nb = y; s_md[li] = nd; }             // lower-bound update
         if (nb != nb0) s_nb[li] = nb;
+        // a stale candidate whose bound is about as small as the distance just merged will be the heap's top within a few
+        // merges: validating it NOW (block-local, below) costs a row scan; waiting costs the same scan plus a whole extra
+        // round of every workgroup.  Bounded: at most MB_EAGER rows per workgroup and merge, the rest stay lazy.
+        if constexpr (MB_EAGER > 0) {
+          if (nb <= -2 && fmin(md, nd) <= eager_thr) { const int pos = atomicAdd(&s_rcount, 1); if (pos < MB_EAGER) s_rl[pos] = z; }
+        }
       } else {
         best = min_pair(best, MinPair{nd, z});
       }
     }
-    part = block_argmin_alt(best, red, rphase);
+    if constexpr (MB_EAGER > 0) mb_stores_done();           // the rescans below read what this pass wrote (own rows)
+    part = block_argmin_alt(best, red, rphase);             // (barrier inside: the list is complete)
+    if constexpr (MB_EAGER > 0) {
+      const int R = min(s_rcount, MB_EAGER);
+      for (int r = 0; r < R; ++r) rescan_row(s_rl[r]);
+      rescans += R;
+      if (R) __syncthreads();                               // candidate writes of thread 0 before the next local minima
+    }
     yprev = y;
   }
   if (b == 0 && tid == 0) g_min_dist[n - 1] = (double)rescans;       // statistics (workgroup 0's rescans; slot n-1 is unused)

@@ -281,6 +281,10 @@ bool JointSearch::begin_frame(int t, const float* tv, const int* ti, int K, floa
   // candidates: everything >= the pre_beam-th largest log-prob, in token order (nonzero())
   const int pb = p_.pre_beam < K ? p_.pre_beam : K;
   const float thr = tv[pb - 1];
+  // the reference compares the WHOLE row with the threshold (`ctc_probs >= thr`): log-probs that tie with it exactly are
+  // candidates too.  The kept list runs past the pre-beam (the host asks for pre_beam + 8); if even its last entry ties, the
+  // run of ties may go on beyond what was kept -- reported, never silently cut (ties_cut_; K == vocabulary keeps everything)
+  if (K > pb && tv[K - 1] >= thr) ties_cut_ = true;
   std::vector<std::pair<int, double>> cands;
   for (int k = 0; k < K; ++k) if (tv[k] >= thr) cands.push_back({ti[k], (double)tv[k]});
   std::sort(cands.begin(), cands.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });

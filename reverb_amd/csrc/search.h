@@ -54,6 +54,8 @@ class JointSearch {
   // engine-side tag of a node (device row of its decoder state), -1 = not decoded
   int tag(int node) const { return tag_[node]; }
   void set_tag(int node, int tag) { tag_[node] = tag; }
+  // some frame's kept top-K list ended inside a run of exact ties with the pre-beam threshold (see begin_frame)
+  bool ties_cut() const { return ties_cut_; }
 
  private:
   struct Node {
@@ -76,6 +78,7 @@ class JointSearch {
   };
   int child(int node, int tok);
   JointParams p_;
+  bool ties_cut_ = false;
   std::vector<Node> nodes_;
   std::vector<int> par_, tok_, tag_;     // compact copies for the engine's path walks (a Node is ~150 bytes)
   std::vector<std::vector<std::pair<int, int>>> child_;     // per node: (token, child id)

@@ -17,7 +17,7 @@
 
 namespace rvb {
 
-static constexpr int TOPK_MAX = 16;
+static constexpr int TOPK_MAX = 64;      // one lane maximum per kept element bounds the threshold search (pass A): k <= 64
 static constexpr int UNR = 4;        // float4 vectors per lane per batch
 static constexpr int CAND = 256;     // candidate slots per row
 
@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
   const float lse = st.wave_lse();
   if constexpr (!TOPK) {
     if (k < 0) {      // CSR form: row r owns targets [ti[r], ti[r+1]) of `target`, results land at the same positions
-      for (int p = ti[row] + lane; p < ti[row + 1]; p += 64) gathered[p] = rd.x[target[p]] - lse;
+      for (int p = ti[row] + lane; p < ti[row + 1]; p += 64) gathered[p] = rd.tail(target[p]) - lse;
     } else if (lane == 0) {
-      gathered[row] = rd.x[target[row]] - lse;
+      gathered[row] = rd.tail(target[row]) - lse;       // (with a blank penalty: the penalised logit, as ctc_logprobs forms it)
     }
     return;
   } else {
@@ -193,16 +193,16 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
 int logsoftmax_topk(hipStream_t s, const float* logits, int M, int V, int ld, int k, float blank_penalty,
                     int blank_id, float* topk_val, int* topk_idx, float* logp_out) {
   if (M <= 0) return OK;
-  if (k < 1 || k > TOPK_MAX || k > V) { set_error("logsoftmax_topk: beam must be in [1,16] and <= vocab"); return E_ARG; }
+  if (k < 1 || k > TOPK_MAX || k > V) { set_error("logsoftmax_topk: beam must be in [1,64] and <= vocab"); return E_ARG; }
   hipLaunchKernelGGL(row_lse_kernel<true>, dim3(cdiv(M, 4)), dim3(256), 0, s, logits, M, V, ld, k, blank_penalty,
                      blank_id, topk_val, topk_idx, logp_out, (const int*)nullptr, (float*)nullptr);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
 
-int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out) {
+int lse_gather(hipStream_t s, const float* logits, int R, int V, int ld, const int* target, float* out, float blank_penalty, int blank_id) {
   if (R <= 0) return OK;
-  hipLaunchKernelGGL(row_lse_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, R, V, ld, 0, 0.f, -1,
+  hipLaunchKernelGGL(row_lse_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, R, V, ld, 0, blank_penalty, blank_penalty != 0.f ? blank_id : -1,
                      (float*)nullptr, (int*)nullptr, (float*)nullptr, target, out);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;

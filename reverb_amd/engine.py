@@ -65,7 +65,11 @@ def model_cfg_from_configs(configs: dict, dtype: str, max_chunks: int, chunk_fra
 
 def joint_topk(methods, beam_size: int) -> Optional[int]:
     """CTC log-probs to keep per frame when `joint_decoding` is among the modes (its pre-beam), else None."""
-    return int(JOINT_PRE_BEAM_RATIO * beam_size) if "joint_decoding" in methods else None
+    if "joint_decoding" not in methods:
+        return None
+    # the pre-beam itself + 8 more: log-probs that tie exactly with the pre-beam threshold are candidates too (the reference
+    # compares the whole row, search.py / beam_search_timesync.py:268-270); the kernel keeps at most 64
+    return min(int(JOINT_PRE_BEAM_RATIO * beam_size) + 8, 64)
 
 
 def _as_numpy_f32(v) -> Optional[np.ndarray]:
@@ -267,8 +271,8 @@ class Engine:
         elif T0 is None:
             T0 = self.cfg.chunk_frames
         k = max(int(beam), int(topk or 0))
-        if k > 16:
-            raise RvbError(f"the CTC kernel keeps at most 16 log-probs per frame; beam {beam}" +
+        if k > 64:
+            raise RvbError(f"the CTC kernel keeps at most 64 log-probs per frame; beam {beam}" +
                            (f" with joint_decoding's pre-beam {topk}" if topk else "") + " needs more")
         check(self.lib.rvb_encode(self.handle, fptr(feats), int(first_chunk), iptr(lens), B, int(T0), k,
                                   float(blank_penalty)), "rvb_encode")

@@ -16,7 +16,9 @@ def test_joint_decoding_f32_matches_reference_class(name):
     eng = Engine(case.cfg, case.sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
     for run in case.js["runs"]:
         beam = run["beam"]
-        eng.encode(case.x, case.lens, beam, topk=int(run["pre_beam_ratio"] * beam))
+        # the pre-beam + 8 log-probs per frame, as ASRModel.decode asks for (engine.joint_topk); round 4: pre-beams beyond 16
+        # (beam 12 -> 18 candidates) and a blank penalty (the reference's ctc_logprobs applies it before the mode sees the rows)
+        eng.encode(case.x, case.lens, beam, run.get("blank_penalty", 0.0), topk=min(int(run["pre_beam_ratio"] * beam) + 8, 64))
         assert eng.encoder_lens().tolist() == case.js["encoder_lens"]
         got = eng.joint_decode(run["ctc_weight"], run["length_bonus"], run["pre_beam_ratio"])
         rows, steps = eng.joint_stats()

@@ -239,7 +239,10 @@ def test_joint_decoding_oracle_matches_reference_class(name):
     lens = mask.squeeze(1).sum(1)
     assert lens.tolist() == case.js["encoder_lens"]
     for run in case.js["runs"]:
-        got = S.joint_decoding(sd, case.cfg, enc, lens, probs, run["ctc_weight"], run["beam"], run["pre_beam_ratio"],
+        bp = run.get("blank_penalty", 0.0)
+        with torch.no_grad():
+            lp = M.ctc_logprobs(sd, enc, bp, 0) if bp else probs
+        got = S.joint_decoding(sd, case.cfg, enc, lens, lp, run["ctc_weight"], run["beam"], run["pre_beam_ratio"],
                                run["length_bonus"], cat)
         for b, want in enumerate(run["chunks"]):
             g = got[b]

@@ -202,7 +202,7 @@ def native_joint(sd, cfg, mem, lpz, run, cat, K=None):
 
     with torch.no_grad():
         decode(0)
-        cap = 256
+        cap = 1024
         dec = np.zeros(cap, np.int32); pn = np.zeros(cap, np.int32); pt = np.zeros(cap, np.int32)
         nd = np.zeros(1, np.int32); npairs = np.zeros(1, np.int32)
         tv_all, ti_all = lpz.topk(K, dim=-1)
@@ -241,10 +241,13 @@ def test_joint_decoding_native_state_machine_matches_reference_class(name):
         probs = M.ctc_logprobs(sd, enc)
     lens = mask.squeeze(1).sum(1)
     for run in case.js["runs"]:
+        bp = run.get("blank_penalty", 0.0)          # round 4: ctc_logprobs(encoder_out, blank_penalty, blank_id) feeds the mode
+        lp = M.ctc_logprobs(sd, enc, bp, 0) if bp else probs
+        pre_beam = int(run["pre_beam_ratio"] * run["beam"])
         for b, want in enumerate(run["chunks"]):
             n = int(lens[b])
-            for K in (None, 16):            # the engine hands over its top-16; ties aside the candidates are the same
-                toks, st, en, conf, score = native_joint(sd, case.cfg, enc[b:b + 1, :n], probs[b, :n], run, cat, K)
+            for K in (None, pre_beam + 8):  # the engine hands over the pre-beam + 8 more (ties with the threshold); same candidates
+                toks, st, en, conf, score = native_joint(sd, case.cfg, enc[b:b + 1, :n], lp[b, :n], run, cat, K)
                 assert toks == want["tokens"], (run, b, K)
                 assert st == want["times"] and en == want["end_times"], (run, b, K)
                 assert abs(score - want["score"]) < 2e-3 * max(1.0, abs(want["score"]))
