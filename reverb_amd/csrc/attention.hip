@@ -25,7 +25,11 @@ namespace rvb {
 
 static constexpr int KT = 64;     // keys per tile
 
-template <typename T, int DKP, bool HAS_POS>
+// FOLD (round 4, bf16 encoder form): (q + u).k + (q + v).p = (q + u).(k + p) + (v - u).p -- the second product of every
+// key tile becomes a per-key constant c[head][position] = (v - u).p (input independent like P itself: a table built when the
+// weights are packed), and K' = k + p is formed once per staged vector on its way into LDS.  Per 64-key tile and wave that is
+// 8 MFMAs and 8 KiB of LDS fragment reads for the scores instead of 16 and 16 KiB, and no P tile in LDS.
+template <typename T, int DKP, bool HAS_POS, bool FOLD = false>
 struct AttnLds {
   static constexpr bool BF = sizeof(T) == 2;
   static constexpr int ROW_K = DKP * (int)sizeof(T) + 16;   // K / P rows (bytes)
@@ -35,17 +39,19 @@ struct AttnLds {
   static constexpr int ROW_V = BF ? DKP * 2 + 32 : KT * (int)sizeof(T) + 16;
   static constexpr int OFF_K = 0;
   static constexpr int OFF_P = OFF_K + KT * ROW_K;
-  static constexpr int OFF_V = HAS_POS ? OFF_P + KT * ROW_K : OFF_P;     // no positional keys: no P tile
-  static constexpr int TOTAL = OFF_V + (BF ? KT : DKP) * ROW_V;
+  static constexpr int OFF_V = (HAS_POS && !FOLD) ? OFF_P + KT * ROW_K : OFF_P;     // no positional keys (or folded into K): no P tile
+  static constexpr int OFF_C = OFF_V + (BF ? KT : DKP) * ROW_V;          // FOLD: the tile's 64 per-key constants (fp32)
+  static constexpr int TOTAL = OFF_C + (FOLD ? KT * 4 : 0);
 };
 
 // NW = waves per workgroup (16 queries each): 8 for the encoder and the cross attention (128-query blocks share a
 // staged key tile), 1 for the decoder's self attention over a hypothesis trie (a hypothesis owns a handful of rows).
-template <typename T, int DKP, bool HAS_POS, int NW>
+template <typename T, int DKP, bool HAS_POS, int NW, bool FOLD = false>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
+  static_assert(!FOLD || (HAS_POS && sizeof(T) == 2), "the folded positional term is built for the bf16 encoder form");
   constexpr int QT = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = AttnLds<T, DKP, HAS_POS>;
+  using L = AttnLds<T, DKP, HAS_POS, FOLD>;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int VE = Mma16<T>::VE;
   constexpr int KC = Mma16<T>::KC;
@@ -128,10 +134,10 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
           ov[e] = Cvt<T>::from_f32(ok ? (qf + bvv) * qscale : 0.f);
         }
         qu[ch] = *(uint4*)ou;
-        if constexpr (HAS_POS) qv[ch] = *(uint4*)ov;
+        if constexpr (HAS_POS && !FOLD) qv[ch] = *(uint4*)ov;
       } else {
         qu[ch] = raw;
-        if constexpr (HAS_POS) qv[ch] = raw;
+        if constexpr (HAS_POS && !FOLD) qv[ch] = raw;
       }
     }
   }
@@ -162,7 +168,19 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   // bank, so whole groups of 4 keys are XOR-swizzled by the row's 8-dim block: key' = key ^ (((dim/VE)&7)<<2).
   constexpr int NV = (KT * VPR + NT - 1) / NT;
   uint4 rk[NV], rp[HAS_POS ? NV : 1], rv[NV];
+  float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);       // FOLD: threads 0..15 carry the tile's 64 per-key constants
+  const float* __restrict__ Cb = FOLD ? a.pos_bias + (size_t)head * a.pos_bias_stride : nullptr;
+  char* sC = smem + L::OFF_C;
   auto gload = [&](int kt0) {
+    if constexpr (FOLD) {
+      if (tid < KT / 4) {
+        const int key = kt0 + 4 * tid;
+        float t4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] = key + r < kvlen ? Cb[key + r] : 0.f;
+        rc = make_float4(t4[0], t4[1], t4[2], t4[3]);
+      }
+    }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + NT * n;
@@ -180,13 +198,26 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
     }
   };
   auto lstore = [&]() {
+    if constexpr (FOLD) { if (tid < KT / 4) *(float4*)(sC + tid * 16) = rc; }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + NT * n;
       if (i < KT * VPR) {
         const int r = i / VPR, c = i - r * VPR;
-        *(uint4*)(sK + r * L::ROW_K + c * 16) = rk[n];
-        if constexpr (HAS_POS) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
+        if constexpr (FOLD) {
+          // K' = k + p: eight bf16 sums in fp32, rounded once
+          const bf16_t* kk = (const bf16_t*)&rk[n];
+          const bf16_t* pp = (const bf16_t*)&rp[n];
+          uint4 o;
+          o.x = pack2_bf16(bf16_to_f32(kk[0]) + bf16_to_f32(pp[0]), bf16_to_f32(kk[1]) + bf16_to_f32(pp[1]));
+          o.y = pack2_bf16(bf16_to_f32(kk[2]) + bf16_to_f32(pp[2]), bf16_to_f32(kk[3]) + bf16_to_f32(pp[3]));
+          o.z = pack2_bf16(bf16_to_f32(kk[4]) + bf16_to_f32(pp[4]), bf16_to_f32(kk[5]) + bf16_to_f32(pp[5]));
+          o.w = pack2_bf16(bf16_to_f32(kk[6]) + bf16_to_f32(pp[6]), bf16_to_f32(kk[7]) + bf16_to_f32(pp[7]));
+          *(uint4*)(sK + r * L::ROW_K + c * 16) = o;
+        } else {
+          *(uint4*)(sK + r * L::ROW_K + c * 16) = rk[n];
+          if constexpr (HAS_POS) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
+        }
         if constexpr (BF) {
           *(uint4*)(sV + r * L::ROW_V + c * 16) = rv[n];
         } else {
@@ -209,12 +240,17 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
     f32x4_t s[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      s[nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if constexpr (FOLD) {         // the accumulation starts from the keys' constants: fragment nf = keys 16 nf + 4 lgrp + r
+        const float4 c4 = *(const float4*)(sC + (nf * 16 + lgrp * 4) * 4);
+        s[nf] = (f32x4_t){c4.x, c4.y, c4.z, c4.w};
+      } else {
+        s[nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const uint4 ak = *(const uint4*)(sK + (nf * 16 + lrow) * L::ROW_K + ch * 64 + lgrp * 16);
         Mma16<T>::run(ak, qu[ch], s[nf]);
-        if constexpr (HAS_POS) {
+        if constexpr (HAS_POS && !FOLD) {
           const uint4 ap = *(const uint4*)(sP + (nf * 16 + lrow) * L::ROW_K + ch * 64 + lgrp * 16);
           Mma16<T>::run(ap, qv[ch], s[nf]);
         }
@@ -341,11 +377,11 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int DKP, bool HAS_POS, int NW>
+template <typename T, int DKP, bool HAS_POS, int NW, bool FOLD = false>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
-  using L = AttnLds<T, DKP, HAS_POS>;
+  using L = AttnLds<T, DKP, HAS_POS, FOLD>;
   static bool attr_set = false;
-  auto kern = attn_kernel<T, DKP, HAS_POS, NW>;
+  auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
     attr_set = true;
@@ -362,6 +398,9 @@ template <typename T>
 static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   const bool pos = a.p != nullptr;
   const int dk = a.dk;
+  if constexpr (sizeof(T) == 2) {      // the folded positional term: bf16, dk <= 64, 128-query workgroups (the encoder's form)
+    if (pos && a.pos_bias != nullptr && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128)) return launch_attn<T, 64, true, 8, true>(s, a);
+  }
 #define RVB_ATTN_CASE(D)                                                           \
   if (dk <= D) {                                                                   \
     if (a.q_block == 16) return launch_attn<T, D, false, 1>(s, a);                 \
@@ -380,6 +419,26 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
 #undef RVB_ATTN_CASE
   set_error("attention: head dim > 128 unsupported");
   return E_UNSUPPORTED;
+}
+
+// c[h][j] = sum_e (v[h][e] - u[h][e]) * P[j][h*dk + e] * scale, P in bf16 as the kernel reads it; one thread per (h, j)
+__global__ __launch_bounds__(256) void pos_bias_kernel(const bf16_t* __restrict__ P, int rows, int p_stride, const float* __restrict__ bu,
+                                                       const float* __restrict__ bv, int heads, int dk, float scale, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= heads * rows) return;
+  const int h = idx / rows, j = idx - h * rows;
+  const bf16_t* pr = P + (size_t)j * p_stride + h * dk;
+  float acc = 0.f;
+  for (int e = 0; e < dk; ++e) acc += (bv[h * dk + e] - bu[h * dk + e]) * bf16_to_f32(pr[e]);
+  out[idx] = acc * scale;
+}
+int attention_pos_bias(hipStream_t s, const void* P, int rows, int p_stride, const float* bias_u, const float* bias_v, int heads, int dk,
+                       float scale, float* out) {
+  if (rows <= 0 || heads <= 0) return OK;
+  hipLaunchKernelGGL(pos_bias_kernel, dim3(cdiv(heads * rows, 256)), dim3(256), 0, s, (const bf16_t*)P, rows, p_stride, bias_u, bias_v, heads, dk,
+                     scale, out);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
 }
 
 int attention(hipStream_t s, int dtype, const AttnArgs& a0) {

@@ -40,6 +40,7 @@ struct LNorm { DevBuf g, b; float eps = 1e-5f; };
 struct EncLayer {
   Linear ffm1, ffm2, ff1, ff2, qkv, att_out, pw1, pw2, lsl;
   DevBuf pos_keys;            // T [Tpos, d] = linear_pos(pe[:Tpos])
+  DevBuf pos_bias;            // bf16 engine: fp32 [heads][Tpos], (pos_bias_v - pos_bias_u) . pos_keys * log2(e)/sqrt(dk) (attention.hip FOLD)
   DevBuf bias_u, bias_v;      // fp32 [h*dk]
   LNorm n_ffm, n_mha, n_conv, n_ff, n_final, n_cnn;
   DevBuf dw_w, dw_b;          // fp32 [K][d] (tap-major), [d]

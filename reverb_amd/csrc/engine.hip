@@ -409,6 +409,13 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
       RVB_TRY(pack_named_linear(e, lp, p + ".self_attn.linear_pos", d, d, false));
       RVB_TRY(L.pos_keys.ensure((size_t)e->pe_rows * d * dt_size(e->dtype)));
       RVB_TRY(run_gemm(e, pe_T.p, d, lp, L.pos_keys.p, d, e->pe_rows, false));
+      if (e->dtype == DT_BF16) {
+        // the positional product folded into a per-key constant (attention.hip FOLD): (v - u) . p_j, in the exp2 domain of the kernel
+        const int dk_enc = d / c.heads;
+        RVB_TRY(L.pos_bias.ensure((size_t)c.heads * e->pe_rows * 4));
+        RVB_TRY(attention_pos_bias(e->stream, L.pos_keys.p, e->pe_rows, d, L.bias_u.as<float>(), L.bias_v.as<float>(), c.heads, dk_enc,
+                                   1.44269504f / std::sqrt((float)dk_enc), L.pos_bias.as<float>()));
+      }
       RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
       lp.w.release(); lp.b.release();
     }
@@ -517,6 +524,10 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     const size_t es = dt_size(e->dtype);
     a.q = e->h.p; a.k = (const char*)e->h.p + (size_t)d * es; a.v = (const char*)e->h.p + (size_t)2 * d * es;
     a.p = L.pos_keys.p;
+    {   // bf16: positional term folded into per-key constants (RVB_ATTN_FOLD=0: the two-product form, for A/B)
+      static const int fold = getenv("RVB_ATTN_FOLD") ? atoi(getenv("RVB_ATTN_FOLD")) : 1;
+      if (fold && L.pos_bias.p) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; }
+    }
     a.q_stride = a.k_stride = a.v_stride = 3 * d; a.p_stride = d; a.o_stride = d;
     a.bias_u = L.bias_u.as<float>(); a.bias_v = L.bias_v.as<float>();
     a.out = e->ao.p;
@@ -535,6 +546,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
                                      (size_t)3 * d * es, (size_t)2 * d * es, M, hipMemcpyDeviceToDevice, e->stream));
       a.k = kvb; a.v = kvb + (size_t)d * es; a.k_stride = a.v_stride = 2 * d;
       a.p = (const char*)L.pos_keys.p + (size_t)(st.offset - st.cache_len) * d * es;
+      if (a.pos_bias) a.pos_bias += (st.offset - st.cache_len);
       a.kv_start = e->d_stream_i32.as<int>(); a.kv_len = e->d_stream_i32.as<int>() + 1;
       a.chunk = 0; a.left = -1;
       keys = st.cache_len + M;
@@ -1872,7 +1884,7 @@ void rvb_destroy(rvb_engine* e) {
   for (auto& L : e->enc) {
     for (Linear* l : {&L.ffm1, &L.ffm2, &L.ff1, &L.ff2, &L.qkv, &L.att_out, &L.pw1, &L.pw2, &L.lsl}) rel_lin(*l);
     for (LNorm* n : {&L.n_ffm, &L.n_mha, &L.n_conv, &L.n_ff, &L.n_final, &L.n_cnn}) rel_n(*n);
-    L.pos_keys.release(); L.bias_u.release(); L.bias_v.release(); L.dw_w.release(); L.dw_b.release();
+    L.pos_keys.release(); L.pos_bias.release(); L.bias_u.release(); L.bias_v.release(); L.dw_w.release(); L.dw_b.release();
   }
   for (Decoder* D : {&e->dec_l, &e->dec_r}) {
     D->embed.release(); rel_lin(D->out); rel_n(D->after);

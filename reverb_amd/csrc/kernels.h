@@ -164,7 +164,14 @@ struct AttnArgs {
   int n_work;
   int q_block;           // queries per workgroup: 0 / 128 (8 waves) or 16 (1 wave; decoder forms only)
   int plain_order;       // tuning (RVB_ATTN_PLAIN=1): keep the launch order instead of the XCD-aware (sequence, head) grouping
+  // bf16 encoder form with the positional term folded (attention.hip FOLD): fp32 [heads][pos_bias_stride], entry j =
+  // (pos_bias_v - pos_bias_u)[head] . p[j][head] * log2(e) / sqrt(dk) for positional row j of `p` (same row offset as `p`); null = two products
+  const float* pos_bias;
+  int pos_bias_stride;
 };
+// builds that table for positional keys P [rows, p_stride] (bf16): out fp32 [heads][rows]
+int attention_pos_bias(hipStream_t s, const void* P, int rows, int p_stride, const float* bias_u, const float* bias_v, int heads, int dk,
+                       float scale, float* out);
 int attention(hipStream_t s, int dtype, const AttnArgs& a);
 
 }  // namespace rvb

@@ -183,6 +183,14 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
   int mq = 0;
   for (int i = 0; i < nseq; ++i) mq = q_len[i] > mq ? q_len[i] : mq;
   a.max_q = mq;
+  // bit 1 of `causal`: the bf16 encoder form with the positional term folded into per-key constants (as the engine runs it)
+  Dev dc;
+  if ((causal & 2) && p && dtype == DT_BF16) {
+    T_TRY(dc.alloc((size_t)heads * p_rows * 4));
+    T_TRY(attention_pos_bias(nullptr, dp.p, p_rows, d, (const float*)du.p, (const float*)dvv.p, heads, dk, 1.44269504f / sqrtf((float)dk),
+                             (float*)dc.p));
+    a.pos_bias = (const float*)dc.p; a.pos_bias_stride = p_rows;
+  }
   T_TRY(attention(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());
   return down_T(dout, dtype, false, out, (size_t)q_rows * d);

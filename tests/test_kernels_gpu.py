@@ -335,6 +335,16 @@ def test_attention_encoder_form(lib, dtype, heads, dk, T, pos):
     tol = 2e-5 if dtype == F32 else 3e-2
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
     assert np.all(out[2 * T:] == 0)     # fully masked chunk -> zeros (attention.py:112-114)
+    if pos and dtype == BF16 and 32 < dk <= 64:
+        # round 4: the form the bf16 engine runs -- (q + u).(k + p) + (v - u).p, the second product a per-key table (attention.hip
+        # FOLD; bit 1 of the test hook's `causal` word builds the table with attention_pos_bias): same scores up to bf16 rounding
+        # of k + p, so the same tolerance against the fp64 reference
+        out2 = np.empty_like(out)
+        _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), fptr(p), fptr(bu), fptr(bv), fptr(out2), B * T, B * T, T,
+                                          heads, dk, iptr(starts), iptr(qlen), iptr(starts), iptr(kv_len), B, 2))
+        np.testing.assert_allclose(out2, ref, rtol=tol, atol=tol)
+        assert np.all(out2[2 * T:] == 0)
+        assert not np.array_equal(out2, out)          # it really is the other kernel
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
