@@ -17,6 +17,8 @@ grep '^{' $O/bench_diar.log | tail -1 > $P/${R}_bench_diar_1h_bf16.json.log
 cp $O/parity_metrics.jsonl $P/${R}_parity_metrics.jsonl
 grep -a "passed" $O/pytest_gpu.log | tail -1 > $P/${R}_pytest_gpu_summary.txt
 grep '^{' $O/bench_r640_forced_dist.log | tail -1 > $P/${R}_bench_r640_1h_forced_dist.json.log
+[ -f $O/bench_r640_forced_dist_posteriors.log ] && grep '^{' $O/bench_r640_forced_dist_posteriors.log | tail -1 > $P/${R}_bench_r640_1h_forced_dist_posteriors.json.log || true
+[ -f $O/bench_joint_3h.log ] && grep '^{' $O/bench_joint_3h.log | tail -1 > $P/${R}_bench_joint_3h_fp8.json.log || true
 [ -f $O/gemm_bench.txt ] && cp $O/gemm_bench.txt $P/${R}_gemm_bench_switches.txt || true
 [ -f $O/gemm_timeline.txt ] && cp $O/gemm_timeline.txt $P/${R}_gemm_timeline.txt || true
 ls -la $P | grep " ${R}_" | awk '{print $5, $9}'

@@ -12,6 +12,8 @@ timeout 300 python bench.py --steps 3 --warmup 1 --dtype fp8 --no-diarization --
 timeout 300 python bench.py --steps 3 --warmup 1 --model r268 --no-diarization --no-pcie --traffic off > $O/bench_r268.log 2>&1
 timeout 400 python bench_diar.py --steps 3 --warmup 1 > $O/bench_diar.log 2>&1
 RVB_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-diarization --no-pcie --traffic off --cpu-baseline-chunks 0 > $O/bench_r640_forced_dist.log 2>&1
+RVB_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-diarization --no-pcie --traffic off --cpu-baseline-chunks 0 --gather posteriors > $O/bench_r640_forced_dist_posteriors.log 2>&1
+timeout 400 python bench_joint.py --hours 3 --steps 2 --warmup 1 > $O/bench_joint_3h.log 2>&1      # config 5's audio length on one GPU
 if [ "${REFRESH_GEMM_LAB:-0}" = 1 ]; then      # the GEMM micro-benchmarks only change when gemm2.hip does
   timeout 200 python scripts/gemm_bench.py 0,-2 4,8 > $O/gemm_bench.txt 2>&1
   timeout 200 python scripts/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
