@@ -409,6 +409,10 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
 //     XCDs), the first to arrive names its XCD (HW_REG_XCC_ID), the first MB_G arrivals on that XCD take tickets, everybody
 //     else returns at once.  Every spin is bounded; a barrier that does not complete sets an abort word, the kernel returns
 //     with status -2 and centroid_linkage() falls back to the one-workgroup loop.
+// Also measured and dropped (profiles/r04_call8_linkage_tagged_exchange.txt): publishing as the barrier -- the round's number in
+// the last word of every entry, every WAVE polling the 16 tag words itself instead of thread 0 polling one arrival counter.
+// Exact, but 256 polling waves on 16 cache lines slow the writers down more than the saved round trip is worth: 111-122 ms
+// instead of 94-97 ms at n = 9 200, 531 instead of 422 ms at n = 27 000, 92 instead of 74 ms in the pipeline.
 static constexpr int MB_G = 16, MB_NT = 1024;
 // Eager validation right after a merge of the stale rows whose bound is within 5 % of the merged distance (to save the extra
 // round they would cost when they reach the top): measured and switched off -- on high-dimensional noise 33 rows per merge

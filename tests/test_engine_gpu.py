@@ -135,7 +135,9 @@ def test_encode_rejects_bad_arguments_and_reports():
     with pytest.raises(RvbError, match="max_chunks"):
         eng.encode(np.zeros((3, case.chunk, 80), np.float32), [case.chunk] * 3, 4)
     with pytest.raises(RvbError, match="beam"):
-        eng.encode(x, lens, 17)
+        eng.encode(x, lens, 65)            # the CTC kernel keeps at most 64 log-probs per frame (16 until round 4)
+    with pytest.raises(RvbError, match="beam"):
+        eng.encode(x, lens, 0)
     with pytest.raises(RvbError):
         eng.rescore([], 0.1, 0.0)          # no search results yet
     eng.close()
