@@ -84,6 +84,11 @@ int rvd_get_emb_fbank(rvd_engine* e, int64_t window, float* out, int32_t* n_fram
  * metric="euclidean") returns for X host fp64 [n][d] -- Z host fp64 [n-1][4] (id_a, id_b, distance, size),
  * rows in merge order, cluster n+k created by row k.  fp64 throughout. */
 int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z);
+/* How many workgroups the merge loop of rvd_centroid_linkage may take (it is persistent: its workgroups keep their CUs for the
+ * whole clustering): 0 = default (16 workgroups of one XCD from 3 000 points on), 1 = one workgroup, 2 / 4 / 8 / 16.  The
+ * dendrogram does not depend on it.  A pipeline that clusters UNDERNEATH another engine's kernels (transcribe_diarize: the ASR
+ * encoder) asks for 4: measured on one hour, joint step 472 ms with 4, 477 with 1, 486 with 8, 493-499 with 16. */
+int rvd_set_linkage_workgroups(rvd_engine* e, int workgroups);
 
 int rvd_set_profiling(rvd_engine* e, int enabled);
 int rvd_reset_timings(rvd_engine* e);

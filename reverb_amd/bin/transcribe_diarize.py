@@ -69,10 +69,17 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
         pcm_d, uri = pipe._load(audio)
         classes, emb = pipe.networks(pcm_d)
         timings["diarization_networks"] = time.perf_counter() - td
-        with ThreadPoolExecutor(1) as ex:
-            fd = ex.submit(pipe.finish, classes, emb, uri)
-            ctm = asr_local()
-            ann = fd.result()
+        # the clustering's merge loop is persistent: with its default 16 workgroups it takes 16 CUs and an XCD's L2 away from the
+        # ASR encoder it runs underneath (1 h: joint step 493-499 ms; 472 ms with 4 workgroups, 477 with one); recordings too long
+        # for 4 workgroups' LDS (more than ~18 000 embeddings) get as many as they need (rvd_set_linkage_workgroups)
+        pipe.engine.set_linkage_workgroups(4)
+        try:
+            with ThreadPoolExecutor(1) as ex:
+                fd = ex.submit(pipe.finish, classes, emb, uri)
+                ctm = asr_local()
+                ann = fd.result()
+        finally:
+            pipe.engine.set_linkage_workgroups(0)
         timings["diarization"] = time.perf_counter() - td
     else:
         ctm = asr_local()

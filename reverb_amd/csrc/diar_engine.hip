@@ -31,6 +31,7 @@ static int emb_batch() {            // windows per trunk pass; RVD_EMB_BATCH ove
 struct rvd_engine {
   rvd_model_cfg cfg;
   int device = 0, dtype = 0;
+  int linkage_workgroups = 0;          // rvd_set_linkage_workgroups: hint for rvd_centroid_linkage's merge loop
   hipStream_t stream = nullptr;
   bool finalized = false;
   std::map<std::string, HostTensor> host;
@@ -821,7 +822,7 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
     {
       DScope sc(e, "linkage");
       rc = centroid_linkage(e->stream, dX.as<double>(), n, d, dD.as<double>(), (uint16_t*)(dI.as<int>() + 2 * n), dI.as<int>(),
-                            dI.as<int>() + n, dM.as<double>(), dZ.as<double>(), dC.p);
+                            dI.as<int>() + n, dM.as<double>(), dZ.as<double>(), dC.p, e->linkage_workgroups);
     }
     if (rc != OK) break;
     if (hipMemcpyAsync(Z, dZ.p, (size_t)(n - 1) * 4 * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
@@ -847,6 +848,15 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
   } while (0);
   dX.release(); dD.release(); dI.release(); dM.release(); dZ.release(); dC.release();
   return rc;
+}
+
+int rvd_set_linkage_workgroups(rvd_engine* e, int workgroups) {
+  if (!e || !(workgroups == 0 || workgroups == 1 || workgroups == 2 || workgroups == 4 || workgroups == 8 || workgroups == 16)) {
+    set_error("rvd_set_linkage_workgroups: 0 (default), 1, 2, 4, 8 or 16");
+    return E_ARG;
+  }
+  e->linkage_workgroups = workgroups;
+  return OK;
 }
 
 int rvd_set_profiling(rvd_engine* e, int enabled) { if (!e) return E_ARG; drain(e); e->profiling = enabled != 0; return OK; }

@@ -266,7 +266,9 @@ int tstp_pool(hipStream_t s, int dtype, const void* x, const int* item_b, const 
 // neighbor [n] ints, min_dist [n] doubles, scratch >= 4 KiB (control block of the multi-workgroup merge loop; null = one
 // workgroup only).  From 3 000 points on the merge loop runs on 16 workgroups of one XCD (RVD_LINKAGE_MB) and the call then
 // returns after the loop has finished (it checks the loop's status and falls back to the one-workgroup loop if needed).
+// `workgroups`: 0 = default (16), 1 = the one-workgroup loop, 2 / 4 / 8 / 16 = that many workgroups (fewer disturb a concurrent
+// kernel less: the joint pipeline clusters underneath the ASR encoder).
 int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
-                     double* min_dist, double* Z, void* scratch);
+                     double* min_dist, double* Z, void* scratch, int workgroups = 0);
 
 }  // namespace rvb

@@ -436,11 +436,11 @@ __device__ inline void mb_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: 
 __device__ inline bool lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }
 
 // all MB_G workgroups have arrived `gen` times; false = gave up (abort word set, by us or by somebody else)
-__device__ inline bool mb_grid_barrier(LkCtl* ctl, unsigned gen, int* s_flag) {
+__device__ inline bool mb_grid_barrier(LkCtl* ctl, unsigned gen, int G, int* s_flag) {
   __syncthreads();                       // every thread of the workgroup has waited for its stores (caller)
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = gen * (unsigned)MB_G;
+    const unsigned target = gen * (unsigned)G;
     unsigned spins = 0;
     int ok = 1;
     while ((int)(__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -460,7 +460,8 @@ __device__ inline bool mb_grid_barrier(LkCtl* ctl, unsigned gen, int* s_flag) {
 }
 
 __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ D, int n, const int* __restrict__ g_neighbor,
-                                                           double* __restrict__ g_min_dist, double* __restrict__ Z, LkCtl* ctl) {
+                                                           double* __restrict__ g_min_dist, double* __restrict__ Z, LkCtl* ctl, int G) {
+  // G = participating workgroups: a power of two <= MB_G (RVD_LINKAGE_G; 16 by default)
   extern __shared__ __attribute__((aligned(16))) char mb_smem[];
   __shared__ MinPair red[2][16];
   __shared__ int s_wtot[16];
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
     int b = -1;
     if (chosen == my) {
       b = __hip_atomic_fetch_add(&ctl->tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (b >= MB_G) b = -1;
+      if (b >= G) b = -1;
     }
     s_b = b;
   }
@@ -487,15 +488,15 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
 
   // ---- LDS: own candidates, rescan list, replicated sizes, sorted live list
   const int ngrp = (n + 15) >> 4;                           // 16-slot groups
-  const int m = ((ngrp + MB_G - 1) / MB_G) << 4;            // own slots (capacity)
+  const int m = ((ngrp + G - 1) / G) << 4;                  // own slots (capacity)
   double* s_md = (double*)mb_smem;                          // [m] candidate distance: exact when valid, a lower bound when stale
   int* s_nb = (int*)(s_md + m);                             // [m] >= 0 valid neighbour, <= -2 stale (neighbour -2 - nb), -1 none
   int* s_rl = s_nb + m;                                     // [m] rows to rescan
   uint16_t* s_sz = (uint16_t*)(s_rl + m);                   // [n]
   uint16_t* s_al = s_sz + ((n + 1) & ~1);                   // [n] live slots, ascending (rebuilt every 256 merges)
-  auto slot_of = [&](int li) -> int { return (((li >> 4) * MB_G + b) << 4) + (li & 15); };
-  auto owner_of = [&](int z) -> int { return (z >> 4) % MB_G; };
-  auto li_of = [&](int z) -> int { return (((z >> 4) / MB_G) << 4) + (z & 15); };
+  auto slot_of = [&](int li) -> int { return (((li >> 4) * G + b) << 4) + (li & 15); };
+  auto owner_of = [&](int z) -> int { return (z >> 4) & (G - 1); };
+  auto li_of = [&](int z) -> int { return (((z >> 4) / G) << 4) + (z & 15); };
   for (int i = tid; i < n; i += MB_NT) s_sz[i] = 1;
   for (int li = tid; li < m; li += MB_NT) {
     const int z = slot_of(li);
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
       }
       mb_stores_done();                                     // the merge pass's stores to D and the entry: acknowledged by the L2
       ++gen;
-      if (!mb_grid_barrier(ctl, gen, &s_flag)) {
+      if (!mb_grid_barrier(ctl, gen, G, &s_flag)) {
         if (b == 0 && tid == 0) g_min_dist[n - 1] = -2.0;
         return;
       }
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
       MinPair gv, gs, gp;
       int gy;
       {
-        const LkEntry* e = &ctl->ent[(gen - 1) & 1][lane & 15];
+        const LkEntry* e = &ctl->ent[(gen - 1) & 1][lane & (G - 1)];      // (lanes beyond G re-read entries: min is idempotent)
         const double vv = mb_ldf(&e->val_v);
         const unsigned long long vxy = mb_ld64(&e->val_x);
         const double sv = mb_ldf(&e->st_v);
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
 }
 
 int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, uint16_t* size, int* cluster_id, int* neighbor,
-                     double* min_dist, double* Z, void* scratch) {
+                     double* min_dist, double* Z, void* scratch, int workgroups) {
   if (n < 2) return OK;
   const int t = cdiv(n, 64);
   const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
@@ -699,9 +700,15 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   // CU's LDS-resident loop is as fast: a merge is a chain of latencies either way)
   const char* mbe = getenv("RVD_LINKAGE_MB");
   const int mb_mode = mbe ? atoi(mbe) : -1;
-  const int ngrp = (n + 15) >> 4, m_own = ((ngrp + MB_G - 1) / MB_G) << 4;
+  // workgroups of the multi-workgroup loop: the caller's hint (rvd_set_linkage_workgroups: 1 = the one-workgroup loop, a power of
+  // two up to 16, 0 = default), RVD_LINKAGE_G overrides; a count whose per-workgroup state does not fit LDS is doubled until it does
+  int G = MB_G;
+  if (workgroups == 2 || workgroups == 4 || workgroups == 8 || workgroups == 16) G = workgroups;
+  if (const char* ge = getenv("RVD_LINKAGE_G")) { const int v = atoi(ge); if (v == 2 || v == 4 || v == 8 || v == 16) G = v; }
+  while (G < MB_G && (size_t)((((n + 15) >> 4) + G - 1) / G << 4) * 16 + (size_t)((n + 1) & ~1) * 4 > 150 * 1024) G *= 2;
+  const int ngrp = (n + 15) >> 4, m_own = ((ngrp + G - 1) / G) << 4;
   const size_t lds_mb = (size_t)m_own * 16 + (size_t)((n + 1) & ~1) * 4;
-  const bool use_mb = scratch != nullptr && !force_global && !no_compact && lds_mb <= 150 * 1024 &&
+  const bool use_mb = scratch != nullptr && workgroups != 1 && !force_global && !no_compact && lds_mb <= 150 * 1024 &&
                       (mb_mode == 1 || (mb_mode < 0 && n >= 3000));
   static bool attr_set = false;
   if (!attr_set) {
@@ -719,7 +726,7 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
       RVB_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(LkCtl), s));
       // at least 64 KiB of LDS per workgroup so that a CU holds one of them (the MB_G participants sit on MB_G different CUs)
       const size_t lds_launch = lds_mb < 96 * 1024 ? 96 * 1024 : lds_mb;
-      hipLaunchKernelGGL(linkage_mb_kernel, dim3(8 * (MB_G + 8)), dim3(MB_NT), lds_launch, s, D, n, neighbor, min_dist, Z, (LkCtl*)scratch);
+      hipLaunchKernelGGL(linkage_mb_kernel, dim3(8 * (G + 8)), dim3(MB_NT), lds_launch, s, D, n, neighbor, min_dist, Z, (LkCtl*)scratch, G);
       RVB_HIP_CHECK(hipGetLastError());
       double status = 0.0;
       RVB_HIP_CHECK(hipMemcpyAsync(&status, min_dist + (n - 1), 8, hipMemcpyDeviceToHost, s));

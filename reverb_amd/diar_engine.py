@@ -137,6 +137,10 @@ class DiarEngine:
         _check(self.lib.rvd_get_emb_fbank(self._h, int(window), fptr(out), C.byref(n)), "rvd_get_emb_fbank")
         return out[:n.value].copy()
 
+    def set_linkage_workgroups(self, workgroups: int = 0):
+        """Workgroups the clustering's merge loop may take (0 default = 16, 1, 2, 4, 8, 16); the dendrogram does not depend on it."""
+        _check(self.lib.rvd_set_linkage_workgroups(self._h, int(workgroups)), "rvd_set_linkage_workgroups")
+
     def centroid_linkage(self, X: np.ndarray) -> np.ndarray:
         """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") on the GPU (fp64)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
