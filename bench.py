@@ -244,6 +244,9 @@ def main():
             # barriers around the timed region, the maximum of the step time -- goes through librvb's own communicator
             # (rvb_comm_*), so a rank holds ONE RCCL communicator
             torch.cuda.set_device(local_rank)
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the container's hostname resolving
+            os.environ["RVB_COMM"] = "cabi"       # tells reverb_amd.dist that this CPU group is a rendezvous: collectives are librvb's
             dist.init_process_group("gloo")
         world = dist.get_world_size()          # what the process group reports, not what the environment claims
     if not STUB and not torch.cuda.is_available():

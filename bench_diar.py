@@ -197,6 +197,9 @@ def main():
         if os.environ.get("RVB_COMM", "cabi") == "torch":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the container's hostname resolving
+            os.environ["RVB_COMM"] = "cabi"       # tells reverb_amd.dist that this CPU group is a rendezvous: collectives are librvb's
             dist.init_process_group("gloo")       # rendezvous only (see bench.py): the collectives are librvb's
         world = dist.get_world_size()
     if not torch.cuda.is_available():

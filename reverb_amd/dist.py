@@ -303,10 +303,12 @@ def default_comm(engine):
     if os.environ.get("RVB_COMM", "cabi") == "torch":
         return None
     if dist.get_backend() != "nccl":
-        # a CPU process group: the gloo tests with stub engines (no GPU: torch.distributed does the gather), or -- round 4 --
-        # a rendezvous-only group on a GPU box, where every collective is librvb's
+        # a CPU process group: either the gloo tests with stub engines (torch.distributed does the gather, on CPU tensors), or
+        # -- round 4 -- the rendezvous-only group of a launcher whose collectives are all librvb's.  The launcher says so
+        # explicitly (bench.py / bench_diar.py export RVB_COMM=cabi before they create the group): a gloo group by itself, even
+        # on a box with GPUs, is NOT taken as permission to bind RCCL (two stub ranks on one GPU would hang in ncclCommInitRank)
         import torch
-        if not torch.cuda.is_available():
+        if os.environ.get("RVB_COMM") != "cabi" or not torch.cuda.is_available():
             return None
     if _DEFAULT_COMM is None or not _DEFAULT_COMM.handle:
         _DEFAULT_COMM = RvbComm.from_torch_group(_device_of(engine))
@@ -342,6 +344,8 @@ def gather_words(send: np.ndarray, device, comm: "RvbComm" = None) -> np.ndarray
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl":
+        device = "cpu"                              # gloo gathers host tensors
     t = torch.from_numpy(send).to(device)
     g = torch.empty(world * send.size, dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(g, t)
