@@ -432,76 +432,83 @@ def _decode_range(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse
     return engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty), nf
 
 
-def _recover_sharded(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, local, ranges, timeout,
-                     why: str):
-    """The failure path of decode_sharded ("worker failure -> re-queue chunk range"; the reference is a
-    single process and has nothing of the kind).  Chunks are independent and idempotent (asr/wenet/cli/reverb.py:220-253), so
-    a missing rank costs only its chunk range:
+def _recover_through_store(what: str, ranges, local_blob: bytes, redo, timeout: float, why: str):
+    """The failure path shared by decode_sharded and diarize_sharded ("worker failure -> re-queue chunk
+    range"; the reference is a single process and has nothing of the kind).  The units of both paths (chunks, windows) are
+    independent and idempotent (asr/wenet/cli/reverb.py:220-253), so a missing rank costs only its range:
 
       1. every surviving rank puts its packed results into the rendezvous store (`rvb/<epoch>/res/<rank>`);
-      2. rank 0 waits `timeout` seconds for them, declares the ranks whose results did not arrive dead, splits their chunk
-         ranges evenly over the survivors and publishes that plan (`rvb/<epoch>/plan`);
-      3. every survivor decodes the extra ranges the plan gives it and publishes them (`rvb/<epoch>/extra/<rank>/<i>`);
-      4. every survivor reads all pieces and assembles the recording in chunk order.
+      2. rank 0 waits `timeout` seconds for them, declares the ranks whose results did not arrive dead, splits their ranges
+         evenly over the survivors and publishes that plan (`rvb/<epoch>/plan`);
+      3. every survivor computes the extra ranges the plan gives it (`redo(a, b) -> bytes`) and publishes them
+         (`rvb/<epoch>/extra/<i>`);
+      4. every survivor reads all pieces.
 
     Rank 0 is the arbiter (it usually hosts the store as well): if rank 0 itself is lost the job fails -- stated, not hidden.
-    Returns {mode: results of all chunks} like the fast path."""
+    Returns (info, pieces): info = {"alive", "dead", "plan", "why"}, pieces = [(a, b, blob)] covering every range in order."""
     import json
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     store = _store()
     tag = f"rvb/{_EPOCH}"
-    nm = len(modes)
-
-    def pack(res):
-        return pack_results([h for m in modes for h in res[m]]).tobytes()
-
-    def unpack(blob, count):
-        rows = unpack_results(np.frombuffer(blob, np.int32))
-        assert len(rows) == count * nm, (len(rows), count, nm)
-        return {m: rows[i * count:(i + 1) * count] for i, m in enumerate(modes)}
-
-    store.set(f"{tag}/res/{rank}", pack(local))
+    store.set(f"{tag}/res/{rank}", local_blob)
     if rank == 0:
         blobs = {r: _store_wait(store, f"{tag}/res/{r}", timeout) for r in range(world)}
         alive = [r for r in range(world) if blobs[r] is not None]
         dead = [r for r in range(world) if blobs[r] is None]
-        plan = []                                   # [dead rank, survivor, c0, c1] in chunk order
+        plan = []                                   # [dead rank, survivor, a, b] in unit order
         for d in dead:
             a, b = ranges[d]
             for surv, (u, v) in zip(alive, chunk_ranges(b - a, len(alive))):
                 if v > u:
                     plan.append([d, surv, a + u, a + v])
         store.set(f"{tag}/plan", json.dumps({"alive": alive, "dead": dead, "plan": plan, "why": why}).encode())
-    blob = _store_wait(store, f"{tag}/plan", 3.0 * timeout + 30.0)
+    long_wait = 3.0 * timeout + 30.0
+    blob = _store_wait(store, f"{tag}/plan", long_wait)
     if blob is None:
-        raise CollectiveFailed(f"decode_sharded: no recovery plan from rank 0 within {3.0 * timeout + 30.0:.0f} s ({why})")
+        raise CollectiveFailed(f"{what}: no recovery plan from rank 0 within {long_wait:.0f} s ({why})")
     info = json.loads(bytes(blob).decode())
     if rank not in info["alive"]:
-        raise CollectiveFailed(f"decode_sharded: rank {rank} was declared dead by rank 0 (its results arrived after {timeout} s)")
-    for i, (d, surv, c0, c1) in enumerate(info["plan"]):
-        if surv == rank:                            # the re-queued work: a dead rank's chunks, decoded here
-            res, _ = _decode_range(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, c0, c1)
-            store.set(f"{tag}/extra/{i}", pack(res))
-    out = {m: [] for m in modes}
+        raise CollectiveFailed(f"{what}: rank {rank} was declared dead by rank 0 (its results arrived after {timeout} s)")
+    for i, (d, surv, a, b) in enumerate(info["plan"]):
+        if surv == rank:                            # the re-queued work: a dead rank's units, computed here
+            store.set(f"{tag}/extra/{i}", redo(a, b))
+    pieces = []
     for r, (a, b) in enumerate(ranges):
         if r in info["alive"]:
             piece = _store_wait(store, f"{tag}/res/{r}", timeout)
             if piece is None:
-                raise CollectiveFailed(f"decode_sharded: results of rank {r} vanished from the store")
-            part = unpack(bytes(piece), b - a)
-            for m in modes:
-                out[m].extend(part[m])
+                raise CollectiveFailed(f"{what}: results of rank {r} vanished from the store")
+            pieces.append((a, b, bytes(piece)))
         else:
-            for i, (d, surv, c0, c1) in enumerate(info["plan"]):
+            for i, (d, surv, u, v) in enumerate(info["plan"]):
                 if d != r:
                     continue
-                piece = _store_wait(store, f"{tag}/extra/{i}", 3.0 * timeout + 30.0)
+                piece = _store_wait(store, f"{tag}/extra/{i}", long_wait)
                 if piece is None:
-                    raise CollectiveFailed(f"decode_sharded: re-queued chunks [{c0}, {c1}) of dead rank {r} never arrived from rank {surv}")
-                part = unpack(bytes(piece), c1 - c0)
-                for m in modes:
-                    out[m].extend(part[m])
+                    raise CollectiveFailed(f"{what}: re-queued range [{u}, {v}) of dead rank {r} never arrived from rank {surv}")
+                pieces.append((u, v, bytes(piece)))
+    return info, pieces
+
+
+def _recover_sharded(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, local, ranges, timeout,
+                     why: str):
+    """decode_sharded after a failed gather: -> {mode: results of all chunks} like the fast path (_recover_through_store)."""
+    nm = len(modes)
+
+    def pack(res):
+        return pack_results([h for m in modes for h in res[m]]).tobytes()
+
+    def redo(c0, c1):
+        return pack(_decode_range(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, c0, c1)[0])
+
+    info, pieces = _recover_through_store("decode_sharded", ranges, pack(local), redo, timeout, why)
+    out = {m: [] for m in modes}
+    for a, b, blob in pieces:
+        rows = unpack_results(np.frombuffer(blob, np.int32))
+        assert len(rows) == (b - a) * nm, (len(rows), a, b, nm)
+        for i, m in enumerate(modes):
+            out[m].extend(rows[i * (b - a):(i + 1) * (b - a)])
     decode_sharded.last_recovery = info            # what happened, for the caller's log
     return out
 
@@ -615,14 +622,20 @@ def unpack_diar_shard(words: np.ndarray, kmax: int):
     return classes, emb
 
 
-def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
+def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, timeout: float = None, **kwargs):
     """Diarize one long recording with the 10 s windows of pyannote's sliding inference split into contiguous
     ranges, one per rank (one process per GPU).  Both networks run on the rank's own windows with no data-path
     collective; ONE all-gather (the same transport as the ASR results: librvb's rvb_allgather_results on GPUs) then
     brings the per-window powerset classes (uint8, 589 B per window) and the speaker embeddings (3 x 256 fp32 per
     window) of every rank to every rank in one packed buffer, and the global part -- speaker count, clustering,
-    reconstruction -- runs identically everywhere.  Returns the Annotation on every rank."""
+    reconstruction -- runs identically everywhere.  Returns the Annotation on every rank.
+
+    `timeout` (seconds; None = wait for ever): as in decode_sharded -- a gather that cannot complete is replaced by the
+    exchange through the rendezvous store, and the windows of a rank that is gone are run by the survivors (round 4)."""
     import torch.distributed as dist
+    global _EPOCH
+    _EPOCH += 1
+    diarize_sharded.last_recovery = None
     world, rank = dist.get_world_size(), dist.get_rank()
     cfg = pipeline.cfg
     win, step = int(cfg["window_samples"]), int(cfg["step_samples"])
@@ -633,16 +646,44 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, **kwargs):
     w0, w1 = ranges[rank]
     frames = segmentation_frames(win)               # known without running the network: ranks with no window need it too
     dim = int(cfg["emb_dim"])
-    classes = emb = None
-    if w1 > w0:
-        s0, s1 = window_sample_range(n, win, step, w0, w1)
+
+    def run_windows(a, b):
+        if b <= a:
+            return None, None
+        s0, s1 = window_sample_range(n, win, step, a, b)
         classes, emb = pipeline.networks(pcm[s0:s1])
-        assert classes.shape == (w1 - w0, frames), (classes.shape, w0, w1, frames)
+        assert classes.shape == (b - a, frames), (classes.shape, a, b, frames)
+        return classes, emb
+
+    classes, emb = run_windows(w0, w1)
     kmax = max(b - a for a, b in ranges)
-    host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, default_comm(pipeline.device_index if getattr(pipeline, "device_index", None) is not None else device))
-    parts = [unpack_diar_shard(host[r], kmax) for r in range(world)]
-    for r, (a, b) in enumerate(ranges):
-        assert parts[r][0].shape[0] == b - a, (r, parts[r][0].shape, a, b)
+    comm = default_comm(pipeline.device_index if getattr(pipeline, "device_index", None) is not None else device)
+    if comm is not None and timeout is not None:
+        comm.set_timeout(timeout)
+    try:
+        host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, comm)
+        parts = [unpack_diar_shard(host[r], kmax) for r in range(world)]
+        for r, (a, b) in enumerate(ranges):
+            assert parts[r][0].shape[0] == b - a, (r, parts[r][0].shape, a, b)
+    except Exception as ex:
+        if timeout is None or not _is_collective_failure(ex):
+            raise
+
+        def redo(a, b):
+            c, e = run_windows(a, b)
+            return pack_diar_shard(c, e, b - a, frames, dim).tobytes()
+
+        info, pieces = _recover_through_store("diarize_sharded", ranges, pack_diar_shard(classes, emb, max(w1 - w0, 1), frames, dim).tobytes(),
+                                              redo, float(timeout), f"{type(ex).__name__}: {ex}")
+        parts = []
+        for a, b, blob in pieces:
+            c, e = unpack_diar_shard(np.frombuffer(blob, np.int32), max(b - a, 1))
+            assert c.shape[0] == b - a, (c.shape, a, b)
+            parts.append((c, e))
+        diarize_sharded.last_recovery = info
     all_c = np.concatenate([c for c, _ in parts])
     all_e = np.concatenate([e for _, e in parts])
     return pipeline.finish(all_c, all_e, uri, **kwargs)
+
+
+diarize_sharded.last_recovery = None

@@ -358,3 +358,44 @@ def test_diarize_sharded_world2_gloo_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == want and got[1] == want
+
+
+def _dying_diar_worker(rank, world, port, q):
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from reverb_amd import synth_diar
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=8))
+    if rank == 1:
+        os._exit(0)                          # dies right after the rendezvous: its windows are never computed
+    pcm = synth_diar.synth_conversation(33.4, seed=9)
+    ann = rdist.diarize_sharded(_diar_pipeline(), pcm, torch.device("cpu"), uri="talk", timeout=2.0)
+    q.put((rank, _rttm(ann), rdist.diarize_sharded.last_recovery))
+    q.close(); q.join_thread()
+    os._exit(0)
+
+
+def test_diarize_sharded_survives_a_dead_rank():
+    """Round 4: the diarization shard has decode_sharded's failure path (dist._recover_through_store): rank 1 dies after the
+    rendezvous, rank 0's gather fails, rank 0 runs rank 1's windows itself and returns the RTTM of a single-process run."""
+    from reverb_amd import synth_diar
+    pcm = synth_diar.synth_conversation(33.4, seed=9)
+    pipe = _diar_pipeline()
+    classes, emb = pipe.networks(pcm)
+    want = _rttm(pipe.finish(classes, emb, "talk"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dying_diar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rank, got, info = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rank == 0 and got == want
+    n_windows = classes.shape[0]
+    assert info["alive"] == [0] and info["dead"] == [1] and info["plan"] == [[1, 0, (n_windows + 1) // 2, n_windows]]
