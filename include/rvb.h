@@ -236,6 +236,12 @@ int rvb_fp8_recalibrate(rvb_engine* e);
  * rvb_encode already runs in fp8 -- how the ranks of a sharded run agree on one set (element-wise maximum of what each rank
  * calibrated on its own slice, reverb_amd/dist.py), and how a deployment pins scales measured once. */
 int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n);
+/* How many values did NOT fit e4m3 at the installed scales since they were calibrated / installed / last reset: the kernels that
+ * write an fp8 operand (the LayerNorms in front of the fp8 GEMMs, the feed-forward's fp8 epilogue) clip to +-448 and count what they
+ * clip, per block and activation slot in the order of rvb_get_fp8_scales (n = 7 * blocks; counts may be NULL to query n).
+ * A calibrated engine decoding audio like its calibration batch reports zeros (2x headroom); anything else says the scales do
+ * not cover this input -- recalibrate (rvb_fp8_recalibrate) or install wider scales.  reset != 0 zeroes the counters. */
+int rvb_get_fp8_saturation(rvb_engine* e, uint32_t* counts, int32_t* n, int reset);
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n);
 /* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's
  * padded [N, L] decoder batch computes (search.py:391-412); `decoder_rows` = rows actually computed: one per DISTINCT

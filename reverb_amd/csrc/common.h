@@ -52,6 +52,11 @@ __device__ inline uint32_t pack4_fp8(float a, float b, float c, float d) {
   r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
   return (uint32_t)r;
 }
+// how many of eight / four values lie outside what e4m3 can hold once scaled (pack4_fp8 clips them to +-448): the fp8 mode's
+// saturation counters (rvb_get_fp8_saturation)
+__device__ inline unsigned fp8_clipped(float a, float b, float c, float d) {
+  return (unsigned)(fabsf(a) > 448.f) + (unsigned)(fabsf(b) > 448.f) + (unsigned)(fabsf(c) > 448.f) + (unsigned)(fabsf(d) > 448.f);
+}
 // host-side e4m3 encode (weights) / decode (tests), same rounding
 __host__ __device__ inline uint8_t f32_to_fp8_host(float f) {
   if (f != f) return 0x7f;

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArg
     }
   };
   float4 v[NV], nx[NV];
+  unsigned nsat = 0, nsat2 = 0;                 // fp8 outputs: values clipped at +-448 (counted only in the fp8 store branches)
   load_row(wave0, v);
   for (int row = wave0; row < a.M; row += nwaves) {
     load_row(row + nwaves, nx);                 // next row of this wave: in flight under the reductions below
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArg
         if (c >= d) continue;
         if constexpr (sizeof(OutT) == 1) {
           const float qs = a.out_inv_scale;            // fp8 operand of the next GEMM: value / (calibrated per-tensor scale)
+          nsat += fp8_clipped(v[i].x * qs, v[i].y * qs, v[i].z * qs, v[i].w * qs) + fp8_clipped(v[i + 1].x * qs, v[i + 1].y * qs, v[i + 1].z * qs, v[i + 1].w * qs);
           *(uint2*)(out + c) = make_uint2(pack4_fp8(v[i].x * qs, v[i].y * qs, v[i].z * qs, v[i].w * qs),
                                           pack4_fp8(v[i + 1].x * qs, v[i + 1].y * qs, v[i + 1].z * qs, v[i + 1].w * qs));
         } else {
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArg
         }
         if (sw_o2f8) {
           const float qs = a.out2_inv_scale;
+          nsat2 += fp8_clipped(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs) + fp8_clipped(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs);
           *(uint2*)((fp8_t*)a.out2 + (size_t)row * d + c) = make_uint2(pack4_fp8(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs),
                                                                        pack4_fp8(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs));
         } else if constexpr (sizeof(AddT) == 2) {
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 4 : 2)) void rownorm_kernel(NormArg
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = nx[i];
   }
+  if (nsat != 0 && a.sat) atomicAdd(a.sat, nsat);          // rare: only lanes that clipped something touch the counter
+  if (nsat2 != 0 && a.sat2) atomicAdd(a.sat2, nsat2);
 #undef COL
 }
 

@@ -148,6 +148,7 @@ struct rvb_engine {
   std::vector<rvb::F8Scales> f8;
   std::vector<unsigned> f8_groups;   // per block: which GEMM groups run in fp8 (bit 0 ffm, 1 qkv, 2 pw1, 3 pw2, 4 ff)
   rvb::DevBuf d_amax;            // fp32 [blocks][8]
+  rvb::DevBuf d_f8sat;           // uint32 [blocks + 1][8]: values clipped at +-448 per activation slot (rvb_get_fp8_saturation)
   hipStream_t stream = nullptr;
   bool finalized = false;
 

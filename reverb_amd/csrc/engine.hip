@@ -228,6 +228,16 @@ static int make_fbank_tables(rvb_engine* e) {
 static int out_frames(int T0) { const int T1 = (T0 - 3) / 2 + 1; return (T1 - 3) / 2 + 1; }
 
 // ------------------------------------------------------------------------------------ gemm wrapper
+// saturation counters of the fp8 activations: one row of 8 per block (+ a guard row: the last block's norm_final names "the next
+// block"); zeroed whenever scales are (re)calibrated or installed
+static int reset_f8sat(rvb_engine* e) {
+  static const int on = getenv("RVB_FP8_SAT") ? atoi(getenv("RVB_FP8_SAT")) : 1;       // 0: no counters (A/B of their cost)
+  if (!on) return OK;
+  RVB_TRY(e->d_f8sat.ensure((e->enc.size() + 1) * 8 * 4));
+  RVB_HIP_CHECK(hipMemsetAsync(e->d_f8sat.p, 0, (e->enc.size() + 1) * 8 * 4, e->stream));
+  return OK;
+}
+
 static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void* C, int ldc, int M, bool out_f32,
                     float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
   GemmArgs g;
@@ -241,8 +251,10 @@ static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void
 // out8 / out2_8 > 0: that output is fp8 bytes of value / scale (the calibrated per-tensor scale of the GEMM that reads it)
 static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bool out_f32, int M, int d,
                     int mode = NORM_LN, int silu = 0, const void* add = nullptr, const LNorm* second = nullptr,
-                    void* out2 = nullptr, float out8 = 0.f, float out2_8 = 0.f, bool x_bf16 = false) {
+                    void* out2 = nullptr, float out8 = 0.f, float out2_8 = 0.f, bool x_bf16 = false, unsigned* sat = nullptr,
+                    unsigned* sat2 = nullptr) {
   NormArgs a;
+  a.sat = sat; a.sat2 = sat2;
   a.x_bf16 = x_bf16 ? 1 : 0;
   a.x = x; a.gamma = n.g.as<float>(); a.beta = n.b.as<float>(); a.eps = n.eps; a.mode = mode; a.silu = silu;
   a.add = add; a.out = out; a.out_f32 = out_f32 ? 1 : 0; a.M = M; a.d = d;
@@ -254,9 +266,11 @@ static int run_norm(rvb_engine* e, const float* x, const LNorm& n, void* out, bo
 }
 // fp8 GEMM: A8 [M, lda] bytes (values / a_scale), L.w8 / L.wscale; out_kind 0 = compute dtype, 1 = fp32, 2 = fp8 (/ out_scale)
 static int run_gemm8(rvb_engine* e, const void* A8, int lda, const Linear& L, void* C, int ldc, int M, float a_scale, int out_kind,
-                     float out_scale = 1.f, float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
+                     float out_scale = 1.f, float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0,
+                     unsigned* sat = nullptr) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.sat = sat;
   g.A = A8; g.W = L.w8.p; g.bias = L.b.as<float>(); g.res = res; g.C = C;
   g.M = M; g.N = L.out; g.K = L.in; g.lda = lda; g.ldw = L.in; g.ldc = ldc; g.ldres = ldres;
   g.alpha = alpha; g.act = act; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.in_fp8 = 1;
@@ -499,9 +513,12 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   auto note = [&](int slot, const void* t, size_t n) -> int {
     return cal ? amax_abs(e->stream, e->dtype, t, n, e->d_amax.as<float>() + (size_t)lidx * 8 + slot) : OK;
   };
+  // saturation counter of activation slot `slot` of this block (same slot numbering as the scales: in_ffm1, h_ffm, in_qkv,
+  // in_pw1, in_pw2, in_ff1, h_ff): the kernels that write an fp8 tensor add the values they had to clip at +-448
+  auto satp = [&](int slot) -> unsigned* { return e->d_f8sat.p ? e->d_f8sat.as<unsigned>() + (size_t)lidx * 8 + slot : nullptr; };
   // macaron feed-forward: x += 0.5 * FFN(LN(x))          encoder_layer.py:199-206
   if (f8_ffm) {
-    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, sc8.in_ffm1, 2, sc8.h_ffm, 1.f, ACT_SILU));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ffm1, e->h.p, ff, M, sc8.in_ffm1, 2, sc8.h_ffm, 1.f, ACT_SILU, nullptr, 0, satp(1)));
     RVB_TRY(run_gemm8(e, e->h.p, ff, L.ffm2, x, d, M, sc8.h_ffm, 1, 1.f, 0.5f, ACT_NONE, x, d));
   } else {
     RVB_TRY(note(0, e->xn.p, (size_t)M * d));
@@ -511,7 +528,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   }
   // rel-pos self attention: x += MHSA(LN(x))              encoder_layer.py:208-216
   if (f8_qkv) {
-    RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_qkv));
+    RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_qkv, 0.f, false, satp(2)));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, sc8.in_qkv, 0));
   } else {
     RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d));
@@ -557,7 +574,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
   // convolution module: x += Conv(LN(x))                   encoder_layer.py:218-229, convolution.py:89-144
   if (f8_pw1) {
-    RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_pw1));
+    RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_pw1, 0.f, false, satp(3)));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, sc8.in_pw1, 0));
   } else {
     RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d));
@@ -597,7 +614,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   const int cmode = e->cfg.cnn_norm == 0 ? NORM_LN : NORM_AFFINE;
   const bool dw16 = e->dtype == DT_BF16;
   if (f8_pw2) {
-    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2, 0.f, dw16));
+    RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, sc8.in_pw2, 0.f, dw16, satp(4)));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw2, x, d, M, sc8.in_pw2, 1, 1.f, 1.f, ACT_NONE, x, d));
   } else {
     RVB_TRY(run_norm(e, e->dconv.as<float>(), L.n_cnn, e->xn.p, false, M, d, cmode, 1, nullptr, nullptr, nullptr, 0.f, 0.f, dw16));
@@ -606,8 +623,8 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   }
   // feed-forward (+ language-specific mix), final norm     encoder_layer.py:231-244 / :372-402
   if (f8_ff) {
-    RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_ff1));
-    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ff1, e->h.p, ff, M, sc8.in_ff1, 2, sc8.h_ff, 1.f, ACT_SILU));
+    RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_ff1, 0.f, false, satp(5)));
+    RVB_TRY(run_gemm8(e, e->xn.p, d, L.ff1, e->h.p, ff, M, sc8.in_ff1, 2, sc8.h_ff, 1.f, ACT_SILU, nullptr, 0, satp(6)));
     RVB_TRY(run_gemm8(e, e->h.p, ff, L.ff2, x, d, M, sc8.h_ff, 1, 1.f, 0.5f, ACT_NONE, x, d));
   } else {
     RVB_TRY(run_norm(e, x, L.n_ff, e->xn.p, false, M, d));
@@ -624,7 +641,9 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   }
   // x = norm_final(x) (+ y for the language-specific block, encoder_layer.py:400), and in the same pass the LayerNorm
   // that always reads it next: the following block's norm_ff_macaron, or the encoder's after_norm (encoder.py:147-148)
-  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr, &next, next_out, 0.f, f8 ? next8 : 0.f));
+  // (the fp8 second output is the NEXT block's in_ffm1: slot 0 of block lidx + 1)
+  RVB_TRY(run_norm(e, x, L.n_final, x, true, M, d, NORM_LN, 0, L.is_lsl ? e->y.p : nullptr, &next, next_out, 0.f, f8 ? next8 : 0.f, false,
+                   nullptr, (f8 && next8 > 0.f && e->d_f8sat.p) ? e->d_f8sat.as<unsigned>() + (size_t)(lidx + 1) * 8 : nullptr));
   return OK;
 }
 
@@ -713,6 +732,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   if (e->fp8 && e->f8_state == 0) {     // first batch of an fp8 engine: bf16 pass that records the activation ranges
     RVB_TRY(e->d_amax.ensure(e->enc.size() * 8 * 4));
     RVB_HIP_CHECK(hipMemsetAsync(e->d_amax.p, 0, e->enc.size() * 8 * 4, e->stream));
+    RVB_TRY(reset_f8sat(e));
     e->f8_state = 1;
   }
   for (int c0 = 0; c0 < B; c0 += SB) {
@@ -739,7 +759,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     void* eo = (char*)e->enc_out.p + (size_t)row0 * d * es;
     const bool f8 = e->fp8 && e->f8_state == 2;
     RVB_TRY(run_norm(e, e->x.as<float>(), e->enc[0].n_ffm, e->xn.p, false, m, d, NORM_LN, 0, nullptr, nullptr, nullptr,
-                     (f8 && (e->f8_groups[0] & 1u)) ? e->f8[0].in_ffm1 : 0.f));
+                     (f8 && (e->f8_groups[0] & 1u)) ? e->f8[0].in_ffm1 : 0.f, 0.f, false, e->d_f8sat.as<unsigned>()));
     for (size_t li = 0; li < e->enc.size(); ++li) {
       const bool last = li + 1 == e->enc.size();
       RVB_TRY(encoder_layer(e, e->enc[li], (int)li, m, nb, T2, last ? e->enc_after : e->enc[li + 1].n_ffm, last ? eo : e->xn.p,
@@ -1873,7 +1893,7 @@ void rvb_destroy(rvb_engine* e) {
                     &e->conv2.w, &e->conv2.b, &e->embed_out.w, &e->embed_out.b, &e->ctc.w, &e->ctc.b,
                     &e->enc_after.g, &e->enc_after.b};
   for (DevBuf* b : bufs) b->release();
-  e->atopv.release(); e->atopi.release(); e->d_stream_i32.release();
+  e->atopv.release(); e->atopi.release(); e->d_stream_i32.release(); e->d_amax.release(); e->d_f8sat.release();
   e->wave_f32.release(); e->wave_in.release(); e->rs_kernel.release();
   e->jlogp.release(); e->jpair_row.release(); e->jpair_tok.release(); e->jpair_out.release();
   for (auto& b : e->jkv) b.release();
@@ -2316,6 +2336,24 @@ int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n) {
     }
   return OK;
 }
+// Values that did not fit e4m3 at the installed scale (clipped to +-448 by the kernels that write the fp8 operands), per block
+// and activation slot in the order of rvb_get_fp8_scales, summed since the scales were calibrated / installed / last reset:
+// the fp8 mode's answer to "the calibration batch was not representative" -- until round 4 such clipping was silent.
+int rvb_get_fp8_saturation(rvb_engine* e, uint32_t* counts, int32_t* n, int reset) {
+  if (!e || !n) { set_error("rvb_get_fp8_saturation: null argument"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_get_fp8_saturation: not an RVB_FP8 engine"); return E_STATE; }
+  *n = (int32_t)(e->enc.size() * 7);
+  if (!e->d_f8sat.p) { if (counts) memset(counts, 0, (size_t)*n * 4); return OK; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  std::vector<uint32_t> raw(e->enc.size() * 8);
+  RVB_HIP_CHECK(hipMemcpyAsync(raw.data(), e->d_f8sat.p, raw.size() * 4, hipMemcpyDeviceToHost, e->stream));
+  if (reset) RVB_HIP_CHECK(hipMemsetAsync(e->d_f8sat.p, 0, (e->enc.size() + 1) * 8 * 4, e->stream));
+  RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+  if (counts)
+    for (size_t l = 0; l < e->enc.size(); ++l)
+      for (int k = 0; k < 7; ++k) counts[l * 7 + k] = raw[l * 8 + k];
+  return OK;
+}
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n) {
   if (!e || !scales) { set_error("rvb_set_fp8_scales: null argument"); return E_ARG; }
   if (!e->fp8) { set_error("rvb_set_fp8_scales: not an RVB_FP8 engine"); return E_STATE; }
@@ -2328,6 +2366,8 @@ int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n) {
   }
   if (e->f8_groups.size() != e->enc.size()) RVB_TRY(set_fp8_policy_impl(e, -1, 0, -1));
   e->f8_state = 2;
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVB_TRY(reset_f8sat(e));
   return OK;
 }
 int rvb_get_rescore_stats(rvb_engine* e, int64_t* decoder_rows, int64_t* pairs) {

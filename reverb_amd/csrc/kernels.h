@@ -33,6 +33,7 @@ struct GemmArgs {
   int in_fp8, out_fp8;
   float a_scale, out_inv_scale;
   const float* w_scale;   // [N]
+  unsigned* sat;          // out_fp8: += the values clipped at +-448 (device counter, nullable)
   long long* dbg;         // test hook (rvb_test_gemm_timeline): per workgroup {start, stage 0 landed, main loop done, end} in 10 ns ticks + HW ids
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
@@ -91,6 +92,8 @@ struct NormArgs {
   // fp8 (e4m3) outputs for the bf16 engine's fp8 GEMMs: bytes of value * inv_scale, saturating
   int out_fp8 = 0, out2_fp8 = 0;
   float out_inv_scale = 1.f, out2_inv_scale = 1.f;
+  unsigned* sat = nullptr;     // fp8 outputs: += the values that were clipped at +-448 (device counters, nullable)
+  unsigned* sat2 = nullptr;
 };
 int rownorm(hipStream_t s, int dtype, const NormArgs& a);
 

@@ -206,6 +206,16 @@ class Engine:
             mask = sum(self.FP8_GROUPS[g] for g in set(groups))
         check(self.lib.rvb_set_fp8_policy(self.handle, int(mask), int(first_block), int(last_block)), "rvb_set_fp8_policy")
 
+    def fp8_saturation(self, reset: bool = False) -> np.ndarray:
+        """fp8 engines: values clipped at +-448 per (block, activation slot) -- [blocks, 7] in the order of fp8_scales() -- since
+        the scales were calibrated / installed / last reset.  All zeros = the scales cover what was decoded."""
+        n = C.c_int32(0)
+        check(self.lib.rvb_get_fp8_saturation(self.handle, None, C.byref(n), 0), "rvb_get_fp8_saturation")
+        out = np.zeros(max(n.value, 1), np.uint32)
+        check(self.lib.rvb_get_fp8_saturation(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n), 1 if reset else 0),
+              "rvb_get_fp8_saturation")
+        return out[:n.value].reshape(-1, 7)
+
     def fp8_scales(self) -> Optional[np.ndarray]:
         """fp8 engines: the calibrated activation scales [blocks, 7], or None before the calibration batch."""
         n = C.c_int32(0)
