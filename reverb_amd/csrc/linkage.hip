@@ -153,6 +153,31 @@ __device__ inline MinPair block_argmin_alt(MinPair p, MinPair (*red)[16], int& p
   return row_argmin(buf[lane & 15]);
 }
 
+// three reductions behind ONE barrier (the multi-workgroup loop: best valid candidate, smallest stale bound, and the share of the
+// new cluster's nearest neighbour left over from the merge pass): a block reduction is ~0.7 us of DPP steps + LDS round trip +
+// barrier, and a round had three of them back to back (profile: 1.8 us per round in "local minima", RVD_LINKAGE_PROF).
+// Buffers hold 48 entries, the unused ones stay +inf.
+// Only WAVE 0 holds the results afterwards (the one thread that publishes them reads them there): the second stage is 3 x 40
+// VALU instructions that 16 waves would otherwise all issue, and a wave whose lanes are all +inf (most of them, for the stale
+// bounds; all of them in the waves beyond the workgroup's own slots) skips its first stage on one ballot -- the merge loop is
+// VALU-issue-bound between its barriers (profile: 1.9 us per round in these reductions).
+__device__ inline void block_argmin3_alt(MinPair& a, MinPair& b, MinPair& c, MinPair (*red)[48], int& phase) {
+  const MinPair none{INFINITY, 0x7fffffff};
+  a = __ballot(a.v < INFINITY) ? wave_argmin(a) : none;
+  b = __ballot(b.v < INFINITY) ? wave_argmin(b) : none;
+  c = __ballot(c.v < INFINITY) ? wave_argmin(c) : none;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  MinPair* buf = red[phase & 1];
+  ++phase;
+  if (lane == 0) { buf[wv] = a; buf[16 + wv] = b; buf[32 + wv] = c; }
+  __syncthreads();
+  if (wv == 0) {
+    a = row_argmin(buf[lane & 15]);
+    b = row_argmin(buf[16 + (lane & 15)]);
+    c = row_argmin(buf[32 + (lane & 15)]);
+  }
+}
+
 // nearest neighbour of every x among y > x (scipy find_min_dist: first index on ties); one block per row
 __global__ __launch_bounds__(256) void nn_init_kernel(const double* __restrict__ D, int n, int* __restrict__ neighbor,
                                                       double* __restrict__ min_dist) {
@@ -391,8 +416,11 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
 //     replicated in every workgroup's LDS: every workgroup applies every merge to its copy.
 //   * a ROUND = every workgroup publishes 48 bytes -- its best VALID candidate (distance, x, neighbour), its smallest STALE lower
 //     bound (distance, z), and its share of the nearest neighbour of the cluster the previous merge created (the minimum of the
-//     distances it just wrote into that row, over its slots above it) -- then ONE grid barrier, then every wave reads the 16
-//     entries and reduces them in registers (DPP), so all workgroups derive the same decision without a second exchange:
+//     distances it just wrote into that row, over its slots above it; the three block reductions share one barrier) -- the
+//     last word carries the round's number; wave 0 of every workgroup polls the 16 tag words, loads the entries, reduces them in
+//     registers (DPP) and hands the result to its workgroup through LDS, so all workgroups derive the same decision without a
+//     second exchange (form A, the first version: an arrival counter, then every wave loads the entries -- one more L2 round
+//     trip per round):
 //       - the best valid candidate is lexicographically (distance, slot) below every stale bound -> that pair is merged (what
 //         scipy's heap pops once its top is valid);
 //       - otherwise the stale rows whose bound lies below the best valid candidate are rescanned, each by its owner, all
@@ -460,13 +488,20 @@ __device__ inline bool mb_grid_barrier(LkCtl* ctl, unsigned gen, int G, int* s_f
 }
 
 __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ D, int n, const int* __restrict__ g_neighbor,
-                                                           double* __restrict__ g_min_dist, double* __restrict__ Z, LkCtl* ctl, int G) {
+                                                           double* __restrict__ g_min_dist, double* __restrict__ Z, LkCtl* ctl, int G,
+                                                           int prof) {
   // G = participating workgroups: a power of two <= MB_G (RVD_LINKAGE_G; 16 by default)
   extern __shared__ __attribute__((aligned(16))) char mb_smem[];
   __shared__ MinPair red[2][16];
+  __shared__ MinPair red3[2][48];
   __shared__ int s_wtot[16];
-  __shared__ int s_b, s_flag, s_rcount, s_acount;
+  __shared__ int s_b, s_flag, s_rcount, s_acount, s_round_y;
+  __shared__ MinPair s_round[3];
   const int tid = threadIdx.x, lane = tid & 63;
+  const bool xchg = (prof & 2) != 0;           // exchange form B (see the round loop)
+  prof &= 1;
+  if (tid < 96) red3[tid / 48][tid % 48] = MinPair{INFINITY, 0x7fffffff};
+  int rphase3 = 0;
   // ---- which workgroups take part
   if (tid == 0) {
     const int my = (int)(__builtin_amdgcn_s_getreg(63508) & 0xf) + 1;      // HW_REG_XCC_ID + 1
@@ -545,6 +580,9 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
     if (tid == 0) { s_md[li_of(z)] = q.v; s_nb[li_of(z)] = q.v < INFINITY ? q.i : -1; }
   };
   long long rescans = 0;
+  long long t_min = 0, t_bar = 0, t_read = 0, t_val = 0, t_merge = 0, tc = 0, rounds = 0;      // RVD_LINKAGE_PROF (workgroup 0)
+  auto tick = [&](long long& acc) { if (prof) { const long long t = wall_clock64(); acc += t - tc; tc = t; } };
+  if (prof) tc = wall_clock64();
   unsigned gen = 0;                                         // grid barriers passed
   int yprev = -1;
   MinPair part{INFINITY, 0x7fffffff};                       // this workgroup's share of the new row's nearest neighbour
@@ -562,8 +600,70 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
           if (s_nb[li] >= 0) lv = min_pair(lv, c); else ls = min_pair(ls, c);
         }
       }
-      lv = block_argmin_alt(lv, red, rphase);
-      ls = block_argmin_alt(ls, red, rphase);
+      block_argmin3_alt(lv, ls, part, red3, rphase3);       // `part`: per-thread after a merge pass, already reduced (idempotent) otherwise
+      tick(t_min);
+      ++rounds;
+      MinPair gv, gs, gp;
+      int gy;
+      if (xchg) {
+        // Exchange form B (default; RVD_LINKAGE_XCHG=0 selects form A below): publishing is the barrier, polled by ONE wave per
+        // workgroup.  Measured against form A on one box: 76-82 vs 96 ms on the 9 200-point benchmark sets, 336 vs 375 ms at
+        // n = 27 000, 65 vs 70 ms in the pipeline (sum of the RVD_LINKAGE_PROF phases).  Thread 0 writes the
+        // data words, waits for them, then the word that carries the round's number; wave 0 polls the G tag words until all show
+        // this round, loads the data words, reduces and hands the result to the other waves through LDS: one L2 round trip less
+        // than {arrive at a counter, poll the counter, every wave loads the entries} (the all-waves polling variant lost to its
+        // 256 pollers; this one has as many pollers as the counter has).
+        mb_stores_done();
+        ++gen;
+        __syncthreads();
+        if (tid < 64) {
+          int ok = 1;
+          if (tid == 0) {
+            LkEntry* e = &ctl->ent[gen & 1][b];
+            const int nbx = lv.v < INFINITY ? s_nb[li_of(lv.i)] : -1;
+            mb_stf(&e->val_v, lv.v);
+            mb_st64(&e->val_x, (unsigned long long)(unsigned)lv.i | ((unsigned long long)(unsigned)nbx << 32));
+            mb_stf(&e->st_v, ls.v);
+            mb_stf(&e->part_v, part.v);
+            mb_st64(&e->part_z, (unsigned long long)(unsigned)part.i);
+            mb_stores_done();
+            mb_st64(&e->st_z, (unsigned long long)(unsigned)ls.i | ((unsigned long long)gen << 32));
+          }
+          const LkEntry* e = &ctl->ent[gen & 1][lane & (G - 1)];
+          unsigned long long tagw;
+          unsigned spins = 0;
+          for (;;) {
+            tagw = mb_ld64(&e->st_z);
+            if (__all((unsigned)(tagw >> 32) == gen)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0) {
+              if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || spins > (1u << 22)) {
+                __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+              }
+            }
+          }
+          const double vv = mb_ldf(&e->val_v);
+          const unsigned long long vxy = mb_ld64(&e->val_x);
+          const double sv = mb_ldf(&e->st_v);
+          const double pv = mb_ldf(&e->part_v);
+          const int pz = (int)(unsigned)mb_ld64(&e->part_z);
+          const int sz = (int)(unsigned)tagw;
+          const int vx = (int)(unsigned)vxy, vy = (int)(unsigned)(vxy >> 32);
+          const MinPair rv = row_argmin(MinPair{vv, vx}), rs = row_argmin(MinPair{sv, sz}), rp = row_argmin(MinPair{pv, pz});
+          const unsigned long long win = __ballot(vv == rv.v && vx == rv.i);
+          const int ry = __shfl(vy, __builtin_ctzll(win | (1ull << 63)));
+          if (tid == 0) { s_round[0] = rv; s_round[1] = rs; s_round[2] = rp; s_round_y = ry; s_flag = ok; }
+        }
+        __syncthreads();
+        if (s_flag == 0) {
+          if (b == 0 && tid == 0) g_min_dist[n - 1] = -2.0;
+          return;
+        }
+        gv = s_round[0]; gs = s_round[1]; gp = s_round[2]; gy = s_round_y;
+        tick(t_bar);
+      } else {
       if (tid == 0) {
         LkEntry* e = &ctl->ent[gen & 1][b];
         const int nbx = lv.v < INFINITY ? s_nb[li_of(lv.i)] : -1;
@@ -580,9 +680,8 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
         if (b == 0 && tid == 0) g_min_dist[n - 1] = -2.0;
         return;
       }
+      tick(t_bar);
       // ---- every wave: the 16 entries, reduced in registers
-      MinPair gv, gs, gp;
-      int gy;
       {
         const LkEntry* e = &ctl->ent[(gen - 1) & 1][lane & (G - 1)];      // (lanes beyond G re-read entries: min is idempotent)
         const double vv = mb_ldf(&e->val_v);
@@ -598,6 +697,8 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
         const unsigned long long win = __ballot(vv == gv.v && vx == gv.i);
         gy = __shfl(vy, __builtin_ctzll(win | (1ull << 63)));
       }
+      }
+      tick(t_read);
       if (yprev >= 0) {
         // the cluster of the previous merge: its (exact) candidate is known only now; installed by its owner, one more competitor
         if (yprev < n - 1) {
@@ -627,6 +728,7 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
       for (int r = 0; r < R; ++r) rescan_row(s_rl[r]);
       rescans += R;
       __syncthreads();                                      // candidate writes of thread 0 before the next local minima
+      tick(t_val);
     }
     if (y < 0 || y >= n || x < 0 || x >= n) {               // uniform
       if (b == 0 && tid == 0) g_min_dist[n - 1] = -1.0;
@@ -676,7 +778,8 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
       }
     }
     if constexpr (MB_EAGER > 0) mb_stores_done();           // the rescans below read what this pass wrote (own rows)
-    part = block_argmin_alt(best, red, rphase);             // (barrier inside: the list is complete)
+    if constexpr (MB_EAGER > 0) part = block_argmin_alt(best, red, rphase);             // (barrier inside: the list is complete)
+    else part = best;                                       // reduced together with the next round's local minima (block_argmin3_alt)
     if constexpr (MB_EAGER > 0) {
       const int R = min(s_rcount, MB_EAGER);
       for (int r = 0; r < R; ++r) rescan_row(s_rl[r]);
@@ -684,7 +787,12 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
       if (R) __syncthreads();                               // candidate writes of thread 0 before the next local minima
     }
     yprev = y;
+    tick(t_merge);
   }
+  if (prof && b == 0 && tid == 0)
+    printf("linkage_mb n=%d G=%d: %lld rounds (%.2f per merge); local minima %.1f ms, publish + barrier %.1f ms, read + decide %.1f ms, "
+           "validation rescans %.1f ms (%lld rows here), merge pass %.1f ms (100 MHz wall clock, workgroup 0)\n", n, G, rounds,
+           (double)rounds / (n - 1), t_min * 1e-5, t_bar * 1e-5, t_read * 1e-5, t_val * 1e-5, rescans, t_merge * 1e-5);
   if (b == 0 && tid == 0) g_min_dist[n - 1] = (double)rescans;       // statistics (workgroup 0's rescans; slot n-1 is unused)
 }
 
@@ -695,7 +803,7 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
   const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
   const bool no_compact = getenv("RVD_LINKAGE_COMPACT") && atoi(getenv("RVD_LINKAGE_COMPACT")) == 0;
-  const int flags = getenv("RVD_LINKAGE_PROF") ? 1 : 0;
+  const int flags = (getenv("RVD_LINKAGE_PROF") ? 1 : 0) | ((getenv("RVD_LINKAGE_XCHG") && atoi(getenv("RVD_LINKAGE_XCHG")) == 0) ? 0 : 2);      // exchange form B unless RVD_LINKAGE_XCHG=0
   // RVD_LINKAGE_MB: 0 = never the multi-workgroup loop, 1 = always (tests: any n), unset = from 3 000 points on (below that one
   // CU's LDS-resident loop is as fast: a merge is a chain of latencies either way)
   const char* mbe = getenv("RVD_LINKAGE_MB");
@@ -726,7 +834,7 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
       RVB_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(LkCtl), s));
       // at least 64 KiB of LDS per workgroup so that a CU holds one of them (the MB_G participants sit on MB_G different CUs)
       const size_t lds_launch = lds_mb < 96 * 1024 ? 96 * 1024 : lds_mb;
-      hipLaunchKernelGGL(linkage_mb_kernel, dim3(8 * (G + 8)), dim3(MB_NT), lds_launch, s, D, n, neighbor, min_dist, Z, (LkCtl*)scratch, G);
+      hipLaunchKernelGGL(linkage_mb_kernel, dim3(8 * (G + 8)), dim3(MB_NT), lds_launch, s, D, n, neighbor, min_dist, Z, (LkCtl*)scratch, G, flags);
       RVB_HIP_CHECK(hipGetLastError());
       double status = 0.0;
       RVB_HIP_CHECK(hipMemcpyAsync(&status, min_dist + (n - 1), 8, hipMemcpyDeviceToHost, s));

@@ -164,6 +164,32 @@ def test_conv1_cmvn(lib, dtype, d):
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 4)
 
 
+@pytest.mark.parametrize("flags", [0, 128, 256])
+@pytest.mark.parametrize("M,N,K,use_res,out_f32", [(4352, 4400, 1344, False, 0), (4100, 4352, 2112, True, 1)])
+def test_gemm2p_ring_many_k_steps_and_reversed_tiles(lib, flags, M, N, K, use_res, out_f32):
+    """the phase loop's half-tile ring (LDS slots refilled by LDS-DMA behind counted `vmcnt` waits; WAR safety argued
+    in gemm2.hip) under more than a toy load -- 21 and 33 K steps (odd counts: the compile-time tail of round 4 takes its three
+    forms on top of an odd number of steady steps), 17 x 18 tiles with ragged edges, and more than 256 tiles so that the K
+    serpentine (bit 7 / 8: tiles of the second wave walk K downwards) really reverses some -- against fp64."""
+    dtype = BF16
+    rng = np.random.default_rng(M + K)
+    A = rnd(dtype, rng.standard_normal((M, K)))
+    W = rnd(dtype, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    res = f32(rng.standard_normal((M, N))) if use_res else None
+    C = np.full((M, N), np.nan, np.float32)
+    lib.rvb_test_set_gemm2_opts(flags, -2)
+    try:
+        _lib.check(lib.rvb_test_gemm(dtype, fptr(A), fptr(W), fptr(bias), fptr(res), fptr(C), M, N, K, 1.0, 0, out_f32, 0, 0, 0, 0, 0))
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+    v = A.astype(np.float64) @ W.astype(np.float64).T + bias + (res if use_res else 0)
+    if out_f32:
+        np.testing.assert_allclose(C, v, rtol=5e-5, atol=3e-4)
+    else:
+        np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("flags", [0, 16])
 @pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32,group_m", [
     (8192, 4096, 320, 1, 1.0, False, 0, -2),     # 512 tiles >= 2 per CU: the persistent form (cross-tile prefetch), SiLU, bf16 out
