@@ -449,7 +449,12 @@ static constexpr int MB_G = 16, MB_NT = 1024;
 static constexpr int MB_EAGER = 0;                       // stale rows a workgroup may validate right after a merge
 static constexpr double MB_EAGER_FACTOR = 1.05;          // ... when their bound is within 5 % of the distance just merged
 struct LkEntry { double val_v; int val_x, val_y; double st_v; int st_z, pad0; double part_v; int part_z, pad1; };   // 48 bytes
-struct LkCtl { int xcc, tickets; unsigned bar; int abort; LkEntry ent[2][MB_G]; };
+// form C of the exchange: four 16-byte pieces, each with the round's number in its last word (a 16-byte aligned dwordx4 store /
+// load is one request to the L2: a piece is never seen torn, and a reader that finds all four tags current has the whole entry)
+struct LkEntry16 { double val_v; int val_x; unsigned tag0; int val_y, st_z, part_z; unsigned tag1; double st_v; unsigned pad2, tag2; double part_v; unsigned pad3, tag3; };
+static_assert(sizeof(LkEntry16) == 64, "published entry, form C: four 16-byte pieces");
+struct LkCtl { int xcc, tickets; unsigned bar; int abort; LkEntry ent[2][MB_G]; LkEntry16 ent16[2][MB_G]; };
+static_assert(sizeof(LkCtl) <= 4096, "the control block's scratch allocation (rvd_centroid_linkage)");
 static_assert(sizeof(LkEntry) == 48, "published entry: six 8-byte words");
 
 __device__ inline unsigned long long mb_ld64(const void* p) {
@@ -461,6 +466,26 @@ __device__ inline void mb_st64(void* p, unsigned long long v) {
 __device__ inline double mb_ldf(const double* p) { return __longlong_as_double((long long)mb_ld64(p)); }
 __device__ inline void mb_stf(double* p, double v) { mb_st64(p, (unsigned long long)__double_as_longlong(v)); }
 __device__ inline void mb_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16-byte sc1 (agent-scope, past the L1) accesses: __hip_atomic_* stops at 8 bytes
+typedef unsigned mb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void mb_st128x4(void* p, mb_u32x4 a, mb_u32x4 b, mb_u32x4 c, mb_u32x4 d) {
+  asm volatile(
+      "global_store_dwordx4 %0, %1, off sc1\n\t"
+      "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+      "global_store_dwordx4 %0, %3, off offset:32 sc1\n\t"
+      "global_store_dwordx4 %0, %4, off offset:48 sc1\n\t"
+      "s_nop 1"
+      :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
+__device__ inline void mb_ld128x4(const void* p, mb_u32x4& a, mb_u32x4& b, mb_u32x4& c, mb_u32x4& d) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
 __device__ inline bool lex_less(double av, int ai, double bv, int bi) { return av < bv || (av == bv && ai < bi); }
 
 // all MB_G workgroups have arrived `gen` times; false = gave up (abort word set, by us or by somebody else)
@@ -498,7 +523,8 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
   __shared__ int s_b, s_flag, s_rcount, s_acount, s_round_y;
   __shared__ MinPair s_round[3];
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool xchg = (prof & 2) != 0;           // exchange form B (see the round loop)
+  const bool xchg = (prof & 2) != 0;           // exchange form B / C (see the round loop)
+  const bool xchg16 = (prof & 4) != 0;         // form C
   prof &= 1;
   if (tid < 96) red3[tid / 48][tid % 48] = MinPair{INFINITY, 0x7fffffff};
   int rphase3 = 0;
@@ -616,7 +642,42 @@ __global__ __launch_bounds__(MB_NT) void linkage_mb_kernel(double* __restrict__ 
         mb_stores_done();
         ++gen;
         __syncthreads();
-        if (tid < 64) {
+        if (tid < 64 && xchg16) {
+          // form C: the whole entry in four tagged 16-byte pieces -- no wait between data and tag on the writer's side, one
+          // round trip on the reader's side once the pieces are there
+          int ok = 1;
+          if (tid == 0) {
+            const int nbx = lv.v < INFINITY ? s_nb[li_of(lv.i)] : -1;
+            const unsigned long long v0 = (unsigned long long)__double_as_longlong(lv.v), v2 = (unsigned long long)__double_as_longlong(ls.v),
+                                     v3 = (unsigned long long)__double_as_longlong(part.v);
+            mb_st128x4(&ctl->ent16[gen & 1][b], (mb_u32x4){(unsigned)v0, (unsigned)(v0 >> 32), (unsigned)lv.i, gen},
+                       (mb_u32x4){(unsigned)nbx, (unsigned)ls.i, (unsigned)part.i, gen}, (mb_u32x4){(unsigned)v2, (unsigned)(v2 >> 32), 0u, gen},
+                       (mb_u32x4){(unsigned)v3, (unsigned)(v3 >> 32), 0u, gen});
+          }
+          const LkEntry16* e = &ctl->ent16[gen & 1][lane & (G - 1)];
+          mb_u32x4 p0, p1, p2, p3;
+          unsigned spins = 0;
+          for (;;) {
+            mb_ld128x4(e, p0, p1, p2, p3);
+            if (__all(p0.w == gen && p1.w == gen && p2.w == gen && p3.w == gen)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0) {
+              if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || spins > (1u << 22)) {
+                __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+              }
+            }
+          }
+          const double vv = __longlong_as_double((long long)(((unsigned long long)p0.y << 32) | p0.x));
+          const double sv = __longlong_as_double((long long)(((unsigned long long)p2.y << 32) | p2.x));
+          const double pv = __longlong_as_double((long long)(((unsigned long long)p3.y << 32) | p3.x));
+          const int vx = (int)p0.z, vy = (int)p1.x, sz = (int)p1.y, pz = (int)p1.z;
+          const MinPair rv = row_argmin(MinPair{vv, vx}), rs = row_argmin(MinPair{sv, sz}), rp = row_argmin(MinPair{pv, pz});
+          const unsigned long long win = __ballot(vv == rv.v && vx == rv.i);
+          const int ry = __shfl(vy, __builtin_ctzll(win | (1ull << 63)));
+          if (tid == 0) { s_round[0] = rv; s_round[1] = rs; s_round[2] = rp; s_round_y = ry; s_flag = ok; }
+        } else if (tid < 64) {
           int ok = 1;
           if (tid == 0) {
             LkEntry* e = &ctl->ent[gen & 1][b];
@@ -803,7 +864,7 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
   const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
   const bool no_compact = getenv("RVD_LINKAGE_COMPACT") && atoi(getenv("RVD_LINKAGE_COMPACT")) == 0;
-  const int flags = (getenv("RVD_LINKAGE_PROF") ? 1 : 0) | ((getenv("RVD_LINKAGE_XCHG") && atoi(getenv("RVD_LINKAGE_XCHG")) == 0) ? 0 : 2);      // exchange form B unless RVD_LINKAGE_XCHG=0
+  const int flags = (getenv("RVD_LINKAGE_PROF") ? 1 : 0) | (getenv("RVD_LINKAGE_XCHG") ? (atoi(getenv("RVD_LINKAGE_XCHG")) == 0 ? 0 : atoi(getenv("RVD_LINKAGE_XCHG")) == 2 ? 6 : 2) : 2);      // exchange form: 0 = A, 1 = B (default), 2 = C
   // RVD_LINKAGE_MB: 0 = never the multi-workgroup loop, 1 = always (tests: any n), unset = from 3 000 points on (below that one
   // CU's LDS-resident loop is as fast: a merge is a chain of latencies either way)
   const char* mbe = getenv("RVD_LINKAGE_MB");
