@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librvb.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "linkage.hip", "diar_engine.hip", "test_api.hip", "comm.hip", "search.cpp", "audio.cpp"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "linkage.hip", "diar_engine.hip", "test_api.hip", "comm.hip", "search.cpp", "audio.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable"]

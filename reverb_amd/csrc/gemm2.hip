@@ -54,6 +54,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // C = act(a_scale * w_scale[n] * sum_k A8[m][k] W8[n][k] + bias[n]) ...; OutT = fp8_t divides by out_scale and saturates.
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
+// One 16-byte global store the compiler's waitcnt bookkeeping does not see (gemm2p_kernel's full-tile epilogue explains why).
+// The data registers are read at issue; the s_nop covers the one wait state gfx9 wants between a store of more than 8 bytes
+// and a VALU write of its data registers (the hazard recognizer does not look into inline asm).
+__device__ inline void store16_hidden(void* q, unsigned a, unsigned b, unsigned c, unsigned d) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(q), "v"(v) : "memory");
+}
 template <typename T, typename OutT, bool CONV, bool MMA32>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,14 +557,111 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         }
       }
     };
+    // Full tiles: the stores are inline asm and the residual comes from a ring of vectors requested RING slabs ahead -- see
+    // finish_fast in gemm2p_kernel (here the generic loop even loaded the residual inside the pass that stores it: one
+    // exposed memory round trip and one drain of the store queue per pass, 16-32 per tile)
+    constexpr int RING = sizeof(OutT) == 4 ? 3 : 2, RV = NQ * (CPL / 4);
+    auto finish_fast = [&](auto actf, auto resc) {
+      constexpr bool HR = decltype(resc)::value;
+      float4 rring[HR ? RING : 1][HR ? RV : 1];
+      auto res_issue_f = [&](int i, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float4* rp = (const float4*)(p.res + (size_t)(m0 + wr * 128 + i * 16 + q * RPP + orow) * p.ldres + col0);
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) rring[HR ? slot : 0][HR ? q * (CPL / 4) + c4 : 0] = rp[c4];
+        }
+      };
+      if constexpr (HR) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) res_issue_f(i, i);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (M32) {
+          const int bi = i >> 1, h = i & 1;
+          const int r32 = 4 * (lane >> 5), c32 = lane & 31;
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(float*)(slab + (8 * qq + r32 + r) * SROW + (bj * 32 + c32) * 4) = acc32[bi][bj][8 * h + 4 * qq + r];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(float*)(slab + (crow + r) * SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int srow = q * RPP + orow;
+          float v[CPL];
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            const float4 t = *(const float4*)(slab + srow * SROW + (ocol + c4 * 4) * 4);
+            v[c4 * 4 + 0] = t.x; v[c4 * 4 + 1] = t.y; v[c4 * 4 + 2] = t.z; v[c4 * 4 + 3] = t.w;
+          }
+          if constexpr (F8) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] *= scv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
+          if constexpr (HR) {
+#pragma unroll
+            for (int c4 = 0; c4 < CPL / 4; ++c4) {
+              const float4 t = rring[i % RING][q * (CPL / 4) + c4];
+              v[c4 * 4 + 0] += t.x; v[c4 * 4 + 1] += t.y; v[c4 * 4 + 2] += t.z; v[c4 * 4 + 3] += t.w;
+            }
+          }
+          OutT* cp = C + (size_t)(m0 + wr * 128 + i * 16 + srow) * p.ldc + col0;
+          if constexpr (sizeof(OutT) == 1) {
+            const float qs = p.out_inv_scale;
+            if (p.sat) {
+              float mx = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+              for (int e2 = 2; e2 < 16; ++e2) mx = fmaxf(mx, fabsf(v[e2]));
+              if (mx * qs > 448.f) {
+                const unsigned ns = fp8_clipped(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs) + fp8_clipped(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs) +
+                                    fp8_clipped(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs) + fp8_clipped(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs);
+                atomicAdd(p.sat, ns);
+              }
+            }
+            store16_hidden(cp, pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                           pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+          } else if constexpr (sizeof(OutT) == 2) {
+            store16_hidden(cp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+          } else {
+            store16_hidden(cp, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+          }
+        }
+        if constexpr (HR) {
+          if (i + RING < 8) res_issue_f(i + RING, i % RING);
+        }
+      }
+    };
+    const bool fast = full && p.fast_epilogue;
+    const bool hr = p.res != nullptr && !res_acc;
+    auto run = [&](auto actf) __attribute__((always_inline)) {
+      if (fast) {
+        if (hr) finish_fast(actf, std::true_type()); else finish_fast(actf, std::false_type());
+      } else {
+        finish_v(actf);
+      }
+    };
     if (p.act == ACT_SILU) {
       // raw v_exp_f32 / v_rcp_f32 (no denormal fix-ups): 5 VALU ops per element, the result is rounded to bf16 anyway
-      if constexpr (sizeof(T) <= 2) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
-      else finish_v([](float x) { return x / (1.0f + expf(-x)); });
+      if constexpr (sizeof(T) <= 2) run([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
+      else run([](float x) { return x / (1.0f + expf(-x)); });
     } else if (p.act == ACT_RELU) {
-      finish_v([](float x) { return fmaxf(x, 0.0f); });
+      run([](float x) { return fmaxf(x, 0.0f); });
     } else {
-      finish_v([](float x) { return x; });
+      run([](float x) { return x; });
     }
     if (p.dbg && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[blockIdx.x * 6 + 3] = wall_clock64(); }
     return;
@@ -1136,11 +1241,11 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         for (int c4 = 0; c4 < CPL / 4; ++c4) rring[slot][q * (CPL / 4) + c4] = rp[c4];
       }
     };
-    if (res_pre) {
-#pragma unroll
-      for (int i = 0; i < RING; ++i) res_issue(i, i);
-    }
     auto finish_v = [&](auto actf) {
+      if (res_pre) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) res_issue(i, i);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_wave_barrier();
@@ -1227,9 +1332,111 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         if (res_pre && i + RING < 8) res_issue(i + RING, i % RING);
       }
     };
-    if (p.act == ACT_SILU) finish_v([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
-    else if (p.act == ACT_RELU) finish_v([](float x) { return fmaxf(x, 0.0f); });
-    else finish_v([](float x) { return x; });
+    // Full tiles (all but the last row / column of tiles).  The generic loop above is correct for them too, but slow for a
+    // reason that has nothing to do with its arithmetic: vmcnt counts loads and stores in one in-order queue, so every wait
+    // hipcc places for a residual vector -- and, because its bookkeeping merges the ragged branch's element loads into the
+    // straight path, it places one in front of the slab reads of EVERY pass, residual or not -- also waits for all the
+    // stores issued before it: each of the 16 (bf16) or 32 (fp32) stores of a wave's tile was drained to memory before the
+    // next pass began (s_waitcnt vmcnt(0) behind every global_store in the round-3 code object; epilogue 4.9 us for a bf16
+    // tile, 7.6 us with SiLU, 16-18 us with an fp32 residual -- scripts/gemm_timeline.py).  Here the stores are inline asm,
+    // invisible to the waitcnt pass: without a residual the loop contains no vector-memory wait at all; with one the
+    // compiler sees loads only and counts them in order (two slabs' worth stay in flight), which is conservative by
+    // exactly the interleaved stores -- a slab's worth of stores drains underneath the next slab instead of in front of it.
+    auto finish_fast = [&](auto actf, auto resc) {
+      constexpr bool HR = decltype(resc)::value;
+      auto res_issue_f = [&](int i, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float4* rp = (const float4*)(p.res + (size_t)(m0 + wr * 128 + i * 16 + q * RPP + orow) * p.ldres + col0);
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) rring[slot][q * (CPL / 4) + c4] = rp[c4];
+        }
+      };
+      if constexpr (HR) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) res_issue_f(i, i);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (F8) {
+          const int bi = i >> 1, hh = i & 1;
+          const int r32 = 4 * (lane >> 5), c32 = lane & 31;
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(float*)(slab + (8 * qq + r32 + r) * P_SROW + (bj * 32 + c32) * 4) = acc32[bi][bj][8 * hh + 4 * qq + r];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(float*)(slab + (crow + r) * P_SROW + (j * 16 + ccol) * 4) = acc[i][j][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int srow = q * RPP + orow;
+          float v[CPL];
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            const float4 tt = *(const float4*)(slab + srow * P_SROW + (ocol + c4 * 4) * 4);
+            v[c4 * 4 + 0] = tt.x; v[c4 * 4 + 1] = tt.y; v[c4 * 4 + 2] = tt.z; v[c4 * 4 + 3] = tt.w;
+          }
+          if constexpr (F8) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] *= scv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = actf(v[e] + biasv[e]) * p.alpha;
+          if constexpr (HR) {
+#pragma unroll
+            for (int c4 = 0; c4 < CPL / 4; ++c4) {
+              const float4 tt = rring[i % RING][q * (CPL / 4) + c4];
+              v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
+            }
+          }
+          OutT* cp = C + (size_t)(m0 + wr * 128 + i * 16 + srow) * p.ldc + col0;
+          if constexpr (sizeof(OutT) == 1) {
+            const float qs = p.out_inv_scale;
+            if (p.sat) {
+              float mx = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+              for (int e2 = 2; e2 < 16; ++e2) mx = fmaxf(mx, fabsf(v[e2]));
+              if (mx * qs > 448.f) {
+                const unsigned ns = fp8_clipped(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs) + fp8_clipped(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs) +
+                                    fp8_clipped(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs) + fp8_clipped(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs);
+                atomicAdd(p.sat, ns);
+              }
+            }
+            store16_hidden(cp, pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                           pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+          } else if constexpr (sizeof(OutT) == 2) {
+            store16_hidden(cp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+          } else {
+            store16_hidden(cp, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+          }
+        }
+        if constexpr (HR) {
+          if (i + RING < 8) res_issue_f(i + RING, i % RING);
+        }
+      }
+    };
+    const bool fast = full && p.fast_epilogue;
+    const bool hr = p.res != nullptr && !res_acc;
+    auto run = [&](auto actf) __attribute__((always_inline)) {
+      if (fast) {
+        if (hr) finish_fast(actf, std::true_type()); else finish_fast(actf, std::false_type());
+      } else {
+        finish_v(actf);
+      }
+    };
+    if (p.act == ACT_SILU) run([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); });
+    else if (p.act == ACT_RELU) run([](float x) { return fmaxf(x, 0.0f); });
+    else run([](float x) { return x; });
     if (p.dbg && tid == 0) { if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[dbg_i * 6 + 3] = wall_clock64(); }
     return;
   }
@@ -1380,6 +1587,8 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          per row) instead of through the LDS transposition: exact, 234 VGPRs, but the epilogue of a K = 1024 tile goes
 //          7.75 -> 10.4 us (ffn1), 5.2 -> 9.8 us (qkv), 4.9 -> 7.5 us (plain) and the GEMMs of the bench hour 105.4 -> 107.4 ms
 //          (profiles/r04_call5_tr_epilogue_linkage_eager.txt): partial-line stores cost more than the LDS round trip saves
+//   bit 10 (round 4) OFF switch of the full-tile epilogue whose stores the waitcnt pass does not see (see finish_fast in
+//          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -1392,6 +1601,7 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
+  p.fast_epilogue = ((g_gemm2_flags >> 10) & 1) ^ 1;
   // K serpentine (round 4): in the kernel benchmark, where one launch is repeated and its operands sit in the Infinity Cache, it
   // is worth +4.6 % on ffn2, +4.3 % on pw1, +5.5 % on embed, -3.7 % on ffn1 (profiles/r04_call2_ab.txt); in the ENGINE, where a
   // GEMM's operands were written by the kernel before it, neither "all shapes" nor "N <= 2048 only" moves the GEMM time of the

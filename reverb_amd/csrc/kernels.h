@@ -27,6 +27,7 @@ struct GemmArgs {
   int cT1, cF1, cT2, cF2, cC;
   int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
   int res_epilogue;   // gemm2p: add the residual in the epilogue (prefetched) instead of preloading the accumulators; leave 0
+  int fast_epilogue;  // gemm2p (filled in by gemm2(); RVB_GEMM2_FLAGS bit 10 turns it off): full tiles store through inline asm; leave 0
   int k_serp;         // gemm2p tuning (RVB_GEMM2_FLAGS bit 7): odd waves of tiles walk K downwards (L2 reuse across waves); leave 0
   // fp8 (OCP e4m3) operands, gemm2 only: A and W are bytes, the accumulator is multiplied by a_scale * w_scale[n];
   // out_fp8: C is written as fp8 of value * out_inv_scale (saturating)
@@ -256,6 +257,12 @@ int conv_pair32(hipStream_t s, const ConvPairArgs& a);
 // conv_gemm.hip: 3x3 stride-1 convolution as an implicit GEMM on the LDS-DMA loop (bf16, Cin % 64 == 0, Cout % 128 == 0);
 // conv2d() routes to it when a.w_ig is set
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
+// conv_stream.hip: the stride-1 3x3 convolutions of the 32- and 64-channel stages (bf16) as a stream of tiles per workgroup
+// (weights resident in LDS, patches by LDS-DMA ahead of the MFMAs); bit-identical with conv2d's direct kernel.
+// RVD_CONV_STREAM=0 turns it off, n >= 1 splits the time axis of a row of tiles over n workgroups.
+#define CONV_STREAM_DEFAULT 0
+bool conv_stream_applicable(int dtype, const ConvArgs& a);
+int conv_stream(hipStream_t s, const ConvArgs& a);
 int conv_igemm(hipStream_t s, const ConvArgs& a);
 
 // weighted mean/std over time of the trunk output x T [B][F+2][TT+2][C] for each item (item_b = batch row,

@@ -209,6 +209,32 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
         assert cosw.min() > 0.995, (flag, cosw)
 
 
+def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch):
+    """conv_stream.hip (the stride-1 convolutions of the 32- and 64-channel stages as a stream of tiles per workgroup: weights
+    resident in LDS, patches by LDS-DMA ahead of the MFMAs, counted vmcnt) against resnet.hip's one-tile-per-workgroup kernel:
+    same operand values, accumulation order and rounding points -- the embeddings must be IDENTICAL, whatever the split of
+    the time axis (1, 2, 3 or 17 workgroups per row of tiles: 17 = one tile each, the pipeline never reaches its steady
+    state), and the counters prove which path ran.  The windows include the zero-padded tail window; 998 frames = 16 full
+    tiles of 62 + one of 6, 80 mel rows = 20 row tiles, the last patch rows and columns clamped to the bordered plane."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, streamed, flops = {}, {}, {}
+    for flag in ("0", "1", "2", "3", "17"):
+        monkeypatch.setenv("RVD_CONV_STREAM", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        streamed[flag] = eng.timing("emb_conv_stream")[2]
+        flops[flag] = eng.timing("emb_conv_32")[1] + eng.timing("emb_conv_64")[1]
+        eng.close()
+    assert streamed["0"] == 0
+    for flag in ("1", "2", "3", "17"):
+        assert streamed[flag] >= 6 + 7, streamed        # 6 convolutions of stage 1 + 7 stride-1 ones of stage 2, per trunk pass
+        assert flops[flag] == flops["0"] > 0
+        assert np.array_equal(out["0"], out[flag]), flag
+
+
 def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
     """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; RVD_CONV_FUSE=1)
     against the same block as two conv2d launches: same operand values, same accumulation order, same rounding points --
