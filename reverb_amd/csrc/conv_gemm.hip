@@ -48,12 +48,12 @@ __device__ inline void cg_dma(const void* g, unsigned lds) {
       : "memory");
 }
 
-// one 16-byte store the compiler's waitcnt pass does not see (see the epilogue); s_nop: the wait state gfx9 wants between a
-// store of more than 8 bytes and a VALU write of its data registers
+// one 16-byte store the compiler's waitcnt pass does not see (see the epilogue); s_nop 1: the TWO wait states gfx950 wants
+// between a store of more than 8 bytes and a VALU write of its data registers (gemm2.hip: store16_hidden)
 __device__ inline void cg_store16(void* q, const uint4& v) {
   typedef unsigned cg_u32x4 __attribute__((ext_vector_type(4)));
   const cg_u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(q), "v"(d) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(q), "v"(d) : "memory");
 }
 
 __device__ inline void cg_pin(uint4& a, uint4& b) {

@@ -55,13 +55,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 // One 16-byte global store the compiler's waitcnt bookkeeping does not see (gemm2p_kernel's full-tile epilogue explains why).
-// The data registers are read at issue; the s_nop covers the one wait state gfx9 wants between a store of more than 8 bytes
-// and a VALU write of its data registers (the hazard recognizer does not look into inline asm).
+// s_nop 1: gfx950 wants TWO wait states between a store of more than 8 bytes and a VALU write of its data registers -- hipcc
+// places them for the stores it knows (one unrelated VALU instruction + s_nop 0 in its own code), its hazard recognizer does
+// not look into inline asm, and with one (s_nop 0) 0.11 % of the stored words carried the NEXT value of the register on a
+// busy chip (scripts/micro/store_hazard.hip, profiles/r04_store_hazard.txt; in the first form of this epilogue: 16-128
+// wrong elements per million in one kernel whose register allocation put a v_add / v_mad right behind a store).  An LDS
+// read into the same registers right behind the store is safe (0 of 2.7e8 words).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ inline void store16_hidden(void* q, unsigned a, unsigned b, unsigned c, unsigned d) {
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(q), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
 }
+
 template <typename T, typename OutT, bool CONV, bool MMA32>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -645,8 +650,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         }
       }
     };
-    const bool fast = full && p.fast_epilogue;
     const bool hr = p.res != nullptr && !res_acc;
+    const bool fast = full && (p.fast_epilogue & (hr ? 2 : 1));
     auto run = [&](auto actf) __attribute__((always_inline)) {
       if (fast) {
         if (hr) finish_fast(actf, std::true_type()); else finish_fast(actf, std::false_type());
@@ -1425,8 +1430,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         }
       }
     };
-    const bool fast = full && p.fast_epilogue;
     const bool hr = p.res != nullptr && !res_acc;
+    const bool fast = full && (p.fast_epilogue & (hr ? 2 : 1));
     auto run = [&](auto actf) __attribute__((always_inline)) {
       if (fast) {
         if (hr) finish_fast(actf, std::true_type()); else finish_fast(actf, std::false_type());
@@ -1589,6 +1594,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          (profiles/r04_call5_tr_epilogue_linkage_eager.txt): partial-line stores cost more than the LDS round trip saves
 //   bit 10 (round 4) OFF switch of the full-tile epilogue whose stores the waitcnt pass does not see (see finish_fast in
 //          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
+//   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -1601,7 +1607,11 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
-  p.fast_epilogue = ((g_gemm2_flags >> 10) & 1) ^ 1;
+  // bit 0: tiles without a residual in the epilogue; bit 1: tiles with one.  Both on by default: in the engine the GEMMs of the
+  // bench hour take 104.6-105.2 ms with the round-3 epilogue (flag bit 10), 101.2 ms with the fast form for tiles without a
+  // residual and for residual tiles of short-K GEMMs only (flag bit 11), 99.7-100.5 ms with it everywhere
+  // (profiles/r04_call16_fast_epilogue.txt; the isolated kernel benchmark is too noisy to rank the last two)
+  p.fast_epilogue = (g_gemm2_flags & 1024) ? 0 : (1 | ((!(g_gemm2_flags & 2048) || p.K * (p.in_fp8 ? 1 : 2) <= 4096) ? 2 : 0));
   // K serpentine (round 4): in the kernel benchmark, where one launch is repeated and its operands sit in the Infinity Cache, it
   // is worth +4.6 % on ffn2, +4.3 % on pw1, +5.5 % on embed, -3.7 % on ffn1 (profiles/r04_call2_ab.txt); in the ENGINE, where a
   // GEMM's operands were written by the kernel before it, neither "all shapes" nor "N <= 2048 only" moves the GEMM time of the

@@ -259,8 +259,10 @@ int conv_pair32(hipStream_t s, const ConvPairArgs& a);
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
 // conv_stream.hip: the stride-1 3x3 convolutions of the 32- and 64-channel stages (bf16) as a stream of tiles per workgroup
 // (weights resident in LDS, patches by LDS-DMA ahead of the MFMAs); bit-identical with conv2d's direct kernel.
-// RVD_CONV_STREAM=0 turns it off, n >= 1 splits the time axis of a row of tiles over n workgroups.
-#define CONV_STREAM_DEFAULT 0
+// RVD_CONV_STREAM=0 turns it off, n >= 1 splits the time axis of a row of tiles over n workgroups (default 1).  The 64-channel
+// stage takes it only with RVD_CONV_STREAM64=1: measured equal to the direct kernel there (52.4 vs 51.5 ms per hour of audio;
+// the 32-channel stage 53.3-55.2 vs 65.7-66.3 ms, profiles/r04_call16_fast_epilogue.txt).
+#define CONV_STREAM_DEFAULT 1
 bool conv_stream_applicable(int dtype, const ConvArgs& a);
 int conv_stream(hipStream_t s, const ConvArgs& a);
 int conv_igemm(hipStream_t s, const ConvArgs& a);

@@ -218,6 +218,7 @@ def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypat
     tiles of 62 + one of 6, 80 mel rows = 20 row tiles, the last patch rows and columns clamped to the bordered plane."""
     from reverb_amd.diar_engine import DiarEngine
     out, streamed, flops = {}, {}, {}
+    monkeypatch.setenv("RVD_CONV_STREAM64", "1")            # the 64-channel stage too (opt-in: measured equal to the direct kernel)
     for flag in ("0", "1", "2", "3", "17"):
         monkeypatch.setenv("RVD_CONV_STREAM", flag)
         eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")

@@ -59,7 +59,7 @@ def test_gemm_epilogue(lib, dtype, act, alpha, use_res, out_f32):
         np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("flags,group_m", [(0, 0), (1, 0), (1, 8), (3, 4), (0, 8), (1, 3), (4, 8), (4, 0), (0, -2), (32, -2), (32, 0)])
+@pytest.mark.parametrize("flags,group_m", [(0, 0), (1, 0), (1, 8), (3, 4), (0, 8), (1, 3), (4, 8), (4, 0), (0, -2), (32, -2), (32, 0), (1024, -2), (2048, 0), (1025, 0)])
 @pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32", [
     (300, 200, 128, 0, 1.0, False, 1),        # one partial tile, aligned rows: LDS-transposed vector epilogue
     (513, 330, 192, 1, 1.0, False, 0),        # unaligned bf16 rows: element-wise epilogue, SiLU
@@ -74,7 +74,10 @@ def test_gemm2_tuning_switches_keep_results(lib, flags, group_m, M, N, K, act, a
     """gemm2.hip's tuning switches (32x32x16 MFMAs with their own fragment / accumulator / epilogue mapping, grouped
     tile order, wave priority; flags 0 = the phase-interleaved loop of round 3, bit 2 = the register-pipelined loop of
     round 2, bit 5 = the residual added in the epilogue from a ring of prefetched vectors, group_m -2 = the per-shape
-    default) against fp64 on asymmetric random operands, every epilogue form."""
+    default; bit 10 = full tiles through the generic epilogue instead of the one with inline-asm stores, bit 11 = residual
+    tiles through it only for short K) against fp64 on asymmetric random operands, every epilogue form.  (The first form of
+    the inline-asm stores left ONE wait state between a 16-byte store and the next VALU write of its data registers: 16-128
+    wrong elements per million in the 32x32 kernel with a residual -- this test found them; gfx950 wants two.)"""
     dtype = BF16
     rng = np.random.default_rng(M + N + K)
     A = rnd(dtype, rng.standard_normal((M, K)))
