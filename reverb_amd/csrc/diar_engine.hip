@@ -21,11 +21,13 @@ constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1; };      // w_ig: conv_gemm.hip's layout (optional)
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
-static int emb_batch() {            // windows per trunk pass; RVD_EMB_BATCH overrides (tuning)
-  static int v = [] { const char* e = getenv("RVD_EMB_BATCH"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
+// windows per trunk pass; RVD_EMB_BATCH overrides (tuning).  768 since round 4: 1 h of audio 385-392 ms at 192, 381 at 384,
+// 373 at 768 (profiles/r04_call17_persistent_batch.txt) -- fewer, longer launches; 27 GB of activations out of 288
+static int emb_batch() {
+  static int v = [] { const char* e = getenv("RVD_EMB_BATCH"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 768; }();
   return v;
 }
-#define EMB_BATCH (emb_batch())      // windows per trunk pass (activations ~36 MB per window in bf16 -> 3.5 GB)
+#define EMB_BATCH (emb_batch())      // windows per trunk pass (activations 35 MB per window in bf16)
 }  // namespace
 
 struct rvd_engine {

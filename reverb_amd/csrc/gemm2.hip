@@ -1143,6 +1143,12 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     constexpr int MODE = decltype(modec)::value;
     constexpr int R = decltype(leftc)::value;
     constexpr bool TAIL = MODE == 1;
+    // MODE 4 (PERSIST): the first K step of a tile that has a predecessor.  Its first three phases wait for half-tiles 2, 3, 4,
+    // which the tile before requested BEFORE its epilogue: behind them in the in-order queue sit that epilogue's NST stores, so
+    // the steady count (everything but the newest 2 * P_DEPTH requests) would also wait for the stores -- the stall that made
+    // the persistent form lose in round 3 (bit 4 in the flag list).  The count is relaxed by exactly those stores; phase 3
+    // waits for half-tile 5, requested behind them, with the steady count again.
+    constexpr int NST = 16 / (64 / (64 / (sizeof(OutT) == 4 ? 4 : (sizeof(OutT) == 2 ? 8 : 16)))) * 8;
     auto ph_head = [&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       constexpr int dt = (j + P_LEAD) / 4;           // 1 or 2 K steps ahead
@@ -1165,6 +1171,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         constexpr int infl = 4 * R - 3 - j;          // = nh - 3 - ph
         if constexpr (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>();
         else if constexpr (infl >= 0) wait_vm<2 * (infl < 0 ? 0 : infl)>();
+      } else if constexpr (MODE == 4 && j < 3) {
+        wait_vm<2 * P_DEPTH + NST>();
       } else {
         wait_vm<2 * P_DEPTH>();
       }
@@ -1181,7 +1189,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     mid(); mma_q(c0, c1, fh, fa_hi, fb1); end(); adv();
     ph_head(std::integral_constant<int, 2>()); read_a_half(h0, fa_lo, s_rd); read_a_half(h1, fa_hi, s_rd); ph_wait(std::integral_constant<int, 2>());
     mid(); mma_q(c1, c1, fa_lo, fa_hi, fb1); end(); adv();
-    ph_head(std::integral_constant<int, 3>()); if constexpr (MODE == 0 || MODE == 2 || (MODE == 1 && R > 1)) read_a_half(h0, fh, s_rd); ph_wait(std::integral_constant<int, 3>());
+    ph_head(std::integral_constant<int, 3>()); if constexpr (MODE == 0 || MODE == 2 || MODE == 4 || (MODE == 1 && R > 1)) read_a_half(h0, fh, s_rd); ph_wait(std::integral_constant<int, 3>());
     mid(); mma_q(c1, c0, fa_lo, fa_hi, fb0); end(); adv();
     ak1 = ak2; ac1 = ac2;
     advance(ak2, ac2);
@@ -1191,6 +1199,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   if constexpr (PERSIST) {
     // one loop shape for every tile (nk >= 4, host-checked): the workgroup's last tile "prefetches" its own first half-tiles
     // again (a_next = a_base: 80 KiB of harmless reads, drained before the workgroup ends) instead of a third form of the loop
+    if (!first_tile) { kstep(std::integral_constant<int, 4>(), c0, 0); t = 1; }
     for (; t < nk - 2; ++t) kstep(std::integral_constant<int, 0>(), c0, t);
     kstep(std::integral_constant<int, 2>(), c0, nk - 2);
     kstep(std::integral_constant<int, 3>(), c0, nk - 1);
