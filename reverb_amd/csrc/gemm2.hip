@@ -854,6 +854,19 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   int s_rd = 1;                     // slot of half-tile ph+1
   int s_st = P_LEAD;                // slot of half-tile ph+P_LEAD
   bool first_tile = true;
+  // Start stagger (p.stagger_ticks > 0: GEMMs whose epilogue adds an fp32 residual).  With the store drains gone, that epilogue
+  // runs AT the HBM roofline -- all 256 CUs reach it together and move 512 KB each (134 MB in 16 us = 8.4 TB/s), while the
+  // K loops between two epilogues leave the memory idle.  Every second workgroup of the FIRST round (one per CU) therefore
+  // starts half a tile late and stays half a tile behind for the whole launch: at any time half the CUs are in their K loop.
+  // The engine's residual shapes have 5.5 rounds of tiles (1408 tiles), so the delayed CUs are the ones that would have idled
+  // through the last half round anyway: the delay costs nothing there.
+  if constexpr (!PERSIST) {
+    // (groups of four XCD-local ids: a row tile's four column tiles -- or four rows of a patch column -- keep their common panel)
+    if (p.stagger_ticks > 0 && blockIdx.x < (unsigned)p.stagger_first && ((blockIdx.x >> 5) & 1)) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   for (;;) {
   const int dbg_i = PERSIST ? lin : (int)blockIdx.x;
   if (p.dbg && tid == 0) {
@@ -1604,6 +1617,9 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //   bit 10 (round 4) OFF switch of the full-tile epilogue whose stores the waitcnt pass does not see (see finish_fast in
 //          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
 //   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
+#ifndef GEMM2_STAGGER_DEFAULT
+#define GEMM2_STAGGER_DEFAULT 0
+#endif
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
   if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
@@ -1627,6 +1643,27 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   // bench hour (104.5 vs 104.6 ms; 102.7 vs 102.7 ms, profiles/r04_call3_linkage_serp.txt).  Off by default; bit 7 = every shape,
   // bit 8 = the shapes with N <= 2048.
   p.k_serp = (g_gemm2_flags & 128) ? 1 : ((g_gemm2_flags & 256) ? (p.N <= 2048 ? 1 : 0) : 0);
+  // start stagger of the residual shapes (see gemm2p_kernel): half a tile, estimated from the K loop (1.4 us per 128-byte K
+  // step) + 18 us of prologue / epilogue; only where the last round of tiles leaves at least half the CUs idle anyway.
+  // RVB_GEMM2_STAGGER: 0 = off, 1 = on (default, see DESIGN tuning log), n > 1 = that many microseconds instead of the estimate
+  {
+    static int mode = -1, ncu = 0;
+    if (mode < 0) {
+      const char* e = getenv("RVB_GEMM2_STAGGER"); mode = e ? atoi(e) : GEMM2_STAGGER_DEFAULT;
+      int dev = 0; hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    }
+    p.stagger_ticks = 0; p.stagger_first = 0;
+    if (mode > 0 && ncu > 0 && p.res != nullptr && p.out_f32 && !p.in_fp8 && dtype == DT_BF16 && !p.conv && (p.fast_epilogue & 2)) {
+      const long long tiles = (long long)cdiv(p.M, B2M) * cdiv(p.N, B2N);
+      const long long last = tiles % ncu;
+      if (tiles > ncu && last > 0 && last <= ncu / 2) {
+        const double us = mode > 1 ? (double)mode : 0.5 * (1.4 * (p.K * 2 / ROW2) + 18.0);
+        p.stagger_ticks = (int)(us * 100.0);          // wall_clock64 ticks of 10 ns
+        p.stagger_first = ncu;
+      }
+    }
+  }
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);

@@ -28,6 +28,7 @@ struct GemmArgs {
   int group_m, prio;  // gemm2 tuning (filled in by gemm2(): tile order, wave priority); leave 0
   int res_epilogue;   // gemm2p: add the residual in the epilogue (prefetched) instead of preloading the accumulators; leave 0
   int fast_epilogue;  // gemm2p (filled in by gemm2(); RVB_GEMM2_FLAGS bit 10 turns it off): full tiles store through inline asm; leave 0
+  int stagger_ticks, stagger_first;   // gemm2p (filled in by gemm2()): start delay of every second first-round workgroup, in 10-ns ticks; leave 0
   int k_serp;         // gemm2p tuning (RVB_GEMM2_FLAGS bit 7): odd waves of tiles walk K downwards (L2 reuse across waves); leave 0
   // fp8 (OCP e4m3) operands, gemm2 only: A and W are bytes, the accumulator is multiplied by a_scale * w_scale[n];
   // out_fp8: C is written as fp8 of value * out_inv_scale (saturating)
