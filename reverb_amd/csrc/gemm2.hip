@@ -1618,7 +1618,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
 //   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
 #ifndef GEMM2_STAGGER_DEFAULT
-#define GEMM2_STAGGER_DEFAULT 0
+#define GEMM2_STAGGER_DEFAULT 1
 #endif
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
@@ -1645,7 +1645,8 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   p.k_serp = (g_gemm2_flags & 128) ? 1 : ((g_gemm2_flags & 256) ? (p.N <= 2048 ? 1 : 0) : 0);
   // start stagger of the residual shapes (see gemm2p_kernel): half a tile, estimated from the K loop (1.4 us per 128-byte K
   // step) + 18 us of prologue / epilogue; only where the last round of tiles leaves at least half the CUs idle anyway.
-  // RVB_GEMM2_STAGGER: 0 = off, 1 = on (default, see DESIGN tuning log), n > 1 = that many microseconds instead of the estimate
+  // RVB_GEMM2_STAGGER: 0 = off, 1 = on (default: GEMMs of the bench hour 100.2 -> 99.0-99.4 ms, out / pw2 launch 206.9 -> 190.9 us,
+  // ffn2 595.6 -> 554.9 us, profiles/r04_call18_stagger.txt), n > 1 = that many microseconds instead of the estimate
   {
     static int mode = -1, ncu = 0;
     if (mode < 0) {
