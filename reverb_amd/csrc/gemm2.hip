@@ -811,8 +811,12 @@ __device__ inline const char* uniform_ptr(const char* q) {
 // NEXT tile (same per-lane offsets, the next tile's scalar bases), so they land underneath the epilogue's stores and the
 // next tile starts multiplying after one barrier: the 2 us first-stage wait and the 0.5-2 us dispatch gap of every tile
 // (scripts/gemm_timeline.py) are gone.  The epilogue's slabs have their own LDS, so nothing waits for anything else.
-template <typename T, typename OutT, bool CONV, bool PERSIST = false>
+// PMODE 2 (round 4): the persistent LOOP without the cross-tile prefetch -- a workgroup per CU walks its tiles, every tile with
+// its own first-stage requests and waits; only the dispatch gap between two workgroups of a CU is gone.
+template <typename T, typename OutT, bool CONV, int PMODE = 0>
 __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
+  constexpr bool PERSIST = PMODE != 0;        // one workgroup per CU walks tiles
+  constexpr bool XPF = PMODE == 1;            // ... and the operand stream runs across tile edges
   static_assert(!(PERSIST && CONV), "the persistent form reuses the per-lane DMA offsets from tile to tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // starts half a tile late and stays half a tile behind for the whole launch: at any time half the CUs are in their K loop.
   // The engine's residual shapes have 5.5 rounds of tiles (1408 tiles), so the delayed CUs are the ones that would have idled
   // through the last half round anyway: the delay costs nothing there.
-  if constexpr (!PERSIST) {
+  if constexpr (!XPF) {
     // (groups of four XCD-local ids: a row tile's four column tiles -- or four rows of a patch column -- keep their common panel)
     if (p.stagger_ticks > 0 && blockIdx.x < (unsigned)p.stagger_first && ((blockIdx.x >> 5) & 1)) {
       const long long t0 = wall_clock64();
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   const char* w_base = uniform_ptr((const char*)((const T*)p.W + (size_t)n0 * p.ldw));
   const char* a_next = a_base;      // PERSIST: the scalar bases of this workgroup's next tile
   const char* w_next = w_base;
-  if (has_next) {
+  if (XPF && has_next) {
     int tm2, tn2;
     tile_of(lin + lin_step, tm2, tn2);
     a_next = uniform_ptr((const char*)((const T*)p.A + (size_t)tm2 * B2M * p.lda));
@@ -978,7 +982,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
                        ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
   // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
   // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
-  if (first_tile) {       // a later tile of a persistent workgroup found its first half-tiles requested by the tile before it
+  if constexpr (PMODE == 2) { s_cur = 0; s_rd = 1; s_st = P_LEAD; }      // every tile restarts the ring (all readers are past the K loop's last barrier)
+  if (first_tile || !XPF) {       // a later tile of a cross-prefetching workgroup found its first half-tiles requested by the tile before it
     for (int h = 0; h < P_LEAD && h < nh; ++h) stage(h, h);
   }
   if (res_acc) {
@@ -1048,7 +1053,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (first_tile) {       // half-tiles 0 and 1 have landed (later tiles: the previous tile's last two phases waited for them)
+  if (first_tile || !XPF) {       // half-tiles 0 and 1 have landed (later tiles: the previous tile's last two phases waited for them)
     const int infl = (nh < P_LEAD ? nh : P_LEAD) - 2;
     if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>(); else wait_vm<0>();
   }
@@ -1209,7 +1214,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   };
   constexpr int NTAIL = (P_LEAD + 3) / 4 + 1;        // K steps whose phases may find nothing left to request / wait for
   int t = 0;
-  if constexpr (PERSIST) {
+  if constexpr (XPF) {
     // one loop shape for every tile (nk >= 4, host-checked): the workgroup's last tile "prefetches" its own first half-tiles
     // again (a_next = a_base: 80 KiB of harmless reads, drained before the workgroup ends) instead of a third form of the loop
     if (!first_tile) { kstep(std::integral_constant<int, 4>(), c0, 0); t = 1; }
@@ -1526,7 +1531,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   };     // epilogue
   epilogue();
   if (!has_next) {
-    if (PERSIST) wait_vm<0>();        // the ring's last (unused) requests must not outlive the workgroup's LDS
+    if (XPF) wait_vm<0>();        // the ring's last (unused) requests must not outlive the workgroup's LDS
     break;
   }
   lin += lin_step;
@@ -1538,11 +1543,13 @@ template <typename T, typename OutT, bool CONV>
 static int launch2p(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
   static int ncu = 0;
-  auto kern = gemm2p_kernel<T, OutT, CONV, false>;
+  auto kern = gemm2p_kernel<T, OutT, CONV, 0>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
-    if constexpr (!CONV && std::is_same<T, bf16_t>::value)
-      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    if constexpr (!CONV && std::is_same<T, bf16_t>::value) {
+      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+      RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    }
     int dev = 0;
     hipDeviceProp_t pr;
     RVB_HIP_CHECK(hipGetDevice(&dev));
@@ -1552,9 +1559,10 @@ static int launch2p(hipStream_t s, const GemmArgs& p) {
   }
   const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
   if constexpr (!CONV && std::is_same<T, bf16_t>::value) {
-    // persistent form: full tiles only, and at least two tiles per CU (otherwise there is nothing to prefetch across)
-    if ((g_gemm2_flags & 16) && ncu >= 8 && p.M % B2M == 0 && p.N % B2N == 0 && tiles >= 2 * ncu && p.K >= 4 * (ROW2 / 2)) {
-      hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, true>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
+    // persistent forms: full tiles only, and at least two tiles per CU; bit 4 = with the cross-tile prefetch, bit 12 = loop only
+    if ((g_gemm2_flags & (16 | 4096)) && ncu >= 8 && p.M % B2M == 0 && p.N % B2N == 0 && tiles >= 2 * ncu && p.K >= 4 * (ROW2 / 2)) {
+      if (g_gemm2_flags & 16) hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, 1>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
+      else hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, 2>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
       RVB_HIP_CHECK(hipGetLastError());
       return OK;
     }
@@ -1617,6 +1625,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //   bit 10 (round 4) OFF switch of the full-tile epilogue whose stores the waitcnt pass does not see (see finish_fast in
 //          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
 //   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
+//   bit 12 the persistent LOOP without cross-tile prefetch (gemm2p_kernel PMODE 2): removes the dispatch gap only
 #ifndef GEMM2_STAGGER_DEFAULT
 #define GEMM2_STAGGER_DEFAULT 1
 #endif

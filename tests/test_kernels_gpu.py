@@ -193,7 +193,7 @@ def test_gemm2p_ring_many_k_steps_and_reversed_tiles(lib, flags, M, N, K, use_re
         np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("flags", [0, 16])
+@pytest.mark.parametrize("flags", [0, 16, 4096])
 @pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32,group_m", [
     (8192, 4096, 320, 1, 1.0, False, 0, -2),     # 512 tiles >= 2 per CU: the persistent form (cross-tile prefetch), SiLU, bf16 out
     (16384, 2048, 256, 0, 0.5, True, 1, 8),      # residual preloaded into the accumulators tile after tile, grouped order, nk = 4
@@ -202,7 +202,8 @@ def test_gemm2p_ring_many_k_steps_and_reversed_tiles(lib, flags, M, N, K, use_re
 def test_gemm2_persistent_tiles(lib, flags, M, N, K, act, alpha, use_res, out_f32, group_m):
     """The persistent form of the phase-interleaved loop (flags 16, opt-in: one workgroup per CU walks the tiles of its XCD's
     run, the ring keeps streaming across tile edges) against fp64 -- every tile of a large problem, and bit-identical to one
-    tile per workgroup (flags 0), which runs the same arithmetic in the same order."""
+    tile per workgroup (flags 0), which runs the same arithmetic in the same order.  flags 4096: the persistent LOOP without the
+    cross-tile prefetch (only the dispatch gap between two workgroups of a CU goes)."""
     rng = np.random.default_rng(M + N + K)
     A = rnd(BF16, rng.standard_normal((M, K)))
     W = rnd(BF16, rng.standard_normal((N, K)) / math.sqrt(K))
@@ -229,7 +230,7 @@ def test_gemm2_persistent_tiles(lib, flags, M, N, K, act, alpha, use_res, out_f3
     if flags == 0:
         _PERSIST_RESULTS[key] = C.copy()
     elif key in _PERSIST_RESULTS:
-        np.testing.assert_array_equal(C, _PERSIST_RESULTS.pop(key))
+        np.testing.assert_array_equal(C, _PERSIST_RESULTS[key])
 
 
 _PERSIST_RESULTS = {}
