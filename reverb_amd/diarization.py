@@ -574,17 +574,51 @@ class SpeakerDiarization:
         t1 = time.perf_counter()
         classes = eng.segment_classes()                                       # argmax on the GPU
         t2 = time.perf_counter()
-        # inactive (window, speaker) pairs are never used downstream: only the active ones are embedded
+        # inactive (window, speaker) pairs are never used downstream: only the active ones are embedded.
+        # Round 4: the host work that needs nothing but the classes runs UNDER the embedding network (eng.embed is a foreign
+        # call: the GIL is free while it waits for the GPU) -- the pooling masks of everything behind the first trunk pass, and
+        # finish()'s speaker count and activity table.  Same functions on the same inputs: results are unchanged.
         runs = self._runs(classes)
-        wi, si, masks = embedding_items_from_classes(classes, bool(self.params["embedding_exclude_overlap"]), 400,
-                                                     self.cfg["window_samples"], runs)
+        excl = bool(self.params["embedding_exclude_overlap"])
+        head = min(W, self.HEAD_WINDOWS)
+        if head < W:
+            wi, si, masks = embedding_items_from_classes(classes[:head], excl, 400, self.cfg["window_samples"])
+        else:
+            wi, si, masks = embedding_items_from_classes(classes, excl, 400, self.cfg["window_samples"], runs)
         t3 = time.perf_counter()
+        step = self.cfg["step_samples"] / self.cfg["sample_rate"]
+        dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
+
+        def tail_items():
+            return embedding_items_from_classes(classes[head:], excl, 400, self.cfg["window_samples"]) if head < W else None
+
+        def count_active():
+            return speaker_count_from_classes(classes, step, dur, runs), active_from_classes(classes, runs)
+
+        pool = self._host_pool()
+        f_tail = pool.submit(tail_items)
+        f_pre = pool.submit(count_active)
         emb = np.full((W, 3, self.cfg["emb_dim"]), np.nan, np.float32)
+        n_items = int(wi.size)
         if wi.size:
             emb[wi, si] = eng.embed(wi.astype(np.int64), masks)
+        tail = f_tail.result()
+        if tail is not None and tail[0].size:
+            wi2, si2, masks2 = tail
+            emb[wi2 + head, si2] = eng.embed((wi2 + head).astype(np.int64), masks2)
+            n_items += int(wi2.size)
+        self._pre = (classes, f_pre)
         t4 = time.perf_counter()
-        self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, windows=W, embeddings=int(wi.size))
+        self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, windows=W, embeddings=n_items)
         return classes, emb
+
+    HEAD_WINDOWS = 768          # = the engine's windows per trunk pass (RVD_EMB_BATCH): the first pass starts on these masks alone
+
+    def _host_pool(self):
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rvd-host")
+        return self._pool
 
     def finish(self, classes: np.ndarray, emb: np.ndarray, uri: Optional[str], num_speakers: Optional[int] = None,
                min_speakers: Optional[int] = None, max_speakers: Optional[int] = None, return_embeddings: bool = False):
@@ -595,10 +629,16 @@ class SpeakerDiarization:
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
         runs = self._runs(classes)
         self._runs_of = self._runs_val = None                                 # one recording at a time: do not keep it alive
-        count = speaker_count_from_classes(classes, step, dur, runs)
+        pre = getattr(self, "_pre", None)
+        self._pre = None
+        if pre is not None and pre[0] is classes:                               # computed under the embedding network by networks()
+            count, active = pre[1].result()
+        else:
+            count, active = speaker_count_from_classes(classes, step, dur, runs), None
         if count.size == 0 or np.max(count) == 0:
             return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)
-        active = active_from_classes(classes, runs)
+        if active is None:
+            active = active_from_classes(classes, runs)
         cp = self.params["clustering"]
         ms = max_speakers if max_speakers is not None else np.inf
         hard, centroids = cluster_embeddings(emb, None, float(cp["threshold"]), int(cp["min_cluster_size"]), cp.get("method", "centroid"),

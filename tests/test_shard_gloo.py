@@ -360,6 +360,27 @@ def test_diarize_sharded_world2_gloo_matches_single_process():
     assert got[0] == want and got[1] == want
 
 
+def test_networks_host_overlap_keeps_results():
+    """Round 4: networks() computes the pooling masks of everything behind the first trunk pass, and finish()'s speaker count /
+    activity table, on a helper thread underneath the embedding call.  Whatever the split point (here: after 1 window, after 2,
+    none), classes, embeddings and the RTTM are those of the unsplit run -- and finish() on a DIFFERENT classes object (what the
+    sharded path hands it after the gather) falls back to computing its inputs itself."""
+    from reverb_amd import synth_diar
+    pcm = synth_diar.synth_conversation(33.4, seed=9)
+    outs = []
+    for head in (10 ** 9, 1, 2):
+        pipe = _diar_pipeline()
+        pipe.HEAD_WINDOWS = head
+        classes, emb = pipe.networks(pcm)
+        assert pipe.timings["embeddings"] == int(np.isfinite(emb[:, :, 0]).sum())
+        outs.append((classes.copy(), emb.copy(), _rttm(pipe.finish(classes, emb, "talk")), _rttm(pipe.finish(classes.copy(), emb, "talk"))))
+    for c, e, r1, r2 in outs[1:]:
+        np.testing.assert_array_equal(c, outs[0][0])
+        assert np.array_equal(np.isnan(e), np.isnan(outs[0][1])) and np.array_equal(np.nan_to_num(e), np.nan_to_num(outs[0][1]))
+        assert r1 == outs[0][2] and r2 == outs[0][2]
+    assert outs[0][2] == outs[0][3] and outs[0][2].count("\n") >= 2
+
+
 def _dying_diar_worker(rank, world, port, q):
     import datetime
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
