@@ -578,13 +578,12 @@ class SpeakerDiarization:
         # Round 4: the host work that needs nothing but the classes runs UNDER the embedding network (eng.embed is a foreign
         # call: the GIL is free while it waits for the GPU) -- the pooling masks of everything behind the first trunk pass, and
         # finish()'s speaker count and activity table.  Same functions on the same inputs: results are unchanged.
-        runs = self._runs(classes)
         excl = bool(self.params["embedding_exclude_overlap"])
-        head = min(W, self.HEAD_WINDOWS)
+        head = min(W, self.HEAD_WINDOWS if os.environ.get("RVD_HOST_OVERLAP", "1") != "0" else W)
         if head < W:
             wi, si, masks = embedding_items_from_classes(classes[:head], excl, 400, self.cfg["window_samples"])
         else:
-            wi, si, masks = embedding_items_from_classes(classes, excl, 400, self.cfg["window_samples"], runs)
+            wi, si, masks = embedding_items_from_classes(classes, excl, 400, self.cfg["window_samples"], self._runs(classes))
         t3 = time.perf_counter()
         step = self.cfg["step_samples"] / self.cfg["sample_rate"]
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
@@ -593,6 +592,7 @@ class SpeakerDiarization:
             return embedding_items_from_classes(classes[head:], excl, 400, self.cfg["window_samples"]) if head < W else None
 
         def count_active():
+            runs = self._runs(classes)              # the run-length view of the whole recording: built here, reused by finish()
             return speaker_count_from_classes(classes, step, dur, runs), active_from_classes(classes, runs)
 
         pool = self._host_pool()
