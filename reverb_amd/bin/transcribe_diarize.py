@@ -72,7 +72,7 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
         # the clustering's merge loop is persistent: with its default 16 workgroups it takes 16 CUs and an XCD's L2 away from the
         # ASR encoder it runs underneath (1 h: joint step 493-499 ms; 472 ms with 4 workgroups, 477 with one); recordings too long
         # for 4 workgroups' LDS (more than ~18 000 embeddings) get as many as they need (rvd_set_linkage_workgroups)
-        pipe.engine.set_linkage_workgroups(4)
+        pipe.engine.set_linkage_workgroups(int(os.environ.get("RVD_JOINT_LINKAGE_G", "4")))
         try:
             with ThreadPoolExecutor(1) as ex:
                 fd = ex.submit(pipe.finish, classes, emb, uri)
