@@ -151,7 +151,8 @@ int rvb_set_decoding_chunk(rvb_engine* e, int chunk_size, int num_left_chunks);
 
 /* RVB_FP8 engines: which GEMM groups of which conformer blocks run on the fp8 MFMA path -- `groups` is a bit mask (1 macaron
  * feed-forward, 2 qkv projection, 4 pointwise conv 1, 8 pointwise conv 2, 16 feed-forward) applied to the blocks
- * first_block .. last_block (last_block < 0: the last one); everything else stays bf16.  groups < 0 restores the default: the
+ * first_block .. last_block (last_block < 0: the last one), plus 32 = the subsampling's second convolution (not per block;
+ * rvb_get_fp8_subsample); everything else stays bf16.  groups < 0 restores the default: the
  * feed-forward modules of every block (17), the policy whose token error rate against the reference stays at the level of the
  * reference's own bf16 autocast (tests/test_fp8_gpu.py).  Takes effect with the next rvb_encode; call after rvb_finalize. */
 int rvb_set_fp8_policy(rvb_engine* e, int groups, int first_block, int last_block);
@@ -242,6 +243,11 @@ int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n);
  * A calibrated engine decoding audio like its calibration batch reports zeros (2x headroom); anything else says the scales do
  * not cover this input -- recalibrate (rvb_fp8_recalibrate) or install wider scales.  reset != 0 zeroes the counters. */
 int rvb_get_fp8_saturation(rvb_engine* e, uint32_t* counts, int32_t* n, int reset);
+/* Round 4: rvb_set_fp8_policy's bit 5 puts the subsampling's second convolution (K = 9 d, a quarter of the encoder's FLOPs;
+ * subsampling.py:189-190) on the fp8 path: conv1 then writes its ReLU output in e4m3 at a scale calibrated with the others.
+ * *scale: that scale (0 while not calibrated -- conv2 then stays bf16; rvb_set_fp8_scales does not install it, a
+ * calibration pass does); *clipped: values of conv1's output beyond 448 * scale since the last reset.  Either may be NULL. */
+int rvb_get_fp8_subsample(rvb_engine* e, float* scale, uint32_t* clipped, int reset);
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n);
 /* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's
  * padded [N, L] decoder batch computes (search.py:391-412); `decoder_rows` = rows actually computed: one per DISTINCT

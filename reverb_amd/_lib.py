@@ -91,6 +91,7 @@ SIGNATURES = {
     "rvb_get_fp8_scales": (C.c_int, [_eng, _f32p, _i32p]),
     "rvb_set_fp8_scales": (C.c_int, [_eng, _f32p, C.c_int32]),
     "rvb_get_fp8_saturation": (C.c_int, [_eng, C.POINTER(C.c_uint32), _i32p, C.c_int]),
+    "rvb_get_fp8_subsample": (C.c_int, [_eng, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]),
     "rvb_get_rescore_stats": (C.c_int, [_eng, _i64p, _i64p]),
     "rvb_get_rescore_logp": (C.c_int, [_eng, C.c_int, C.c_int, C.c_int, _f32p]),
     "rvb_comm_unique_id": (C.c_int, [C.c_void_p]),

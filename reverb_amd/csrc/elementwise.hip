@@ -20,11 +20,15 @@ namespace rvb {
 // ------------------------------------------------------------------------------------------------
 static constexpr int CONV1_ROWS = 4;      // output time rows per workgroup: the 72 weights of a thread are loaded once for all of them
 
+// T = fp8_t (round 4, RVB_FP8 with conv2 in the policy): the output is value / scale in e4m3 (ReLU output: >= 0), 8 bytes per
+// thread and pixel, values beyond 448 clipped and counted in *sat.  amax (calibration pass, bf16 output): the running maximum
+// of the output as float bits -- the values are non-negative, so an unsigned atomicMax orders them.
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ feats, const float* __restrict__ mean,
                                                     const float* __restrict__ istd, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, int T0,
-                                                    int F0, int T1, int F1, int d) {
+                                                    int F0, int T1, int F1, int d, float inv_scale, unsigned* __restrict__ amax,
+                                                    unsigned* __restrict__ sat) {
   extern __shared__ float s_in[];  // [2 * CONV1_ROWS + 1][F0]: the input rows of CONV1_ROWS output rows (stride 2, 3 taps)
   const int t1_0 = blockIdx.x * CONV1_ROWS, b = blockIdx.y;
   const int nrow = min(CONV1_ROWS, T1 - t1_0);
@@ -40,6 +44,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
   const int nslots = 256 / per;                 // f1 slots sharing the block
   const int cgl = threadIdx.x % per, fslot = threadIdx.x / per;
   if (fslot >= nslots) return;
+  float vmax = 0.f;
+  unsigned nclip = 0;
   for (int cg = cgl; cg < ncg; cg += per) {
     float wr[8][9], br[8];
     // weights tap-major [9][d]: the 8 channels of a thread are 32 contiguous bytes, the threads of a wave contiguous
@@ -69,7 +75,16 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
           o[c] = fmaxf(acc, 0.f);
         }
         T* dst = orow + (size_t)f1 * d + cg * 8;
-        if constexpr (sizeof(T) == 2) {
+        if (amax) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) vmax = fmaxf(vmax, o[c]);
+        }
+        if constexpr (sizeof(T) == 1) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) o[c] *= inv_scale;
+          if (sat) nclip += fp8_clipped(o[0], o[1], o[2], o[3]) + fp8_clipped(o[4], o[5], o[6], o[7]);
+          *(uint2*)dst = make_uint2(pack4_fp8(o[0], o[1], o[2], o[3]), pack4_fp8(o[4], o[5], o[6], o[7]));
+        } else if constexpr (sizeof(T) == 2) {
           *(uint4*)dst = make_uint4(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7]));
         } else {
           ((float4*)dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -78,19 +93,31 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
       }
     }
   }
+  if (amax) {
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(amax, __float_as_uint(vmax));
+  }
+  if (sat && nclip) atomicAdd(sat, nclip);
 }
 
 int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* mean, const float* istd,
-                    const float* w, const float* b, void* out, int B, int T0, int F0, int d) {
+                    const float* w, const float* b, void* out, int B, int T0, int F0, int d, float out_fp8_scale, unsigned* amax,
+                    unsigned* sat) {
   const int T1 = (T0 - 3) / 2 + 1, F1 = (F0 - 3) / 2 + 1;
   if (B <= 0 || T1 <= 0) return OK;
   if (d % 8) { set_error("subsample_conv1: d must be a multiple of 8"); return E_ARG; }
   dim3 grid(cdiv(T1, CONV1_ROWS), B);
   const size_t sh = (2 * CONV1_ROWS + 1) * F0 * sizeof(float);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(conv1_kernel<bf16_t>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (bf16_t*)out, T0, F0, T1, F1, d);
+  if (out_fp8_scale > 0.f) {
+    if (dtype != DT_BF16) { set_error("subsample_conv1: fp8 output belongs to the bf16 engine"); return E_ARG; }
+    hipLaunchKernelGGL(conv1_kernel<fp8_t>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (fp8_t*)out, T0, F0, T1, F1, d,
+                       1.f / out_fp8_scale, (unsigned*)nullptr, sat);
+  } else if (dtype == DT_BF16)
+    hipLaunchKernelGGL(conv1_kernel<bf16_t>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (bf16_t*)out, T0, F0, T1, F1, d, 1.f, amax,
+                       (unsigned*)nullptr);
   else
-    hipLaunchKernelGGL(conv1_kernel<float>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (float*)out, T0, F0, T1, F1, d);
+    hipLaunchKernelGGL(conv1_kernel<float>, grid, dim3(256), sh, s, feats, mean, istd, w, b, (float*)out, T0, F0, T1, F1, d, 1.f, amax,
+                       (unsigned*)nullptr);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

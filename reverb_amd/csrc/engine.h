@@ -147,7 +147,9 @@ struct rvb_engine {
   int f8_state = 0;              // 0 not calibrated, 1 calibrating (bf16 pass collecting max |.|), 2 fp8 GEMMs active
   std::vector<rvb::F8Scales> f8;
   std::vector<unsigned> f8_groups;   // per block: which GEMM groups run in fp8 (bit 0 ffm, 1 qkv, 2 pw1, 3 pw2, 4 ff)
-  rvb::DevBuf d_amax;            // fp32 [blocks][8]
+  rvb::DevBuf d_amax;            // fp32 [blocks + 1][8]; row `blocks`, slot 0: the subsampling's conv1 output (conv2's fp8 operand)
+  bool f8_conv2 = false;         // policy bit 5: conv2 of the subsampling (K = 9 d, 27 % of the encoder's FLOPs) in fp8
+  float f8_x1 = 0.f;             // calibrated scale of conv1's output (0: not calibrated -> conv2 stays bf16)
   rvb::DevBuf d_f8sat;           // uint32 [blocks + 1][8]: values clipped at +-448 per activation slot (rvb_get_fp8_saturation)
   hipStream_t stream = nullptr;
   bool finalized = false;

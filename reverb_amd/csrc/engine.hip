@@ -341,7 +341,7 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
       for (int co = 0; co < d; ++co)
         for (int ci = 0; ci < d; ++ci)
           for (int k = 0; k < 9; ++k) w[((size_t)co * 9 + k) * d + ci] = t->data[((size_t)co * d + ci) * 9 + k];
-      RVB_TRY(pack_linear(e, e->conv2, w.data(), t2->data.data(), d, 9 * d));
+      RVB_TRY(pack_linear(e, e->conv2, w.data(), t2->data.data(), d, 9 * d, true));      // + fp8 copy in RVB_FP8 mode (policy bit 5)
       RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
     {  // out.0 [o][c*F2+f] -> [o][f*d+c]: our conv2 output is (t, f, c) not the reference's (t, c, f)
@@ -488,6 +488,7 @@ static int set_fp8_policy_impl(rvb_engine* e, int groups, int first_block, int l
   e->f8_groups.assign(nb, 0u);
   for (int l = 0; l < nb; ++l)
     if (l >= first_block && l <= last_block) e->f8_groups[l] = mask & 31u;
+  e->f8_conv2 = (mask & 32u) != 0;           // not per block: the subsampling's conv2
   return OK;
 }
 
@@ -730,8 +731,8 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   }
   e->slices.clear();
   if (e->fp8 && e->f8_state == 0) {     // first batch of an fp8 engine: bf16 pass that records the activation ranges
-    RVB_TRY(e->d_amax.ensure(e->enc.size() * 8 * 4));
-    RVB_HIP_CHECK(hipMemsetAsync(e->d_amax.p, 0, e->enc.size() * 8 * 4, e->stream));
+    RVB_TRY(e->d_amax.ensure((e->enc.size() + 1) * 8 * 4));
+    RVB_HIP_CHECK(hipMemsetAsync(e->d_amax.p, 0, (e->enc.size() + 1) * 8 * 4, e->stream));
     RVB_TRY(reset_f8sat(e));
     e->f8_state = 1;
   }
@@ -741,10 +742,15 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
     const int row0 = c0 * T2;
     e->cur_lens = e->d_enc_lens.as<int>() + c0;       // per-chunk arrays of this slice (starts are slice-relative)
     // Conv2dSubsampling4 (subsampling.py:201-226): cmvn+conv1 -> conv2 (implicit GEMM) -> linear * sqrt(d)
+    // fp8 mode with conv2 in the policy (bit 5): conv1 writes e4m3 at the calibrated scale and conv2 runs on the fp8 phase loop
+    const bool f8c2 = e->fp8 && e->f8_state == 2 && e->f8_conv2 && e->f8_x1 > 0.f && e->conv2.w8.p && d % 128 == 0;
+    const bool calx = e->fp8 && e->f8_state == 1;
     {
       Scope sc(e, "subsample");
       RVB_TRY(subsample_conv1(e->stream, e->dtype, d_feats + (size_t)c0 * T0 * F0, e->cmvn_mean.as<float>(),
-                              e->cmvn_istd.as<float>(), e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, nb, T0, F0, d));
+                              e->cmvn_istd.as<float>(), e->conv1_w.as<float>(), e->conv1_b.as<float>(), e->X1.p, nb, T0, F0, d,
+                              f8c2 ? e->f8_x1 : 0.f, calx ? e->d_amax.as<unsigned>() + e->enc.size() * 8 : nullptr,
+                              (f8c2 && e->d_f8sat.p) ? e->d_f8sat.as<unsigned>() + e->enc.size() * 8 + 1 : nullptr));
     }
     {
       GemmArgs g;
@@ -752,7 +758,8 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
       g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
       g.M = nb * T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
       g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
-      Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
+      if (f8c2) { g.W = e->conv2.w8.p; g.in_fp8 = 1; g.a_scale = e->f8_x1; g.w_scale = e->conv2.wscale.as<float>(); }
+      Scope sc(e, f8c2 ? "gemm_fp8" : "gemm", 2.0 * g.M * (double)g.N * g.K);
       RVB_TRY(gemm(e->stream, e->dtype, g));
     }
     RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, m, true, std::sqrt((float)d)));
@@ -784,7 +791,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   if (e->f8_state == 1) {
     // per-tensor scales: a power of two with headroom (2 * amax maps inside +-448; fp8 is floating point, so headroom
     // costs no relative precision); later batches saturate only beyond twice the calibration batch's maximum
-    std::vector<float> am(e->enc.size() * 8);
+    std::vector<float> am((e->enc.size() + 1) * 8);
     RVB_HIP_CHECK(hipMemcpyAsync(am.data(), e->d_amax.p, am.size() * 4, hipMemcpyDeviceToHost, e->stream));
     RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->f8.resize(e->enc.size());
@@ -793,6 +800,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
       const float* a = am.data() + l * 8;
       e->f8[l] = {sc(a[0]), sc(a[1]), sc(a[2]), sc(a[3]), sc(a[4]), sc(a[5]), sc(a[6])};
     }
+    e->f8_x1 = am[e->enc.size() * 8] > 0.f ? sc(am[e->enc.size() * 8]) : 0.f;       // conv1's output (>= 0: the float bits were max'ed as unsigned)
     if (e->f8_groups.size() != e->enc.size()) RVB_TRY(set_fp8_policy_impl(e, -1, 0, -1));     // default policy (or RVB_FP8_*)
     e->f8_state = 2;
   }
@@ -2003,7 +2011,7 @@ int rvb_host_free(void* p) {
 int rvb_set_fp8_policy(rvb_engine* e, int groups, int first_block, int last_block) {
   if (!e) { set_error("rvb_set_fp8_policy: null engine"); return E_ARG; }
   if (!e->fp8) { set_error("rvb_set_fp8_policy: not an RVB_FP8 engine"); return E_STATE; }
-  if (groups > 31 || first_block < 0) { set_error("rvb_set_fp8_policy: groups is a 5-bit mask, first_block >= 0"); return E_ARG; }
+  if (groups > 63 || first_block < 0) { set_error("rvb_set_fp8_policy: groups is a 6-bit mask (bit 5: the subsampling's conv2), first_block >= 0"); return E_ARG; }
   return set_fp8_policy_impl(e, groups, first_block, last_block);
 }
 
@@ -2352,6 +2360,21 @@ int rvb_get_fp8_saturation(rvb_engine* e, uint32_t* counts, int32_t* n, int rese
   if (counts)
     for (size_t l = 0; l < e->enc.size(); ++l)
       for (int k = 0; k < 7; ++k) counts[l * 7 + k] = raw[l * 8 + k];
+  return OK;
+}
+int rvb_get_fp8_subsample(rvb_engine* e, float* scale, uint32_t* clipped, int reset) {
+  if (!e) { set_error("rvb_get_fp8_subsample: null engine"); return E_ARG; }
+  if (!e->fp8) { set_error("rvb_get_fp8_subsample: not an RVB_FP8 engine"); return E_STATE; }
+  if (scale) *scale = e->f8_state == 2 ? e->f8_x1 : 0.f;
+  if (clipped) *clipped = 0;
+  if (e->d_f8sat.p && (clipped || reset)) {
+    unsigned* slot = e->d_f8sat.as<unsigned>() + e->enc.size() * 8 + 1;
+    uint32_t v = 0;
+    RVB_HIP_CHECK(hipMemcpyAsync(&v, slot, 4, hipMemcpyDeviceToHost, e->stream));
+    if (reset) RVB_HIP_CHECK(hipMemsetAsync(slot, 0, 4, e->stream));
+    RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (clipped) *clipped = v;
+  }
   return OK;
 }
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n) {

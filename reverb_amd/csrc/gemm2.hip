@@ -1587,7 +1587,10 @@ static int launch2(hipStream_t s, const GemmArgs& p) {
 }
 
 bool gemm2_applicable(int dtype, const GemmArgs& p) {
-  if (p.in_fp8) return dtype == DT_BF16 && !p.conv && p.K % 128 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.M >= 1 && p.N >= 64 &&
+  // fp8 with the convolution gather (round 4: conv2 of the subsampling, K = 9 d): the phase-interleaved loop, bf16 output
+  if (p.in_fp8 && p.conv) return dtype == DT_BF16 && p.K % 128 == 0 && p.cC % 128 == 0 && p.ldw % 16 == 0 && p.M >= 1 && p.N >= 64 &&
+                                 p.act != ACT_LRELU && p.w_scale != nullptr && !p.out_f32 && !p.out_fp8 && p.res == nullptr;
+  if (p.in_fp8) return dtype == DT_BF16 && p.K % 128 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.M >= 1 && p.N >= 64 &&
                        p.act != ACT_LRELU && p.w_scale != nullptr;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   if (p.K % bke || p.lda % (bke / 8) || p.ldw % (bke / 8)) return false;
@@ -1674,6 +1677,7 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
       }
     }
   }
+  if (p.in_fp8 && p.conv) return launch2p<fp8_t, bf16_t, true>(s, p);      // K = 9 d: 72 fp8 K steps, where the phase loop pays
   if (p.in_fp8 && (g_gemm2_flags & 8)) {      // fp8 on the phase-interleaved loop: opt-in, measured slower (see the flag list)
     if (p.out_fp8) return launch2p<fp8_t, fp8_t, false>(s, p);
     if (p.out_f32) return launch2p<fp8_t, float, false>(s, p);

@@ -71,7 +71,8 @@ int resample_f32(hipStream_t s, const float* wave, int64_t n_in, const float* ke
 // CMVN + Conv2d(1,d,3,stride 2) + ReLU; feats fp32 [B,T0,F0] -> out T [B,T1,F1,d] (NHWC)
 int subsample_conv1(hipStream_t s, int dtype, const float* feats, const float* mean, const float* istd,
                     const float* w /*[9][d]: tap-major, conv.0.weight transposed at load*/, const float* b /*[d]*/, void* out, int B, int T0, int F0,
-                    int d);
+                    int d, float out_fp8_scale = 0.f /*> 0: out is e4m3 of value / scale*/, unsigned* amax = nullptr /*running max, float bits*/,
+                    unsigned* sat = nullptr /*fp8 output: += clipped values*/);
 
 enum { NORM_LN = 0, NORM_AFFINE = 1 };
 struct NormArgs {

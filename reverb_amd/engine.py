@@ -193,7 +193,7 @@ class Engine:
         """Chunk mask of the encoder self-attention for the next encode() calls (<= 0: full context)."""
         check(self.lib.rvb_set_decoding_chunk(self.handle, int(chunk_size), int(num_left_chunks)), "rvb_set_decoding_chunk")
 
-    FP8_GROUPS = {"ffn_macaron": 1, "qkv": 2, "pointwise_conv1": 4, "pointwise_conv2": 8, "ffn": 16}
+    FP8_GROUPS = {"ffn_macaron": 1, "qkv": 2, "pointwise_conv1": 4, "pointwise_conv2": 8, "ffn": 16, "subsample_conv2": 32}
 
     def set_fp8_policy(self, groups=None, first_block: int = 0, last_block: int = -1):
         """fp8 engines: the GEMM groups (names of FP8_GROUPS, or a bit mask) of blocks first_block..last_block that run on
@@ -215,6 +215,13 @@ class Engine:
         check(self.lib.rvb_get_fp8_saturation(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n), 1 if reset else 0),
               "rvb_get_fp8_saturation")
         return out[:n.value].reshape(-1, 7)
+
+    def fp8_subsample(self, reset: bool = False):
+        """fp8 engines with "subsample_conv2" in the policy: (scale of conv1's fp8 output -- 0.0 before the calibration batch --,
+        values of it clipped at 448 * scale since the last reset)."""
+        sc, cl = C.c_float(0.0), C.c_uint32(0)
+        check(self.lib.rvb_get_fp8_subsample(self.handle, C.byref(sc), C.byref(cl), 1 if reset else 0), "rvb_get_fp8_subsample")
+        return float(sc.value), int(cl.value)
 
     def fp8_scales(self) -> Optional[np.ndarray]:
         """fp8 engines: the calibrated activation scales [blocks, 7], or None before the calibration batch."""

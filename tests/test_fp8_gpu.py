@@ -138,6 +138,46 @@ def test_fp8_engine_against_reference(name):
     eng.close()
 
 
+def test_fp8_subsampling_conv2_policy_bit():
+    """Round 4: policy bit 5 ("subsample_conv2") -- conv1 writes its ReLU output in e4m3 at a calibrated scale and conv2 (K = 9 d, a
+    quarter of the encoder's FLOPs) runs on the fp8 phase loop with the convolution gather.  The bit moves that GEMM's FLOPs from
+    the bf16 to the fp8 counter, nothing of conv1's output is clipped on the calibration batch, the encoder output stays the
+    reference's (cos), and the token errors are held to the same yardstick as the default policy."""
+    from golden_util import LongCase
+    from reverb_amd.engine import Engine
+    from test_longform_gpu import MODES, RefBf16, _assert_reduced_precision, _record, _tap_metrics, _ter
+    name = "r640_chunk"
+    case = LongCase(name)
+    n = 2
+    x = np.concatenate([case.chunk_feats(c)[0] for c in range(n)])
+    lens = np.array(case.js["lens"][:n], np.int32)
+    eng = Engine(case.cfg, case.sd, dtype="fp8", device=0, max_chunks=n, chunk_frames=case.chunk, cat_embs=case.cat)
+    assert eng.fp8_subsample() == (0.0, 0)                          # not calibrated yet
+    eng.encode(x, lens, case.beam)                                  # calibration batch (bf16)
+    scale, clipped = eng.fp8_subsample()
+    assert scale > 0 and math.log2(scale) == round(math.log2(scale)) and clipped == 0
+    flops = {}
+    for policy in (17, 17 | 32):
+        eng.set_fp8_policy(policy)
+        eng.reset_timings()
+        eng.encode(x, lens, case.beam)
+        flops[policy] = (eng.timing("gemm")["flops"], eng.timing("gemm_fp8")["flops"])
+    d = case.cfg["encoder_conf"]["output_size"]
+    assert flops[17 | 32][1] - flops[17][1] == flops[17][0] - flops[17 | 32][0] > 2.0 * 9 * d * d * 100        # conv2's FLOPs changed sides
+    m0 = _tap_metrics(eng, case, 0, 0)
+    ref = RefBf16(name)
+    fm = ref.frame_disagreement(eng)
+    ter = _ter(eng.search(MODES, case.ctc_weight, case.reverse_weight), case)
+    _record(case=name, dtype="fp8", policy="feed-forward + subsampling conv2", ter={m: list(v) for m, v in ter.items()}, chunk0=m0, frames=fm,
+            reference_bf16_ter=ref.ter)
+    assert eng.fp8_subsample()[1] == 0                               # the calibration batch itself never clips (2x headroom)
+    assert m0["cos"] > 0.995, m0
+    _assert_reduced_precision(name, "fp8 + conv2", ter, fm, ref, slack=FP8_SLACK)
+    with pytest.raises(_lib.RvbError, match="6-bit"):
+        eng.set_fp8_policy(64)
+    eng.close()
+
+
 def test_fp8_needs_dims_of_128():
     from golden_util import Case
     from reverb_amd._lib import RvbError
