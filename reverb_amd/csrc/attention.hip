@@ -290,24 +290,35 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nf][r]);
     mx = rows_max(mx);
     const float m_new = fmaxf(m_run, mx);
-    float al = 1.f, ps = 0.f;
-    if (m_new == -INFINITY) {                     // every key so far is masked for this query
+    // Branch-free since round 4: while every key so far is masked for this query (m_new = -inf) the reference point is 0, so that
+    // exp(-inf - 0) = 0 gives the zeros the old "all masked" branch wrote by hand -- hipcc had turned that branch into 18
+    // register clears + an exec-masked block that EVERY tile executed.  al = exp(-inf) = 0 instead of 1 there, on o = l = 0.
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    float al, ps;
+    if constexpr (BF) {
+      // pairs: the subtraction and the running sum are packed (v_pk_add_f32); the sum's order differs from the scalar loop's
+      // in the last bit at most (bf16 engine only: its probabilities are rounded to bf16 right below)
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      al = __builtin_amdgcn_exp2f(m_run - m_use);
+      const f32x2_t mm = {m_use, m_use};
+      f32x2_t acc = {0.f, 0.f};
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) s[nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2_t dd = (f32x2_t){s[nf][r], s[nf][r + 1]} - mm;
+          const f32x2_t pp = {__builtin_amdgcn_exp2f(dd.x), __builtin_amdgcn_exp2f(dd.y)};
+          s[nf][r] = pp.x; s[nf][r + 1] = pp.y;
+          acc += pp;
+        }
+      ps = acc.x + acc.y;
     } else {
-      if constexpr (BF) {
-        al = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      al = expf(m_run - m_use);
+      ps = 0.f;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(s[nf][r] - m_new); s[nf][r] = pv; ps += pv; }
-      } else {
-        al = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float pv = expf(s[nf][r] - m_new); s[nf][r] = pv; ps += pv; }
-      }
+        for (int r = 0; r < 4; ++r) { const float pv = expf(s[nf][r] - m_use); s[nf][r] = pv; ps += pv; }
     }
     ps = rows_sum(ps);
     l_run = l_run * al + ps;
