@@ -269,3 +269,18 @@ def test_vectorised_word_speaker_join_equals_the_per_word_function():
         want = [A.speaker_for_segment(float(s), float(d), turns) for s, d in zip(starts, durs)]
         assert A.speakers_for_words(starts, durs, turns, block=64) == want
     assert A.speakers_for_words([1.0], [0.5], []) == [""]
+
+
+def test_fcluster_distance_shortcut_equals_scipy():
+    """cluster_embeddings cuts the dendrogram with scipy's compiled routine directly (no Python-side validation of Z): same labels
+    as scipy.cluster.hierarchy.fcluster, also on centroid dendrograms with inversions and at thresholds on merge heights."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from reverb_amd.diarization import _fcluster_distance
+    rng = np.random.default_rng(3)
+    for n, d in ((2, 4), (7, 3), (200, 16), (1500, 8)):
+        x = rng.standard_normal((n, d))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        z = linkage(x, method="centroid", metric="euclidean")
+        for t in (0.0, 0.3, 0.7045654963945799, float(z[len(z) // 2, 2]), 10.0):
+            np.testing.assert_array_equal(_fcluster_distance(z, t), fcluster(z, t, criterion="distance"))
+
