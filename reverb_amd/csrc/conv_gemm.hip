@@ -63,7 +63,9 @@ __device__ inline void cg_pin(uint4& a, uint4& b) {
   a = make_uint4(x[0], x[1], x[2], x[3]); b = make_uint4(y[0], y[1], y[2], y[3]);
 }
 
-template <int BN>
+// SC: the block's projection shortcut rides in this convolution's K loop (ConvArgs::in2; its own instantiation, so that the plain
+// form keeps its registers: the 256-channel tile sits at 254 VGPRs)
+template <int BN, bool SC = false>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cg_smem[];
   constexpr int BKB = 128, BKE = 64;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   const int m0 = tm * 256, n0 = tn * BN;
   const bf16_t* __restrict__ in = (const bf16_t*)p.in;
   const bf16_t* __restrict__ w = (const bf16_t*)p.w_ig;
+  const size_t ldw = (size_t)9 * Cin + (SC ? p.Cin2 : 0);      // weight row: 9 taps (+ the fused shortcut's channels)
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cg_smem;
 
   // ---- DMA sources: wave w stages pixels [32w, 32w+32) and weight rows [8 WP w, +8 WP); source column swizzled
@@ -109,15 +112,38 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
     const int row = wave * (WP * 8) + i * 8 + lr;
-    w_src[i] = w + (size_t)(n0 + row) * 9 * Cin + (lc ^ ((row >> 1) & 7)) * 8;
+    w_src[i] = w + (size_t)(n0 + row) * ldw + (lc ^ ((row >> 1) & 7)) * 8;
   }
   const int cpt = Cin / BKE;                                   // K steps per tap
+  const int nk9 = 9 * cpt;
   auto issue = [&](int kt) __attribute__((always_inline)) {
+    const unsigned dst = lds_base + (kt & 1) * STAGE;
+    if (SC && kt >= nk9) {
+      // fused projection shortcut (p.in2): K step j of the 1 x 1 / stride-s2 convolution of the block's input -- pixel
+      // (s2 fo + 1, s2 to + 1) of its bordered tensor, channels [64 j, +64); the per-lane addresses are rebuilt here (one or
+      // two K steps per tile: cheaper than four more pointers alive through the main loop)
+      const int j = kt - nk9;
+      const bf16_t* in2 = (const bf16_t*)p.in2;
+      const int TP2 = p.Ti2 + 2, FP2 = p.Fi2 + 2, s2 = p.stride2, C2 = p.Cin2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + lr;
+        int m = m0 + row;
+        if (m >= M) m = M - 1;
+        const int b = m / (F * T), rem = m - b * (F * T);
+        const int fo = rem / T, to = rem - fo * T;
+        const bf16_t* src = in2 + ((size_t)(b * FP2 + s2 * fo + 1) * TP2 + s2 * to + 1) * C2 + j * BKE + (lc ^ ((row >> 1) & 7)) * 8;
+        cg_dma(src, dst + (wave * 32 + i * 8) * BKB);
+      }
+      const size_t woff2 = (size_t)9 * Cin + (size_t)j * BKE;
+#pragma unroll
+      for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff2, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+      return;
+    }
     const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKE;
     const int kh = tap / 3, kw = tap - kh * 3;
     const size_t aoff = (size_t)(kh * TPi + kw) * Cin + c0;
     const size_t woff = (size_t)tap * Cin + c0;
-    const unsigned dst = lds_base + (kt & 1) * STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) cg_dma(a_src[i] + aoff, dst + (wave * 32 + i * 8) * BKB);
 #pragma unroll
@@ -135,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
   const int a_off = (wr * TM + frow) * BKB;
   const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
-  const int nk = 9 * cpt, nq = 2 * nk;                         // nk >= 9
+  const int nk = nk9 + (SC ? p.Cin2 / BKE : 0), nq = 2 * nk;      // nk >= 9
   uint4 fa[2][FI], fb[2][FJ];
   auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
@@ -288,10 +314,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   if (p.res) epilogue(std::true_type()); else epilogue(std::false_type());
 }
 
-template <int BN>
+template <int BN, bool SC>
 int launch_igemm(hipStream_t st, const ConvArgs& p) {
   const int lds = 2 * (256 + BN) * 128;
-  auto kern = conv_igemm_kernel<BN>;
+  auto kern = conv_igemm_kernel<BN, SC>;
   static bool attr_set = false;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -309,13 +335,15 @@ int launch_igemm(hipStream_t st, const ConvArgs& p) {
 bool conv_igemm_applicable(int dtype, const ConvArgs& p) {
   if (!(dtype == DT_BF16 && p.w_ig != nullptr && p.taps == 9 && p.Cin % 64 == 0 && p.Cout % 128 == 0 &&
         (int64_t)p.B * p.Fo * p.To < (int64_t)1 << 31)) return false;
+  if (p.in2 && (p.Cin2 % 64 || p.res != nullptr || p.Fo != (p.Fi2 - 1) / p.stride2 + 1 || p.To != (p.Ti2 - 1) / p.stride2 + 1)) return false;
   if (p.stride == 1) return p.Fo == p.Fi && p.To == p.Ti;
   return p.stride == 2 && p.Fo == (p.Fi - 1) / 2 + 1 && p.To == (p.Ti - 1) / 2 + 1;      // Conv2d(k 3, stride 2, pad 1)
 }
 
 int conv_igemm(hipStream_t s, const ConvArgs& p) {
   if (p.B <= 0) return OK;
-  return p.Cout % 256 == 0 ? launch_igemm<256>(s, p) : launch_igemm<128>(s, p);
+  if (p.in2) return p.Cout % 256 == 0 ? launch_igemm<256, true>(s, p) : launch_igemm<128, true>(s, p);
+  return p.Cout % 256 == 0 ? launch_igemm<256, false>(s, p) : launch_igemm<128, false>(s, p);
 }
 
 }  // namespace rvb

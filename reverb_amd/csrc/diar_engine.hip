@@ -18,7 +18,8 @@ namespace {
 struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
 constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 // ResNet34 trunk: conv weights packed [tap][Cin/CK][Cout][CK] with BatchNorm folded in
-struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1; };      // w_ig: conv_gemm.hip's layout (optional)
+struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1;      // w_ig: conv_gemm.hip's layout (optional)
+               DevBuf w_ig_sc, b_sc; };      // second convolution of a block with a projection shortcut: w_ig rows + the shortcut's, summed biases
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
 // windows per trunk pass; RVD_EMB_BATCH overrides (tuning).  768 since round 4: 1 h of audio 385-392 ms at 192, 381 at 384,
@@ -406,6 +407,37 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   return up_f32(e, c.b, pb.data(), pb.size());
 }
 
+// RVD_CONV_SC_FUSE=1 (round 4, opt-in until measured): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4
+// rides in the K loop of the block's second convolution (conv_gemm.hip, ConvArgs::in2) instead of being a kernel of its own whose
+// output is written, read back as the residual and rounded to bf16 on the way: rows [cout][9 cout + cin_sc], bias = b_2 + b_sc.
+int pack_fused_shortcut(rvd_engine* e, ResBlock& B, const std::string& p) {
+  const char* f = getenv("RVD_CONV_SC_FUSE");
+  if (!(f && atoi(f) == 1) || !B.has_sc || !B.c2.w_ig.p || B.sc.cin % 64 || B.sc.taps != 1) return OK;
+  const int cout = B.c2.cout, cin = B.c2.cin, c2 = B.sc.cin;
+  const HostTensor *w, *g, *b, *m, *v, *ws, *gs, *bs, *ms, *vs;
+  RVD_TRY(need(e, p + ".conv2.weight", (size_t)cout * cin * 9, &w));
+  RVD_TRY(need(e, p + ".bn2.weight", cout, &g));
+  RVD_TRY(need(e, p + ".bn2.bias", cout, &b));
+  RVD_TRY(need(e, p + ".bn2.running_mean", cout, &m));
+  RVD_TRY(need(e, p + ".bn2.running_var", cout, &v));
+  RVD_TRY(need(e, p + ".shortcut.0.weight", (size_t)cout * c2, &ws));
+  RVD_TRY(need(e, p + ".shortcut.1.weight", cout, &gs));
+  RVD_TRY(need(e, p + ".shortcut.1.bias", cout, &bs));
+  RVD_TRY(need(e, p + ".shortcut.1.running_mean", cout, &ms));
+  RVD_TRY(need(e, p + ".shortcut.1.running_var", cout, &vs));
+  const size_t ld = (size_t)9 * cin + c2;
+  std::vector<float> pg((size_t)cout * ld), pb(cout);
+  for (int o = 0; o < cout; ++o) {
+    const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f), ss = gs->data[o] / std::sqrt(vs->data[o] + 1e-5f);
+    pb[o] = (b->data[o] - m->data[o] * sc) + (bs->data[o] - ms->data[o] * ss);
+    for (int t = 0; t < 9; ++t)
+      for (int ci = 0; ci < cin; ++ci) pg[(size_t)o * ld + (size_t)t * cin + ci] = w->data[((size_t)o * cin + ci) * 9 + t] * sc;
+    for (int ci = 0; ci < c2; ++ci) pg[(size_t)o * ld + (size_t)9 * cin + ci] = ws->data[(size_t)o * c2 + ci] * ss;
+  }
+  RVD_TRY(pack_T(e, B.c2.w_ig_sc, pg.data(), pg.size()));
+  return up_f32(e, B.c2.b_sc, pb.data(), pb.size());
+}
+
 int finalize_embedding(rvd_engine* e) {
   const rvd_model_cfg& c = e->cfg;
   const std::string S = "embedding.resnet.";
@@ -440,6 +472,7 @@ int finalize_embedding(rvd_engine* e) {
       RVD_TRY(pack_conv_bn(e, B.c2, p + ".conv2", p + ".bn2", cout, cout, 3, 1));
       B.has_sc = stride != 1 || cin != cout;
       if (B.has_sc) RVD_TRY(pack_conv_bn(e, B.sc, p + ".shortcut.0", p + ".shortcut.1", cout, cin, 1, stride));
+      RVD_TRY(pack_fused_shortcut(e, B, p));
       cin = cout;
     }
   }
@@ -524,6 +557,22 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
         continue;
       }
       RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+      if (Bk.has_sc && Bk.c2.w_ig_sc.p) {        // the projection shortcut inside the second convolution's K loop (RVD_CONV_SC_FUSE=1)
+        ConvArgs a{};
+        a.in = tmp; a.w = Bk.c2.w.p; a.bias = Bk.c2.b_sc.as<float>(); a.res = nullptr; a.out = out;
+        a.B = B; a.Fi = d.F; a.Ti = d.T; a.Cin = Bk.c2.cin; a.Fo = d.F; a.To = d.T; a.Cout = Bk.c2.cout;
+        a.stride = 1; a.taps = 9; a.relu = 1;
+        a.w_ig = Bk.c2.w_ig_sc.p;
+        a.in2 = x; a.Cin2 = Bk.sc.cin; a.Fi2 = dx.F; a.Ti2 = dx.T; a.stride2 = Bk.sc.stride;
+        if (!conv_igemm_applicable(e->dtype, a)) { set_error("fused shortcut: shape not supported by the implicit-GEMM kernel"); return E_UNSUPPORTED; }
+        e->prof["emb_conv_igemm"].launches += 1;
+        e->prof["emb_conv_sc_fused"].launches += 1;
+        { DScope sc(e, ("emb_conv_" + std::to_string(Bk.c2.cout)).c_str(),
+                    2.0 * (double)B * d.F * d.T * Bk.c2.cout * ((double)Bk.c2.cin * 9 + Bk.sc.cin));
+          RVD_TRY(conv2d(e->stream, e->dtype, a)); }
+        x = out; dx = d; xi = oi;
+        continue;
+      }
       const void* res = x;
       if (Bk.has_sc) {
         RVD_TRY(run_conv(e, Bk.sc, x, dx, nullptr, e->act[li][3].p, d, B, 0));
@@ -652,7 +701,7 @@ void rvd_destroy(rvd_engine* e) {
   for (auto* b : ebufs) b->release();
   for (auto& st : e->stages)
     for (auto& blk : st)
-      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); }
+      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); cw->w_ig_sc.release(); cw->b_sc.release(); }
   for (auto& row : e->act) for (auto& b : row) b.release();
   (void)hipStreamDestroy(e->stream);
   delete e;

@@ -241,6 +241,11 @@ struct ConvArgs {
   int taps;           // 9 (3x3, pad 1) | 1 (1x1)
   int relu;
   const void* w_ig;   // bf16 [Cout][9][Cin] (BN folded) for conv_gemm.hip, or null (last: ConvArgs a{} leaves it null)
+  // conv_gemm.hip, fused projection shortcut (round 4, opt-in): out = relu(conv3x3(in) + conv1x1_stride(in2) + bias) -- the second
+  // convolution of a ResNet block that changes shape takes the block's 1x1 / stride-2 shortcut into its own K loop: w_ig rows are
+  // then [9 Cin + Cin2] long (the shortcut's weights appended), bias is the sum of both, res must be null
+  const void* in2;    // bf16 [B][Fi2+2][Ti2+2][Cin2] or null
+  int Cin2, Fi2, Ti2, stride2;
 };
 int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
 // resnet.hip: a whole stride-1 BasicBlock of 32 channels in one kernel (bf16): out = relu(conv_b(relu(conv_a(in))) + in), BN

@@ -1,6 +1,8 @@
 """Parity of the HIP diarization networks (rvd_* C ABI) with the oracle's restatement of the
 pyannote architectures (oracle/diar_ref.py; parity unpinned -- pyannote.audio is not available
 here, see the oracle's header) on seeded synthetic weights."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -234,6 +236,35 @@ def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypat
         assert streamed[flag] >= 6 + 7, streamed        # 6 convolutions of stage 1 + 7 stride-1 ones of stage 2, per trunk pass
         assert flops[flag] == flops["0"] > 0
         assert np.array_equal(out["0"], out[flag]), flag
+
+
+@pytest.mark.skipif(os.environ.get("RVB_TEST_CANDIDATES") != "1",
+                    reason="round-4 candidate (RVD_CONV_SC_FUSE=1): compiled and wired, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
+def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, monkeypatch):
+    """RVD_CONV_SC_FUSE=1 (round 4, opt-in): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4 becomes one
+    or two extra K steps of the block's second convolution (conv_gemm.hip, ConvArgs::in2) -- no shortcut kernel, no residual tensor.
+    Not bit-identical by construction (the shortcut's output is no longer rounded to bf16 before it is added), so: the embeddings
+    agree with the unfused run far tighter than either does with the fp32 oracle, and the counters prove which path ran."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, fused, sc = {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_SC_FUSE", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        fused[flag] = eng.timing("emb_conv_sc_fused")[2]
+        sc[flag] = eng.timing("emb_conv_sc")[2]
+        eng.close()
+    assert fused["0"] == 0 and fused["1"] >= 2                # stages 3 and 4, per trunk pass
+    assert sc["1"] == sc["0"] - fused["1"] > 0                # stage 2's shortcut (64 output channels) stays a kernel of its own
+    active = emb_case["masks"].sum(1) > 0
+    a, b, want = out["0"][active], out["1"][active], emb_case["want"][active]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() > 0.9995, cos
+    cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
+    assert cosw.min() > 0.995, cosw
 
 
 def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
