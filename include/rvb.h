@@ -308,6 +308,10 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
                      int silu, const float* add, float* out, int out_f32, int M, int d);
 int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
                    const float* b, float* out, int B, int T0, int F0, int d);
+/* round-4 candidate: the fp8 implicit-GEMM convolution (csrc/conv_gemm.hip conv_igemm8_kernel) on host floats, see test_api.hip */
+int rvb_test_conv_igemm_fp8(const float* x, const float* w, const float* bias, const float* res, float* out, float* out8, int B,
+                            int Fi, int Ti, int Cin, int Cout, int stride, int relu, float a_scale, float out8_scale, float* x_deq,
+                            float* w_deq, float* amax);
 /* host only: the `joint_decoding` state machine of one chunk (csrc/search.cpp JointSearch: transformer/search.py:450-496,
  * espnet/beam_search_timesync.py), driven frame by frame; the caller supplies the attention log-probs it asks for */
 void* rvb_test_joint_new(int beam, int pre_beam, int blank, int sos, double w_ctc, double w_dec, double bonus);

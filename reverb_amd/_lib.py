@@ -115,6 +115,8 @@ SIGNATURES = {
     "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
                                    C.c_int, C.c_int]),
     "rvb_test_conv1": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rvb_test_conv_igemm_fp8": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, C.c_float, _f32p, _f32p, _f32p]),
     "rvb_test_joint_new": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]),
     "rvb_test_joint_free": (None, [C.c_void_p]),
     "rvb_test_joint_begin": (C.c_int, [C.c_void_p, C.c_int, _f32p, _i32p, C.c_int, C.c_float, C.c_float, _i32p, _i32p, _i32p, _i32p, _i32p,

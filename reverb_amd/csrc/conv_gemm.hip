@@ -314,6 +314,218 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   if (p.res) epilogue(std::true_type()); else epilogue(std::false_type());
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// fp8 form (round 4 CANDIDATE: compiled, not yet run on a GPU).  Same tile (256 pixels x BN channels), same LDS-DMA gather and
+// source swizzle; a 128-byte row is now 128 channels of e4m3, so a K step covers a whole tap of the 128-channel stage (half a
+// tap of the 256-channel one), and the wave tile is 32 x 32 accumulator blocks fed by v_mfma_scale_f32_32x32x64_f8f6f4 at unit
+// block scales -- operand layout, fragment addressing and the slab mapping of the blocks are gemm2_kernel's fp8 path
+// (scripts/micro/f8_probe.hip).  Plain loop: one 64/96-KiB stage per K step, the next one in flight under the MFMAs.
+// Epilogue: acc * (a_scale * w_scale[n]) + bias (+ bf16 residual) -> ReLU -> bf16 and / or e4m3 output.
+typedef __attribute__((ext_vector_type(16))) float cg_f32x16;
+typedef __attribute__((ext_vector_type(8))) int cg_i32x8;
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char cg_smem[];
+  constexpr int BKB = 128;                                   // bytes = channels per K step
+  constexpr int NWN = BN / 64, NWM = 8 / NWN;
+  constexpr int TM = 256 / NWM, MB = TM / 32;                // wave tile TM pixels x 64 channels = MB x 2 blocks
+  constexpr int STAGE = (256 + BN) * BKB;
+  constexpr int WP = BN / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWN, wc = wave % NWN;
+  const int F = p.Fo, T = p.To, Cin = p.Cin, Cout = p.Cout;
+  const int TP = T + 2, FP = F + 2;
+  const int TPi = p.Ti + 2, FPi = p.Fi + 2, S = p.stride;
+  const int M = p.B * F * T;
+  const int tiles_n = Cout / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const char* __restrict__ in = (const char*)p.in8;
+  const char* __restrict__ w = (const char*)p.w8;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cg_smem;
+
+  const int lr = lane >> 3, lc = lane & 7;
+  const char* a_src[4];
+  const char* w_src[WP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + lr;
+    int m = m0 + row;
+    if (m >= M) m = M - 1;
+    const int b = m / (F * T), rem = m - b * (F * T);
+    const int fo = rem / T, to = rem - fo * T;
+    a_src[i] = in + ((size_t)(b * FPi + S * fo) * TPi + S * to) * Cin + (lc ^ ((row >> 1) & 7)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int row = wave * (WP * 8) + i * 8 + lr;
+    w_src[i] = w + (size_t)(n0 + row) * 9 * Cin + (lc ^ ((row >> 1) & 7)) * 16;
+  }
+  const int cpt = Cin / BKB;
+  const int nk = 9 * cpt;
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKB;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const size_t aoff = (size_t)(kh * TPi + kw) * Cin + c0;
+    const size_t woff = (size_t)tap * Cin + c0;
+    const unsigned dst = lds_base + (kt & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cg_dma(a_src[i] + aoff, dst + (wave * 32 + i * 8) * BKB);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+  };
+
+  cg_f32x16 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // lane = (row 0..31 of a block, half g); its 32 bytes of a k64 slice are the 16-byte columns 2g, 2g + 1 (swizzled as stored)
+  const int frow = lane & 31, g = lane >> 5;
+  const int swz = (frow >> 1) & 7;
+  int rlo[2], rhi[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) { rlo[sl] = ((sl * 4 + 2 * g) ^ swz) << 4; rhi[sl] = ((sl * 4 + 2 * g + 1) ^ swz) << 4; }
+  const int a_off = (wr * TM + frow) * BKB;
+  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage kt
+    __syncthreads();                                       // ... everybody's; nobody reads stage kt - 1 any more
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* st = cg_smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      cg_i32x8 a8[MB], b8[2];
+#pragma unroll
+      for (int bi = 0; bi < MB; ++bi) {
+        const uint4 lo = *(const uint4*)(st + a_off + bi * 32 * BKB + rlo[sl]), hi = *(const uint4*)(st + a_off + bi * 32 * BKB + rhi[sl]);
+        a8[bi] = (cg_i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const uint4 lo = *(const uint4*)(st + b_off + bj * 32 * BKB + rlo[sl]), hi = *(const uint4*)(st + b_off + bj * 32 * BKB + rhi[sl]);
+        b8[bj] = (cg_i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[bi], b8[bj], acc[bi][bj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+  }
+  const int ch0 = n0 + wc * 64 + (lane & 3) * 16;
+  float bias_r[16], sc_r[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 sq = *(const float4*)(p.w8_scale + ch0 + q * 4);
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bq = *(const float4*)(p.bias + ch0 + q * 4);
+    sc_r[q * 4 + 0] = sq.x * p.a_scale; sc_r[q * 4 + 1] = sq.y * p.a_scale; sc_r[q * 4 + 2] = sq.z * p.a_scale; sc_r[q * 4 + 3] = sq.w * p.a_scale;
+    bias_r[q * 4 + 0] = bq.x; bias_r[q * 4 + 1] = bq.y; bias_r[q * 4 + 2] = bq.z; bias_r[q * 4 + 3] = bq.w;
+  }
+  __syncthreads();                                             // every wave is done with the stages: the slabs go there
+
+  // ---- epilogue: rows [16 i, 16 i + 16) of the wave tile = half hh = i & 1 of block row bi = i >> 1 (registers 8 hh .. 8 hh + 7:
+  // C/D of a 32 x 32 block: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); through the wave's slab a lane then
+  // owns 16 consecutive channels of one pixel
+  constexpr int SROW = 64 * 4 + 16;
+  char* slab = cg_smem + wave * (16 * SROW);
+  const int orow = lane >> 2, oseg = (lane & 3) * 16;
+  const int r32 = 4 * (lane >> 5), c32 = lane & 31;
+  float vmax = 0.f;
+  unsigned nclip = 0;
+#pragma unroll
+  for (int i = 0; i < TM / 16; ++i) {
+    const int bi = i >> 1, hh = i & 1;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(float*)(slab + (8 * qq + r32 + r) * SROW + (bj * 32 + c32) * 4) = acc[bi][bj][8 * hh + 4 * qq + r];
+    __builtin_amdgcn_wave_barrier();
+    const int mrow = m0 + wr * TM + i * 16 + orow;
+    const int m = min(mrow, M - 1);
+    const int b = m / (F * T), rem = m - b * (F * T);
+    const int fo = rem / T, to = rem - fo * T;
+    const size_t pix = ((size_t)(b * FP + fo + 1) * TP + to + 1) * Cout + ch0;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = *(const float4*)(slab + orow * SROW + (oseg + q * 4) * 4);
+      v[q * 4 + 0] = x.x * sc_r[q * 4 + 0] + bias_r[q * 4 + 0]; v[q * 4 + 1] = x.y * sc_r[q * 4 + 1] + bias_r[q * 4 + 1];
+      v[q * 4 + 2] = x.z * sc_r[q * 4 + 2] + bias_r[q * 4 + 2]; v[q * 4 + 3] = x.w * sc_r[q * 4 + 3] + bias_r[q * 4 + 3];
+    }
+    if (p.res) {
+      const bf16_t* rp = (const bf16_t*)p.res + pix;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint4 raw = *(const uint4*)(rp + q * 8);
+        const bf16_t* re = (const bf16_t*)&raw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q * 8 + e] += bf16_to_f32(re[e]);
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (mrow >= M) continue;
+    if (p.amax8) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+    }
+    if (p.out) {
+      bf16_t* op = (bf16_t*)p.out + pix;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        *(uint4*)(op + q * 8) = make_uint4(pack2_bf16(v[q * 8 + 0], v[q * 8 + 1]), pack2_bf16(v[q * 8 + 2], v[q * 8 + 3]),
+                                           pack2_bf16(v[q * 8 + 4], v[q * 8 + 5]), pack2_bf16(v[q * 8 + 6], v[q * 8 + 7]));
+    }
+    if (p.out8) {
+      const float qs = p.out8_inv_scale;
+      if (p.sat8) nclip += fp8_clipped(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs) + fp8_clipped(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs) +
+                           fp8_clipped(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs) + fp8_clipped(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs);
+      *(uint4*)((char*)p.out8 + pix) = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
+                                                  pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
+    }
+  }
+  if (p.amax8) {
+    vmax = wave_max(vmax);
+    if (lane == 0 && vmax > 0.f) atomicMax(p.amax8, __float_as_uint(vmax));
+  }
+  if (p.sat8 && nclip) atomicAdd(p.sat8, nclip);
+}
+
+template <int BN>
+int launch_igemm8(hipStream_t st, const ConvArgs& p) {
+  const int lds = 2 * (256 + BN) * 128;
+  auto kern = conv_igemm8_kernel<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int64_t M = (int64_t)p.B * p.Fo * p.To;
+  const int64_t tiles = ((M + 255) / 256) * (p.Cout / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, p);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 template <int BN, bool SC>
 int launch_igemm(hipStream_t st, const ConvArgs& p) {
   const int lds = 2 * (256 + BN) * 128;
@@ -338,6 +550,19 @@ bool conv_igemm_applicable(int dtype, const ConvArgs& p) {
   if (p.in2 && (p.Cin2 % 64 || p.res != nullptr || p.Fo != (p.Fi2 - 1) / p.stride2 + 1 || p.To != (p.Ti2 - 1) / p.stride2 + 1)) return false;
   if (p.stride == 1) return p.Fo == p.Fi && p.To == p.Ti;
   return p.stride == 2 && p.Fo == (p.Fi - 1) / 2 + 1 && p.To == (p.Ti - 1) / 2 + 1;      // Conv2d(k 3, stride 2, pad 1)
+}
+
+bool conv_igemm8_applicable(int dtype, const ConvArgs& p) {
+  if (!(dtype == DT_BF16 && p.in8 != nullptr && p.w8 != nullptr && p.w8_scale != nullptr && p.taps == 9 && p.Cin % 128 == 0 &&
+        p.Cout % 128 == 0 && p.in2 == nullptr && (p.out != nullptr || p.out8 != nullptr) && (int64_t)p.B * p.Fo * p.To < (int64_t)1 << 31))
+    return false;
+  if (p.stride == 1) return p.Fo == p.Fi && p.To == p.Ti;
+  return p.stride == 2 && p.Fo == (p.Fi - 1) / 2 + 1 && p.To == (p.Ti - 1) / 2 + 1;
+}
+
+int conv_igemm8(hipStream_t s, const ConvArgs& p) {
+  if (p.B <= 0) return OK;
+  return p.Cout % 256 == 0 ? launch_igemm8<256>(s, p) : launch_igemm8<128>(s, p);
 }
 
 int conv_igemm(hipStream_t s, const ConvArgs& p) {

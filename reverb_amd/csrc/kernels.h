@@ -246,6 +246,18 @@ struct ConvArgs {
   // then [9 Cin + Cin2] long (the shortcut's weights appended), bias is the sum of both, res must be null
   const void* in2;    // bf16 [B][Fi2+2][Ti2+2][Cin2] or null
   int Cin2, Fi2, Ti2, stride2;
+  // conv_gemm.hip, fp8 form (round 4 candidate: conv_igemm8_kernel; stages 3-4 of the ResNet34 trunk):
+  // the A operand is the e4m3 copy of the bordered NHWC activation (value = fp8 * a_scale), the weights e4m3 with one scale
+  // per output channel; outputs: bf16 (out, nullable) and / or e4m3 at out8_inv_scale (out8, nullable: the next convolution's
+  // operand); amax8 (nullable) receives the running maximum of the output as float bits (ReLU output: >= 0)
+  const void* in8;        // fp8 [B][Fi+2][Ti+2][Cin] or null (null: the bf16 kernels)
+  const void* w8;         // fp8 [Cout][9][Cin]
+  const float* w8_scale;  // [Cout]
+  float a_scale;
+  void* out8;             // fp8 [B][Fo+2][To+2][Cout] or null
+  float out8_inv_scale;
+  unsigned* amax8;
+  unsigned* sat8;         // += values of the fp8 output clipped at 448
 };
 int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
 // resnet.hip: a whole stride-1 BasicBlock of 32 channels in one kernel (bf16): out = relu(conv_b(relu(conv_a(in))) + in), BN
@@ -264,6 +276,8 @@ int conv_pair32(hipStream_t s, const ConvPairArgs& a);
 // conv_gemm.hip: 3x3 stride-1 convolution as an implicit GEMM on the LDS-DMA loop (bf16, Cin % 64 == 0, Cout % 128 == 0);
 // conv2d() routes to it when a.w_ig is set
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
+bool conv_igemm8_applicable(int dtype, const ConvArgs& a);      // fp8 operands (a.in8 != null)
+int conv_igemm8(hipStream_t s, const ConvArgs& a);
 // conv_stream.hip: the stride-1 3x3 convolutions of the 32- and 64-channel stages (bf16) as a stream of tiles per workgroup
 // (weights resident in LDS, patches by LDS-DMA ahead of the MFMAs); bit-identical with conv2d's direct kernel.
 // RVD_CONV_STREAM=0 turns it off, n >= 1 splits the time axis of a row of tiles over n workgroups (default 1).  The 64-channel

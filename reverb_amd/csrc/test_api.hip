@@ -317,6 +317,83 @@ int rvb_test_gemm_fp8(const float* A, const float* W, const float* bias, const f
   return OK;
 }
 
+// fp8 implicit-GEMM convolution of conv_gemm.hip (round 4 candidate) on host floats.  x [B][Fi][Ti][Cin] and w [Cout][9][Cin] are
+// quantised as the engine would (per tensor / per output channel) and laid out as the kernel wants them (bordered NHWC); x_deq /
+// w_deq (nullable) receive the values the quantised operands stand for.  res (nullable) [B][Fo][To][Cout] is rounded to bf16.
+// Outputs (either nullable): out [B][Fo][To][Cout] from the kernel's bf16 tensor, out8 the same from its e4m3 tensor (de-quantised
+// with out8_scale); *amax receives the running maximum the kernel recorded.
+int rvb_test_conv_igemm_fp8(const float* x, const float* w, const float* bias, const float* res, float* out, float* out8, int B,
+                            int Fi, int Ti, int Cin, int Cout, int stride, int relu, float a_scale, float out8_scale, float* x_deq,
+                            float* w_deq, float* amax) {
+  T_TRY(need_gpu());
+  const int Fo = (Fi - 1) / stride + 1, To = (Ti - 1) / stride + 1;
+  const size_t npi = (size_t)B * (Fi + 2) * (Ti + 2) * Cin, npo = (size_t)B * (Fo + 2) * (To + 2) * Cout;
+  std::vector<uint8_t> qx(npi, 0), qw((size_t)Cout * 9 * Cin);
+  for (int b = 0; b < B; ++b)
+    for (int f = 0; f < Fi; ++f)
+      for (int t = 0; t < Ti; ++t)
+        for (int c = 0; c < Cin; ++c) {
+          const size_t si = (((size_t)b * Fi + f) * Ti + t) * Cin + c;
+          const uint8_t q = f32_to_fp8_host(x[si] / a_scale);
+          qx[(((size_t)b * (Fi + 2) + f + 1) * (Ti + 2) + t + 1) * Cin + c] = q;
+          if (x_deq) x_deq[si] = fp8_to_f32_host(q) * a_scale;
+        }
+  std::vector<float> ws(Cout);
+  const size_t K = (size_t)9 * Cin;
+  for (int n = 0; n < Cout; ++n) {
+    float am = 0.f;
+    for (size_t k = 0; k < K; ++k) am = fmaxf(am, fabsf(w[(size_t)n * K + k]));
+    ws[n] = am > 0.f ? am / 448.f : 1.f;
+    for (size_t k = 0; k < K; ++k) {
+      qw[(size_t)n * K + k] = f32_to_fp8_host(w[(size_t)n * K + k] / ws[n]);
+      if (w_deq) w_deq[(size_t)n * K + k] = fp8_to_f32_host(qw[(size_t)n * K + k]) * ws[n];
+    }
+  }
+  Dev dx, dw, ds, db, dr, dout, dout8, dam;
+  T_TRY(up_raw(dx, qx.data(), qx.size())); T_TRY(up_raw(dw, qw.data(), qw.size())); T_TRY(up_raw(ds, ws.data(), (size_t)Cout * 4));
+  T_TRY(up_raw(db, bias, (size_t)Cout * 4));
+  if (res) {
+    std::vector<bf16_t> rb(npo, 0);
+    for (int b = 0; b < B; ++b)
+      for (int f = 0; f < Fo; ++f)
+        for (int t = 0; t < To; ++t)
+          for (int c = 0; c < Cout; ++c)
+            rb[(((size_t)b * (Fo + 2) + f + 1) * (To + 2) + t + 1) * Cout + c] = f32_to_bf16(res[(((size_t)b * Fo + f) * To + t) * Cout + c]);
+    T_TRY(up_raw(dr, rb.data(), npo * 2));
+  }
+  if (out) { T_TRY(dout.alloc(npo * 2)); RVB_HIP_CHECK(hipMemset(dout.p, 0, npo * 2)); }
+  if (out8) { T_TRY(dout8.alloc(npo)); RVB_HIP_CHECK(hipMemset(dout8.p, 0, npo)); }
+  T_TRY(dam.alloc(4)); RVB_HIP_CHECK(hipMemset(dam.p, 0, 4));
+  ConvArgs a{};
+  a.bias = (const float*)db.p; a.res = dr.p; a.out = dout.p;
+  a.B = B; a.Fi = Fi; a.Ti = Ti; a.Cin = Cin; a.Fo = Fo; a.To = To; a.Cout = Cout; a.stride = stride; a.taps = 9; a.relu = relu;
+  a.in8 = dx.p; a.w8 = dw.p; a.w8_scale = (const float*)ds.p; a.a_scale = a_scale; a.out8 = dout8.p; a.out8_inv_scale = 1.f / out8_scale;
+  a.amax8 = (unsigned*)dam.p;
+  if (!conv_igemm8_applicable(DT_BF16, a)) { set_error("rvb_test_conv_igemm_fp8: shape not supported (channels multiples of 128, 3x3, stride 1 | 2)"); return E_ARG; }
+  T_TRY(conv_igemm8(nullptr, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  if (amax) RVB_HIP_CHECK(hipMemcpy(amax, dam.p, 4, hipMemcpyDeviceToHost));
+  if (out) {
+    std::vector<bf16_t> ob(npo);
+    RVB_HIP_CHECK(hipMemcpy(ob.data(), dout.p, npo * 2, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int f = 0; f < Fo; ++f)
+        for (int t = 0; t < To; ++t)
+          for (int c = 0; c < Cout; ++c)
+            out[(((size_t)b * Fo + f) * To + t) * Cout + c] = bf16_to_f32(ob[(((size_t)b * (Fo + 2) + f + 1) * (To + 2) + t + 1) * Cout + c]);
+  }
+  if (out8) {
+    std::vector<uint8_t> o8(npo);
+    RVB_HIP_CHECK(hipMemcpy(o8.data(), dout8.p, npo, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int f = 0; f < Fo; ++f)
+        for (int t = 0; t < To; ++t)
+          for (int c = 0; c < Cout; ++c)
+            out8[(((size_t)b * Fo + f) * To + t) * Cout + c] = fp8_to_f32_host(o8[(((size_t)b * (Fo + 2) + f + 1) * (To + 2) + t + 1) * Cout + c]) * out8_scale;
+  }
+  return OK;
+}
+
 // LayerNorm with fp8 outputs (first stage and / or the fused second LayerNorm); results returned de-quantised
 int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, float eps, int silu, int M, int d, float scale,
                          float* out, const float* gamma2, const float* beta2, float eps2, float scale2, float* out1_f32, float* out2) {

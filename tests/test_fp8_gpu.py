@@ -301,3 +301,55 @@ def test_fp8_saturation_is_counted_not_silent():
     eng.encode(x, lens, case.beam)
     assert int(eng.fp8_saturation().sum()) == 0
     eng.close()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("RVB_TEST_CANDIDATES") != "1",
+                    reason="round-4 candidate (conv_igemm8_kernel): compiled, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
+@pytest.mark.parametrize("B,Fi,Ti,Cin,Cout,stride,relu,use_res", [
+    (2, 20, 30, 128, 128, 1, 1, True),        # the 128-channel stage: one K step per tap, two row tiles + a partial one
+    (1, 10, 27, 256, 256, 1, 1, True),        # the 256-channel stage: two K steps per tap, 4 x 2 blocks per wave
+    (2, 21, 31, 128, 256, 2, 1, False),       # the stride-2 convolution that opens stage 4
+    (1, 9, 40, 128, 128, 1, 0, False),        # no ReLU (signed outputs: the amax is of |.|)
+])
+def test_fp8_implicit_gemm_convolution_against_fp64_on_the_quantised_values(lib, B, Fi, Ti, Cin, Cout, stride, relu, use_res):
+    """conv_gemm.hip conv_igemm8_kernel (the MFMA-bound stages of the ResNet34 trunk on the fp8 path): a 3x3 /
+    pad 1 convolution on e4m3 operands against fp64 on exactly the values those operands stand for -- gather, operand layout of
+    the 32x32x64 scaled MFMA, block-to-slab mapping, scales, bias, bf16 residual, ReLU, both output forms, the recorded maximum."""
+    rng = np.random.default_rng(B + Fi + Ti + Cin + Cout)
+    x = f32(np.abs(rng.standard_normal((B, Fi, Ti, Cin))) * 1.3)               # post-ReLU activations
+    w = f32(rng.standard_normal((Cout, 9, Cin)) / math.sqrt(9 * Cin) * (1 + rng.random((Cout, 1, 1)) * 3))
+    bias = f32(rng.standard_normal(Cout) * 0.3)
+    Fo, To = (Fi - 1) // stride + 1, (Ti - 1) // stride + 1
+    res = f32(rng.standard_normal((B, Fo, To, Cout))) if use_res else None
+    a_scale = float(2.0 ** math.ceil(math.log2(np.abs(x).max() * 2 / 448)))
+    xd, wd = np.empty_like(x), np.empty_like(w)
+    out = np.full((B, Fo, To, Cout), np.nan, np.float32)
+    out8 = np.full((B, Fo, To, Cout), np.nan, np.float32)
+    amax = np.zeros(1, np.float32)
+    # reference on the de-quantised operands (filled by a first call), then the output scale from it
+    out8_scale = 1.0
+    for attempt in range(2):
+        _lib.check(lib.rvb_test_conv_igemm_fp8(fptr(x), fptr(w), fptr(bias), fptr(res), fptr(out), fptr(out8), B, Fi, Ti, Cin, Cout, stride,
+                                               relu, a_scale, out8_scale, fptr(xd), fptr(wd), fptr(amax)))
+        xp = np.zeros((B, Fi + 2, Ti + 2, Cin), np.float64)
+        xp[:, 1:-1, 1:-1] = xd
+        v = np.zeros((B, Fo, To, Cout), np.float64)
+        for kh in range(3):
+            for kw in range(3):
+                patch = xp[:, kh:kh + stride * (Fo - 1) + 1:stride, kw:kw + stride * (To - 1) + 1:stride]
+                v += patch @ wd[:, kh * 3 + kw].astype(np.float64).T
+        v += bias
+        if use_res:
+            from util import bf16_round
+            v += bf16_round(res).astype(np.float64)
+        if relu:
+            v = np.maximum(v, 0)
+        out8_scale = float(2.0 ** math.ceil(math.log2(max(np.abs(v).max(), 1e-6) * 2 / 448)))
+    tol = 2e-4 * np.abs(v).max() + 1e-2 * np.abs(v)                            # scaled-MFMA K reduction + one bf16 rounding
+    assert np.all(np.abs(out - v) <= tol), float(np.abs(out - v).max())
+    grid = _e4m3_grid() * out8_scale
+    near = grid[np.abs(grid[None, :] - v.reshape(-1, 1)[:4000]).argmin(1)]      # e4m3 output: the nearest representable value
+    step = np.maximum(np.abs(near) / 8, out8_scale * 2.0 ** -9)
+    assert np.all(np.abs(out8.reshape(-1)[:4000] - v.reshape(-1)[:4000]) <= step + tol.reshape(-1)[:4000])
+    assert abs(float(amax[0]) - float(np.abs(out).max())) <= 1e-2 * float(np.abs(v).max())
+
