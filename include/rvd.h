@@ -89,6 +89,13 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
  * dendrogram does not depend on it.  A pipeline that clusters UNDERNEATH another engine's kernels (transcribe_diarize: the ASR
  * encoder) asks for 4: measured on one hour, joint step 472 ms with 4, 477 with 1, 486 with 8, 493-499 with 16. */
 int rvd_set_linkage_workgroups(rvd_engine* e, int workgroups);
+/* Round 4 CANDIDATE (compiled, not yet run on a GPU): with RVD_EMB_FP8=1 in the environment at rvd_finalize, stages 3-4 of the ResNet34
+ * trunk (the MFMA-bound half of the embedding network) run on e4m3 operands (csrc/conv_gemm.hip conv_igemm8_kernel): weights scaled
+ * per output channel at load, activations per tensor at scales calibrated by the FIRST trunk pass of the engine (which runs in bf16).
+ * *state: 0 = off or not calibrated, 1 = calibrating, 2 = active; scales (nullable; *n in: capacity, out: 32) = the activation
+ * scales, index ((stage - 2) * 8 + block) * 2 + {0: first convolution's output, 1: block output}; *clipped (nullable) = values that
+ * did not fit e4m3 at those scales so far. */
+int rvd_get_emb_fp8(rvd_engine* e, int32_t* state, float* scales, int32_t* n, uint32_t* clipped);
 
 int rvd_set_profiling(rvd_engine* e, int enabled);
 int rvd_reset_timings(rvd_engine* e);

@@ -19,7 +19,8 @@ struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
 constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 // ResNet34 trunk: conv weights packed [tap][Cin/CK][Cout][CK] with BatchNorm folded in
 struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1;      // w_ig: conv_gemm.hip's layout (optional)
-               DevBuf w_ig_sc, b_sc; };      // second convolution of a block with a projection shortcut: w_ig rows + the shortcut's, summed biases
+               DevBuf w_ig_sc, b_sc;
+               DevBuf w8, w8s; };            // RVD_EMB_FP8=1: e4m3 copy [cout][9][cin] + per-output-channel scales (conv_igemm8_kernel)      // second convolution of a block with a projection shortcut: w_ig rows + the shortcut's, summed biases
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
 constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_MEL = 80;
 // windows per trunk pass; RVD_EMB_BATCH overrides (tuning).  768 since round 4: 1 h of audio 385-392 ms at 192, 381 at 384,
@@ -71,6 +72,13 @@ struct rvd_engine {
   int64_t emb_frames = 0;
   int nfr = 0;                            // fbank frames per window (998)
   DevBuf act[4][4];                       // per stage: three rotating activation buffers + the shortcut
+  // RVD_EMB_FP8=1 (round 4 candidate, not yet run on a GPU): stages 3-4 of the trunk on the fp8 implicit-GEMM kernel.  act8 = e4m3
+  // copies of those stages' rotating buffers; scale8[((li - 2) * 8 + block) * 2 + {0: first convolution's output, 1: block output}],
+  // calibrated by the first trunk pass (bf16, running maxima in d_amax8); emb_f8_state 0 not calibrated, 1 calibrating, 2 active
+  bool emb_fp8 = false;
+  int emb_f8_state = 0;
+  DevBuf act8[4][3], d_amax8, d_sat8;
+  std::vector<float> scale8;
   int act_cap = 0;
   DevBuf e_win, e_mean, e_item_b, e_mask, e_stats, e_out;
 
@@ -403,6 +411,22 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
         for (int ci = 0; ci < cin; ++ci) pg[((size_t)o * taps + t) * cin + ci] = w->data[((size_t)o * cin + ci) * taps + t] * sc;
     }
     RVD_TRY(pack_T(e, c.w_ig, pg.data(), pg.size()));
+    if (e->emb_fp8 && cin % 128 == 0) {          // e4m3 copy, one scale per output channel (as engine.hip's pack_linear)
+      std::vector<uint8_t> q(pg.size());
+      std::vector<float> ws(cout);
+      const size_t K = (size_t)taps * cin;
+      for (int o = 0; o < cout; ++o) {
+        float am = 0.f;
+        for (size_t kk = 0; kk < K; ++kk) am = std::max(am, std::fabs(pg[(size_t)o * K + kk]));
+        ws[o] = am > 0.f ? am / 448.f : 1.f;
+        const float inv = 1.f / ws[o];
+        for (size_t kk = 0; kk < K; ++kk) q[(size_t)o * K + kk] = f32_to_fp8_host(pg[(size_t)o * K + kk] * inv);
+      }
+      RVD_TRY(c.w8.ensure(q.size()));
+      RVB_HIP_CHECK(hipMemcpyAsync(c.w8.p, q.data(), q.size(), hipMemcpyHostToDevice, e->stream));
+      RVD_TRY(up_f32(e, c.w8s, ws.data(), ws.size()));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
   }
   return up_f32(e, c.b, pb.data(), pb.size());
 }
@@ -443,6 +467,7 @@ int finalize_embedding(rvd_engine* e) {
   const std::string S = "embedding.resnet.";
   const int m = c.emb_channels;
   if (m != 32) { set_error("embedding: this build supports m_channels = 32 (ResNet34 of pyannote/wespeaker-voxceleb-resnet34-LM)"); return E_UNSUPPORTED; }
+  { const char* f8 = getenv("RVD_EMB_FP8"); e->emb_fp8 = f8 && atoi(f8) == 1 && e->dtype == DT_BF16; e->emb_f8_state = 0; }
   // stem: Conv2d(1, m, 3) + BN folded, fp32 weights [m][9]
   const HostTensor *w, *g, *b, *mu, *v;
   RVD_TRY(need(e, S + "conv1.weight", (size_t)m * 9, &w));
@@ -505,6 +530,10 @@ int ensure_emb_workspace(rvd_engine* e, int B) {
       if (k == 3 && li == 0) continue;            // stage 1 has no projection shortcut
       RVD_TRY(e->act[li][k].ensure(bytes));
       RVB_HIP_CHECK(hipMemsetAsync(e->act[li][k].p, 0, bytes, e->stream));   // the zero border is never written again
+      if (e->emb_fp8 && li >= 2 && k < 3) {
+        RVD_TRY(e->act8[li][k].ensure(bytes / ts));
+        RVB_HIP_CHECK(hipMemsetAsync(e->act8[li][k].p, 0, bytes / ts, e->stream));
+      }
     }
   }
   e->act_cap = B;
@@ -556,7 +585,44 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
         x = out; dx = d; xi = oi;
         continue;
       }
+      const bool f8blk = e->emb_fp8 && li >= 2 && Bk.c2.w8.p && (bi == 0 || Bk.c1.w8.p);
+      if (f8blk && e->emb_f8_state == 2) {
+        // ---- fp8 path (candidate): block 0 of a stage keeps its stride-2 first convolution and its shortcut in bf16 (their input is the
+        // previous stage's bf16 tensor) and quantises the result; every other 3x3 convolution of stages 3-4 reads e4m3 operands
+        const size_t n_el = (size_t)B * (d.F + 2) * (d.T + 2) * d.C;
+        const int si = ((li - 2) * 8 + (int)bi) * 2;
+        const float s_tmp = e->scale8[si], s_out = e->scale8[si + 1];
+        unsigned* sat = e->d_sat8.p ? e->d_sat8.as<unsigned>() : nullptr;
+        void* tmp8 = e->act8[li][ti].p;
+        void* out8 = e->act8[li][oi].p;
+        const void* res = x;
+        auto conv8 = [&](const ConvW& cw, const void* in8, float a_scale, const void* resid, void* o16, void* o8, float o8_scale) -> int {
+          ConvArgs a{};
+          a.bias = cw.b.as<float>(); a.res = resid; a.out = o16;
+          a.B = B; a.Fi = d.F; a.Ti = d.T; a.Cin = cw.cin; a.Fo = d.F; a.To = d.T; a.Cout = cw.cout; a.stride = 1; a.taps = 9; a.relu = 1;
+          a.in8 = in8; a.w8 = cw.w8.p; a.w8_scale = cw.w8s.as<float>(); a.a_scale = a_scale; a.out8 = o8; a.out8_inv_scale = 1.f / o8_scale; a.sat8 = sat;
+          if (!conv_igemm8_applicable(e->dtype, a)) { set_error("fp8 trunk: shape not supported by conv_igemm8"); return E_UNSUPPORTED; }
+          e->prof["emb_conv_fp8"].launches += 1;
+          DScope sc(e, ("emb_conv_" + std::to_string(cw.cout)).c_str(), 2.0 * (double)B * d.F * d.T * cw.cout * cw.cin * 9);
+          return conv_igemm8(e->stream, a);
+        };
+        if (bi == 0) {
+          RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+          RVD_TRY(act_quant_fp8(e->stream, tmp, tmp8, n_el, s_tmp, sat));
+          if (Bk.has_sc) {
+            RVD_TRY(run_conv(e, Bk.sc, x, dx, nullptr, e->act[li][3].p, d, B, 0));
+            res = e->act[li][3].p;
+          }
+        } else {
+          RVD_TRY(conv8(Bk.c1, e->act8[li][xi].p, e->scale8[si - 1], nullptr, nullptr, tmp8, s_tmp));      // x8 = the previous block's e4m3 output
+        }
+        RVD_TRY(conv8(Bk.c2, tmp8, s_tmp, res, out, out8, s_out));
+        x = out; dx = d; xi = oi;
+        continue;
+      }
       RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+      if (f8blk && e->emb_f8_state == 1)
+        RVD_TRY(act_amax_bf16(e->stream, tmp, (size_t)B * (d.F + 2) * (d.T + 2) * d.C, e->d_amax8.as<unsigned>() + ((li - 2) * 8 + (int)bi) * 2));
       if (Bk.has_sc && Bk.c2.w_ig_sc.p) {        // the projection shortcut inside the second convolution's K loop (RVD_CONV_SC_FUSE=1)
         ConvArgs a{};
         a.in = tmp; a.w = Bk.c2.w.p; a.bias = Bk.c2.b_sc.as<float>(); a.res = nullptr; a.out = out;
@@ -579,6 +645,8 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
         res = e->act[li][3].p;
       }
       RVD_TRY(run_conv(e, Bk.c2, tmp, d, res, out, d, B, 1));
+      if (f8blk && e->emb_f8_state == 1)
+        RVD_TRY(act_amax_bf16(e->stream, out, (size_t)B * (d.F + 2) * (d.T + 2) * d.C, e->d_amax8.as<unsigned>() + ((li - 2) * 8 + (int)bi) * 2 + 1));
       x = out; dx = d; xi = oi;
     }
   }
@@ -622,7 +690,23 @@ int embed_impl(rvd_engine* e, const int64_t* win, const float* mask, int n, floa
     RVB_HIP_CHECK(hipMemcpyAsync(e->e_mask.p, mask + (size_t)i0 * frames, (size_t)ni * frames * 4, hipMemcpyHostToDevice, e->stream));
     RVB_HIP_CHECK(hipStreamSynchronize(e->stream));    // uniq / item_b are locals
     const void* trunk = nullptr;
+    if (e->emb_fp8 && e->emb_f8_state == 0) {          // the first trunk pass of an fp8 engine runs in bf16 and records the ranges
+      RVD_TRY(e->d_amax8.ensure(32 * 4));
+      RVD_TRY(e->d_sat8.ensure(4));
+      RVB_HIP_CHECK(hipMemsetAsync(e->d_amax8.p, 0, 32 * 4, e->stream));
+      RVB_HIP_CHECK(hipMemsetAsync(e->d_sat8.p, 0, 4, e->stream));
+      e->emb_f8_state = 1;
+    }
     RVD_TRY(run_trunk(e, B, &trunk));
+    if (e->emb_f8_state == 1) {
+      float am[32];
+      RVB_HIP_CHECK(hipMemcpyAsync(am, e->d_amax8.p, sizeof(am), hipMemcpyDeviceToHost, e->stream));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+      e->scale8.assign(32, 1.f);
+      for (int i = 0; i < 32; ++i)
+        if (am[i] > 0.f) e->scale8[i] = std::exp2(std::ceil(std::log2(2.f * am[i] / 448.f)));      // power of two, 2x headroom (as engine.hip)
+      e->emb_f8_state = 2;
+    }
     { DScope sc(e, "emb_pool");
       RVD_TRY(tstp_pool(e->stream, e->dtype, trunk, e->e_item_b.as<int>(), e->e_mask.as<float>(), frames, ni, d3.F, d3.T, d3.C, e->e_stats.p)); }
     { DScope sc(e, "emb_linear", 2.0 * (double)ni * stats * c.emb_dim);
@@ -701,7 +785,7 @@ void rvd_destroy(rvd_engine* e) {
   for (auto* b : ebufs) b->release();
   for (auto& st : e->stages)
     for (auto& blk : st)
-      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); cw->w_ig_sc.release(); cw->b_sc.release(); }
+      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); cw->w_ig_sc.release(); cw->b_sc.release(); cw->w8.release(); cw->w8s.release(); }
   for (auto& row : e->act) for (auto& b : row) b.release();
   (void)hipStreamDestroy(e->stream);
   delete e;
@@ -900,6 +984,26 @@ int rvd_centroid_linkage(rvd_engine* e, const double* X, int n, int d, double* Z
   } while (0);
   dX.release(); dD.release(); dI.release(); dM.release(); dZ.release(); dC.release();
   return rc;
+}
+
+int rvd_get_emb_fp8(rvd_engine* e, int32_t* state, float* scales, int32_t* n, uint32_t* clipped) {
+  if (!e) { set_error("rvd_get_emb_fp8: null engine"); return E_ARG; }
+  if (state) *state = e->emb_fp8 ? e->emb_f8_state : 0;
+  if (n) {
+    const int cap = *n;
+    *n = 32;
+    if (scales && e->emb_f8_state == 2)
+      for (int i = 0; i < 32 && i < cap; ++i) scales[i] = e->scale8[i];
+  }
+  if (clipped) {
+    *clipped = 0;
+    if (e->d_sat8.p) {
+      RVB_HIP_CHECK(hipSetDevice(e->device));
+      RVB_HIP_CHECK(hipMemcpyAsync(clipped, e->d_sat8.p, 4, hipMemcpyDeviceToHost, e->stream));
+      RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+  }
+  return OK;
 }
 
 int rvd_set_linkage_workgroups(rvd_engine* e, int workgroups) {

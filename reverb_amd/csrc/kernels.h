@@ -278,6 +278,10 @@ int conv_pair32(hipStream_t s, const ConvPairArgs& a);
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
 bool conv_igemm8_applicable(int dtype, const ConvArgs& a);      // fp8 operands (a.in8 != null)
 int conv_igemm8(hipStream_t s, const ConvArgs& a);
+// resnet.hip (round 4 candidate): e4m3 copy of a bf16 activation tensor at one scale (value = fp8 * scale), and the running
+// maximum of |x| as float bits (calibration)
+int act_quant_fp8(hipStream_t s, const void* in_bf16, void* out_fp8, size_t n, float scale, unsigned* sat);
+int act_amax_bf16(hipStream_t s, const void* in_bf16, size_t n, unsigned* amax);
 // conv_stream.hip: the stride-1 3x3 convolutions of the 32- and 64-channel stages (bf16) as a stream of tiles per workgroup
 // (weights resident in LDS, patches by LDS-DMA ahead of the MFMAs); bit-identical with conv2d's direct kernel.
 // RVD_CONV_STREAM=0 turns it off, n >= 1 splits the time axis of a row of tiles over n workgroups (default 1).  The 64-channel

@@ -11,6 +11,7 @@
 // taps' weights in LDS once, and the 9 taps read shifted A fragments from the same patch (16 consecutive
 // time positions x 64 bytes = a conflict-free 1 KiB run), i.e. every input byte is fetched from HBM/L2
 // once per block instead of 9 times as an im2col GEMM would.
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -115,6 +116,52 @@ int emb_conv1(hipStream_t s, int dtype, const float* fb, const int64_t* win, con
   const int blocks = B * cdiv(NT_, ST_TT);
   if (dtype == DT_BF16) hipLaunchKernelGGL(emb_conv1_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, fb, win, mean, w, bias, (bf16_t*)out, B, F, NT_, frames_per_step, C);
   else hipLaunchKernelGGL(emb_conv1_kernel<float>, dim3(blocks), dim3(256), 0, s, fb, win, mean, w, bias, (float*)out, B, F, NT_, frames_per_step, C);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------ fp8 copies of activations (round 4 candidate)
+// bf16 -> e4m3 at one scale per tensor (the A operand of conv_gemm.hip's fp8 kernel), and the running maximum of |x| that the
+// calibration pass turns into that scale.  Whole bordered tensors: the zero border stays zero.  16 bytes in, 8 bytes out per thread.
+__global__ __launch_bounds__(256) void act_quant_kernel(const bf16_t* __restrict__ in, uint8_t* __restrict__ out, size_t n8, float inv_scale,
+                                                        unsigned* __restrict__ sat) {
+  unsigned nclip = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 u = ((const uint4*)in)[i];
+    const bf16_t* e = (const bf16_t*)&u;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(e[k]) * inv_scale;
+    if (sat) nclip += fp8_clipped(v[0], v[1], v[2], v[3]) + fp8_clipped(v[4], v[5], v[6], v[7]);
+    ((uint2*)out)[i] = make_uint2(pack4_fp8(v[0], v[1], v[2], v[3]), pack4_fp8(v[4], v[5], v[6], v[7]));
+  }
+  if (sat && nclip) atomicAdd(sat, nclip);
+}
+__global__ __launch_bounds__(256) void act_amax_kernel(const bf16_t* __restrict__ in, size_t n8, unsigned* __restrict__ amax) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 u = ((const uint4*)in)[i];
+    const bf16_t* e = (const bf16_t*)&u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(bf16_to_f32(e[k])));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+}
+int act_quant_fp8(hipStream_t s, const void* in_bf16, void* out_fp8, size_t n, float scale, unsigned* sat) {
+  if (n == 0) return OK;
+  if (n % 8 || !(scale > 0.f)) { set_error("act_quant_fp8: element count must be a multiple of 8 and the scale positive"); return E_ARG; }
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(act_quant_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 256 * 16)), dim3(256), 0, s, (const bf16_t*)in_bf16,
+                     (uint8_t*)out_fp8, n8, 1.f / scale, sat);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+int act_amax_bf16(hipStream_t s, const void* in_bf16, size_t n, unsigned* amax) {
+  if (n == 0) return OK;
+  if (n % 8) { set_error("act_amax_bf16: element count must be a multiple of 8"); return E_ARG; }
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(act_amax_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 256 * 16)), dim3(256), 0, s, (const bf16_t*)in_bf16, n8, amax);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -141,6 +141,14 @@ class DiarEngine:
         """Workgroups the clustering's merge loop may take (0 default = 16, 1, 2, 4, 8, 16); the dendrogram does not depend on it."""
         _check(self.lib.rvd_set_linkage_workgroups(self._h, int(workgroups)), "rvd_set_linkage_workgroups")
 
+    def emb_fp8(self):
+        """RVD_EMB_FP8=1 engines (round-4 candidate): (state 0 off / not calibrated, 1 calibrating, 2 active; activation scales [32];
+        values clipped so far)."""
+        st, n, cl = C.c_int32(0), C.c_int32(32), C.c_uint32(0)
+        sc = np.zeros(32, np.float32)
+        _check(self.lib.rvd_get_emb_fp8(self._h, C.byref(st), fptr(sc), C.byref(n), C.byref(cl)), "rvd_get_emb_fp8")
+        return int(st.value), sc, int(cl.value)
+
     def centroid_linkage(self, X: np.ndarray) -> np.ndarray:
         """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") on the GPU (fp64)."""
         X = np.ascontiguousarray(X, dtype=np.float64)

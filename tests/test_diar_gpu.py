@@ -267,6 +267,43 @@ def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, m
     assert cosw.min() > 0.995, cosw
 
 
+@pytest.mark.skipif(os.environ.get("RVB_TEST_CANDIDATES") != "1",
+                    reason="round-4 candidate (RVD_EMB_FP8=1): compiled and wired, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
+def test_trunk_stages_3_and_4_in_fp8(case, emb_case, monkeypatch):
+    """RVD_EMB_FP8=1 (round 4): stages 3-4 of the ResNet34 trunk on e4m3 operands (conv_igemm8_kernel), per-tensor
+    activation scales from the first trunk pass.  The first embed() call calibrates (bf16: it must equal the bf16 engine's result
+    exactly); the second runs the fp8 kernels (counter), clips nothing of what it was calibrated on, and its embeddings stay close
+    to the bf16 ones and to the fp32 oracle."""
+    from reverb_amd.diar_engine import DiarEngine
+    monkeypatch.setenv("RVD_EMB_FP8", "0")
+    ref = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+    ref.upload(case["pcm"])
+    want16 = ref.embed(emb_case["wins"], emb_case["masks"])
+    assert ref.emb_fp8()[0] == 0
+    ref.close()
+    monkeypatch.setenv("RVD_EMB_FP8", "1")
+    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+    eng.upload(case["pcm"])
+    assert eng.emb_fp8()[0] == 0
+    first = eng.embed(emb_case["wins"], emb_case["masks"])                    # calibration pass
+    assert np.array_equal(first, want16)
+    state, scales, clipped = eng.emb_fp8()
+    assert state == 2 and clipped == 0
+    used = scales[[((li - 2) * 8 + bi) * 2 + k for li, nb in ((2, 6), (3, 3)) for bi in range(nb) for k in (0, 1)]]
+    assert np.all(used > 0) and np.all(np.log2(used) == np.round(np.log2(used)))
+    eng.reset_timings()
+    got = eng.embed(emb_case["wins"], emb_case["masks"])
+    assert eng.timing("emb_conv_fp8")[2] == 2 * (6 + 3) - 2                   # every 3x3 convolution of stages 3-4 but the two stride-2 ones
+    assert eng.emb_fp8()[2] == 0
+    active = emb_case["masks"].sum(1) > 0
+    a, b, want = want16[active], got[active], emb_case["want"][active]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() > 0.99, cos
+    cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
+    assert cosw.min() > 0.99, cosw
+    eng.close()
+
+
 def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
     """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; RVD_CONV_FUSE=1)
     against the same block as two conv2d launches: same operand values, same accumulation order, same rounding points --
