@@ -21,8 +21,8 @@
 //   NT = Cin = Cout = 64: 2 chunks, 3 patch buffers (two items ahead), 156 800 B     -> one workgroup per CU
 //
 // Ordering.  Every vector-memory instruction whose latency matters is inline asm, so hipcc's waitcnt pass sees none of them
-// (it drains vmcnt(0) in front of a ds_read behind an LDS-DMA, and once stores are pending it treats the counter as
-// unordered and waits for 0 in front of every load result): the kernel counts vmcnt itself.  Iteration k =
+// (it drains vmcnt(0) in front of a ds_read behind an LDS-DMA, and any wait it places for a load result also drains the
+// stores issued before it -- one queue): the kernel counts vmcnt itself.  Iteration k =
 //   {residual loads of this tile (last chunk only); DMA of item k + PD; multiply item k; vmcnt(6 (PD - 1)) -- everything
 //    older than the DMA just issued has landed: item k + 1's pieces, the residual vectors, the previous tile's stores;
 //    s_barrier; (last chunk) epilogue + stores}.
