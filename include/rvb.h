@@ -39,7 +39,11 @@ typedef struct rvb_engine rvb_engine;
 /* Model dimensions: the values the reference reads from config.yaml
  * (asr/wenet/utils/init_model.py:102-183; cli/reverb.py:62-98). */
 typedef struct rvb_model_cfg {
-  int32_t dtype;         /* RVB_F32 | RVB_BF16 */
+  int32_t struct_size;   /* sizeof(rvb_model_cfg) as the CALLER's binding lays it out: rvb_create refuses any other value
+                            (RVB_E_ARG, "ABI mismatch"), so a binding written against an older header -- a field short, as
+                            INTEGRATION.md's stub was after round 3 added cnn_causal -- fails by name instead of making the
+                            library read past the caller's struct */
+  int32_t dtype;         /* RVB_F32 | RVB_BF16 | RVB_FP8 */
   int32_t input_dim;     /* input_dim (80 mel bins) */
   int32_t vocab;         /* output_dim */
   int32_t d_model;       /* encoder_conf.output_size */
@@ -64,6 +68,8 @@ typedef struct rvb_model_cfg {
 
 const char* rvb_last_error(void);
 const char* rvb_version(void);
+/* sizeof(rvb_model_cfg) of THIS build: what a binding's struct_size has to equal (a binding can assert it at load) */
+int rvb_model_cfg_size(void);
 
 /* ReverbASR.__init__ / init_model / load_checkpoint (cli/reverb.py:46-98,
  * utils/init_model.py:99-277, utils/checkpoint.py:29-80): create an engine, stream the

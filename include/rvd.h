@@ -28,6 +28,7 @@ extern "C" {
 typedef struct rvd_engine rvd_engine;
 
 typedef struct rvd_model_cfg {
+  int32_t struct_size;      /* sizeof(rvd_model_cfg) in the caller's binding; rvd_create refuses any other value (rvb.h) */
   int32_t dtype;            /* RVB_F32 (0) exact-parity mode, RVB_BF16 (1) bf16 MFMA inputs, fp32 accumulate */
   int32_t sample_rate;      /* 16000 */
   int32_t window_samples;   /* 160000 (10 s) */
@@ -44,6 +45,7 @@ typedef struct rvd_model_cfg {
 } rvd_model_cfg;
 
 const char* rvd_last_error(void);
+int rvd_model_cfg_size(void);   /* sizeof(rvd_model_cfg) of this build */
 
 int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out);
 void rvd_destroy(rvd_engine* e);

@@ -28,9 +28,18 @@ class AudioInfo(C.Structure):
                 ("reserved", C.c_int32)]
 
 
-class ModelCfg(C.Structure):
+class _SizedCfg(C.Structure):
+    """A config struct whose first field carries its own size (checked by rvb_create / rvd_create)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        if "struct_size" not in kw:
+            self.struct_size = C.sizeof(type(self))
+
+
+class ModelCfg(_SizedCfg):
     _fields_ = [(n, C.c_int32) for n in (
-        "dtype", "input_dim", "vocab", "d_model", "heads", "ffn_dim", "num_blocks", "cnn_kernel",
+        "struct_size", "dtype", "input_dim", "vocab", "d_model", "heads", "ffn_dim", "num_blocks", "cnn_kernel",
         "cnn_norm", "num_langs", "dec_heads", "dec_ffn_dim", "dec_blocks", "dec_r_blocks", "blank_id",
         "sos_id", "eos_id", "max_chunks", "chunk_frames", "cnn_causal")]
 
@@ -46,6 +55,7 @@ _eng = C.c_void_p
 SIGNATURES = {
     "rvb_last_error": (C.c_char_p, []),
     "rvb_version": (C.c_char_p, []),
+    "rvb_model_cfg_size": (C.c_int, []),
     "rvb_create": (C.c_int, [C.POINTER(ModelCfg), C.c_int, C.POINTER(_eng)]),
     "rvb_destroy": (None, [_eng]),
     "rvb_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),
@@ -152,16 +162,17 @@ SIGNATURES = {
 
 
 
-class DiarCfg(C.Structure):
+class DiarCfg(_SizedCfg):
     """rvd_model_cfg of include/rvd.h."""
     _fields_ = [(n, C.c_int32) for n in (
-        "dtype", "sample_rate", "window_samples", "step_samples", "sinc_filters", "sinc_channels", "lstm_hidden",
+        "struct_size", "dtype", "sample_rate", "window_samples", "step_samples", "sinc_filters", "sinc_channels", "lstm_hidden",
         "lstm_layers", "linear_dim", "linear_layers", "num_classes", "emb_channels", "emb_dim")]
 
 
 # every exported symbol of include/rvd.h (diarization networks; same shared library)
 DIAR_SIGNATURES = {
     "rvd_last_error": (C.c_char_p, []),
+    "rvd_model_cfg_size": (C.c_int, []),
     "rvd_create": (C.c_int, [C.POINTER(DiarCfg), C.c_int, C.POINTER(_eng)]),
     "rvd_destroy": (None, [_eng]),
     "rvd_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),

@@ -739,9 +739,16 @@ extern "C" {
 
 const char* rvd_last_error(void) { return rvb::last_error(); }
 
+int rvd_model_cfg_size(void) { return (int)sizeof(rvd_model_cfg); }
+
 int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
   if (!cfg || !out) { set_error("rvd_create: null argument"); return E_ARG; }
   *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(rvd_model_cfg)) {
+    set_error("rvd_create: ABI mismatch: rvd_model_cfg.struct_size is " + std::to_string(cfg->struct_size) + ", this library's struct has " +
+              std::to_string(sizeof(rvd_model_cfg)) + " bytes (bind it field by field from include/rvd.h)");
+    return E_ARG;
+  }
   if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) { set_error("rvd_create: dtype must be RVB_F32 or RVB_BF16"); return E_ARG; }
   if (cfg->lstm_hidden != 128 || cfg->sinc_filters != 80 || cfg->sinc_filters % 8 || cfg->sinc_channels < 1 || cfg->sinc_channels > 64 ||
       cfg->lstm_layers < 1 || cfg->linear_layers < 0 || cfg->linear_layers > 2 || (cfg->linear_layers && cfg->linear_dim % 8) ||

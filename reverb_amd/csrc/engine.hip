@@ -1859,8 +1859,15 @@ extern "C" {
 const char* rvb_last_error(void) { return last_error(); }
 const char* rvb_version(void) { return "librvb 0.1 (gfx950)"; }
 
+int rvb_model_cfg_size(void) { return (int)sizeof(rvb_model_cfg); }
+
 int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
   if (!cfg || !out) { set_error("rvb_create: null argument"); return E_ARG; }
+  if (cfg->struct_size != (int32_t)sizeof(rvb_model_cfg)) {
+    set_error("rvb_create: ABI mismatch: rvb_model_cfg.struct_size is " + std::to_string(cfg->struct_size) + ", this library's struct has " +
+              std::to_string(sizeof(rvb_model_cfg)) + " bytes (bind it field by field from include/rvb.h)");
+    return E_ARG;
+  }
   if (cfg->dtype != RVB_F32 && cfg->dtype != RVB_BF16 && cfg->dtype != RVB_FP8) { set_error("rvb_create: bad dtype"); return E_ARG; }
   if (cfg->d_model <= 0 || cfg->heads <= 0 || cfg->d_model % cfg->heads || cfg->d_model % 8 || cfg->ffn_dim % 8 ||
       cfg->dec_ffn_dim % 8 || cfg->input_dim != 80 || cfg->vocab < 2 || cfg->num_blocks < 1 ||

@@ -36,6 +36,39 @@ def test_struct_layout_matches_header():
     body = text[text.index("typedef struct rvb_model_cfg {"):text.index("} rvb_model_cfg;")]
     fields = re.findall(r"int32_t\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _lib.ModelCfg._fields_]
+    assert fields[0] == "struct_size" and _lib.ModelCfg().struct_size == 4 * len(fields)
+
+
+def _integration_stub_fields(struct_comment):
+    """Field names of the ctypes stub INTEGRATION.md shows for `struct_comment` (the list a maintainer would paste)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    at = text.index("# struct " + struct_comment)
+    body = text[at:text.index(")]", at)]
+    return re.findall(r'"([a-z_0-9]+)"', body)
+
+
+def test_integration_stub_binds_the_header_field_for_field():
+    """the document's stub had 19 fields against the header's 20.  The stub is parsed out of the
+    document and compared with the headers, for both config structs and the audio info struct."""
+    for header, struct, comment in (("rvb.h", "rvb_model_cfg", "rvb_model_cfg"), ("rvd.h", "rvd_model_cfg", "rvd_model_cfg")):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        body = text[text.index("typedef struct %s {" % struct):text.index("} %s;" % struct)]
+        assert _integration_stub_fields(comment) == re.findall(r"int32_t\s+([a-z_0-9]+);", body), header
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rvb.h")).read(), flags=re.S)
+    body = text[text.index("typedef struct rvb_audio_info {"):text.index("} rvb_audio_info;")]
+    assert _integration_stub_fields("rvb_audio_info") == re.findall(r"int(?:32|64)_t\s+([a-z_0-9]+);", body)
+
+
+def test_a_binding_of_another_size_is_refused_by_name(lib):
+    """A struct one field short (what following the stale document produced) or long must not be read: RVB_E_ARG."""
+    assert lib.rvb_model_cfg_size() == ctypes.sizeof(_lib.ModelCfg) and lib.rvd_model_cfg_size() == ctypes.sizeof(_lib.DiarCfg)
+    h = ctypes.c_void_p()
+    for size in (ctypes.sizeof(_lib.ModelCfg) - 4, ctypes.sizeof(_lib.ModelCfg) + 4, 0):
+        cfg = _lib.ModelCfg(struct_size=size)
+        assert lib.rvb_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1 and b"ABI mismatch" in lib.rvb_last_error()
+    dcfg = _lib.DiarCfg(struct_size=ctypes.sizeof(_lib.DiarCfg) - 4)
+    assert lib.rvd_create(ctypes.byref(dcfg), 0, ctypes.byref(h)) == -1 and b"ABI mismatch" in lib.rvd_last_error()
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
