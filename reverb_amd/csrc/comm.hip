@@ -103,13 +103,17 @@ static int comm_wait(rvb_comm* c, const char* what) {
   if (c->timeout_s <= 0.0) { RVB_HIP_CHECK(hipStreamSynchronize(c->stream)); return rvb::OK; }
   if (!c->done) RVB_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
   RVB_HIP_CHECK(hipEventRecord(c->done, c->stream));
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(c->timeout_s);
+  const auto start = std::chrono::steady_clock::now();
+  const auto deadline = start + std::chrono::duration<double>(c->timeout_s);
   for (;;) {
     const hipError_t q = hipEventQuery(c->done);
     if (q == hipSuccess) return rvb::OK;
     if (q != hipErrorNotReady) { rvb::set_error(std::string(what) + ": " + hipGetErrorString(q)); return rvb::E_HIP; }
-    if (std::chrono::steady_clock::now() > deadline) break;
-    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const auto now = std::chrono::steady_clock::now();
+    if (now > deadline) break;
+    // a healthy collective of this size completes in tens of microseconds: poll without sleeping for the first 500 us so that
+    // a timeout costs the barriers around a timed region nothing, then back off
+    if (now - start > std::chrono::microseconds(500)) std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
   c->dead = true;
   if (g_rccl.abort && c->nccl) {
@@ -160,6 +164,12 @@ int rvb_comm_allgather(rvb_comm* c, const void* send, int64_t bytes, void* recv)
 
 int rvb_comm_set_timeout(rvb_comm* c, double seconds) {
   if (!c || seconds < 0.0) { set_error("rvb_comm_set_timeout: bad argument"); return E_ARG; }
+  if (seconds > 0.0) {
+    // without ncclCommAbort a timed-out collective cannot be torn down: its kernel and the copy into the caller's host
+    // buffer would stay queued and could land after the caller has freed that buffer -- refuse the timeout
+    RVB_TRY_RC(load_rccl());
+    if (!g_rccl.abort) { set_error("rvb_comm_set_timeout: this librccl has no ncclCommAbort; collectives cannot be given a deadline"); return E_UNSUPPORTED; }
+  }
   c->timeout_s = seconds;
   return OK;
 }

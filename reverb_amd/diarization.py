@@ -516,7 +516,6 @@ class SpeakerDiarization:
         self.device_index: Optional[int] = None
         self._engine = None
         self.timings: Dict[str, float] = {}
-        self._runs_of, self._runs_val = None, None
 
     # pyannote API --------------------------------------------------------------------------------
     def to(self, device):
@@ -576,16 +575,14 @@ class SpeakerDiarization:
         return pcm, os.path.splitext(os.path.basename(path))[0]
 
     def _runs(self, classes: np.ndarray) -> ClassRuns:
-        """run-length view of `classes`, shared by networks() and finish() when they see the same array"""
-        if self._runs_of is not classes:
-            self._runs_of, self._runs_val = classes, ClassRuns(classes, self.cfg["step_samples"] / self.cfg["sample_rate"],
-                                                               self.cfg["window_samples"] / self.cfg["sample_rate"])
-        return self._runs_val
+        """run-length view of `classes` (built once per recording: networks() hands it to finish() through `_pre`)"""
+        return ClassRuns(classes, self.cfg["step_samples"] / self.cfg["sample_rate"], self.cfg["window_samples"] / self.cfg["sample_rate"])
 
-    def networks(self, pcm: np.ndarray):
+    def networks(self, pcm: np.ndarray, prepare_finish: bool = True):
         """The GPU part on one recording (or one rank's slice of it): argmax powerset classes per window frame
         (uint8 [W, frames]) and one embedding per active (window, local speaker) pair (float32 [W, 3, dim], NaN
-        where the speaker is inactive)."""
+        where the speaker is inactive).  `prepare_finish=False` (the sharded path: finish() will see the gathered
+        classes of every rank, not this slice) skips the part of finish() that is otherwise precomputed here."""
         import time
         eng = self.engine
         t0 = time.perf_counter()
@@ -599,10 +596,12 @@ class SpeakerDiarization:
         # finish()'s speaker count and activity table.  Same functions on the same inputs: results are unchanged.
         excl = bool(self.params["embedding_exclude_overlap"])
         head = min(W, self.HEAD_WINDOWS if os.environ.get("RVD_HOST_OVERLAP", "1") != "0" else W)
+        runs_all = None
         if head < W:
             wi, si, masks = embedding_items_from_classes(classes[:head], excl, 400, self.cfg["window_samples"])
         else:
-            wi, si, masks = embedding_items_from_classes(classes, excl, 400, self.cfg["window_samples"], self._runs(classes))
+            runs_all = self._runs(classes)
+            wi, si, masks = embedding_items_from_classes(classes, excl, 400, self.cfg["window_samples"], runs_all)
         t3 = time.perf_counter()
         step = self.cfg["step_samples"] / self.cfg["sample_rate"]
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
@@ -611,12 +610,14 @@ class SpeakerDiarization:
             return embedding_items_from_classes(classes[head:], excl, 400, self.cfg["window_samples"]) if head < W else None
 
         def count_active():
-            runs = self._runs(classes)              # the run-length view of the whole recording: built here, reused by finish()
-            return speaker_count_from_classes(classes, step, dur, runs), active_from_classes(classes, runs)
+            # the run-length view of the whole recording: built here (helper thread), handed to finish() WITH the results --
+            # finish() takes all three from the future and never builds or reads it concurrently
+            runs = runs_all if runs_all is not None else self._runs(classes)
+            return speaker_count_from_classes(classes, step, dur, runs), active_from_classes(classes, runs), runs
 
         pool = self._host_pool()
         f_tail = pool.submit(tail_items)
-        f_pre = pool.submit(count_active)
+        f_pre = pool.submit(count_active) if prepare_finish else None
         emb = np.full((W, 3, self.cfg["emb_dim"]), np.nan, np.float32)
         n_items = int(wi.size)
         if wi.size:
@@ -626,7 +627,7 @@ class SpeakerDiarization:
             wi2, si2, masks2 = tail
             emb[wi2 + head, si2] = eng.embed((wi2 + head).astype(np.int64), masks2)
             n_items += int(wi2.size)
-        self._pre = (classes, f_pre)
+        self._pre = (classes, f_pre) if f_pre is not None else None
         t4 = time.perf_counter()
         self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, windows=W, embeddings=n_items)
         return classes, emb
@@ -646,13 +647,14 @@ class SpeakerDiarization:
         t0 = time.perf_counter()
         step = self.cfg["step_samples"] / self.cfg["sample_rate"]
         dur = self.cfg["window_samples"] / self.cfg["sample_rate"]
-        runs = self._runs(classes)
-        self._runs_of = self._runs_val = None                                 # one recording at a time: do not keep it alive
         pre = getattr(self, "_pre", None)
-        self._pre = None
+        self._pre = None                                                        # one recording at a time: do not keep it alive
         if pre is not None and pre[0] is classes:                               # computed under the embedding network by networks()
-            count, active = pre[1].result()
+            count, active, runs = pre[1].result()
         else:
+            if pre is not None:
+                pre[1].result()                                                 # another recording's: let the helper finish first
+            runs = self._runs(classes)
             count, active = speaker_count_from_classes(classes, step, dur, runs), None
         if count.size == 0 or np.max(count) == 0:
             return (Annotation(uri), np.zeros((0, self.cfg["emb_dim"]))) if return_embeddings else Annotation(uri)

@@ -404,6 +404,35 @@ class CollectiveFailed(RuntimeError):
 
 
 _EPOCH = 0          # decode_sharded calls so far: every rank calls in lockstep, so this names one call's keys in the store
+_KNOWN_DEAD: set = set()    # ranks a recovery declared dead: later calls give them no units and do not wait for them
+
+
+def _drop_default_comm():
+    """After a failed collective the RCCL communicator is aborted and refuses every further call (rvb_comm_set_timeout):
+    free it and forget it, so that nothing later in the process (another recording, the caller's own barrier) is handed a
+    dead handle (ADVICE r4).  With dead ranks on record the sharded entry points exchange through the store from then on;
+    with none (a transient failure) the next call builds a fresh communicator."""
+    global _DEFAULT_COMM
+    if _DEFAULT_COMM is not None:
+        try:
+            _DEFAULT_COMM.close()
+        except Exception:
+            pass
+        _DEFAULT_COMM = None
+
+
+def ranges_over_alive(n_units: int, world: int) -> List[Tuple[int, int]]:
+    """chunk_ranges over the ranks not known to be dead; a dead rank keeps an empty range at the position where its units
+    would have started, so the list stays in unit order and `ranges[rank]` stays valid for every rank."""
+    alive = [r for r in range(world) if r not in _KNOWN_DEAD]
+    parts = chunk_ranges(n_units, max(len(alive), 1))
+    out, c, k = [], 0, 0
+    for r in range(world):
+        if r in _KNOWN_DEAD or not alive:
+            out.append((c, c))
+        else:
+            out.append(parts[k]); c = parts[k][1]; k += 1
+    return out
 
 
 def _store():
@@ -447,13 +476,18 @@ def _recover_through_store(what: str, ranges, local_blob: bytes, redo, timeout: 
     Rank 0 is the arbiter (it usually hosts the store as well): if rank 0 itself is lost the job fails -- stated, not hidden.
     Returns (info, pieces): info = {"alive", "dead", "plan", "why"}, pieces = [(a, b, blob)] covering every range in order."""
     import json
+    import time
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     store = _store()
     tag = f"rvb/{_EPOCH}"
+    _drop_default_comm()
     store.set(f"{tag}/res/{rank}", local_blob)
     if rank == 0:
-        blobs = {r: _store_wait(store, f"{tag}/res/{r}", timeout) for r in range(world)}
+        # ONE deadline for all ranks (not `timeout` per rank: with several dead ranks the survivors would give up on the plan
+        # first); ranks already on record as dead are not waited for at all
+        deadline = time.time() + timeout
+        blobs = {r: None if r in _KNOWN_DEAD else _store_wait(store, f"{tag}/res/{r}", deadline - time.time()) for r in range(world)}
         alive = [r for r in range(world) if blobs[r] is not None]
         dead = [r for r in range(world) if blobs[r] is None]
         plan = []                                   # [dead rank, survivor, a, b] in unit order
@@ -468,6 +502,7 @@ def _recover_through_store(what: str, ranges, local_blob: bytes, redo, timeout: 
     if blob is None:
         raise CollectiveFailed(f"{what}: no recovery plan from rank 0 within {long_wait:.0f} s ({why})")
     info = json.loads(bytes(blob).decode())
+    _KNOWN_DEAD.update(info["dead"])
     if rank not in info["alive"]:
         raise CollectiveFailed(f"{what}: rank {rank} was declared dead by rank 0 (its results arrived after {timeout} s)")
     for i, (d, surv, a, b) in enumerate(info["plan"]):
@@ -528,7 +563,7 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
     decode_sharded.last_recovery = None
     world, rank = dist.get_world_size(), dist.get_rank()
     n_chunks = -(-num_frames(len(pcm)) // chunk_size)
-    ranges = chunk_ranges(n_chunks, world)
+    ranges = ranges_over_alive(n_chunks, world)
     c0, c1 = ranges[rank]
     s0, s1 = sample_range(len(pcm), chunk_size, c0, c1)
     local = {m: [] for m in modes}
@@ -536,6 +571,14 @@ def decode_sharded(engine, pcm: np.ndarray, modes, chunk_size: int, beam_size: i
     if s1 > s0:
         engine.upload_pcm(pcm[s0:s1])
         nf = engine.fbank()
+    if _KNOWN_DEAD:
+        # an earlier call lost ranks: no collective can complete any more.  The survivors share the recording among
+        # themselves and exchange through the store straight away (nobody waits for the dead; a rank that dies NOW is
+        # found and its range re-queued as before)
+        if s1 > s0:
+            local = engine.decode_resident(nf, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty)
+        return _recover_sharded(engine, pcm, modes, chunk_size, beam_size, ctc_weight, reverse_weight, blank_penalty, local, ranges,
+                                float(timeout if timeout is not None else 60.0), "ranks %s lost earlier" % sorted(_KNOWN_DEAD))
     comm = default_comm(engine)
     if comm is not None and timeout is not None:
         comm.set_timeout(timeout)
@@ -642,7 +685,7 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, timeout: float 
     n = len(pcm)
     full = (n - win) // step + 1 if n >= win else 0
     n_windows = full + (1 if (n < win or (n - win) % step > 0) else 0)
-    ranges = chunk_ranges(n_windows, world)
+    ranges = ranges_over_alive(n_windows, world)
     w0, w1 = ranges[rank]
     frames = segmentation_frames(win)               # known without running the network: ranks with no window need it too
     dim = int(cfg["emb_dim"])
@@ -651,22 +694,28 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, timeout: float 
         if b <= a:
             return None, None
         s0, s1 = window_sample_range(n, win, step, a, b)
-        classes, emb = pipeline.networks(pcm[s0:s1])
+        classes, emb = pipeline.networks(pcm[s0:s1], prepare_finish=False)    # finish() sees the gathered windows, not this slice
         assert classes.shape == (b - a, frames), (classes.shape, a, b, frames)
         return classes, emb
 
     classes, emb = run_windows(w0, w1)
     kmax = max(b - a for a, b in ranges)
-    comm = default_comm(pipeline.device_index if getattr(pipeline, "device_index", None) is not None else device)
-    if comm is not None and timeout is not None:
-        comm.set_timeout(timeout)
+    comm = None
+    if not _KNOWN_DEAD:
+        comm = default_comm(pipeline.device_index if getattr(pipeline, "device_index", None) is not None else device)
+        if comm is not None and timeout is not None:
+            comm.set_timeout(timeout)
     try:
+        if _KNOWN_DEAD:                             # ranks were lost by an earlier call: straight to the store exchange
+            if timeout is None:
+                timeout = 60.0
+            raise CollectiveFailed("ranks %s lost earlier" % sorted(_KNOWN_DEAD))
         host = gather_words(pack_diar_shard(classes, emb, kmax, frames, dim), device, comm)
         parts = [unpack_diar_shard(host[r], kmax) for r in range(world)]
         for r, (a, b) in enumerate(ranges):
             assert parts[r][0].shape[0] == b - a, (r, parts[r][0].shape, a, b)
     except Exception as ex:
-        if timeout is None or not _is_collective_failure(ex):
+        if timeout is None or not (isinstance(ex, CollectiveFailed) or _is_collective_failure(ex)):
             raise
 
         def redo(a, b):

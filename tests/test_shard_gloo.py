@@ -187,7 +187,15 @@ def _dying_worker(rank, world, port, q, mode):
         rdist.all_gather_results = broken
     pcm = synth.synth_audio(37.3, seed=11)
     res = rdist.decode_sharded(_StubAsrEngine(), pcm, _MODES, 500, 10, 0.1, 0.0, torch.device("cpu"), timeout=2.0)
-    q.put((rank, {m: [_row(h) for h in res[m]] for m in _MODES}, rdist.decode_sharded.last_recovery))
+    first = rdist.decode_sharded.last_recovery
+    # the NEXT recording of the same process.  With a rank on record as dead the survivors share it among
+    # themselves and exchange through the store at once -- no wait for the dead rank, nothing re-decoded
+    import time
+    t0 = time.time()
+    res2 = rdist.decode_sharded(_StubAsrEngine(), pcm, _MODES, 500, 10, 0.1, 0.0, torch.device("cpu"), timeout=2.0)
+    second = dict(rdist.decode_sharded.last_recovery or {}, seconds=time.time() - t0, known_dead=sorted(rdist._KNOWN_DEAD),
+                  same={m: [_row(h) for h in res2[m]] == [_row(h) for h in res[m]] for m in _MODES})
+    q.put((rank, {m: [_row(h) for h in res[m]] for m in _MODES}, dict(first, second=second)))
     if mode != "kill":
         dist.barrier()
         dist.destroy_process_group()
@@ -228,10 +236,14 @@ def test_decode_sharded_survives_a_dead_rank_and_a_dead_collective(mode):
     for r, (rows, info) in got.items():
         assert rows == want, f"rank {r}"
         assert info is not None and info["alive"] == ([0] if mode == "kill" else [0, 1])
+        second = info["second"]
+        assert all(second["same"].values())
         if mode == "kill":
             assert info["dead"] == [1] and info["plan"] == [[1, 0, 4, 8]]         # rank 1's chunks 4..7, re-queued on rank 0
+            assert second["known_dead"] == [1] and second["alive"] == [0] and second["plan"] == [] and second["seconds"] < 1.5
         else:
             assert info["dead"] == [] and info["plan"] == []
+            assert second["known_dead"] == []                                     # nobody died: the next call tries the collective again
 
 
 def test_greedy_results_survive_the_gather_for_get_output():
