@@ -76,12 +76,12 @@ def cpu_baseline(cfg, seg_sd, emb_sd, pcm, n_windows):
 
 
 def conv_traffic(hours, dtype):
-    """HBM bytes per convolution launch (ResNet34 trunk: conv_kernel / conv_igemm_kernel / conv_pair32_kernel) from two nested
+    """HBM bytes per convolution launch (ResNet34 trunk: conv_kernel / conv_stream_kernel / conv_igemm_kernel) from two nested
     rocprofv3 --pmc passes over one step of this command (see bench.pmc_traffic)."""
     import bench
     sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--hours", str(hours),
            "--dtype", dtype, "--cpu-baseline-windows", "0", "--traffic", "off"]
-    return bench.pmc_traffic(sub, ("conv_kernel", "conv_igemm", "conv_pair32"), "bench_diar.py")
+    return bench.pmc_traffic(sub, ("conv_kernel", "conv_stream", "conv_igemm", "conv_block"), "bench_diar.py")
 
 
 def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype="bf16", cpu_windows=16, traffic="off"):

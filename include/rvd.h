@@ -29,7 +29,9 @@ typedef struct rvd_engine rvd_engine;
 
 typedef struct rvd_model_cfg {
   int32_t struct_size;      /* sizeof(rvd_model_cfg) in the caller's binding; rvd_create refuses any other value (rvb.h) */
-  int32_t dtype;            /* RVB_F32 (0) exact-parity mode, RVB_BF16 (1) bf16 MFMA inputs, fp32 accumulate */
+  int32_t dtype;            /* RVB_F32 (0) exact-parity mode, RVB_BF16 (1) bf16 MFMA inputs, fp32 accumulate, RVB_FP8 (2) = the
+                               bf16 engine with the 3x3 convolutions of the embedding trunk's stages 3-4 on e4m3 operands
+                               (BASELINE configs[4]; scales calibrated by the first rvd_embed call, see rvd_get_emb_fp8) */
   int32_t sample_rate;      /* 16000 */
   int32_t window_samples;   /* 160000 (10 s) */
   int32_t step_samples;     /* 16000  (segmentation_step 0.1 x window) */

@@ -120,6 +120,10 @@ SIGNATURES = {
     "rvb_reset_timings": (C.c_int, [_eng]),
     "rvb_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),
     "rvb_wer_counts": (C.c_int, [_i32p, C.c_int64, _i32p, C.c_int64, _i64p]),
+}
+
+# librvb_test.so (csrc/test_api.h): raw kernel / host-search hooks for tests/ and scripts/ -- not in the product library
+TEST_SIGNATURES = {
     "rvb_test_gemm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
@@ -195,11 +199,33 @@ DIAR_SIGNATURES = {
 }
 
 _lib = None
+_test_lib = None
+TEST_LIB_PATH = os.path.join(_HERE, "librvb_test.so")
+
+
+def load_test():
+    """dlopen librvb_test.so: the product's objects plus the rvb_test_* hooks (tests and tuning scripts only)."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RvbError(f"{TEST_LIB_PATH} not found: run `python -m reverb_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(TEST_LIB_PATH)
+    for name, (res, args) in list(SIGNATURES.items()) + list(DIAR_SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _test_lib = lib
+    return lib
 
 
 def load():
-    """dlopen librvb.so and declare every prototype; raises if the build is missing."""
+    """dlopen librvb.so and declare every prototype; raises if the build is missing.
+    RVB_LAB=1 (tests and tuning scripts that A/B kernel variants) hands out librvb_test.so instead: the same objects, built
+    to read the tuning switches of csrc/common.h's lab_env() from the environment -- the product library ignores them."""
     global _lib
+    if os.environ.get("RVB_LAB") == "1":
+        return load_test()
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -217,7 +243,12 @@ def load():
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().rvb_last_error()
-        raise RvbError(f"{what or 'librvb'} failed ({rc}): {msg.decode('utf8', 'replace') if msg else ''}")
+        text = msg.decode('utf8', 'replace') if msg else ''
+        if _test_lib is not None:            # the call may have been one of librvb_test.so's: its own thread-local message
+            tmsg = _test_lib.rvb_last_error()
+            if tmsg and tmsg != msg:
+                text = (text + " | librvb_test: " if text else "") + tmsg.decode('utf8', 'replace')
+        raise RvbError(f"{what or 'librvb'} failed ({rc}): {text}")
 
 
 def fptr(a):

@@ -2,6 +2,11 @@
 
 `python -m reverb_amd.build` or `reverb_amd.build.build()`.  hipcc cross-compiles without a GPU.
 Objects are cached under reverb_amd/csrc/_build and rebuilt when a source or header is newer.
+
+Two shared objects come out:
+  librvb.so        the PRODUCT: exports include/rvb.h + include/rvd.h and nothing else of the C ABI
+  librvb_test.so   the same objects + csrc/test_api.hip (rvb_test_*: raw kernel / host-search hooks, csrc/test_api.h) and
+                   engine.hip compiled with -DRVB_TEST_API; loaded by tests/ and scripts/ only (reverb_amd._lib.load_test)
 """
 import os
 import subprocess
@@ -11,7 +16,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librvb.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "linkage.hip", "diar_engine.hip", "test_api.hip", "comm.hip", "search.cpp", "audio.cpp"]
+OUT_TEST = os.path.join(HERE, "librvb_test.so")
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "linkage.hip", "diar_engine.hip", "comm.hip", "search.cpp", "audio.cpp"]
+TEST_SOURCES = ["test_api.hip", ("engine.hip", "engine_testapi", ["-DRVB_TEST_API"])]      # (source, object stem, extra flags)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable"]
@@ -31,14 +38,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
+def _compile(item):
+    src, stem, extra = item if isinstance(item, tuple) else (item, os.path.splitext(item)[0], [])
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
-    obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(bdir, stem + ".o")
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + _headers()):
         lang = ["-x", "hip"] if src.endswith(".hip") else []
-        cmd = [HIPCC] + FLAGS + lang + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra + lang + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -51,15 +59,18 @@ def build(force=False, verbose=True):
     if force:
         for f in os.listdir(os.path.join(CSRC, "_build")) if os.path.isdir(os.path.join(CSRC, "_build")) else []:
             os.remove(os.path.join(CSRC, "_build", f))
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(_compile, SOURCES))
-    if _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread", "-ldl"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    if verbose:
-        print("built", OUT)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES) + len(TEST_SOURCES))) as ex:
+        all_objs = list(ex.map(_compile, SOURCES + TEST_SOURCES))
+    objs, test_objs = all_objs[:len(SOURCES)], all_objs[len(SOURCES):]
+    engine_obj = objs[SOURCES.index("engine.hip")]
+    for out, members in ((OUT, objs), (OUT_TEST, [o for o in objs if o != engine_obj] + test_objs)):
+        if _stale(out, members):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + members + ["-lpthread", "-ldl"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", out)
     return OUT
 
 

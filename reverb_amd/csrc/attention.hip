@@ -419,7 +419,7 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
     // A/B switch for the encoder's form (dk 33..64, 128-query workgroups, positional keys): RVB_ATTN_PADK=16 = the 144-byte row
     // pitch of rounds 1-3 (2-way bank conflicts on every S-phase fragment read: 10.41 vs 9.99 ms per hour, SQ_LDS_BANK_CONFLICT
     // 2.1e8 vs 0 on a quarter hour, profiles/r04_call7_attention_padk_pmc.txt); every other form uses the 32-byte pad
-    static const int padk = getenv("RVB_ATTN_PADK") ? atoi(getenv("RVB_ATTN_PADK")) : 32;
+    static const int padk = lab_env("RVB_ATTN_PADK") ? atoi(lab_env("RVB_ATTN_PADK")) : 32;
     if (pos && padk == 16 && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128)) return launch_attn<T, 64, true, 8, false, 16>(s, a);
   }
 #define RVB_ATTN_CASE(D)                                                           \
@@ -464,7 +464,7 @@ int attention_pos_bias(hipStream_t s, const void* P, int rows, int p_stride, con
 
 int attention(hipStream_t s, int dtype, const AttnArgs& a0) {
   if (a0.nseq <= 0 || a0.max_q <= 0) return OK;
-  static const int plain = getenv("RVB_ATTN_PLAIN") ? atoi(getenv("RVB_ATTN_PLAIN")) : 0;      // tuning: A/B of the block order
+  static const int plain = lab_env("RVB_ATTN_PLAIN") ? atoi(lab_env("RVB_ATTN_PLAIN")) : 0;      // tuning: A/B of the block order
   AttnArgs a = a0;
   if (plain) a.plain_order = 1;
   const int ve = dtype == DT_BF16 ? 8 : 4;

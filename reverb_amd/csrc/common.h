@@ -186,4 +186,8 @@ enum { OK = 0, E_ARG = -1, E_HIP = -2, E_STATE = -3, E_NOMEM = -4, E_UNSUPPORTED
 namespace rvb {
 void set_error(const std::string& msg);  // thread-local last error (engine.hip)
 const char* last_error();
+// Tuning / diagnosis switches (kernel variants, A/B legs of scripts/, the measured-slower alternatives the tuning log keeps):
+// the PRODUCT library never reads them -- lab_env() returns nullptr there and every switch takes its default.  Only
+// librvb_test.so (engine.hip compiled with -DRVB_TEST_API; reverb_amd._lib: RVB_LAB=1) consults the environment.
+const char* lab_env(const char* name);
 }

@@ -347,7 +347,7 @@ int launch_stream(hipStream_t st, const ConvArgs& p, int tsplit) {
 }
 
 int stream_mode() {       // RVD_CONV_STREAM: 0 = off, n >= 1 = on with the time axis of a row split over n workgroups
-  const char* e = getenv("RVD_CONV_STREAM");        // read per call: the tests switch it between engines
+  const char* e = lab_env("RVD_CONV_STREAM");        // read per call: the tests switch it between engines
   return e ? atoi(e) : CONV_STREAM_DEFAULT;
 }
 
@@ -355,7 +355,7 @@ int stream_mode() {       // RVD_CONV_STREAM: 0 = off, n >= 1 = on with the time
 
 bool conv_stream_applicable(int dtype, const ConvArgs& p) {
   if (stream_mode() <= 0) return false;
-  if (p.Cin == 64) { const char* e = getenv("RVD_CONV_STREAM64"); if (!(e && atoi(e) == 1)) return false; }
+  if (p.Cin == 64) { const char* e = lab_env("RVD_CONV_STREAM64"); if (!(e && atoi(e) == 1)) return false; }
   return dtype == DT_BF16 && p.taps == 9 && p.stride == 1 && p.Cin == p.Cout && (p.Cin == 32 || p.Cin == 64) && p.Fo == p.Fi && p.To == p.Ti &&
          (int64_t)(p.Fi + 2) * (p.Ti + 2) * p.Cin * 2 < ((int64_t)1 << 31) && (int64_t)p.B * cdiv(p.Fo, CS_OF) * 64 < ((int64_t)1 << 31);
 }

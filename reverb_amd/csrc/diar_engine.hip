@@ -75,7 +75,7 @@ struct rvd_engine {
   // RVD_EMB_FP8=1 (round 4 candidate, not yet run on a GPU): stages 3-4 of the trunk on the fp8 implicit-GEMM kernel.  act8 = e4m3
   // copies of those stages' rotating buffers; scale8[((li - 2) * 8 + block) * 2 + {0: first convolution's output, 1: block output}],
   // calibrated by the first trunk pass (bf16, running maxima in d_amax8); emb_f8_state 0 not calibrated, 1 calibrating, 2 active
-  bool emb_fp8 = false;
+  bool emb_fp8 = false, want_fp8 = false;      // want_fp8: created with dtype RVB_FP8
   int emb_f8_state = 0;
   DevBuf act8[4][3], d_amax8, d_sat8;
   std::vector<float> scale8;
@@ -401,7 +401,7 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   // [cout][tap][cin].  Validated on hardware in round 2 (tests/test_diar_gpu.py: both kernels against the oracle and
   // against each other; 806 / 1150 TFLOP/s vs 555-598 for the direct kernel); RVD_CONV_IGEMM=0 selects the direct kernel.
   // Round 4: the stride-2 convolutions that open stages 3 and 4 go there too (RVD_CONV_IGEMM=1: stride 1 only, as in round 2).
-  const char* ig = getenv("RVD_CONV_IGEMM");
+  const char* ig = lab_env("RVD_CONV_IGEMM");
   const int ig_mode = ig ? atoi(ig) : 2;
   if (ig_mode != 0 && e->dtype == DT_BF16 && k == 3 && (stride == 1 || (stride == 2 && ig_mode >= 2)) && cin % 64 == 0 && cout % 128 == 0) {
     std::vector<float> pg((size_t)cout * taps * cin);
@@ -431,12 +431,13 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   return up_f32(e, c.b, pb.data(), pb.size());
 }
 
-// RVD_CONV_SC_FUSE=1 (round 4, opt-in until measured): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4
+// Default since round 5 (measured: shortcut kernels 12.1 -> 5.2 ms per hour, the 256-channel stage 21.4 -> 25.0 ms, step 358-360
+// -> 355-359 ms, profiles/r05_call1.txt; and one rounding point fewer): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4
 // rides in the K loop of the block's second convolution (conv_gemm.hip, ConvArgs::in2) instead of being a kernel of its own whose
 // output is written, read back as the residual and rounded to bf16 on the way: rows [cout][9 cout + cin_sc], bias = b_2 + b_sc.
 int pack_fused_shortcut(rvd_engine* e, ResBlock& B, const std::string& p) {
-  const char* f = getenv("RVD_CONV_SC_FUSE");
-  if (!(f && atoi(f) == 1) || !B.has_sc || !B.c2.w_ig.p || B.sc.cin % 64 || B.sc.taps != 1) return OK;
+  const char* f = lab_env("RVD_CONV_SC_FUSE");           // lab: 0 = the shortcut as a kernel of its own (until round 5)
+  if ((f && atoi(f) == 0) || !B.has_sc || !B.c2.w_ig.p || B.sc.cin % 64 || B.sc.taps != 1) return OK;
   const int cout = B.c2.cout, cin = B.c2.cin, c2 = B.sc.cin;
   const HostTensor *w, *g, *b, *m, *v, *ws, *gs, *bs, *ms, *vs;
   RVD_TRY(need(e, p + ".conv2.weight", (size_t)cout * cin * 9, &w));
@@ -467,7 +468,8 @@ int finalize_embedding(rvd_engine* e) {
   const std::string S = "embedding.resnet.";
   const int m = c.emb_channels;
   if (m != 32) { set_error("embedding: this build supports m_channels = 32 (ResNet34 of pyannote/wespeaker-voxceleb-resnet34-LM)"); return E_UNSUPPORTED; }
-  { const char* f8 = getenv("RVD_EMB_FP8"); e->emb_fp8 = f8 && atoi(f8) == 1 && e->dtype == DT_BF16; e->emb_f8_state = 0; }
+  // rvd_model_cfg.dtype = RVB_FP8: the bf16 engine with stages 3-4 of the trunk on e4m3 operands (lab: RVD_EMB_FP8=1 on a bf16 engine)
+  { const char* f8 = lab_env("RVD_EMB_FP8"); e->emb_fp8 = (e->want_fp8 || (f8 && atoi(f8) == 1)) && e->dtype == DT_BF16; e->emb_f8_state = 0; }
   // stem: Conv2d(1, m, 3) + BN folded, fp32 weights [m][9]
   const HostTensor *w, *g, *b, *mu, *v;
   RVD_TRY(need(e, S + "conv1.weight", (size_t)m * 9, &w));
@@ -573,18 +575,6 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
       const int oi = xi < 0 ? 1 : (xi + 2) % 3;
       void* tmp = e->act[li][ti].p;
       void* out = e->act[li][oi].p;
-      if (!Bk.has_sc && dx.F == d.F && dx.T == d.T &&
-          conv_pair32_applicable(e->dtype, Bk.c1.cin, Bk.c1.cout, Bk.c2.cout, Bk.c1.stride, Bk.c2.stride, Bk.c1.taps, Bk.c2.taps)) {
-        // the whole residual block in one kernel (resnet.hip conv_pair32_kernel): x read once, out written once
-        ConvPairArgs a{};
-        a.in = x; a.wa = Bk.c1.w.p; a.ba = Bk.c1.b.as<float>(); a.wb = Bk.c2.w.p; a.bb = Bk.c2.b.as<float>(); a.out = out;
-        a.B = B; a.F = d.F; a.T = d.T;
-        e->prof["emb_conv_fused"].launches += 1;
-        { DScope sc(e, "emb_conv_32", 2.0 * 2.0 * (double)B * d.F * d.T * 32 * 32 * 9);
-          RVD_TRY(conv_pair32(e->stream, a)); }
-        x = out; dx = d; xi = oi;
-        continue;
-      }
       const bool f8blk = e->emb_fp8 && li >= 2 && Bk.c2.w8.p && (bi == 0 || Bk.c1.w8.p);
       if (f8blk && e->emb_f8_state == 2) {
         // ---- fp8 path (candidate): block 0 of a stage keeps its stride-2 first convolution and its shortcut in bf16 (their input is the
@@ -749,7 +739,7 @@ int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
               std::to_string(sizeof(rvd_model_cfg)) + " bytes (bind it field by field from include/rvd.h)");
     return E_ARG;
   }
-  if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16) { set_error("rvd_create: dtype must be RVB_F32 or RVB_BF16"); return E_ARG; }
+  if (cfg->dtype != DT_F32 && cfg->dtype != DT_BF16 && cfg->dtype != RVB_FP8) { set_error("rvd_create: dtype must be RVB_F32, RVB_BF16 or RVB_FP8"); return E_ARG; }
   if (cfg->lstm_hidden != 128 || cfg->sinc_filters != 80 || cfg->sinc_filters % 8 || cfg->sinc_channels < 1 || cfg->sinc_channels > 64 ||
       cfg->lstm_layers < 1 || cfg->linear_layers < 0 || cfg->linear_layers > 2 || (cfg->linear_layers && cfg->linear_dim % 8) ||
       cfg->linear_dim > 256 || cfg->num_classes < 1 || cfg->num_classes > 16 || cfg->sample_rate != 16000 ||
@@ -764,7 +754,13 @@ int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
   }
   RVB_HIP_CHECK(hipSetDevice(device));
   rvd_engine* e = new rvd_engine();
-  e->cfg = *cfg; e->device = device; e->dtype = cfg->dtype;
+  e->cfg = *cfg; e->device = device;
+  // RVB_FP8 = BASELINE configs[4] "fp8 MFMA GEMMs" on the diarization side: everything as in the bf16 engine except the 3x3
+  // convolutions of the ResNet34 trunk's stages 3-4 (128 / 256 channels, the MFMA-bound half of the trunk), which run on
+  // v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands (conv_igemm8_kernel); scales calibrated by the first rvd_embed call
+  e->want_fp8 = cfg->dtype == RVB_FP8;
+  e->dtype = e->want_fp8 ? (int)DT_BF16 : cfg->dtype;
+  e->cfg.dtype = e->dtype;
   RVB_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->f1 = (cfg->window_samples - SINC_K) / SINC_STRIDE + 1; e->p1 = e->f1 / 3;
   e->f2 = e->p1 - (CONV_K - 1); e->p2 = e->f2 / 3;

@@ -231,7 +231,7 @@ static int out_frames(int T0) { const int T1 = (T0 - 3) / 2 + 1; return (T1 - 3)
 // saturation counters of the fp8 activations: one row of 8 per block (+ a guard row: the last block's norm_final names "the next
 // block"); zeroed whenever scales are (re)calibrated or installed
 static int reset_f8sat(rvb_engine* e) {
-  static const int on = getenv("RVB_FP8_SAT") ? atoi(getenv("RVB_FP8_SAT")) : 1;       // 0: no counters (A/B of their cost)
+  static const int on = lab_env("RVB_FP8_SAT") ? atoi(lab_env("RVB_FP8_SAT")) : 1;       // 0: no counters (A/B of their cost)
   if (!on) return OK;
   RVB_TRY(e->d_f8sat.ensure((e->enc.size() + 1) * 8 * 4));
   RVB_HIP_CHECK(hipMemsetAsync(e->d_f8sat.p, 0, (e->enc.size() + 1) * 8 * 4, e->stream));
@@ -479,10 +479,10 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
 static int set_fp8_policy_impl(rvb_engine* e, int groups, int first_block, int last_block) {
   const int nb = (int)e->enc.size();
   if (nb == 0) { set_error("rvb_set_fp8_policy before rvb_finalize"); return E_STATE; }
-  unsigned mask = groups < 0 ? (getenv("RVB_FP8_GROUPS") ? (unsigned)atoi(getenv("RVB_FP8_GROUPS")) : 17u) : (unsigned)groups;
+  unsigned mask = groups < 0 ? (lab_env("RVB_FP8_GROUPS") ? (unsigned)atoi(lab_env("RVB_FP8_GROUPS")) : 17u) : (unsigned)groups;
   if (groups < 0) {
-    if (getenv("RVB_FP8_FIRST")) first_block = atoi(getenv("RVB_FP8_FIRST"));
-    if (getenv("RVB_FP8_LAST")) last_block = atoi(getenv("RVB_FP8_LAST"));
+    if (lab_env("RVB_FP8_FIRST")) first_block = atoi(lab_env("RVB_FP8_FIRST"));
+    if (lab_env("RVB_FP8_LAST")) last_block = atoi(lab_env("RVB_FP8_LAST"));
   }
   if (last_block < 0) last_block = nb - 1;
   e->f8_groups.assign(nb, 0u);
@@ -543,7 +543,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     a.q = e->h.p; a.k = (const char*)e->h.p + (size_t)d * es; a.v = (const char*)e->h.p + (size_t)2 * d * es;
     a.p = L.pos_keys.p;
     {   // bf16: positional term folded into per-key constants (RVB_ATTN_FOLD=1; default: the two-product form)
-      static const int fold = getenv("RVB_ATTN_FOLD") ? atoi(getenv("RVB_ATTN_FOLD")) : 0;     // measured slower (10.3 -> 10.8 ms per hour): opt-in
+      static const int fold = lab_env("RVB_ATTN_FOLD") ? atoi(lab_env("RVB_ATTN_FOLD")) : 0;     // measured slower (10.3 -> 10.8 ms per hour): opt-in
       if (fold && L.pos_bias.p) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; }
     }
     a.q_stride = a.k_stride = a.v_stride = 3 * d; a.p_stride = d; a.o_stride = d;
@@ -553,7 +553,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     a.kv_start = e->d_seq_start.as<int>(); a.kv_len = e->cur_lens;
     a.nseq = B; a.heads = heads; a.dk = dk; a.max_q = T; a.causal = 0; a.sqrt_dk = std::sqrt((float)dk);
     a.chunk = e->dec_chunk; a.left = e->dec_left;          // add_optional_chunk_mask, encoder.py:140-145
-    { static const int qb = getenv("RVB_ATTN_QBLOCK") ? atoi(getenv("RVB_ATTN_QBLOCK")) : 0; a.q_block = qb; }   // tuning: 64 / 128 queries per workgroup
+    { static const int qb = lab_env("RVB_ATTN_QBLOCK") ? atoi(lab_env("RVB_ATTN_QBLOCK")) : 0; a.q_block = qb; }   // tuning: 64 / 128 queries per workgroup
     double keys = T;
     if (li >= 0) {
       // attention.py:361-369: k = cat(key_cache, k), v = cat(value_cache, v); pos_emb = position_encoding(offset -
@@ -706,7 +706,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
   // measured on the 176-chunk bench batch: first slice 96/112/128/144/160 -> 201.1/199.8/198.6/197.4/198.9 ms
   int SB = B >= 16 ? (B * 7 + 9) / 10 : B;            // chunks in the first (largest) slice
   if (B >= 64) SB = B - 32;
-  if (const char* ov = getenv("RVB_SLICE0")) { const int v = atoi(ov); if (v > 0 && v <= B) SB = v; }   // tuning override
+  if (const char* ov = lab_env("RVB_SLICE0")) { const int v = atoi(ov); if (v > 0 && v <= B) SB = v; }   // tuning override
   const int Ms = SB * T2;
   RVB_TRY(e->X1.ensure((size_t)SB * T1 * F1 * d * es));
   RVB_TRY(e->X2.ensure((size_t)SB * T2 * F2 * d * es));
@@ -1859,7 +1859,24 @@ extern "C" {
 const char* rvb_last_error(void) { return last_error(); }
 const char* rvb_version(void) { return "librvb 0.1 (gfx950)"; }
 
+}  // extern "C" (reopened below)
+namespace rvb {
+#ifdef RVB_TEST_API
+const char* lab_env(const char* name) { return getenv(name); }      // librvb_test.so: the lab build reads its switches
+#else
+const char* lab_env(const char*) { return nullptr; }                // librvb.so: defaults only
+#endif
+}  // namespace rvb
+extern "C" {
+
 int rvb_model_cfg_size(void) { return (int)sizeof(rvb_model_cfg); }
+
+// host only (no GPU needed): word alignment counts for reverb_amd/wer_evaluation/align.py (search.cpp edit_counts)
+int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_t n_hyp, int64_t* counts) {
+  if ((!ref && n_ref > 0) || (!hyp && n_hyp > 0) || !counts || n_ref < 0 || n_hyp < 0) { set_error("rvb_wer_counts: bad argument"); return E_ARG; }
+  edit_counts(ref, n_ref, hyp, n_hyp, counts);
+  return OK;
+}
 
 int rvb_create(const rvb_model_cfg* cfg, int device, rvb_engine** out) {
   if (!cfg || !out) { set_error("rvb_create: null argument"); return E_ARG; }
@@ -2428,6 +2445,8 @@ int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, i
 
 }  // extern "C"
 
+#ifdef RVB_TEST_API      // librvb_test.so only (csrc/test_api.h): hooks into this file's static functions
+#include "test_api.h"
 // host only: the rescoring trie of given hypotheses (tests/test_search_native.py checks it against a Python trie).
 // tokens: the hypotheses back to back; lens / chunk_of: per hypothesis (chunk ids ascending).  Outputs sized by the caller:
 // rows <= P = sum(len + 1); tok, pos [rows]; path, tgt, pair_slot [P]; hq_start, hq_len, hq_pos0 [n_hyps]; tgt_ptr [rows + 1].
@@ -2517,3 +2536,4 @@ extern "C" int rvb_test_fbank(const int16_t* pcm, int64_t n_samples, float* feat
   for (DevBuf* b : {&e.fb_window, &e.fb_twiddle, &e.fb_melw, &e.fb_lo, &e.fb_hi}) b->release();
   return r;
 }
+#endif   // RVB_TEST_API

@@ -1634,8 +1634,8 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 #endif
 int g_gemm2_flags = -1, g_gemm2_group_m = -1;
 static void gemm2_opts_from_env() {
-  if (g_gemm2_flags < 0) { const char* e = getenv("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
-  if (g_gemm2_group_m == -1) { const char* e = getenv("RVB_GEMM2_GROUP_M"); g_gemm2_group_m = e ? atoi(e) : GEMM2_DEFAULT_GROUP_M; }
+  if (g_gemm2_flags < 0) { const char* e = lab_env("RVB_GEMM2_FLAGS"); g_gemm2_flags = e ? atoi(e) : GEMM2_DEFAULT_FLAGS; }
+  if (g_gemm2_group_m == -1) { const char* e = lab_env("RVB_GEMM2_GROUP_M"); g_gemm2_group_m = e ? atoi(e) : GEMM2_DEFAULT_GROUP_M; }
 }
 
 int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
@@ -1662,7 +1662,7 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   {
     static int mode = -1, ncu = 0;
     if (mode < 0) {
-      const char* e = getenv("RVB_GEMM2_STAGGER"); mode = e ? atoi(e) : GEMM2_STAGGER_DEFAULT;
+      const char* e = lab_env("RVB_GEMM2_STAGGER"); mode = e ? atoi(e) : GEMM2_STAGGER_DEFAULT;
       int dev = 0; hipDeviceProp_t pr;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
     }

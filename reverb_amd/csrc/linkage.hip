@@ -862,18 +862,18 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
   if (n < 2) return OK;
   const int t = cdiv(n, 64);
   const size_t lds = (size_t)n * 14 + 16, lds_c = (size_t)n * 16 + 16;      // + the sorted slot list of the compacting variant
-  const bool force_global = getenv("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
-  const bool no_compact = getenv("RVD_LINKAGE_COMPACT") && atoi(getenv("RVD_LINKAGE_COMPACT")) == 0;
-  const int flags = (getenv("RVD_LINKAGE_PROF") ? 1 : 0) | (getenv("RVD_LINKAGE_XCHG") ? (atoi(getenv("RVD_LINKAGE_XCHG")) == 0 ? 0 : atoi(getenv("RVD_LINKAGE_XCHG")) == 2 ? 6 : 2) : 2);      // exchange form: 0 = A, 1 = B (default), 2 = C
+  const bool force_global = lab_env("RVD_LINKAGE_GLOBAL") != nullptr;      // test hook: exercise the large-n variant on small inputs
+  const bool no_compact = lab_env("RVD_LINKAGE_COMPACT") && atoi(lab_env("RVD_LINKAGE_COMPACT")) == 0;
+  const int flags = (lab_env("RVD_LINKAGE_PROF") ? 1 : 0) | (lab_env("RVD_LINKAGE_XCHG") ? (atoi(lab_env("RVD_LINKAGE_XCHG")) == 0 ? 0 : atoi(lab_env("RVD_LINKAGE_XCHG")) == 2 ? 6 : 2) : 2);      // exchange form: 0 = A, 1 = B (default), 2 = C
   // RVD_LINKAGE_MB: 0 = never the multi-workgroup loop, 1 = always (tests: any n), unset = from 3 000 points on (below that one
   // CU's LDS-resident loop is as fast: a merge is a chain of latencies either way)
-  const char* mbe = getenv("RVD_LINKAGE_MB");
+  const char* mbe = lab_env("RVD_LINKAGE_MB");
   const int mb_mode = mbe ? atoi(mbe) : -1;
   // workgroups of the multi-workgroup loop: the caller's hint (rvd_set_linkage_workgroups: 1 = the one-workgroup loop, a power of
   // two up to 16, 0 = default), RVD_LINKAGE_G overrides; a count whose per-workgroup state does not fit LDS is doubled until it does
   int G = MB_G;
   if (workgroups == 2 || workgroups == 4 || workgroups == 8 || workgroups == 16) G = workgroups;
-  if (const char* ge = getenv("RVD_LINKAGE_G")) { const int v = atoi(ge); if (v == 2 || v == 4 || v == 8 || v == 16) G = v; }
+  if (const char* ge = lab_env("RVD_LINKAGE_G")) { const int v = atoi(ge); if (v == 2 || v == 4 || v == 8 || v == 16) G = v; }
   while (G < MB_G && (size_t)((((n + 15) >> 4) + G - 1) / G << 4) * 16 + (size_t)((n + 1) & ~1) * 4 > 150 * 1024) G *= 2;
   const int ngrp = (n + 15) >> 4, m_own = ((ngrp + G - 1) / G) << 4;
   const size_t lds_mb = (size_t)m_own * 16 + (size_t)((n + 1) & ~1) * 4;
@@ -904,7 +904,7 @@ int centroid_linkage(hipStream_t s, const double* X, int n, int d, double* D, ui
       // a barrier gave up (the workgroups did not all become resident on one XCD): start over on the one-workgroup loop --
       // unless the multi-workgroup loop was asked for by name (tests): then this is an error, never a silent fall-back
       if (mb_mode == 1) { set_error("centroid_linkage: the multi-workgroup merge loop (RVD_LINKAGE_MB=1) gave up at a grid barrier"); return E_STATE; }
-      if (getenv("RVD_LINKAGE_PROF")) fprintf(stderr, "linkage: multi-workgroup loop aborted, falling back to one workgroup\n");
+      if (lab_env("RVD_LINKAGE_PROF")) fprintf(stderr, "linkage: multi-workgroup loop aborted, falling back to one workgroup\n");
       const double inf = INFINITY;
       RVB_HIP_CHECK(hipMemcpyAsync(min_dist + (n - 1), &inf, 8, hipMemcpyHostToDevice, s));
       RVB_HIP_CHECK(hipStreamSynchronize(s));

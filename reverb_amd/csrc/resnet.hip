@@ -392,224 +392,6 @@ int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
   return launch_conv<float, 32>(s, p);
 }
 
-// ------------------------------------------------------------------------------------ fused BasicBlock, 32 channels (bf16)
-// out = relu(conv_b(relu(conv_a(x) + ba)) + bb + x): the two 3x3 convolutions of a stride-1 residual block in one kernel.
-// As two conv2d launches the 32-channel stage moves five tensor passes through HBM per block (x read, mid written, mid
-// read, x read again as the residual, out written) for 18 kFLOP per pixel -- it runs at 4.5 TB/s, not on the MFMA pipe.
-// Here x is read once and out written once; the intermediate tile (with its one-pixel halo recomputed) stays in LDS.
-//
-// A workgroup (4 waves) owns 2 mel rows of one window and walks their 62-frame tiles: output 2 x 62, intermediate 4 x 64,
-// input patch 6 x 66 pixels.  conv_a: wave w computes intermediate row w (4 m-tiles x 9 taps x 2 channel halves = 72
-// MFMAs), adds the bias, applies ReLU, zeroes what lies outside the image (conv_b's zero padding) and writes bf16 into LDS
-// -- exactly the value the unfused path stores.  conv_b: wave w computes output row w >> 1, frames 32 (w & 1) .. +31
-// (36 MFMAs), adds bias and the residual (the patch's centre, still in LDS), ReLU, and stores through a transposing slab.
-// Both weight sets stay in LDS for all tiles of the row; the next tile's patch is in flight (registers) under the MFMAs.
-// Accumulation order, rounding points and operand values are those of conv_kernel: results are bit-identical.
-namespace {
-constexpr int CP_OT = 62, CP_MT = 64, CP_PT = 66;     // frames per tile: output, intermediate, patch
-constexpr int CP_OF = 2, CP_MF = 4, CP_PF = 6;        // mel rows
-constexpr int CP_PATCH = CP_PF * CP_PT * 64;          // 25 344 B
-constexpr int CP_MID = CP_MF * CP_MT * 64 + 128;      // + overrun of the last row's shifted reads
-constexpr int CP_W = 9 * 32 * 64;                     // one convolution's weights
-constexpr int CP_LDS = CP_PATCH + CP_MID + 2 * CP_W;  // 78 720 B: two workgroups per CU
-}  // namespace
-
-__global__ __launch_bounds__(256, 2) void conv_pair32_kernel(ConvPairArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char cp_smem[];
-  char* sP = cp_smem;
-  char* sM = cp_smem + CP_PATCH;
-  char* sWa = sM + CP_MID;
-  char* sWb = sWa + CP_W;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int F = p.F, T = p.T, FP = F + 2, TP = T + 2;
-  const int tiles_f = (F + CP_OF - 1) / CP_OF, tiles_t = (T + CP_OT - 1) / CP_OT;
-  const int b = blockIdx.x / tiles_f, tf = blockIdx.x - b * tiles_f;
-  const int f0 = tf * CP_OF;
-  const bf16_t* __restrict__ in = (const bf16_t*)p.in + (size_t)b * FP * TP * 32;
-  bf16_t* __restrict__ out = (bf16_t*)p.out + (size_t)b * FP * TP * 32;
-
-  // weights: 2 x 1152 16-byte vectors, staged once
-  for (int v = tid; v < 2 * (CP_W / 16); v += 256) {
-    const bool second = v >= CP_W / 16;
-    const int vv = second ? v - CP_W / 16 : v;
-    *(uint4*)((second ? sWb : sWa) + vv * 16) = *(const uint4*)((const char*)(second ? p.wb : p.wa) + vv * 16);
-  }
-  // patch staging coordinates of this thread (padded-plane row / column relative to the tile's patch origin)
-  constexpr int NPV = CP_PF * CP_PT * 4, PV = (NPV + 255) / 256;
-  int prow[PV], pcol[PV];
-#pragma unroll
-  for (int i = 0; i < PV; ++i) {
-    const int v = tid + i * 256, px = v >> 2;
-    prow[i] = v < NPV ? px / CP_PT : -1000;
-    pcol[i] = px - (px / CP_PT) * CP_PT;
-  }
-  uint4 pr[PV];
-  auto load_patch = [&](int tt) {
-    const int pf0 = f0 - 1, pt0 = tt * CP_OT - 1;       // padded index of the patch origin (unpadded f0 - 2, t0 - 2)
-#pragma unroll
-    for (int i = 0; i < PV; ++i) {
-      const int gf = pf0 + prow[i], gt = pt0 + pcol[i];
-      const int piece = (tid + i * 256) & 3;
-      pr[i] = (prow[i] >= 0 && gf >= 0 && gf < FP && gt >= 0 && gt < TP) ? *(const uint4*)(in + ((size_t)gf * TP + gt) * 32 + piece * 8)
-                                                                        : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto store_patch = [&]() {
-#pragma unroll
-    for (int i = 0; i < PV; ++i) { const int v = tid + i * 256; if (v < NPV) *(uint4*)(sP + v * 16) = pr[i]; }
-  };
-  float ba[2], bb[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { ba[j] = p.ba[j * 16 + li]; bb[j] = p.bb[j * 16 + li]; }
-
-  load_patch(0);
-  store_patch();
-  __syncthreads();
-  for (int tt = 0; tt < tiles_t; ++tt) {
-    const int t0 = tt * CP_OT;
-    if (tt + 1 < tiles_t) load_patch(tt + 1);            // in flight under this tile's MFMAs
-
-    // ---- conv_a: intermediate row `wave`, 64 frames ----
-    f32x4_t acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    {
-      uint4 bf[2][2], af[2][4];
-      auto read_frags = [&](int tap, int buf) {
-        const int kh = tap / 3, kw = tap - kh * 3;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[buf][j] = *(const uint4*)(sWa + (tap * 32 + j * 16 + li) * 64 + lg * 16);
-        const char* arow = sP + ((wave + kh) * CP_PT + kw) * 64 + lg * 16;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[buf][mi] = *(const uint4*)(arow + (mi * 16 + li) * 64);
-      };
-      read_frags(0, 0);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cur = tap & 1;
-        if (tap + 1 < 9) read_frags(tap + 1, cur ^ 1);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) Mma16<bf16_t>::run(af[cur][mi], bf[cur][j], acc[mi][j]);
-      }
-    }
-    {   // bias + ReLU + zero outside the image -> bf16 intermediate tile (C layout: pixel 4 lg + r of the m-tile, channel li + 16 j)
-      const int fm = f0 - 1 + wave;
-      const bool frow_ok = fm >= 0 && fm < F;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int mc = mi * 16 + lg * 4 + r;
-          const int tm = t0 - 1 + mc;
-          const bool ok = frow_ok && tm >= 0 && tm < T;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float v = ok ? fmaxf(acc[mi][j][r] + ba[j], 0.f) : 0.f;
-            *(bf16_t*)(sM + (wave * CP_MT + mc) * 64 + (j * 16 + li) * 2) = f32_to_bf16(v);
-          }
-        }
-    }
-    __syncthreads();
-
-    // ---- conv_b: output row wave >> 1, frames 32 (wave & 1) .. +31 ----
-    const int orow = wave >> 1, oc0 = (wave & 1) * 32;
-    f32x4_t acb[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acb[mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    {
-      uint4 bf[2][2], af[2][2];
-      auto read_frags = [&](int tap, int buf) {
-        const int kh = tap / 3, kw = tap - kh * 3;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[buf][j] = *(const uint4*)(sWb + (tap * 32 + j * 16 + li) * 64 + lg * 16);
-        const char* arow = sM + ((orow + kh) * CP_MT + oc0 + kw) * 64 + lg * 16;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[buf][mi] = *(const uint4*)(arow + (mi * 16 + li) * 64);
-      };
-      read_frags(0, 0);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cur = tap & 1;
-        if (tap + 1 < 9) read_frags(tap + 1, cur ^ 1);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) Mma16<bf16_t>::run(af[cur][mi], bf[cur][j], acb[mi][j]);
-      }
-    }
-    // bias + residual (patch centre: row orow + 2, frame o + 2) + ReLU, still in the C layout
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = oc0 + mi * 16 + lg * 4 + r;
-        const char* xr = sP + ((orow + 2) * CP_PT + o + 2) * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float res = bf16_to_f32(*(const bf16_t*)(xr + (j * 16 + li) * 2));
-          acb[mi][j][r] = fmaxf(acb[mi][j][r] + bb[j] + res, 0.f);
-        }
-      }
-    __syncthreads();                                     // every wave is done with the patch and the intermediate tile
-
-    // ---- store: 16-pixel slabs transposed through LDS (over the patch) -> one 16-byte vector of 8 channels per lane ----
-    {
-      constexpr int SROW = 32 * 4 + 16;
-      char* slab = sP + wave * (16 * SROW);
-      const int spx = lane >> 2, sch = (lane & 3) * 8;
-      const int f = f0 + orow;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) *(float*)(slab + (lg * 4 + r) * SROW + (j * 16 + li) * 4) = acb[mi][j][r];
-        __builtin_amdgcn_wave_barrier();
-        const float4 x0 = *(const float4*)(slab + spx * SROW + sch * 4);
-        const float4 x1 = *(const float4*)(slab + spx * SROW + sch * 4 + 16);
-        const int o = oc0 + mi * 16 + spx, t = t0 + o;
-        if (o < CP_OT && t < T && f < F)
-          *(uint4*)(out + ((size_t)(f + 1) * TP + t + 1) * 32 + sch) =
-              make_uint4(pack2_bf16(x0.x, x0.y), pack2_bf16(x0.z, x0.w), pack2_bf16(x1.x, x1.y), pack2_bf16(x1.z, x1.w));
-      }
-    }
-    if (tt + 1 < tiles_t) {
-      __syncthreads();                                   // slabs read
-      store_patch();
-      __syncthreads();
-    }
-  }
-}
-
-bool conv_pair32_applicable(int dtype, int cin, int cmid, int cout, int stride_a, int stride_b, int taps_a, int taps_b) {
-  // opt-in (RVD_CONV_FUSE=1): measured 73.5 ms for the 32-channel stage against 67 ms for two conv2d launches once their
-  // residual reads were taken off the slab loop -- two HBM passes instead of five, but five barriers per 124 output pixels
-  const char* e = getenv("RVD_CONV_FUSE");          // read per call: the tests switch it between engines
-  const bool off = !(e && atoi(e) == 1);
-  return !off && dtype == DT_BF16 && cin == 32 && cmid == 32 && cout == 32 && stride_a == 1 && stride_b == 1 && taps_a == 9 && taps_b == 9;
-}
-
-int conv_pair32(hipStream_t s, const ConvPairArgs& a) {
-  if (a.B <= 0) return OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pair32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS));
-    attr_set = true;
-  }
-  const int blocks = a.B * ((a.F + CP_OF - 1) / CP_OF);
-  hipLaunchKernelGGL(conv_pair32_kernel, dim3(blocks), dim3(256), CP_LDS, s, a);
-  RVB_HIP_CHECK(hipGetLastError());
-  return OK;
-}
-
 // ------------------------------------------------------------------------------------ masked statistics pooling (TSTP)
 // pyannote StatsPool with frame weights: w = nearest-resampled mask; v1 = sum w + 1e-8; mean = sum(x w)/v1;
 // var = sum(w (x-mean)^2) / (v1 - sum(w^2)/v1 + 1e-8); output [mean | std], feature index = channel*F + f

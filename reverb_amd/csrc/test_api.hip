@@ -5,7 +5,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/rvb.h"
+#include "test_api.h"
 #include "kernels.h"
 #include "search.h"
 
@@ -424,13 +424,6 @@ int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, 
     RVB_HIP_CHECK(hipMemcpy(q.data(), dout.p, q.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < q.size(); ++i) out[i] = fp8_to_f32_host(q[i]) * scale;
   }
-  return OK;
-}
-
-// host only (no GPU needed): word alignment counts for reverb_amd/wer_evaluation/align.py
-int rvb_wer_counts(const int32_t* ref, int64_t n_ref, const int32_t* hyp, int64_t n_hyp, int64_t* counts) {
-  if ((!ref && n_ref > 0) || (!hyp && n_hyp > 0) || !counts || n_ref < 0 || n_hyp < 0) { set_error("rvb_wer_counts: bad argument"); return E_ARG; }
-  edit_counts(ref, n_ref, hyp, n_hyp, counts);
   return OK;
 }
 

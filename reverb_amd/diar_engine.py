@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import DiarCfg, RvbError, fptr
 
-DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32, "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16}
+DTYPES = {"f32": _lib.RVB_F32, "fp32": _lib.RVB_F32, "float32": _lib.RVB_F32, "bf16": _lib.RVB_BF16, "bfloat16": _lib.RVB_BF16, "fp8": _lib.RVB_FP8}
 
 
 def _check(rc: int, what: str):

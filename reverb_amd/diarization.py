@@ -595,7 +595,7 @@ class SpeakerDiarization:
         # call: the GIL is free while it waits for the GPU) -- the pooling masks of everything behind the first trunk pass, and
         # finish()'s speaker count and activity table.  Same functions on the same inputs: results are unchanged.
         excl = bool(self.params["embedding_exclude_overlap"])
-        head = min(W, self.HEAD_WINDOWS if os.environ.get("RVD_HOST_OVERLAP", "1") != "0" else W)
+        head = min(W, self.HEAD_WINDOWS)
         runs_all = None
         if head < W:
             wi, si, masks = embedding_items_from_classes(classes[:head], excl, 400, self.cfg["window_samples"])

@@ -8,7 +8,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reverb_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_test()
 SHAPES = [  # (M, N, K, act, out_f32, with_res, label)  -- the r640 1-hour workload (first slice: 144 chunks)
     (73728, 4096, 1024, 1, 0, 0, "ffn1"), (73728, 1024, 4096, 0, 1, 1, "ffn2"), (73728, 3072, 1024, 0, 0, 0, "qkv"),
     (73728, 1024, 1024, 0, 1, 1, "out/pw2"), (73728, 2048, 1024, 0, 0, 0, "pw1"), (8192, 10001, 1024, 0, 1, 0, "ctc slab"),

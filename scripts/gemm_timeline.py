@@ -3,7 +3,7 @@ how many workgroups sit in their epilogue at the same time."""
 import ctypes as C, sys
 import numpy as np
 from reverb_amd import _lib
-lib = _lib.load()
+lib = _lib.load_test()
 M = 73728
 for name, N, K, act, of32, res in (("ffn1", 4096, 1024, 1, 0, 0), ("out/pw2", 1024, 1024, 0, 1, 1), ("ffn2", 1024, 4096, 0, 1, 1),
                                    ("qkv", 3072, 1024, 0, 0, 0), ("plain N=K=1024 bf16 out", 1024, 1024, 0, 0, 0), ("N=K=1024 fp32 out, no residual", 1024, 1024, 0, 1, 0)):

@@ -36,7 +36,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def lab(monkeypatch):
+    """Engines created inside the test bind librvb_test.so, the build that reads the tuning switches (RVD_CONV_STREAM,
+    RVD_LINKAGE_MB, ...) from the environment; the product library ignores them (csrc/common.h lab_env)."""
+    monkeypatch.setenv("RVB_LAB", "1")
+
+
 @pytest.fixture(scope="session")
 def lib():
     from reverb_amd import _lib
-    return _lib.load()
+    return _lib.load_test()        # librvb_test.so: the product's objects + the rvb_test_* hooks (csrc/test_api.h)

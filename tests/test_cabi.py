@@ -17,13 +17,35 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(rvb_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_every_declared_symbol_is_exported_and_bound(lib):
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()                                   # the PRODUCT library
     names = declared_symbols()
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"librvb.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in reverb_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
+
+
+def test_product_library_carries_no_test_hooks(lib):
+    """the rvb_test_* hooks live in librvb_test.so (csrc/test_api.h); the product .so exports the two
+    public headers and nothing else of the C ABI."""
+    import subprocess
+    assert not any(n.startswith("rvb_test_") for n in declared_symbols())
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = {l.split()[-1] for l in nm.stdout.splitlines() if l.strip()}
+        assert not [n for n in exported if n.startswith(("rvb_test_", "rvd_test_"))]
+        c_abi = {n for n in exported if re.fullmatch(r"rv[bd]_[a-z0-9_]+", n)}
+        assert c_abi == set(_lib.SIGNATURES) | set(_lib.DIAR_SIGNATURES), c_abi ^ (set(_lib.SIGNATURES) | set(_lib.DIAR_SIGNATURES))
+    product = _lib.load()
+    text = open(os.path.join(ROOT, "reverb_amd", "csrc", "test_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(rvb_test_[a-z0-9_]+)\s*\(", text)))
+    assert hooks == sorted(_lib.TEST_SIGNATURES) and len(hooks) >= 20
+    for n in hooks:
+        assert hasattr(lib, n), f"librvb_test.so does not export {n}"
+        assert not hasattr(product, n), f"librvb.so exports the test hook {n}"
 
 
 def test_version_and_frame_count(lib):

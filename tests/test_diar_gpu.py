@@ -14,6 +14,18 @@ from reverb_amd import synth_diar as SD
 pytestmark = pytest.mark.gpu
 
 
+def _record(**kw):
+    """measured parity numbers of this run -> gpurun_out/parity_metrics.jsonl (copied to profiles/ when judged)"""
+    import json
+    from conftest import ROOT
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
 def windows_of(pcm, cfg):
     wav = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
     n, win, step = wav.shape[0], cfg["window_samples"], cfg["step_samples"]
@@ -182,7 +194,7 @@ def test_embedding_bf16_close_to_oracle(case, emb_case):
     eng.close()
 
 
-def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch):
+def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
     """conv_gemm.hip (stages 3-4 of the ResNet34, default) against resnet.hip's direct convolution kernel on the same
     bf16 weights and inputs: the two differ only in fp32 summation order, so the embeddings agree far tighter than
     either does with the fp32 oracle; the timing keys prove that both kernels really ran."""
@@ -211,7 +223,7 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
         assert cosw.min() > 0.995, (flag, cosw)
 
 
-def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch):
+def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
     """conv_stream.hip (the stride-1 convolutions of the 32- and 64-channel stages as a stream of tiles per workgroup: weights
     resident in LDS, patches by LDS-DMA ahead of the MFMAs, counted vmcnt) against resnet.hip's one-tile-per-workgroup kernel:
     same operand values, accumulation order and rounding points -- the embeddings must be IDENTICAL, whatever the split of
@@ -238,10 +250,8 @@ def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypat
         assert np.array_equal(out["0"], out[flag]), flag
 
 
-@pytest.mark.skipif(os.environ.get("RVB_TEST_CANDIDATES") != "1",
-                    reason="round-4 candidate (RVD_CONV_SC_FUSE=1): compiled and wired, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
-def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, monkeypatch):
-    """RVD_CONV_SC_FUSE=1 (round 4, opt-in): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4 becomes one
+def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, monkeypatch, lab):
+    """Default since round 5 (first run on a GPU there; lab switch RVD_CONV_SC_FUSE=0 = the separate kernel): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4 becomes one
     or two extra K steps of the block's second convolution (conv_gemm.hip, ConvArgs::in2) -- no shortcut kernel, no residual tensor.
     Not bit-identical by construction (the shortcut's output is no longer rounded to bf16 before it is added), so: the embeddings
     agree with the unfused run far tighter than either does with the fp32 oracle, and the counters prove which path ran."""
@@ -267,22 +277,18 @@ def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, m
     assert cosw.min() > 0.995, cosw
 
 
-@pytest.mark.skipif(os.environ.get("RVB_TEST_CANDIDATES") != "1",
-                    reason="round-4 candidate (RVD_EMB_FP8=1): compiled and wired, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
-def test_trunk_stages_3_and_4_in_fp8(case, emb_case, monkeypatch):
-    """RVD_EMB_FP8=1 (round 4): stages 3-4 of the ResNet34 trunk on e4m3 operands (conv_igemm8_kernel), per-tensor
+def test_trunk_stages_3_and_4_in_fp8(case, emb_case):
+    """DiarEngine(dtype="fp8") = rvd_model_cfg.dtype RVB_FP8 (BASELINE configs[4]; first run on a GPU in round 5): stages 3-4 of the ResNet34 trunk on e4m3 operands (conv_igemm8_kernel), per-tensor
     activation scales from the first trunk pass.  The first embed() call calibrates (bf16: it must equal the bf16 engine's result
     exactly); the second runs the fp8 kernels (counter), clips nothing of what it was calibrated on, and its embeddings stay close
     to the bf16 ones and to the fp32 oracle."""
     from reverb_amd.diar_engine import DiarEngine
-    monkeypatch.setenv("RVD_EMB_FP8", "0")
     ref = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
     ref.upload(case["pcm"])
     want16 = ref.embed(emb_case["wins"], emb_case["masks"])
     assert ref.emb_fp8()[0] == 0
     ref.close()
-    monkeypatch.setenv("RVD_EMB_FP8", "1")
-    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+    eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="fp8")
     eng.upload(case["pcm"])
     assert eng.emb_fp8()[0] == 0
     first = eng.embed(emb_case["wins"], emb_case["masks"])                    # calibration pass
@@ -298,31 +304,14 @@ def test_trunk_stages_3_and_4_in_fp8(case, emb_case, monkeypatch):
     active = emb_case["masks"].sum(1) > 0
     a, b, want = want16[active], got[active], emb_case["want"][active]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-    assert cos.min() > 0.99, cos
     cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
+    cosw16 = (a * want).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(want, axis=1))
+    _record(test="trunk_stages_3_and_4_in_fp8", cos_fp8_vs_bf16_min=float(cos.min()), cos_fp8_vs_bf16_mean=float(cos.mean()),
+            cos_fp8_vs_fp32_oracle_min=float(cosw.min()), cos_bf16_vs_fp32_oracle_min=float(cosw16.min()), embeddings=int(active.sum()))
+    assert cos.min() > 0.99, cos
     assert cosw.min() > 0.99, cosw
     eng.close()
 
-
-def test_fused_residual_blocks_equal_the_two_convolutions(case, emb_case, monkeypatch):
-    """resnet.hip conv_pair32_kernel (a whole 32-channel BasicBlock per launch, the intermediate tensor in LDS; RVD_CONV_FUSE=1)
-    against the same block as two conv2d launches: same operand values, same accumulation order, same rounding points --
-    the embeddings must be IDENTICAL, and the counters prove which path ran."""
-    from reverb_amd.diar_engine import DiarEngine
-    out, fused, flops = {}, {}, {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RVD_CONV_FUSE", flag)
-        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
-        eng.upload(case["pcm"])
-        eng.reset_timings(); eng.set_profiling(True)
-        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
-        eng.set_profiling(False)
-        fused[flag] = eng.timing("emb_conv_fused")[2]
-        flops[flag] = eng.timing("emb_conv_32")[1]
-        eng.close()
-    assert fused["0"] == 0 and fused["1"] >= 3           # the three stride-1 blocks of stage 1, per trunk pass
-    assert flops["0"] == flops["1"] > 0                    # the algorithmic work is counted the same way
-    assert np.array_equal(out["0"], out["1"])
 
 
 # ------------------------------------------------------------------------------------ clustering on the GPU
@@ -347,7 +336,7 @@ def test_centroid_linkage_matches_scipy(case, n, d, seed):
 
 
 @pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (17, 8, 5), (257, 16, 2), (1500, 256, 3), (3100, 64, 4), (6000, 32, 6)])
-def test_centroid_linkage_on_sixteen_workgroups_matches_scipy_and_the_one_workgroup_loop(case, monkeypatch, n, d, seed):
+def test_centroid_linkage_on_sixteen_workgroups_matches_scipy_and_the_one_workgroup_loop(case, monkeypatch, lab, n, d, seed):
     """Round 4: the merge loop on 16 persistent workgroups of one XCD (linkage.hip linkage_mb_kernel: one grid barrier per
     merge, exact nearest-neighbour candidates, agent-scope relaxed atomics through the XCD's L2).  RVD_LINKAGE_MB=1 forces it
     for any n (the default takes it from 3 000 points on).  Pinned to scipy like the one-workgroup loop -- same merges in
@@ -373,7 +362,7 @@ def test_centroid_linkage_on_sixteen_workgroups_matches_scipy_and_the_one_workgr
     assert np.array_equal(fcluster(got["1"], 0.7045654963945799, "distance"), fcluster(want, 0.7045654963945799, "distance"))
 
 
-def test_centroid_linkage_without_slot_compaction_matches_scipy(case, monkeypatch):
+def test_centroid_linkage_without_slot_compaction_matches_scipy(case, monkeypatch, lab):
     """10 240 < n <= ~11 500 points keep the LDS-resident state but not the re-dealt slot lists (registers for ten batches of
     1024): RVD_LINKAGE_COMPACT=0 runs that variant on a small input."""
     from scipy.cluster.hierarchy import linkage
@@ -390,7 +379,7 @@ def test_centroid_linkage_without_slot_compaction_matches_scipy(case, monkeypatc
     assert np.abs(got[:, 2] - want[:, 2]).max() < 1e-9
 
 
-def test_centroid_linkage_large_n_variant_matches_scipy(case, monkeypatch):
+def test_centroid_linkage_large_n_variant_matches_scipy(case, monkeypatch, lab):
     """More than ~11 500 points (3 h of audio) do not fit the LDS-resident state: the same loop then keeps its state in
     global memory.  RVD_LINKAGE_GLOBAL forces that variant on a small input so that it is checked against scipy too."""
     from scipy.cluster.hierarchy import linkage

@@ -303,8 +303,6 @@ def test_fp8_saturation_is_counted_not_silent():
     eng.close()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("RVB_TEST_CANDIDATES") != "1",
-                    reason="round-4 candidate (conv_igemm8_kernel): compiled, not yet run on a GPU; RVB_TEST_CANDIDATES=1 runs it")
 @pytest.mark.parametrize("B,Fi,Ti,Cin,Cout,stride,relu,use_res", [
     (2, 20, 30, 128, 128, 1, 1, True),        # the 128-channel stage: one K step per tap, two row tiles + a partial one
     (1, 10, 27, 256, 256, 1, 1, True),        # the 256-channel stage: two K steps per tap, 4 x 2 blocks per wave

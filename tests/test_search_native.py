@@ -15,7 +15,7 @@ C1_LOGITS = [[2.0, 0.1, 0.0, -1.0, -1.0], [0.2, 2.5, 0.1, -1.0, -0.5], [0.3, 2.0
 
 
 def native_prefix(lp: torch.Tensor, T: int, beam: int, blank: int = 0):
-    lib = _lib.load()
+    lib = _lib.load_test()
     tv, ti = lp.topk(beam, dim=-1)
     tv = np.ascontiguousarray(tv.numpy(), np.float32); ti = np.ascontiguousarray(ti.numpy(), np.int32)
     ml = max(T, 1)
@@ -97,7 +97,7 @@ def test_native_search_on_the_reference_goldens():
     written by the unmodified reference in oracle/gen_golden.py) -- no oracle in between."""
     import pytest
     from tests.golden_util import CASES, Case
-    lib = _lib.load()
+    lib = _lib.load_test()
     checked = 0
     for name in CASES:
         case = Case(name)
@@ -125,7 +125,7 @@ def test_rescoring_trie_against_a_python_trie(reversed_):
     pair must map to the row of ITS prefix and to its own target, a hypothesis' new rows must be a contiguous suffix of its
     path, and nothing may be shared across chunks."""
     import ctypes as C
-    lib = _lib.load()
+    lib = _lib.load_test()
     rng = np.random.default_rng(5 + reversed_)
     sos = eos = 99
     hyps, chunk_of = [], []
@@ -181,7 +181,7 @@ def native_joint(sd, cfg, mem, lpz, run, cat, K=None):
     import ctypes as C
     import torch.nn.functional as F
     from oracle import model_ref as M
-    lib = _lib.load()
+    lib = _lib.load_test()
     V = cfg["output_dim"]
     sos, beam = V - 1, run["beam"]
     pre_beam = int(run["pre_beam_ratio"] * beam)
@@ -257,6 +257,6 @@ def test_joint_decoding_native_state_machine_matches_reference_class(name):
 def test_host_pool_runs_every_item_once():
     """The worker pool behind the CTC search and the trie building (csrc/engine.h HostPool): jobs of varying width reuse the
     same threads; each work item of each job runs exactly once."""
-    lib = _lib.load()
+    lib = _lib.load_test()
     for threads, items, rounds in ((1, 10, 3), (4, 1000, 30), (16, 37, 50), (32, 0, 5), (8, 100000, 4)):
         _lib.check(lib.rvb_test_host_pool(threads, items, rounds), "rvb_test_host_pool")
