@@ -18,7 +18,9 @@ At N = 1 the same JSON line also carries
                     (FETCH_SIZE, WRITE_SIZE; corrected as MI355X_MICROARCH.md prescribes), `--traffic off` skips them
   pcie_inclusive    the same step with the 115 MB/h PCM upload from host memory inside it (never `value`)
   diarization       BASELINE configs[3] as a sub-record (bench_diar.py's step: own value, roofline, cpu_baseline)
-  joint_fp8         BASELINE configs[4] as a sub-record (bench_joint.py: ASR in fp8 + diarization + word->speaker join)
+  joint_fp8         BASELINE configs[4] as a sub-record (bench_joint.py: 3 h recording, ASR + diarization with their fp8 GEMMs,
+                    word->speaker join; carries sharded_s / replicated_s for the 8-GPU arithmetic)
+  parity_f32, asr_fp8, r268   the headline step in the exact-parity mode, with fp8 GEMMs, and on the smaller planning point
   cpu_baseline      the oracle (CPU port of the reference) on the first chunks of the same workload
 """
 from __future__ import annotations
@@ -58,7 +60,7 @@ def parse(argv=None):
     p.add_argument("--beam", type=int, default=10)
     p.add_argument("--ctc-weight", type=float, default=0.1)
     p.add_argument("--reverse-weight", type=float, default=0.0)
-    p.add_argument("--cpu-baseline-chunks", type=int, default=4, help="0 disables the CPU baseline leg")
+    p.add_argument("--cpu-baseline-chunks", type=int, default=8, help="0 disables the CPU baseline leg (BASELINE.md section 3: >= 8 chunks)")
     p.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     p.add_argument("--traffic", default="auto", choices=["auto", "off"],
                    help="auto: at N = 1 measure the GEMMs' HBM traffic with two nested rocprofv3 --pmc passes")
@@ -69,6 +71,8 @@ def parse(argv=None):
                         "all-gather of that posterior payload is timed once outside it (`xgmi_allgather` in the line)")
     p.add_argument("--no-diarization", action="store_true", help="skip the diarization sub-record (N = 1 only)")
     p.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (N = 1 only)")
+    p.add_argument("--no-variants", action="store_true", help="skip the parity_f32 / asr_fp8 / r268 sub-records (N = 1 only)")
+    p.add_argument("--joint-hours", type=float, default=3.0, help="length of the joint_fp8 sub-record's recording (BASELINE configs[4]: 3 h)")
     return p.parse_args(argv)
 
 
@@ -216,6 +220,61 @@ def diarization_record(device, steps=2, warmup=1, hours=1.0, dtype="bf16", cpu_w
                           cpu_windows=cpu_windows, traffic=traffic)
 
 
+# ------------------------------------------------------------------------------------------------ ASR variants (sub-records)
+def asr_variant(local_rank, model, dtype, hours, beam, ctc_weight, reverse_weight, steps=2, warmup=1, state=None, note=None):
+    """The headline step (fbank -> encoder -> CTC search -> rescoring -> host results, PCM resident) for another (model, dtype):
+    a compact sub-record -- RTFx, ms per step and the GEMM roofline fraction against that dtype's dense MFMA peak, measured
+    the same way as the main line (HIP events around the GEMM launches of the timed steps)."""
+    import torch
+    from reverb_amd import synth
+    from reverb_amd.engine import Engine
+    chunk = 2051
+    seconds = hours * 3600.0
+    n_samples = int(round(seconds * 16000))
+    n_chunks = -(-(1 + (n_samples - 400) // 160) // chunk)
+    cfg, sd = state if state is not None else synth.calibrated_state_dict(model, 0)
+    eng = Engine(cfg, sd, dtype=dtype, device=local_rank, max_chunks=n_chunks, chunk_frames=chunk)
+    del sd
+    try:
+        pcm = eng.pinned_pcm(n_samples)
+        pcm[:] = synth.synth_audio(seconds, seed=1234)
+        eng.upload_pcm(pcm)
+
+        def step():
+            return eng.decode_resident(eng.fbank(), ["attention_rescoring"], chunk, beam, ctc_weight, reverse_weight)["attention_rescoring"]
+
+        for _ in range(max(warmup, 1)):          # fp8: the first pass calibrates the activation scales (and runs in bf16)
+            step()
+        eng.reset_timings()
+        eng.set_profiling(True, gemm_only=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hyps = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.set_profiling(False)
+        g, g8 = eng.timing("gemm"), eng.timing("gemm_fp8")
+    finally:
+        eng.close()
+    rec = {"value": round(seconds * steps / dt, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(dt / steps * 1e3, 2),
+           "steps": steps, "warmup": max(warmup, 1), "dtype": dtype,
+           "workload": f"Reverb-ASR attention_rescoring, {hours:g} h in {n_chunks} chunks, synthetic {model} weights "
+                       f"(d={cfg['encoder_conf']['output_size']}), beam {beam}",
+           "tokens_per_step": int(sum(len(h.tokens) for h in hyps))}
+    k, peak = (g8, PEAK_TFLOPS["fp8"]) if dtype == "fp8" and g8 and g8["ms"] > 0 else (g, PEAK_TFLOPS["bf16" if dtype == "fp8" else dtype])
+    if k and k["ms"] > 0:
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "kernel": "fp8 GEMM launches" if k is g8 else f"{'bf16' if dtype == 'fp8' else dtype} GEMM launches",
+                           "gemm_ms_per_step": round(k["ms"] / steps, 3)}
+        if k is g8 and g and g["ms"] > 0:
+            rec["roofline"]["bf16_gemm_ms_per_step"] = round(g["ms"] / steps, 3)
+    if note:
+        rec["note"] = note
+    return rec
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -270,6 +329,7 @@ def main():
     else:
         from reverb_amd.engine import Engine
         cfg, sd = synth.calibrated_state_dict(args.model, 0)
+        state = (cfg, sd)                                   # the variants below reuse the weights (same model, other dtypes)
         eng = Engine(cfg, sd, dtype=args.dtype, device=local_rank, max_chunks=per_launch, chunk_frames=chunk)
         pcm = eng.pinned_pcm(n_samples)                   # page-locked host buffer the "reader" fills (rvb_host_alloc)
         pcm[:] = synth.synth_audio(seconds, seed=1234 + rank)
@@ -460,11 +520,28 @@ def main():
                 out["diarization"] = diarization_record(device, traffic=args.traffic)
             except Exception as ex:        # the headline line must not die with the second workload
                 out["diarization"] = {"error": f"{type(ex).__name__}: {ex}"}
-            try:                           # BASELINE configs[4]: joint pipeline, ASR encoder GEMMs in fp8
+            try:                           # BASELINE configs[4]: joint pipeline on a 3 h recording, fp8 MFMA GEMMs on both sides
                 import bench_joint
-                out["joint_fp8"] = bench_joint.run(local_rank, steps=2, warmup=1, hours=args.hours, dtype="fp8", model=args.model)
+                out["joint_fp8"] = bench_joint.run(local_rank, steps=2, warmup=1, hours=args.joint_hours, dtype="fp8", model=args.model,
+                                                   state=state)
             except Exception as ex:
                 out["joint_fp8"] = {"error": f"{type(ex).__name__}: {ex}"}
+        if not args.no_variants:
+            # the same step in the other modes: f32 = the only mode whose token ids are bit-exact against the
+            # reference (tests/test_longform_gpu.py decodes this very hour with 0 edits); fp8 = BASELINE configs[4]'s GEMM dtype
+            # on the ASR side alone; r268 = the smaller planning point of SURVEY section 8 (d = 640)
+            kw = dict(hours=args.hours, beam=args.beam, ctc_weight=args.ctc_weight, reverse_weight=args.reverse_weight)
+            for key, model, dtype, steps, note in (
+                    ("parity_f32", args.model, "f32", 1, "exact-parity mode: v_mfma_f32_16x16x4_f32, ids identical to the reference on this hour"),
+                    ("asr_fp8", args.model, "fp8", 3, "default fp8 policy: feed-forward GEMMs on e4m3 operands"),
+                    ("r268", "r268", args.dtype, 3, None)):
+                if key == "asr_fp8" and args.dtype == "fp8" or key == "r268" and args.model == "r268":
+                    continue
+                try:
+                    out[key] = asr_variant(local_rank, model, dtype, steps=steps, warmup=1, note=note,
+                                           state=state if model == args.model else None, **kw)
+                except Exception as ex:
+                    out[key] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in the C stdout buffer: get it out first,

@@ -238,8 +238,11 @@ int rvb_get_rescored_batch(rvb_engine* e, int32_t* lens, int32_t* tokens, int32_
 /* fp8 engines: forget the activation scales; the next rvb_encode calibrates again (in bf16) on its batch */
 int rvb_fp8_recalibrate(rvb_engine* e);
 /* fp8 engines: the calibrated per-tensor activation scales, 7 per conformer block (inputs of macaron FFN 1 / its hidden /
- * qkv / pointwise conv 1 / pointwise conv 2 / FFN 1 / its hidden; powers of two, value = fp8 * scale).  get: *n = 0 while the
- * engine is not calibrated; `scales` may be NULL to query n.  set: installs scales and ends calibration, so that the very next
+ * qkv / pointwise conv 1 / pointwise conv 2 / FFN 1 / its hidden; powers of two, value = fp8 * scale), followed by ONE more entry:
+ * the scale of conv1's fp8 output (policy bit 5; 0 = not measured, conv2 then runs in bf16) -- n = 7 * blocks + 1 (round 5: until
+ * then the subsampling scale was not part of the vector and ranks of a sharded run could not agree on it).  get: *n = 0 while the
+ * engine is not calibrated; `scales` may be NULL to query n.  set: n = 7 * blocks (subsampling scale untouched) or 7 * blocks + 1;
+ * installs scales and ends calibration, so that the very next
  * rvb_encode already runs in fp8 -- how the ranks of a sharded run agree on one set (element-wise maximum of what each rank
  * calibrated on its own slice, reverb_amd/dist.py), and how a deployment pins scales measured once. */
 int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n);
@@ -251,8 +254,7 @@ int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n);
 int rvb_get_fp8_saturation(rvb_engine* e, uint32_t* counts, int32_t* n, int reset);
 /* Round 4: rvb_set_fp8_policy's bit 5 puts the subsampling's second convolution (K = 9 d, a quarter of the encoder's FLOPs;
  * subsampling.py:189-190) on the fp8 path: conv1 then writes its ReLU output in e4m3 at a scale calibrated with the others.
- * *scale: that scale (0 while not calibrated -- conv2 then stays bf16; rvb_set_fp8_scales does not install it, a
- * calibration pass does); *clipped: values of conv1's output beyond 448 * scale since the last reset.  Either may be NULL. */
+ * *scale: that scale (0 while not calibrated -- conv2 then stays bf16; the last entry of rvb_get / rvb_set_fp8_scales); *clipped: values of conv1's output beyond 448 * scale since the last reset.  Either may be NULL. */
 int rvb_get_fp8_subsample(rvb_engine* e, float* scale, uint32_t* clipped, int reset);
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n);
 /* Work of the last rvb_attention_rescore: `pairs` = (hypothesis, position) log-probs served = the rows the reference's

@@ -48,6 +48,10 @@ typedef struct rvd_model_cfg {
 
 const char* rvd_last_error(void);
 int rvd_model_cfg_size(void);   /* sizeof(rvd_model_cfg) of this build */
+/* distinct windows one pass of the embedding trunk takes (768 unless RVD_EMB_BATCH says otherwise; halved by rvd_embed when the
+ * activations of that many windows -- 35 MB each in bf16 -- cannot be allocated): a host that prepares pooling masks underneath
+ * the first pass (reverb_amd/diarization.py) needs the masks of exactly this many windows up front */
+int rvd_emb_windows_per_pass(rvd_engine* e);
 
 int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out);
 void rvd_destroy(rvd_engine* e);

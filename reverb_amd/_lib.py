@@ -177,6 +177,7 @@ class DiarCfg(_SizedCfg):
 DIAR_SIGNATURES = {
     "rvd_last_error": (C.c_char_p, []),
     "rvd_model_cfg_size": (C.c_int, []),
+    "rvd_emb_windows_per_pass": (C.c_int, [_eng]),
     "rvd_create": (C.c_int, [C.POINTER(DiarCfg), C.c_int, C.POINTER(_eng)]),
     "rvd_destroy": (None, [_eng]),
     "rvd_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),

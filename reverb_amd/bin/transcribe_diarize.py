@@ -15,7 +15,8 @@ import time
 import numpy as np
 
 
-def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, overlap=True, **decode_kw):
+def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, world=1, rank=0, overlap=True, linkage_workgroups=4,
+        **decode_kw):
     """overlap (single process): both diarization networks run first (they fill the GPU); then the diarization's host part --
     speaker counting, the clustering (a 150 ms per hour merge loop on ONE compute unit), reconstruction -- runs in a second
     host thread underneath the ASR encoder, which fills the other 255 compute units on its own HIP stream (ctypes releases
@@ -72,7 +73,7 @@ def run(audio, asr, pipe, out_dir, mode="attention_rescoring", device=None, worl
         # the clustering's merge loop is persistent: with its default 16 workgroups it takes 16 CUs and an XCD's L2 away from the
         # ASR encoder it runs underneath (1 h: joint step 493-499 ms; 472 ms with 4 workgroups, 477 with one); recordings too long
         # for 4 workgroups' LDS (more than ~18 000 embeddings) get as many as they need (rvd_set_linkage_workgroups)
-        pipe.engine.set_linkage_workgroups(int(os.environ.get("RVD_JOINT_LINKAGE_G", "4")))
+        pipe.engine.set_linkage_workgroups(int(linkage_workgroups))
         try:
             with ThreadPoolExecutor(1) as ex:
                 fd = ex.submit(pipe.finish, classes, emb, uri)
@@ -109,7 +110,7 @@ def main(argv=None):
     p.add_argument("--pipeline-model", required=True, help="diarization pipeline directory (config.yaml, segmentation.pt, embedding.pt)")
     p.add_argument("--out-dir", required=True)
     p.add_argument("--mode", default="attention_rescoring")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"], help="fp8: ASR encoder GEMMs in fp8 (diarization stays bf16)")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"], help="fp8: the ASR encoder's feed-forward GEMMs and stages 3-4 of the embedding ResNet34 on e4m3 operands")
     p.add_argument("--sequential", action="store_true", help="do not overlap ASR and diarization")
     args = p.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +125,7 @@ def main(argv=None):
     from reverb_amd.diarization import Pipeline
     from reverb_amd.reverb import load_model
     asr = load_model(args.asr_model, gpu=local, dtype=args.dtype, max_chunks=256)
-    pipe = Pipeline.from_pretrained(args.pipeline_model, dtype="bf16" if args.dtype == "fp8" else args.dtype).to(f"cuda:{local}")
+    pipe = Pipeline.from_pretrained(args.pipeline_model, dtype=args.dtype).to(f"cuda:{local}")
     for audio in args.audios:
         _, ann, stm, t = run(audio, asr, pipe, args.out_dir, args.mode, device, world, rank, overlap=not args.sequential)
         if rank == 0:

@@ -29,7 +29,8 @@ static int emb_batch() {
   static int v = [] { const char* e = getenv("RVD_EMB_BATCH"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 768; }();
   return v;
 }
-#define EMB_BATCH (emb_batch())      // windows per trunk pass (activations 35 MB per window in bf16)
+// windows per trunk pass (activations 35 MB per window in bf16); per engine since round 5: halved when the workspace does not fit
+#define EMB_BATCH (e->emb_batch > 0 ? e->emb_batch : (e->emb_batch = emb_batch()))
 }  // namespace
 
 struct rvd_engine {
@@ -75,6 +76,7 @@ struct rvd_engine {
   // RVD_EMB_FP8=1 (round 4 candidate, not yet run on a GPU): stages 3-4 of the trunk on the fp8 implicit-GEMM kernel.  act8 = e4m3
   // copies of those stages' rotating buffers; scale8[((li - 2) * 8 + block) * 2 + {0: first convolution's output, 1: block output}],
   // calibrated by the first trunk pass (bf16, running maxima in d_amax8); emb_f8_state 0 not calibrated, 1 calibrating, 2 active
+  int emb_batch = 0;                     // windows per trunk pass (0 = not chosen yet: RVD_EMB_BATCH or 768)
   bool emb_fp8 = false, want_fp8 = false;      // want_fp8: created with dtype RVB_FP8
   int emb_f8_state = 0;
   DevBuf act8[4][3], d_amax8, d_sat8;
@@ -669,7 +671,17 @@ int embed_impl(rvd_engine* e, const int64_t* win, const float* mask, int n, floa
       ++i1;
     }
     const int B = (int)uniq.size(), ni = i1 - i0;
-    RVD_TRY(ensure_emb_workspace(e, B));
+    {
+      const int rc = ensure_emb_workspace(e, B);
+      if (rc == E_NOMEM && EMB_BATCH > 16) {        // the activations of B windows do not fit beside what else lives on this GPU:
+        e->emb_batch = EMB_BATCH / 2;               // fewer windows per pass from here on, same results
+        for (auto& row : e->act) for (auto& b : row) b.release();
+        for (auto& row : e->act8) for (auto& b : row) b.release();
+        e->act_cap = 0;
+        continue;                                   // regroup the same items under the smaller batch
+      }
+      if (rc != OK) return rc;
+    }
     RVD_TRY(e->e_win.ensure((size_t)B * 8));
     RVD_TRY(e->e_item_b.ensure((size_t)ni * 4));
     RVD_TRY(e->e_mask.ensure((size_t)ni * frames * 4));
@@ -730,6 +742,11 @@ extern "C" {
 const char* rvd_last_error(void) { return rvb::last_error(); }
 
 int rvd_model_cfg_size(void) { return (int)sizeof(rvd_model_cfg); }
+
+int rvd_emb_windows_per_pass(rvd_engine* e) {
+  if (!e) { set_error("rvd_emb_windows_per_pass: null engine"); return E_ARG; }
+  return EMB_BATCH;
+}
 
 int rvd_create(const rvd_model_cfg* cfg, int device, rvd_engine** out) {
   if (!cfg || !out) { set_error("rvd_create: null argument"); return E_ARG; }

@@ -2359,13 +2359,15 @@ int rvb_get_fp8_scales(rvb_engine* e, float* scales, int32_t* n) {
   if (!e || !n) { set_error("rvb_get_fp8_scales: null argument"); return E_ARG; }
   if (!e->fp8) { set_error("rvb_get_fp8_scales: not an RVB_FP8 engine"); return E_STATE; }
   if (e->f8_state != 2) { *n = 0; return OK; }                       // not calibrated yet
-  *n = (int32_t)(e->f8.size() * 7);
-  if (scales)
+  *n = (int32_t)(e->f8.size() * 7 + 1);
+  if (scales) {
     for (size_t l = 0; l < e->f8.size(); ++l) {
       const F8Scales& f = e->f8[l];
       const float v[7] = {f.in_ffm1, f.h_ffm, f.in_qkv, f.in_pw1, f.in_pw2, f.in_ff1, f.h_ff};
       for (int k = 0; k < 7; ++k) scales[l * 7 + k] = v[k];
     }
+    scales[e->f8.size() * 7] = e->f8_x1;      // conv1's fp8 output (policy bit 5); 0 = not measured: conv2 stays bf16
+  }
   return OK;
 }
 // Values that did not fit e4m3 at the installed scale (clipped to +-448 by the kernels that write the fp8 operands), per block
@@ -2404,8 +2406,16 @@ int rvb_get_fp8_subsample(rvb_engine* e, float* scale, uint32_t* clipped, int re
 int rvb_set_fp8_scales(rvb_engine* e, const float* scales, int32_t n) {
   if (!e || !scales) { set_error("rvb_set_fp8_scales: null argument"); return E_ARG; }
   if (!e->fp8) { set_error("rvb_set_fp8_scales: not an RVB_FP8 engine"); return E_STATE; }
-  if (!e->finalized || n != (int32_t)(e->enc.size() * 7)) { set_error("rvb_set_fp8_scales: need 7 scales per conformer block of a finalized engine"); return E_ARG; }
-  for (int i = 0; i < n; ++i) if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) { set_error("rvb_set_fp8_scales: scales must be positive and finite"); return E_ARG; }
+  const int32_t nb7 = (int32_t)(e->enc.size() * 7);
+  if (!e->finalized || (n != nb7 && n != nb7 + 1)) {
+    set_error("rvb_set_fp8_scales: need 7 scales per conformer block of a finalized engine (+ optionally the subsampling scale, as rvb_get_fp8_scales returns them)");
+    return E_ARG;
+  }
+  for (int i = 0; i < nb7; ++i) if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) { set_error("rvb_set_fp8_scales: scales must be positive and finite"); return E_ARG; }
+  if (n == nb7 + 1) {     // the vector of rvb_get_fp8_scales: its last entry is conv1's output scale (0 = none -> conv2 in bf16)
+    if (!(scales[nb7] >= 0.f) || !std::isfinite(scales[nb7])) { set_error("rvb_set_fp8_scales: the subsampling scale must be >= 0 and finite"); return E_ARG; }
+    e->f8_x1 = scales[nb7];
+  }
   e->f8.resize(e->enc.size());
   for (size_t l = 0; l < e->enc.size(); ++l) {
     const float* v = scales + l * 7;

@@ -141,9 +141,16 @@ class DiarEngine:
         """Workgroups the clustering's merge loop may take (0 default = 16, 1, 2, 4, 8, 16); the dendrogram does not depend on it."""
         _check(self.lib.rvd_set_linkage_workgroups(self._h, int(workgroups)), "rvd_set_linkage_workgroups")
 
+    def emb_windows_per_pass(self) -> int:
+        """distinct windows one pass of the embedding trunk takes (rvd_emb_windows_per_pass)"""
+        n = self.lib.rvd_emb_windows_per_pass(self._h)
+        if n < 0:
+            _check(n, "rvd_emb_windows_per_pass")
+        return int(n)
+
     def emb_fp8(self):
-        """RVD_EMB_FP8=1 engines (round-4 candidate): (state 0 off / not calibrated, 1 calibrating, 2 active; activation scales [32];
-        values clipped so far)."""
+        """dtype="fp8" engines (ResNet34 stages 3-4 on e4m3 operands): (state 0 off / not calibrated, 1 calibrating, 2 active;
+        activation scales [32]; values clipped at +-448 so far)."""
         st, n, cl = C.c_int32(0), C.c_int32(32), C.c_uint32(0)
         sc = np.zeros(32, np.float32)
         _check(self.lib.rvd_get_emb_fp8(self._h, C.byref(st), fptr(sc), C.byref(n), C.byref(cl)), "rvd_get_emb_fp8")

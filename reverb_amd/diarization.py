@@ -595,7 +595,8 @@ class SpeakerDiarization:
         # call: the GIL is free while it waits for the GPU) -- the pooling masks of everything behind the first trunk pass, and
         # finish()'s speaker count and activity table.  Same functions on the same inputs: results are unchanged.
         excl = bool(self.params["embedding_exclude_overlap"])
-        head = min(W, self.HEAD_WINDOWS)
+        head_windows = self.HEAD_WINDOWS or (eng.emb_windows_per_pass() if hasattr(eng, "emb_windows_per_pass") else 768)
+        head = min(W, head_windows)
         runs_all = None
         if head < W:
             wi, si, masks = embedding_items_from_classes(classes[:head], excl, 400, self.cfg["window_samples"])
@@ -632,7 +633,7 @@ class SpeakerDiarization:
         self.timings = dict(upload=t1 - t0, segmentation=t2 - t1, host_masks=t3 - t2, embedding=t4 - t3, windows=W, embeddings=n_items)
         return classes, emb
 
-    HEAD_WINDOWS = 768          # = the engine's windows per trunk pass (RVD_EMB_BATCH): the first pass starts on these masks alone
+    HEAD_WINDOWS = None         # None = the engine's windows per trunk pass: the first pass starts on these masks alone (tests set a number)
 
     def _host_pool(self):
         if getattr(self, "_pool", None) is None:

@@ -384,12 +384,13 @@ def share_fp8_scales(engine, n_frames: int, chunk_size: int, beam_size: int, dev
     engines that are calibrated already (scales stick to an engine across recordings)."""
     if getattr(engine, "dtype", None) != "fp8" or not hasattr(engine, "fp8_scales"):
         return
-    mine = engine.fp8_scales()
+    vector = getattr(engine, "fp8_scale_vector", engine.fp8_scales)      # with conv1's output scale (ADVICE r4); stubs: blocks only
+    mine = vector()
     if mine is None and n_frames > 0:
         engine.decode_resident(n_frames, ["ctc_greedy_search"], chunk_size, beam_size, 0.0, 0.0)      # bf16 pass, records max |.|
-        mine = engine.fp8_scales()
+        mine = vector()
     nb = int(engine.cfg.num_blocks)
-    send = np.zeros(1 + nb * 7, np.float32)
+    send = np.zeros(1 + nb * 7 + (1 if vector is not engine.fp8_scales else 0), np.float32)
     if mine is not None:
         send[0] = 1.0
         send[1:] = mine.reshape(-1)

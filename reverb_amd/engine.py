@@ -223,19 +223,27 @@ class Engine:
         check(self.lib.rvb_get_fp8_subsample(self.handle, C.byref(sc), C.byref(cl), 1 if reset else 0), "rvb_get_fp8_subsample")
         return float(sc.value), int(cl.value)
 
-    def fp8_scales(self) -> Optional[np.ndarray]:
-        """fp8 engines: the calibrated activation scales [blocks, 7], or None before the calibration batch."""
+    def fp8_scale_vector(self) -> Optional[np.ndarray]:
+        """fp8 engines: EVERY calibrated activation scale as rvb_get_fp8_scales returns them -- 7 per conformer block, then the
+        scale of conv1's fp8 output (policy group "subsample_conv2"; 0.0 = not measured) -- or None before the calibration
+        batch.  This is the vector ranks of a sharded run exchange (dist.share_fp8_scales) and set_fp8_scales() installs."""
         n = C.c_int32(0)
         check(self.lib.rvb_get_fp8_scales(self.handle, None, C.byref(n)), "rvb_get_fp8_scales")
         if n.value == 0:
             return None
         out = np.empty(n.value, np.float32)
         check(self.lib.rvb_get_fp8_scales(self.handle, fptr(out), C.byref(n)), "rvb_get_fp8_scales")
-        return out.reshape(-1, 7)
+        return out
+
+    def fp8_scales(self) -> Optional[np.ndarray]:
+        """fp8 engines: the calibrated activation scales of the conformer blocks [blocks, 7], or None before the calibration batch."""
+        v = self.fp8_scale_vector()
+        return None if v is None else v[:(v.size // 7) * 7].reshape(-1, 7)
 
     def set_fp8_scales(self, scales):
         """Install activation scales (e.g. the element-wise maximum over the ranks of a sharded run, or scales measured
-        once): the engine counts as calibrated, the next encode runs in fp8."""
+        once): the engine counts as calibrated, the next encode runs in fp8.  Accepts [blocks, 7] (the subsampling scale is
+        left as it is) or the whole fp8_scale_vector()."""
         a = np.ascontiguousarray(scales, dtype=np.float32).reshape(-1)
         check(self.lib.rvb_set_fp8_scales(self.handle, fptr(a), len(a)), "rvb_set_fp8_scales")
 
