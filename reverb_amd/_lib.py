@@ -128,6 +128,7 @@ TEST_SIGNATURES = {
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
                                    C.c_int, C.c_int]),
+    "rvb_test_conv_block32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_conv1": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_conv_igemm_fp8": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, _f32p, _f32p, _f32p]),

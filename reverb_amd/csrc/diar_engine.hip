@@ -577,6 +577,18 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
       const int oi = xi < 0 ? 1 : (xi + 2) % 3;
       void* tmp = e->act[li][ti].p;
       void* out = e->act[li][oi].p;
+      if (!Bk.has_sc && dx.F == d.F && dx.T == d.T &&
+          conv_block32_applicable(e->dtype, Bk.c1.cin, Bk.c1.cout, Bk.c2.cout, Bk.c1.stride, Bk.c2.stride, Bk.c1.taps, Bk.c2.taps, d.F, d.T)) {
+        // the whole residual block in one kernel (conv_block.hip): x read once, out written once, the intermediate tensor in LDS
+        ConvBlockArgs a{};
+        a.in = x; a.wa = Bk.c1.w.p; a.ba = Bk.c1.b.as<float>(); a.wb = Bk.c2.w.p; a.bb = Bk.c2.b.as<float>(); a.out = out;
+        a.B = B; a.F = d.F; a.T = d.T;
+        e->prof["emb_conv_block"].launches += 1;
+        { DScope sc(e, "emb_conv_32", 2.0 * 2.0 * (double)B * d.F * d.T * 32 * 32 * 9);
+          RVD_TRY(conv_block32(e->stream, a)); }
+        x = out; dx = d; xi = oi;
+        continue;
+      }
       const bool f8blk = e->emb_fp8 && li >= 2 && Bk.c2.w8.p && (bi == 0 || Bk.c1.w8.p);
       if (f8blk && e->emb_f8_state == 2) {
         // ---- fp8 path (candidate): block 0 of a stage keeps its stride-2 first convolution and its shortcut in bf16 (their input is the

@@ -260,6 +260,19 @@ struct ConvArgs {
   unsigned* sat8;         // += values of the fp8 output clipped at 448
 };
 int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
+// conv_block.hip: a whole stride-1 BasicBlock of 32 channels in one kernel (bf16): out = relu(conv_b(relu(conv_a(in) + ba)) + bb + in),
+// BN folded; the intermediate tensor lives in LDS, the residual comes out of the input patch.  Same tensor layouts as conv2d.
+struct ConvBlockArgs {
+  const void* in;      // bf16 [B][F+2][T+2][32]
+  const void* wa;      // bf16 [9][1][32][32] (conv2d's layout)
+  const float* ba;     // [32]
+  const void* wb;
+  const float* bb;
+  void* out;           // bf16 [B][F+2][T+2][32]
+  int B, F, T;
+};
+bool conv_block32_applicable(int dtype, int cin, int cmid, int cout, int stride_a, int stride_b, int taps_a, int taps_b, int F, int T);
+int conv_block32(hipStream_t s, const ConvBlockArgs& a);
 // conv_gemm.hip: 3x3 stride-1 convolution as an implicit GEMM on the LDS-DMA loop (bf16, Cin % 64 == 0, Cout % 128 == 0);
 // conv2d() routes to it when a.w_ig is set
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);

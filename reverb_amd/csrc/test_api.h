@@ -16,6 +16,8 @@ int rvb_test_gemm(int dtype, const float* A, const float* W, const float* bias, 
                   int conv, int cT1, int cF1, int cC, int cB);
 int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, int mode,
                      int silu, const float* add, float* out, int out_f32, int M, int d);
+/* conv_block.hip (a whole 32-channel BasicBlock per launch) on host floats, unbordered NHWC in / out, torch weight layout */
+int rvb_test_conv_block32(const float* x, const float* wa, const float* ba, const float* wb, const float* bb, float* out, int B, int F, int T);
 int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
                    const float* b, float* out, int B, int T0, int F0, int d);
 /* round-4 candidate: the fp8 implicit-GEMM convolution (csrc/conv_gemm.hip conv_igemm8_kernel) on host floats, see test_api.hip */

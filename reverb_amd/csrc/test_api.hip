@@ -120,6 +120,51 @@ int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float
   return down_T(dout, dtype, false, out, n);
 }
 
+// conv_block.hip on host floats: x [B][F][T][32] (unbordered NHWC), wa / wb [32][32][3][3] as torch stores Conv2d weights (BatchNorm
+// already folded by the caller), ba / bb [32]; out [B][F][T][32].  Builds the bordered planes and conv2d's weight layout.
+int rvb_test_conv_block32(const float* x, const float* wa, const float* ba, const float* wb, const float* bb, float* out, int B, int F, int T) {
+  T_TRY(need_gpu());
+  if (!x || !wa || !ba || !wb || !bb || !out || B < 1 || F < 1 || T < 1) { set_error("rvb_test_conv_block32: bad argument"); return E_ARG; }
+  const int FP = F + 2, TP = T + 2;
+  const size_t np = (size_t)B * FP * TP * 32;
+  std::vector<bf16_t> xb(np, 0);
+  for (int b = 0; b < B; ++b)
+    for (int f = 0; f < F; ++f)
+      for (int t = 0; t < T; ++t)
+        for (int c = 0; c < 32; ++c) xb[(((size_t)b * FP + f + 1) * TP + t + 1) * 32 + c] = f32_to_bf16(x[(((size_t)b * F + f) * T + t) * 32 + c]);
+  auto pack_w = [](const float* w) {                 // [o][ci][kh][kw] -> [tap][1][o][ci]
+    std::vector<bf16_t> p((size_t)9 * 32 * 32);
+    for (int o = 0; o < 32; ++o)
+      for (int ci = 0; ci < 32; ++ci)
+        for (int t = 0; t < 9; ++t) p[((size_t)t * 32 + o) * 32 + ci] = f32_to_bf16(w[((size_t)o * 32 + ci) * 9 + t]);
+    return p;
+  };
+  const std::vector<bf16_t> pa = pack_w(wa), pb = pack_w(wb);
+  Dev dx, dwa, dwb, dba, dbb, dout;
+  T_TRY(up_raw(dx, xb.data(), np * 2)); T_TRY(up_raw(dwa, pa.data(), pa.size() * 2)); T_TRY(up_raw(dwb, pb.data(), pb.size() * 2));
+  T_TRY(up_raw(dba, ba, 32 * 4)); T_TRY(up_raw(dbb, bb, 32 * 4));
+  T_TRY(dout.alloc(np * 2 + 256)); RVB_HIP_CHECK(hipMemset(dout.p, 0, np * 2 + 256));
+  if (!conv_block32_applicable(DT_BF16, 32, 32, 32, 1, 1, 9, 9, F, T)) { set_error("rvb_test_conv_block32: the fused block is switched off (RVD_CONV_BLOCK=0)"); return E_STATE; }
+  ConvBlockArgs a{};
+  a.in = dx.p; a.wa = dwa.p; a.ba = (const float*)dba.p; a.wb = dwb.p; a.bb = (const float*)dbb.p; a.out = dout.p; a.B = B; a.F = F; a.T = T;
+  T_TRY(conv_block32(nullptr, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<bf16_t> ob(np);
+  RVB_HIP_CHECK(hipMemcpy(ob.data(), dout.p, np * 2, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b)
+    for (int f = 0; f < F; ++f)
+      for (int t = 0; t < T; ++t)
+        for (int c = 0; c < 32; ++c) out[(((size_t)b * F + f) * T + t) * 32 + c] = bf16_to_f32(ob[(((size_t)b * FP + f + 1) * TP + t + 1) * 32 + c]);
+  // the zero border of the output plane must be untouched (the next convolution relies on it)
+  for (int b = 0; b < B; ++b)
+    for (int f = 0; f < FP; ++f)
+      for (int t = 0; t < TP; ++t)
+        if (f == 0 || f == FP - 1 || t == 0 || t == TP - 1)
+          for (int c = 0; c < 32; ++c)
+            if (ob[(((size_t)b * FP + f) * TP + t) * 32 + c] != 0) { set_error("rvb_test_conv_block32: the kernel wrote into the zero border"); return E_STATE; }
+  return OK;
+}
+
 int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
                         const int32_t* lens, float* out, int B, int T, int d, int K, int causal, const float* hist,
                         int hist_rows) {

@@ -214,11 +214,18 @@ class ClassRuns:
         self.hi = self.starts[self.w] + self.b
 
     def overlap_add(self, sel: np.ndarray, col: np.ndarray, ncol: int, weights: Optional[np.ndarray] = None) -> np.ndarray:
-        """sum over the runs `sel` of weights * [lo <= t < hi] into column `col` -> float64 (total, ncol)."""
-        n = (self.total + 1) * ncol
-        up = np.bincount(self.lo[sel] * ncol + col, weights=weights, minlength=n)
-        dn = np.bincount(self.hi[sel] * ncol + col, weights=weights, minlength=n)
-        return np.cumsum((up - dn).reshape(self.total + 1, ncol), axis=0)[:self.total].astype(np.float64, copy=False)
+        """sum over the runs `sel` of weights * [lo <= t < hi] into column `col` -> float64 (total, ncol).
+        The difference array is laid out column by column (each column's running sum is a contiguous pass; round 5: 3 h of
+        audio took 90 ms in the row-major form) and handed back as the transposed view, which is also the layout _top_count
+        wants; one bincount carries the +w at run starts and the -w at run ends."""
+        stride = self.total + 1
+        lo, hi = self.lo[sel], self.hi[sel]
+        base = col * stride
+        w = np.ones(lo.size, np.float64) if weights is None else np.asarray(weights, np.float64)
+        d = np.bincount(np.concatenate([lo + base, hi + base]), weights=np.concatenate([w, -w]), minlength=stride * ncol)
+        d = d.reshape(ncol, stride)
+        np.cumsum(d, axis=1, out=d)
+        return d[:, :self.total].T
 
     def coverage(self) -> np.ndarray:
         """number of chunks that cover each file-level frame: float64 (total,)."""

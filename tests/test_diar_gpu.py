@@ -200,6 +200,7 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
     either does with the fp32 oracle; the timing keys prove that both kernels really ran."""
     from reverb_amd.diar_engine import DiarEngine
     out, flops, ig = {}, {}, {}
+    monkeypatch.setenv("RVD_CONV_SC_FUSE", "0")      # the shortcut as a kernel of its own in all three runs: the FLOP counts compare
     for flag in ("0", "1", "2"):            # 2 = the default since round 4: the stride-2 convolutions of stages 3-4 as well
         monkeypatch.setenv("RVD_CONV_IGEMM", flag)
         eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
@@ -312,6 +313,59 @@ def test_trunk_stages_3_and_4_in_fp8(case, emb_case):
     assert cosw.min() > 0.99, cosw
     eng.close()
 
+
+
+def test_fused_basic_block_equals_two_convolutions(case, emb_case, monkeypatch, lab):
+    """conv_block.hip conv_block32_kernel (round 5, default): a whole stride-1 BasicBlock of the 32-channel stage per launch -- the
+    intermediate tensor stays in LDS, the residual comes out of the input patch -- against the same block as two convolution
+    launches (lab switch RVD_CONV_BLOCK=0): same operand values, same accumulation order, same rounding points, so the
+    embeddings must be IDENTICAL; the counters prove which path ran and that the FLOPs credited are the same."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, fused, flops, streamed = {}, {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_BLOCK", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        fused[flag] = eng.timing("emb_conv_block")[2]
+        flops[flag] = eng.timing("emb_conv_32")[1]
+        streamed[flag] = eng.timing("emb_conv_stream")[2]
+        eng.close()
+    assert fused["0"] == 0 and fused["1"] >= 3                     # the three blocks of stage 1, per trunk pass
+    assert streamed["0"] - streamed["1"] == 2 * fused["1"]         # each replaces two streamed convolutions
+    assert flops["1"] == flops["0"] > 0
+    assert np.array_equal(out["0"], out["1"])
+
+
+def test_fused_basic_block_on_ragged_shapes(lib):
+    """The fused block through librvb_test.so's hook on planes whose height is not a multiple of 4 and whose width is not a
+    multiple of 60 (partial row tiles, a partial last time tile, a single tile), against fp64 on the bf16-rounded operands with
+    the intermediate rounded to bf16 as the kernel (and the unfused path) rounds it."""
+    from reverb_amd import _lib
+    from util import bf16_round, f32
+    rng = np.random.default_rng(5)
+    for B, F, T in ((2, 6, 61), (1, 9, 130), (1, 3, 17), (1, 4, 60)):
+        x = bf16_round(f32(np.abs(rng.standard_normal((B, F, T, 32)))))
+        wa = bf16_round(f32(rng.standard_normal((32, 32, 3, 3)) / 12.0))
+        wb = bf16_round(f32(rng.standard_normal((32, 32, 3, 3)) / 12.0))
+        ba, bb = f32(rng.standard_normal(32) * 0.1), f32(rng.standard_normal(32) * 0.1)
+        got = np.zeros((B, F, T, 32), np.float32)
+        _lib.check(lib.rvb_test_conv_block32(_lib.fptr(x), _lib.fptr(wa), _lib.fptr(ba), _lib.fptr(wb), _lib.fptr(bb), _lib.fptr(got), B, F, T))
+
+        def conv(inp, w, b):            # NHWC 3x3 pad 1, fp64
+            p = np.pad(inp.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+            o = np.zeros(inp.shape[:3] + (32,))
+            for kh in range(3):
+                for kw in range(3):
+                    o += p[:, kh:kh + F, kw:kw + T, :] @ w[:, :, kh, kw].astype(np.float64).T
+            return o + b
+        mid = bf16_round(f32(np.maximum(conv(x, wa, ba), 0.0)))
+        want = np.maximum(conv(mid, wb, bb) + x, 0.0)
+        err = np.abs(got - want)
+        assert err.max() < 2e-2 * max(1.0, np.abs(want).max()), (B, F, T, err.max())
+        assert np.mean(err > 1e-2 * np.abs(want).max()) < 1e-3, (B, F, T)      # bf16 output rounding (and rare double roundings of mid)
 
 
 # ------------------------------------------------------------------------------------ clustering on the GPU
