@@ -234,6 +234,7 @@ def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypat
     from reverb_amd.diar_engine import DiarEngine
     out, streamed, flops = {}, {}, {}
     monkeypatch.setenv("RVD_CONV_STREAM64", "1")            # the 64-channel stage too (opt-in: measured equal to the direct kernel)
+    monkeypatch.setenv("RVD_CONV_BLOCK", "0")                # stage 1 as single convolutions (the default fuses its blocks: conv_block.hip)
     for flag in ("0", "1", "2", "3", "17"):
         monkeypatch.setenv("RVD_CONV_STREAM", flag)
         eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
