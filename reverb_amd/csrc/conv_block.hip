@@ -23,25 +23,39 @@
 //     LDS-DMA's source side for the patches and on the write side for mid: every lane group of a fragment read then covers all
 //     64 banks once.
 //
+// Third form (the one below) -- the two convolutions are ROLES of different waves, one tile apart:
+//   waves 0-3 (A)  first convolution of tile k+1: 24 m-tiles of 16 pixels, 6 per wave, weights of conv_a in registers; bias + ReLU +
+//                  zeroing; mid(k+1) written to LDS
+//   waves 4-7 (B)  epilogue of tile k-1 (bias + residual + ReLU, stores), then the second convolution of tile k from mid(k): output
+//                  row w - 4, 4 m-tiles, weights of conv_b in registers; the residual vectors of tile k read out of patch k
+// Every SIMD holds one wave of each role and there is ONE barrier per tile; 149 VGPRs.  Measured EQUAL to the second form (all 8
+// waves in the same phase, two barriers per tile: 42.5-43.0 vs 42.8 ms per hour, profiles/r05_call4_*.txt, r05_call5_*.txt), so
+// phase serialisation was not what was left.  What the counters say (profiles/r05_call7_conv_block_counters.txt, per hour):
+//   HBM       58 GB read (the 4 halo rows of a patch come out of the L2: 1.03 x the plane) + 55 GB written = 113 GB in 42.8 ms =
+//             2.6 TB/s; the two-launch form moves 170 + 111 = 281 GB at 5.2 TB/s -- THAT form is bound by HBM, this one is not
+//   LDS       bank-conflict cycles 10 % of the LDS-active cycles (two-launch form: 44 %), the LDS 27 % busy
+//   MFMA      SQ_VALU_MFMA_BUSY_CYCLES = 41 % of the launch (1.5 x the useful FLOPs with the halo rows and the 64-wide m-tiles: 0.99 PF/s)
+//   waves     33 % issuing, 43 % stalled at issue (matrix pipe / dependency), 24 % parked at the barrier or a counter; 3.25 VALU
+//             instructions per MFMA
+// i.e. 3.0 us per tile of which 1.2 us are MFMA time; the remainder is VALU work sharing the issue slots (bias / ReLU / zeroing /
+// packing / residual: next step packed fp32 math), four LDS-DMA issues per wave and tile, and a workgroup's start-up (weights,
+// first patch, the one-tile offset of role B) paid once per 17 tiles.
+//
 // Geometry (unbordered coordinates; the tensors carry a one-pixel zero border, element (f, t) sits at bordered (f + 1, t + 1)):
 //   workgroup = 512 threads = 8 waves, owns output rows f0 .. f0+3 of one window and walks tiles of 60 frames, t0 = 60 tt
 //   patch  8 rows x 64 pixels x 64 B: bordered rows f0-1 .. f0+6, bordered columns t0-1 .. t0+62 (clamped into the plane: what the
-//          clamp changes only feeds mid positions outside the image, and those are set to zero)
+//          clamp changes only feeds mid positions outside the image, and those are set to zero); a ring of THREE (tile k for the
+//          residual, tile k+1 for conv_a, tile k+2 arriving)
 //   mid    6 rows x 64 pixels: rows f0-1 .. f0+4, columns t0-1 .. t0+62 (columns 62, 63 are never used); ZERO outside the image --
-//          the zero border the second convolution sees in the unfused path
-//   conv_a 24 m-tiles of 16 pixels, 3 per wave;  conv_b 16 m-tiles, 2 per wave (row w >> 1, pixels 32 (w & 1) .. +31)
-//   LDS    patches 2 x 32 768 + mid 24 576 (+ pads) = 90 368 B: one workgroup per CU, two waves per SIMD
+//          the zero border the second convolution sees in the unfused path; TWO buffers (tile k read, tile k+1 written)
+//   LDS    patches 3 x 32 768 + mid 2 x 24 576 (+ pads) = 147 840 B: one workgroup per CU, two waves per SIMD
 //
-// Iteration k (tile k of the walk):
-//   a. LDS-DMA of patch k+1 into the other patch buffer (its readers -- conv_a and the residual reads of tile k-1 -- finished
-//      before barrier B of iteration k-1)
-//   b. conv_a on patch k; the wave's residual vectors are read from the patch; bias + ReLU + zeroing; mid written
-//      (mid's readers -- conv_b of tile k-1 -- finished before barrier A of iteration k-1)
-//   c. barrier B: mid visible
-//   d. conv_b on mid
-//   e. s_waitcnt vmcnt(0): this wave's pieces of patch k+1 have landed (and the stores of tile k-1 have drained: they were issued
-//      a whole tile ago); barrier A: patch k+1 visible, mid free
-//   f. epilogue in registers: bias + residual + ReLU, one 16-byte store per lane and m-tile, draining under iteration k+1
+// Body k of the walk (all waves; then `s_waitcnt vmcnt(0) lgkmcnt(0)` and the barrier):
+//   all  LDS-DMA of patch k+2 into ring slot (k+2) % 3 -- last read in body k-1 (residual of tile k-1) and k-2 (conv_a of tile k-1)
+//   A    conv_a(k+1) from ring slot (k+1) % 3 (requested in body k-1, landed before that body's barrier) -> mid[(k+1) & 1], last
+//        read by conv_b(k-1) in body k-1
+//   B    epilogue(k-1) from registers: its stores are issued at the top of the body, right behind the DMA, so the vmcnt(0) at the
+//        end of the body finds them drained; conv_b(k) from mid[k & 1] (written in body k-1); residual vectors of tile k
 //
 // Results: operand values, accumulation order (taps 0..8, one 32-channel K step each) and rounding points (mid and out rounded to
 // bf16 after bias / residual / ReLU in fp32) are those of two conv_stream / conv_kernel launches
@@ -61,8 +75,9 @@ constexpr int CB_ROW = CB_PT * 64;                   // one patch / mid row: 4 0
 constexpr int CB_PATCH = CB_PF * CB_ROW;             // 32 768 B
 constexpr int CB_MID = CB_MF * CB_ROW;               // 24 576 B
 constexpr int CB_OFF_P0 = 0;
-constexpr int CB_OFF_MID = CB_OFF_P0 + 2 * CB_PATCH + 128;        // 128 B: the two pixels garbage m-tile positions read past a buffer
-constexpr int CB_LDS = CB_OFF_MID + CB_MID + 128;
+constexpr int CB_OFF_MID = CB_OFF_P0 + 3 * CB_PATCH + 128;        // 128 B: the two pixels garbage m-tile positions read past a buffer
+constexpr int CB_MID_PITCH = CB_MID + 128;
+constexpr int CB_LDS = CB_OFF_MID + 2 * CB_MID_PITCH;
 
 typedef unsigned cb_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -107,16 +122,18 @@ __device__ inline const char* cb_uniform(const char* q) {
   return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-// 9 taps of one convolution for NM m-tiles of this wave.  w: the weight fragments (registers); img: patch or mid; a[m][kw]: this
-// lane's swizzled byte offset of m-tile m's pixel at column shift kw, row shift 0 (a row further down is + CB_ROW: the swizzle
-// does not depend on the row); the pixel fragments of tap + 1 are read before the MFMAs of tap are issued.
+// 9 taps of one convolution for NM consecutive m-tiles of this wave.  w: the weight fragments (registers); img: patch or mid at the
+// wave's first m-tile; a[kw]: this lane's swizzled byte offset at column shift kw, row shift 0.  The next m-tile is 16 pixels =
+// 1 024 B further (m-tiles are numbered along rows and a row is four of them), a row further down is + CB_ROW; neither changes
+// bit 2 of the pixel index, so the swizzle is the same and both are immediate offsets of the read.  The pixel fragments of
+// tap + 1 are read before the MFMAs of tap are issued.
 template <int NM>
-__device__ inline void cb_conv9(const uint4 (&w)[9][2], const char* img, const unsigned (&a)[NM][3], f32x4_t (&acc)[NM][2]) {
+__device__ inline void cb_conv9(const uint4 (&w)[9][2], const char* img, const unsigned (&a)[3], f32x4_t (&acc)[NM][2]) {
   uint4 xf[2][NM];
   auto read_frags = [&](int tap, int buf) __attribute__((always_inline)) {
     const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) xf[buf][m] = *(const uint4*)(img + a[m][kw] + kh * CB_ROW);
+    for (int m = 0; m < NM; ++m) xf[buf][m] = *(const uint4*)(img + a[kw] + m * 1024 + kh * CB_ROW);
   };
 #pragma unroll
   for (int m = 0; m < NM; ++m)
@@ -176,115 +193,117 @@ __global__ __launch_bounds__(512, 2) void conv_block32_kernel(ConvBlockArgs p, i
     unsigned off[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) off[g] = rowoff + (unsigned)min(max(t0 - 1 + g * 16 + ppx, 0), TP - 1) * (CB_NT * 2) + piece_b;
-    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(lds_base + CB_OFF_P0 + (k & 1) * CB_PATCH + wave * CB_ROW));
+    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(lds_base + CB_OFF_P0 + (k % 3) * CB_PATCH + wave * CB_ROW));
   };
   issue(0);
+  if (n_tiles > 1) issue(1);
 
-  // ---- both weight sets into registers: lane (li, lg) supplies, for n-tile j, the row of channel (li >> 2) * 8 + j * 4 + (li & 3),
-  // k chunk lg (global layout [tap][channel][64 B])
-  uint4 wa[9][2], wb[9][2];
+  // ---- this wave's role and its weight set, in registers: lane (li, lg) supplies, for n-tile j, the row of channel
+  // (li >> 2) * 8 + j * 4 + (li & 3), k chunk lg (global layout [tap][channel][64 B]); its 8 channels are then lg * 8 .. + 7
+  // (accumulator (j, r) is channel lg * 8 + j * 4 + r)
+  const bool role_a = wave < 4;
+  uint4 w[9][2];
+  float bias_r[8];
   {
-    const char* ga = (const char*)p.wa;
-    const char* gb = (const char*)p.wb;
+    const char* gw = (const char*)(role_a ? p.wa : p.wb);
+    const float* gb = role_a ? p.ba : p.bb;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ch = (li >> 2) * 8 + j * 4 + (li & 3);
-        wa[tap][j] = *(const uint4*)(ga + (tap * CB_NT + ch) * 64 + lg * 16);
-        wb[tap][j] = *(const uint4*)(gb + (tap * CB_NT + ch) * 64 + lg * 16);
-      }
+      for (int j = 0; j < 2; ++j) w[tap][j] = *(const uint4*)(gw + (tap * CB_NT + (li >> 2) * 8 + j * 4 + (li & 3)) * 64 + lg * 16);
+    const float4 b0 = *(const float4*)(gb + lg * 8), b1 = *(const float4*)(gb + lg * 8 + 4);
+    bias_r[0] = b0.x; bias_r[1] = b0.y; bias_r[2] = b0.z; bias_r[3] = b0.w; bias_r[4] = b1.x; bias_r[5] = b1.y; bias_r[6] = b1.z; bias_r[7] = b1.w;
   }
-  // this lane's 8 channels are lg * 8 .. + 7: accumulator (j, r) is channel lg * 8 + j * 4 + r
-  float ba_r[8], bb_r[8];
-  {
-    const float4 a0 = *(const float4*)(p.ba + lg * 8), a1 = *(const float4*)(p.ba + lg * 8 + 4);
-    const float4 b0 = *(const float4*)(p.bb + lg * 8), b1 = *(const float4*)(p.bb + lg * 8 + 4);
-    ba_r[0] = a0.x; ba_r[1] = a0.y; ba_r[2] = a0.z; ba_r[3] = a0.w; ba_r[4] = a1.x; ba_r[5] = a1.y; ba_r[6] = a1.z; ba_r[7] = a1.w;
-    bb_r[0] = b0.x; bb_r[1] = b0.y; bb_r[2] = b0.z; bb_r[3] = b0.w; bb_r[4] = b1.x; bb_r[5] = b1.y; bb_r[6] = b1.z; bb_r[7] = b1.w;
-  }
-
-  // ---- this wave's m-tiles.  conv_a: indices 3 w .. 3 w + 2 of (mid row r, 16-pixel group mi) = divmod(idx, 4);
-  //      conv_b: output row w >> 1, pixel groups 2 (w & 1) and 2 (w & 1) + 1.  Lane (li, lg) = (pixel li of the m-tile, chunk lg).
-  int ar[3], ami[3];
-  unsigned aoff[3][3], moff[3];          // conv_a: fragment offsets per column shift; where this lane's mid vector goes
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    ar[m] = (wave * 3 + m) >> 2; ami[m] = (wave * 3 + m) & 3;
-    const unsigned g = (unsigned)(ar[m] * CB_PT + ami[m] * 16 + li);
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) aoff[m][kw] = cb_swz(g + kw, lg);
-    moff[m] = cb_swz(g, lg);
-  }
-  const int brow = wave >> 1, bmi0 = (wave & 1) * 2;
-  unsigned boff[2][3], roff[2];          // conv_b: fragment offsets in mid; the residual vector in the patch
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const unsigned g = (unsigned)(brow * CB_PT + (bmi0 + m) * 16 + li);
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) boff[m][kw] = cb_swz(g + kw, lg);
-    roff[m] = cb_swz(g + 2 * CB_PT + 2, lg);                   // x(f, t) = patch(row + 2, column + 2)
-  }
-  char* mid = cb_smem + CB_OFF_MID;
-  const int fo = f0 + brow;                                    // this wave's output row
-  const unsigned frow_off = (unsigned)(min(fo, p.F - 1) + 1) * TP;
-
-  // ---- prologue: patch 0 landed, visible
-  cb_wait_all();
+  char* mid0 = cb_smem + CB_OFF_MID;
+  cb_wait_all();                       // patches 0 (and 1) landed
   __syncthreads();
 
-  for (int k = 0; k < n_tiles; ++k) {
-    const int t0 = (tt0 + k) * CB_OT;
-    const char* patch = cb_smem + CB_OFF_P0 + (k & 1) * CB_PATCH;
-    if (k + 1 < n_tiles) issue(k + 1);                                         // (a)
-
-    // (b) first convolution: mid(r, px) = sum_taps wa[tap] . patch(r + kh, px + kw)
-    {
-      f32x4_t acc[3][2];
-      cb_conv9<3>(wa, patch, aoff, acc);
+  if (role_a) {
+    // ======== role A: first convolution, one tile ahead.  m-tiles 6 w .. 6 w + 5 of (mid row r, 16-pixel group mi) = divmod(idx, 4)
+    // (m-tile idx sits at pixel 16 idx of the row-major [6][64] mid image: consecutive m-tiles are 1 024 B apart)
+    unsigned aoff[3];                      // this lane's fragment offset at the wave's first m-tile, per column shift
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int f = f0 - 1 + ar[m], t = t0 - 1 + ami[m] * 16 + li;
-        const bool inside = f >= 0 && f < p.F && t >= 0 && t < p.T;            // outside: the zero border conv_b must see
+    for (int kw = 0; kw < 3; ++kw) aoff[kw] = cb_swz((unsigned)(wave * 6 * 16 + li + kw), lg);
+    const unsigned moff = cb_swz((unsigned)(wave * 6 * 16 + li), lg);      // where this lane's mid vector of m-tile 0 goes
+    auto conv_a = [&](int k) __attribute__((always_inline)) {      // mid(r, px) = sum_taps wa[tap] . patch(r + kh, px + kw), tile k
+      const int t0 = (tt0 + k) * CB_OT;
+      const char* patch = cb_smem + CB_OFF_P0 + (k % 3) * CB_PATCH;
+      char* mid = mid0 + (k & 1) * CB_MID_PITCH;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {            // two halves of three m-tiles: 24 accumulator + 24 fragment registers live at a time
+        f32x4_t acc[3][2];
+        cb_conv9<3>(w, patch + h * 3 * 1024, aoff, acc);
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm) {
+          const int m = h * 3 + mm, idx = wave * 6 + m;
+          const int f = f0 - 1 + (idx >> 2), t = t0 - 1 + (idx & 3) * 16 + li;
+          const bool inside = f >= 0 && f < p.F && t >= 0 && t < p.T;            // outside: the zero border conv_b must see
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[mm][e >> 2][e & 3] + bias_r[e], 0.f) : 0.f;
+          *(uint4*)(mid + moff + m * 1024) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        }
+      }
+    };
+    conv_a(0);
+    cb_wait_lds();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int k = 0; k < n_tiles; ++k) {
+      if (k + 2 < n_tiles) issue(k + 2);
+      if (k + 1 < n_tiles) conv_a(k + 1);
+      cb_wait_all();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  } else {
+    // ======== role B: second convolution of output row w - 4 (its four 16-pixel groups), residual, stores
+    const int brow = wave - 4;
+    unsigned boff[3];                      // fragment offset in mid at the row's first m-tile, per column shift
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) boff[kw] = cb_swz((unsigned)(brow * CB_PT + li + kw), lg);
+    const unsigned roff = cb_swz((unsigned)((brow + 2) * CB_PT + li + 2), lg);      // residual: x(f, t) = patch(row + 2, column + 2)
+    const int fo = f0 + brow;                                  // this wave's output row
+    const unsigned frow_off = (unsigned)(min(fo, p.F - 1) + 1) * TP;
+    f32x4_t acc2[2][2][2];                 // [half][m-tile of the half][n-tile]
+    cb_u32x4 rp[4];
+    auto epilogue = [&](int k) __attribute__((always_inline)) {    // bias + residual + ReLU in fp32, one 16-byte store per lane and m-tile
+      const int t0 = (tt0 + k) * CB_OT;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[m][e >> 2][e & 3] + ba_r[e], 0.f) : 0.f;
-        *(uint4*)(mid + moff[m]) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-      }
-    }
-    // the residual of this wave's outputs, read before barrier B (see the file header)
-    cb_u32x4 rp[2];
+        for (int e = 0; e < 8; ++e) v[e] = acc2[m >> 1][m & 1][e >> 2][e & 3] + bias_r[e];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) rp[m] = *(const cb_u32x4*)(patch + roff[m]);
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += __uint_as_float(rp[m][e] << 16);
+          v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        const int o = m * 16 + li, t = t0 + o;
+        if (o < CB_OT && t < p.T && fo < p.F)
+          *(uint4*)(out_b + ((size_t)(frow_off + t + 1) * CB_NT + lg * 8) * 2) =
+              make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+      }
+    };
     cb_wait_lds();
-    __builtin_amdgcn_s_barrier();                                              // (c) barrier B
+    __builtin_amdgcn_s_barrier();          // role A's conv_a(0)
     asm volatile("" ::: "memory");
-
-    // (d) second convolution: out(row, o) = sum_taps wb[tap] . mid(row + kh, o + kw)
-    f32x4_t acc2[2][2];
-    cb_conv9<2>(wb, mid, boff, acc2);
-    cb_wait_all();                                                             // (e)
-    __builtin_amdgcn_s_barrier();                                              //     barrier A
-    asm volatile("" ::: "memory");
-
-    // (f) epilogue: bias + residual + ReLU in fp32, one 16-byte store per lane and m-tile (a wave stores 1 KiB contiguous)
+    for (int k = 0; k < n_tiles; ++k) {
+      if (k + 2 < n_tiles) issue(k + 2);
+      if (k > 0) epilogue(k - 1);
+      // out(row, o) = sum_taps wb[tap] . mid(row + kh, o + kw), tile k; then its residual vectors out of patch k
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float v[8];
+      for (int h = 0; h < 2; ++h) cb_conv9<2>(w, mid0 + (k & 1) * CB_MID_PITCH + h * 2 * 1024, boff, acc2[h]);      // two halves: 16 fragment registers live
+      const char* patch = cb_smem + CB_OFF_P0 + (k % 3) * CB_PATCH;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc2[m][e >> 2][e & 3] + bb_r[e];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] += __uint_as_float(rp[m][e] << 16);
-        v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      const int o = (bmi0 + m) * 16 + li, t = t0 + o;
-      if (o < CB_OT && t < p.T && fo < p.F)
-        *(uint4*)(out_b + ((size_t)(frow_off + t + 1) * CB_NT + lg * 8) * 2) =
-            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+      for (int m = 0; m < 4; ++m) rp[m] = *(const cb_u32x4*)(patch + roff + m * 1024);
+      cb_wait_all();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    epilogue(n_tiles - 1);
   }
 }
 

@@ -5,7 +5,7 @@ for d, _, files in os.walk(sys.argv[1]):
     for f in files:
         if f.endswith("counter_collection.csv"):
             for r in csv.DictReader(open(os.path.join(d, f))):
-                k = r["Kernel_Name"].split("(")[0].replace("void rvb::", "")[:70]
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rvb::", "")[:70]
                 if len(sys.argv) > 2 and not any(w in k for w in sys.argv[2:]):
                     continue
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
