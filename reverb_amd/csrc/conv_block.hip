@@ -40,6 +40,11 @@
 // i.e. 3.0 us per tile of which 1.2 us are MFMA time; the remainder is VALU work sharing the issue slots (bias / ReLU / zeroing /
 // packing / residual: next step packed fp32 math), four LDS-DMA issues per wave and tile, and a workgroup's start-up (weights,
 // first patch, the one-tile offset of role B) paid once per 17 tiles.
+// Measured and rejected (profiles/r05_call8_conv_block_fourth_form.txt): patches requested TWO tiles ahead by the role-A waves
+// only (8 pieces each, `s_waitcnt vmcnt(8)` before the barrier), role B taking its residual from the input plane with plain
+// loads and storing in the same body through stores hidden from the waitcnt pass -- bit-identical, 45.4-45.5 ms against 42.8:
+// the tile time does not come from the one-tile prefetch distance either, and the eight DMA issues per tile on the waves that
+// also carry 60 % of the MFMAs cost more than the deeper prefetch returns.
 //
 // Geometry (unbordered coordinates; the tensors carry a one-pixel zero border, element (f, t) sits at bordered (f + 1, t + 1)):
 //   workgroup = 512 threads = 8 waves, owns output rows f0 .. f0+3 of one window and walks tiles of 60 frames, t0 = 60 tt
