@@ -4,63 +4,46 @@
 //     out = relu(conv3x3_b(mid) + b_b + x)    the residual x comes out of the input patch that is in LDS anyway
 //
 // Why (round 5; VERDICT r4 "next" #2): as two conv_stream launches a block moves five tensor passes through HBM (x read, mid
-// written, mid read, x read again as the residual, out written; 1.55 KB per output pixel with the halo rows) for 37 kFLOP per
-// pixel.  Here x is read once (8 patch rows for 4 output rows) and out written once: 0.79 KB per output pixel.
+// written, mid read, x read again as the residual, out written) for 37 kFLOP per pixel: 281 GB per hour of audio at 5.2 TB/s --
+// that form IS bound by HBM (profiles/r05_call7_conv_block_counters.txt).  Here x is read once (8 patch rows for 4 output rows, the
+// 4 halo rows served by the L2: 1.03 x the plane from HBM) and out written once: 113 GB per hour.
 //
-// What the first form of this kernel taught (profiles/r05_call3_*.txt: correct, bit-identical, and 61 ms per hour against 54-56
-// for two launches): these stages are not bound by HBM alone but by their LDS operations -- (i) the [pixel][64 B] patch layout
-// serves a wave's ds_read_b128 with a 2-way bank conflict in every lane group (lanes {0-3, 12-15} of a group sit 12 pixels =
-// 768 B = 0 mod 256 apart), so every fragment read took 8 cycles instead of 4; (ii) the accumulators (pixels x channels) went
-// through a per-wave LDS slab to reach a store-friendly layout: 61 LDS cycles per 16-pixel m-tile, more than its 18 MFMAs;
-// (iii) the weights' fragments were re-read from LDS for every tile.  This form removes all three:
+// Geometry (unbordered coordinates; the tensors carry a one-pixel zero border, element (f, t) sits at bordered (f + 1, t + 1)):
+//   workgroup = 256 threads = 4 waves, owns output rows f0 .. f0+3 of one window and walks tiles of 60 frames, t0 = 60 tt
+//   patch  8 rows x 64 pixels x 64 B: bordered rows f0-1 .. f0+6, bordered columns t0-1 .. t0+62 (clamped into the plane: what the
+//          clamp changes only feeds mid positions outside the image, and those are set to zero); ONE buffer
+//   mid    6 rows x 64 pixels: rows f0-1 .. f0+4, columns t0-1 .. t0+62 (columns 62, 63 are never used); ZERO outside the image --
+//          the zero border the second convolution sees in the unfused path
+//   conv_a 24 m-tiles of 16 pixels, 6 per wave (two halves of three);  conv_b output row w, 4 m-tiles (two halves of two)
+//   LDS    patch 32 768 + mid 24 576 (+ pads) = 57 600 B and 248 VGPRs: TWO workgroups per CU, two waves per SIMD
+//
+// What makes it fast (each measured on the way, bit-identical throughout; "ms" = the stage per hour of audio, two launches: 54-56):
 //   * operand roles swapped: A = weights (M = channels), B = pixels (N = pixels), and the weight ROWS a lane supplies are chosen
 //     so that accumulator row (lane >> 4) * 4 + r of n-tile j is channel (lane >> 4) * 8 + j * 4 + r: a lane ends up holding 8
 //     CONSECUTIVE channels of ONE pixel -- exactly the 16 bytes it writes (to mid in LDS, or to the output in HBM: a wave stores
-//     1 KiB contiguous).  No transposition, no slab, no wave barriers;
-//   * both weight sets live in REGISTERS (2 x 9 taps x 2 n-tiles x 16 B per lane = 144 VGPRs of the 256 a wave has at two
-//     waves per SIMD), loaded once per workgroup; LDS holds only pixels;
+//     1 KiB contiguous).  The first form (pixels x channels accumulators through a per-wave LDS slab, 61 LDS cycles per m-tile,
+//     weights and slabs in LDS: 61 ms, SLOWER than two launches) showed that these stages are bound by their LDS operations once
+//     HBM is out of the way;
+//   * both weight sets live in REGISTERS (2 x 9 taps x 2 n-tiles x 16 B per lane = 144 VGPRs), loaded once per workgroup: LDS holds
+//     only pixels, and no fragment of a weight is ever re-read;
 //   * the 16-byte chunks of a pixel are XOR-swizzled with bit 2 of the pixel index (chunk ^= 2 for pixels 4-7 mod 8), on the
-//     LDS-DMA's source side for the patches and on the write side for mid: every lane group of a fragment read then covers all
-//     64 banks once.
+//     LDS-DMA's source side for the patch and on the write side for mid: the plain [pixel][64 B] layout serves a ds_read_b128
+//     with a 2-way bank conflict in every lane group (lanes {0-3, 12-15} of a group sit 12 pixels = 768 B = 0 mod 256 apart);
+//     bank-conflict cycles 44 % -> 10 % of the LDS-active cycles.  Together: 42.5-43.0 ms (8 waves, two patch buffers, all waves in
+//     the same phase, two barriers per tile);
+//   * the same with the two convolutions as ROLES of different waves one tile apart (one barrier per tile): 42.8 ms -- equal; with
+//     the patches requested two tiles ahead by the role-A waves: 45.4 ms -- slower (profiles/r05_call5_*, r05_call8_*).  Neither
+//     phase serialisation inside a workgroup nor the prefetch distance was what was left: a tile took 3.0 us of which 1.2 us are
+//     MFMA time (MFMA busy 41 %, waves 33 % issuing / 43 % stalled at issue / 24 % parked, 3.25 VALU instructions per MFMA);
+//   * what did help is the ordinary remedy: FOUR waves and ONE patch buffer per workgroup, so that two workgroups share a CU and
+//     fill each other's barriers, DMA waits and VALU phases -- no prefetch across tiles at all: **39.3-39.5 ms**
+//     (profiles/r05_call9_conv_block_two_workgroups.txt).
 //
-// Third form (the one below) -- the two convolutions are ROLES of different waves, one tile apart:
-//   waves 0-3 (A)  first convolution of tile k+1: 24 m-tiles of 16 pixels, 6 per wave, weights of conv_a in registers; bias + ReLU +
-//                  zeroing; mid(k+1) written to LDS
-//   waves 4-7 (B)  epilogue of tile k-1 (bias + residual + ReLU, stores), then the second convolution of tile k from mid(k): output
-//                  row w - 4, 4 m-tiles, weights of conv_b in registers; the residual vectors of tile k read out of patch k
-// Every SIMD holds one wave of each role and there is ONE barrier per tile; 149 VGPRs.  Measured EQUAL to the second form (all 8
-// waves in the same phase, two barriers per tile: 42.5-43.0 vs 42.8 ms per hour, profiles/r05_call4_*.txt, r05_call5_*.txt), so
-// phase serialisation was not what was left.  What the counters say (profiles/r05_call7_conv_block_counters.txt, per hour):
-//   HBM       58 GB read (the 4 halo rows of a patch come out of the L2: 1.03 x the plane) + 55 GB written = 113 GB in 42.8 ms =
-//             2.6 TB/s; the two-launch form moves 170 + 111 = 281 GB at 5.2 TB/s -- THAT form is bound by HBM, this one is not
-//   LDS       bank-conflict cycles 10 % of the LDS-active cycles (two-launch form: 44 %), the LDS 27 % busy
-//   MFMA      SQ_VALU_MFMA_BUSY_CYCLES = 41 % of the launch (1.5 x the useful FLOPs with the halo rows and the 64-wide m-tiles: 0.99 PF/s)
-//   waves     33 % issuing, 43 % stalled at issue (matrix pipe / dependency), 24 % parked at the barrier or a counter; 3.25 VALU
-//             instructions per MFMA
-// i.e. 3.0 us per tile of which 1.2 us are MFMA time; the remainder is VALU work sharing the issue slots (bias / ReLU / zeroing /
-// packing / residual: next step packed fp32 math), four LDS-DMA issues per wave and tile, and a workgroup's start-up (weights,
-// first patch, the one-tile offset of role B) paid once per 17 tiles.
-// Measured and rejected (profiles/r05_call8_conv_block_fourth_form.txt): patches requested TWO tiles ahead by the role-A waves
-// only (8 pieces each, `s_waitcnt vmcnt(8)` before the barrier), role B taking its residual from the input plane with plain
-// loads and storing in the same body through stores hidden from the waitcnt pass -- bit-identical, 45.4-45.5 ms against 42.8:
-// the tile time does not come from the one-tile prefetch distance either, and the eight DMA issues per tile on the waves that
-// also carry 60 % of the MFMAs cost more than the deeper prefetch returns.
-//
-// Geometry (unbordered coordinates; the tensors carry a one-pixel zero border, element (f, t) sits at bordered (f + 1, t + 1)):
-//   workgroup = 512 threads = 8 waves, owns output rows f0 .. f0+3 of one window and walks tiles of 60 frames, t0 = 60 tt
-//   patch  8 rows x 64 pixels x 64 B: bordered rows f0-1 .. f0+6, bordered columns t0-1 .. t0+62 (clamped into the plane: what the
-//          clamp changes only feeds mid positions outside the image, and those are set to zero); a ring of THREE (tile k for the
-//          residual, tile k+1 for conv_a, tile k+2 arriving)
-//   mid    6 rows x 64 pixels: rows f0-1 .. f0+4, columns t0-1 .. t0+62 (columns 62, 63 are never used); ZERO outside the image --
-//          the zero border the second convolution sees in the unfused path; TWO buffers (tile k read, tile k+1 written)
-//   LDS    patches 3 x 32 768 + mid 2 x 24 576 (+ pads) = 147 840 B: one workgroup per CU, two waves per SIMD
-//
-// Body k of the walk (all waves; then `s_waitcnt vmcnt(0) lgkmcnt(0)` and the barrier):
-//   all  LDS-DMA of patch k+2 into ring slot (k+2) % 3 -- last read in body k-1 (residual of tile k-1) and k-2 (conv_a of tile k-1)
-//   A    conv_a(k+1) from ring slot (k+1) % 3 (requested in body k-1, landed before that body's barrier) -> mid[(k+1) & 1], last
-//        read by conv_b(k-1) in body k-1
-//   B    epilogue(k-1) from registers: its stores are issued at the top of the body, right behind the DMA, so the vmcnt(0) at the
-//        end of the body finds them drained; conv_b(k) from mid[k & 1] (written in body k-1); residual vectors of tile k
+// Iteration k (tile k of the walk):
+//   conv_a on the patch; bias + ReLU + zeroing; mid written; the wave's residual vectors read out of the patch; barrier B (mid
+//   visible, the patch free); LDS-DMA of patch k+1 into the patch buffer; conv_b on mid; `s_waitcnt vmcnt(0)` (this wave's pieces of
+//   patch k+1 have landed; the stores of tile k-1, issued a tile ago, have drained) and barrier A (patch k+1 visible, mid free);
+//   epilogue in registers: bias + residual + ReLU, one 16-byte store per lane and m-tile, draining under iteration k+1.
 //
 // Results: operand values, accumulation order (taps 0..8, one 32-channel K step each) and rounding points (mid and out rounded to
 // bf16 after bias / residual / ReLU in fp32) are those of two conv_stream / conv_kernel launches
@@ -79,10 +62,8 @@ constexpr int CB_OT = 60, CB_PT = 64, CB_PF = 8, CB_MF = 6, CB_OF = 4, CB_NT = 3
 constexpr int CB_ROW = CB_PT * 64;                   // one patch / mid row: 4 096 B
 constexpr int CB_PATCH = CB_PF * CB_ROW;             // 32 768 B
 constexpr int CB_MID = CB_MF * CB_ROW;               // 24 576 B
-constexpr int CB_OFF_P0 = 0;
-constexpr int CB_OFF_MID = CB_OFF_P0 + 3 * CB_PATCH + 128;        // 128 B: the two pixels garbage m-tile positions read past a buffer
-constexpr int CB_MID_PITCH = CB_MID + 128;
-constexpr int CB_LDS = CB_OFF_MID + 2 * CB_MID_PITCH;
+constexpr int CB_OFF_MID = CB_PATCH + 128;              // 128 B: the two pixels garbage m-tile positions read past a buffer
+constexpr int CB_LDS = CB_OFF_MID + CB_MID + 128;
 
 typedef unsigned cb_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -158,7 +139,8 @@ __device__ inline void cb_conv9(const uint4 (&w)[9][2], const char* img, const u
   }
 }
 
-__global__ __launch_bounds__(512, 2) void conv_block32_kernel(ConvBlockArgs p, int tsplit) {
+
+__global__ __launch_bounds__(256, 2) void conv_block32_kernel(ConvBlockArgs p, int tsplit) {
   extern __shared__ __attribute__((aligned(16))) char cb_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,9 +148,6 @@ __global__ __launch_bounds__(512, 2) void conv_block32_kernel(ConvBlockArgs p, i
   const int FP = p.F + 2, TP = p.T + 2;
   const int tiles_f = (p.F + CB_OF - 1) / CB_OF, tiles_t = (p.T + CB_OT - 1) / CB_OT;
   const int per = (tiles_t + tsplit - 1) / tsplit;
-
-  // workgroup -> (window, mel-row tile, part of the time axis); each XCD (workgroup id mod 8) takes a contiguous run of the linear
-  // order, so that the workgroups that share halo rows run on the same L2 at about the same time (as conv_stream.hip)
   int lin;
   {
     const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
@@ -182,133 +161,109 @@ __global__ __launch_bounds__(512, 2) void conv_block32_kernel(ConvBlockArgs p, i
   const int tt0 = sp * per, tt1 = min(tiles_t, tt0 + per);
   const int n_tiles = tt1 - tt0;
   if (n_tiles <= 0) return;
-
   const char* in_b = cb_uniform((const char*)p.in + (size_t)b * FP * TP * CB_NT * 2);
   char* out_b = (char*)p.out + (size_t)b * FP * TP * CB_NT * 2;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cb_smem;
 
-  // ---- DMA coordinates: wave w brings patch row w (bordered row f0 - 1 + w, clamped), four pieces of 16 pixels.  The LDS image is
-  // lane-linear (lane i's 16 bytes land at M0 + 16 i), so the chunk swizzle is applied to the SOURCE: LDS position (pixel, chunk')
-  // receives global chunk chunk' ^ 2 [pixel bit 2]; within a piece pixel = lane >> 2, so that bit is lane bit 4
-  const unsigned rowoff = (unsigned)(min(max(f0 - 1 + wave, 0), FP - 1) * TP) * (CB_NT * 2);
+  // wave w brings patch rows 2 w and 2 w + 1 (8 pieces); chunk swizzle on the source side as in the 8-wave kernel
+  const unsigned rowoff0 = (unsigned)(min(max(f0 - 1 + 2 * wave, 0), FP - 1) * TP) * (CB_NT * 2);
+  const unsigned rowoff1 = (unsigned)(min(max(f0 + 2 * wave, 0), FP - 1) * TP) * (CB_NT * 2);
   const int ppx = lane >> 2;
   const unsigned piece_b = (unsigned)((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
   auto issue = [&](int k) __attribute__((always_inline)) {
     const int t0 = (tt0 + k) * CB_OT;
-    unsigned off[4];
+    unsigned px[4], off[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) off[g] = rowoff + (unsigned)min(max(t0 - 1 + g * 16 + ppx, 0), TP - 1) * (CB_NT * 2) + piece_b;
-    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(lds_base + CB_OFF_P0 + (k % 3) * CB_PATCH + wave * CB_ROW));
+    for (int g = 0; g < 4; ++g) px[g] = (unsigned)min(max(t0 - 1 + g * 16 + ppx, 0), TP - 1) * (CB_NT * 2) + piece_b;
+    const unsigned dst = lds_base + 2 * wave * CB_ROW;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) off[g] = rowoff0 + px[g];
+    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(dst));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) off[g] = rowoff1 + px[g];
+    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(dst + CB_ROW));
   };
   issue(0);
-  if (n_tiles > 1) issue(1);
-
-  // ---- this wave's role and its weight set, in registers: lane (li, lg) supplies, for n-tile j, the row of channel
-  // (li >> 2) * 8 + j * 4 + (li & 3), k chunk lg (global layout [tap][channel][64 B]); its 8 channels are then lg * 8 .. + 7
-  // (accumulator (j, r) is channel lg * 8 + j * 4 + r)
-  const bool role_a = wave < 4;
-  uint4 w[9][2];
-  float bias_r[8];
+  uint4 wa[9][2], wb[9][2];
+  float ba_r[8], bb_r[8];
   {
-    const char* gw = (const char*)(role_a ? p.wa : p.wb);
-    const float* gb = role_a ? p.ba : p.bb;
+    const char* ga = (const char*)p.wa;
+    const char* gb = (const char*)p.wb;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) w[tap][j] = *(const uint4*)(gw + (tap * CB_NT + (li >> 2) * 8 + j * 4 + (li & 3)) * 64 + lg * 16);
-    const float4 b0 = *(const float4*)(gb + lg * 8), b1 = *(const float4*)(gb + lg * 8 + 4);
-    bias_r[0] = b0.x; bias_r[1] = b0.y; bias_r[2] = b0.z; bias_r[3] = b0.w; bias_r[4] = b1.x; bias_r[5] = b1.y; bias_r[6] = b1.z; bias_r[7] = b1.w;
+      for (int j = 0; j < 2; ++j) {
+        const int ch = (li >> 2) * 8 + j * 4 + (li & 3);
+        wa[tap][j] = *(const uint4*)(ga + (tap * CB_NT + ch) * 64 + lg * 16);
+        wb[tap][j] = *(const uint4*)(gb + (tap * CB_NT + ch) * 64 + lg * 16);
+      }
+    const float4 a0 = *(const float4*)(p.ba + lg * 8), a1 = *(const float4*)(p.ba + lg * 8 + 4);
+    const float4 b0 = *(const float4*)(p.bb + lg * 8), b1 = *(const float4*)(p.bb + lg * 8 + 4);
+    ba_r[0] = a0.x; ba_r[1] = a0.y; ba_r[2] = a0.z; ba_r[3] = a0.w; ba_r[4] = a1.x; ba_r[5] = a1.y; ba_r[6] = a1.z; ba_r[7] = a1.w;
+    bb_r[0] = b0.x; bb_r[1] = b0.y; bb_r[2] = b0.z; bb_r[3] = b0.w; bb_r[4] = b1.x; bb_r[5] = b1.y; bb_r[6] = b1.z; bb_r[7] = b1.w;
   }
-  char* mid0 = cb_smem + CB_OFF_MID;
-  cb_wait_all();                       // patches 0 (and 1) landed
+  unsigned aoff[3], boff[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    aoff[kw] = cb_swz((unsigned)(wave * 6 * 16 + li + kw), lg);
+    boff[kw] = cb_swz((unsigned)(wave * CB_PT + li + kw), lg);
+  }
+  const unsigned moff = cb_swz((unsigned)(wave * 6 * 16 + li), lg);
+  const unsigned roff = cb_swz((unsigned)((wave + 2) * CB_PT + li + 2), lg);
+  const char* patch = cb_smem;
+  char* mid = cb_smem + CB_OFF_MID;
+  const int fo = f0 + wave;
+  const unsigned frow_off = (unsigned)(min(fo, p.F - 1) + 1) * TP;
+  cb_wait_all();
   __syncthreads();
 
-  if (role_a) {
-    // ======== role A: first convolution, one tile ahead.  m-tiles 6 w .. 6 w + 5 of (mid row r, 16-pixel group mi) = divmod(idx, 4)
-    // (m-tile idx sits at pixel 16 idx of the row-major [6][64] mid image: consecutive m-tiles are 1 024 B apart)
-    unsigned aoff[3];                      // this lane's fragment offset at the wave's first m-tile, per column shift
+  for (int k = 0; k < n_tiles; ++k) {
+    const int t0 = (tt0 + k) * CB_OT;
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) aoff[kw] = cb_swz((unsigned)(wave * 6 * 16 + li + kw), lg);
-    const unsigned moff = cb_swz((unsigned)(wave * 6 * 16 + li), lg);      // where this lane's mid vector of m-tile 0 goes
-    auto conv_a = [&](int k) __attribute__((always_inline)) {      // mid(r, px) = sum_taps wa[tap] . patch(r + kh, px + kw), tile k
-      const int t0 = (tt0 + k) * CB_OT;
-      const char* patch = cb_smem + CB_OFF_P0 + (k % 3) * CB_PATCH;
-      char* mid = mid0 + (k & 1) * CB_MID_PITCH;
+    for (int h = 0; h < 2; ++h) {
+      f32x4_t acc[3][2];
+      cb_conv9<3>(wa, patch + h * 3 * 1024, aoff, acc);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {            // two halves of three m-tiles: 24 accumulator + 24 fragment registers live at a time
-        f32x4_t acc[3][2];
-        cb_conv9<3>(w, patch + h * 3 * 1024, aoff, acc);
-#pragma unroll
-        for (int mm = 0; mm < 3; ++mm) {
-          const int m = h * 3 + mm, idx = wave * 6 + m;
-          const int f = f0 - 1 + (idx >> 2), t = t0 - 1 + (idx & 3) * 16 + li;
-          const bool inside = f >= 0 && f < p.F && t >= 0 && t < p.T;            // outside: the zero border conv_b must see
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[mm][e >> 2][e & 3] + bias_r[e], 0.f) : 0.f;
-          *(uint4*)(mid + moff + m * 1024) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-        }
-      }
-    };
-    conv_a(0);
-    cb_wait_lds();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    for (int k = 0; k < n_tiles; ++k) {
-      if (k + 2 < n_tiles) issue(k + 2);
-      if (k + 1 < n_tiles) conv_a(k + 1);
-      cb_wait_all();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-  } else {
-    // ======== role B: second convolution of output row w - 4 (its four 16-pixel groups), residual, stores
-    const int brow = wave - 4;
-    unsigned boff[3];                      // fragment offset in mid at the row's first m-tile, per column shift
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) boff[kw] = cb_swz((unsigned)(brow * CB_PT + li + kw), lg);
-    const unsigned roff = cb_swz((unsigned)((brow + 2) * CB_PT + li + 2), lg);      // residual: x(f, t) = patch(row + 2, column + 2)
-    const int fo = f0 + brow;                                  // this wave's output row
-    const unsigned frow_off = (unsigned)(min(fo, p.F - 1) + 1) * TP;
-    f32x4_t acc2[2][2][2];                 // [half][m-tile of the half][n-tile]
-    cb_u32x4 rp[4];
-    auto epilogue = [&](int k) __attribute__((always_inline)) {    // bias + residual + ReLU in fp32, one 16-byte store per lane and m-tile
-      const int t0 = (tt0 + k) * CB_OT;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int mm = 0; mm < 3; ++mm) {
+        const int m = h * 3 + mm, idx = wave * 6 + m;
+        const int f = f0 - 1 + (idx >> 2), t = t0 - 1 + (idx & 3) * 16 + li;
+        const bool inside = f >= 0 && f < p.F && t >= 0 && t < p.T;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc2[m >> 1][m & 1][e >> 2][e & 3] + bias_r[e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] += __uint_as_float(rp[m][e] << 16);
-          v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        const int o = m * 16 + li, t = t0 + o;
-        if (o < CB_OT && t < p.T && fo < p.F)
-          *(uint4*)(out_b + ((size_t)(frow_off + t + 1) * CB_NT + lg * 8) * 2) =
-              make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[mm][e >> 2][e & 3] + ba_r[e], 0.f) : 0.f;
+        *(uint4*)(mid + moff + m * 1024) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
       }
-    };
-    cb_wait_lds();
-    __builtin_amdgcn_s_barrier();          // role A's conv_a(0)
-    asm volatile("" ::: "memory");
-    for (int k = 0; k < n_tiles; ++k) {
-      if (k + 2 < n_tiles) issue(k + 2);
-      if (k > 0) epilogue(k - 1);
-      // out(row, o) = sum_taps wb[tap] . mid(row + kh, o + kw), tile k; then its residual vectors out of patch k
-#pragma unroll
-      for (int h = 0; h < 2; ++h) cb_conv9<2>(w, mid0 + (k & 1) * CB_MID_PITCH + h * 2 * 1024, boff, acc2[h]);      // two halves: 16 fragment registers live
-      const char* patch = cb_smem + CB_OFF_P0 + (k % 3) * CB_PATCH;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) rp[m] = *(const cb_u32x4*)(patch + roff + m * 1024);
-      cb_wait_all();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
     }
-    epilogue(n_tiles - 1);
+    cb_u32x4 rp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rp[m] = *(const cb_u32x4*)(patch + roff + m * 1024);
+    cb_wait_lds();
+    __builtin_amdgcn_s_barrier();                      // B: mid visible, the patch is free
+    asm volatile("" ::: "memory");
+    if (k + 1 < n_tiles) issue(k + 1);
+    f32x4_t acc2[2][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) cb_conv9<2>(wb, mid + h * 2 * 1024, boff, acc2[h]);
+    cb_wait_all();
+    __builtin_amdgcn_s_barrier();                      // A: patch k+1 visible, mid free
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc2[m >> 1][m & 1][e >> 2][e & 3] + bb_r[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] += __uint_as_float(rp[m][e] << 16);
+        v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      const int o = m * 16 + li, t = t0 + o;
+      if (o < CB_OT && t < p.T && fo < p.F)
+        *(uint4*)(out_b + ((size_t)(frow_off + t + 1) * CB_NT + lg * 8) * 2) =
+            make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+    }
   }
 }
 
@@ -331,7 +286,7 @@ int conv_block32(hipStream_t s, const ConvBlockArgs& a) {
   const int tsplit = 1;
   const int64_t blocks = (int64_t)a.B * cdiv(a.F, CB_OF) * tsplit;
   if (blocks >= ((int64_t)1 << 31)) { set_error("conv_block32: too many workgroups"); return E_ARG; }
-  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)blocks), dim3(512), CB_LDS, s, a, tsplit);
+  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)blocks), dim3(256), CB_LDS, s, a, tsplit);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
