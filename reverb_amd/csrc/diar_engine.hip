@@ -552,6 +552,7 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
   a.w_ig = c.w_ig.p;
   const std::string nm = std::string(c.taps == 1 ? "emb_conv_sc" : (c.stride == 2 ? "emb_conv_s2_" : "emb_conv_")) + (c.taps == 1 ? "" : std::to_string(c.cout));
   if (conv_igemm_applicable(e->dtype, a)) e->prof["emb_conv_igemm"].launches += 1;    // how many went to conv_gemm.hip
+  else if (conv_row64_applicable(e->dtype, a)) e->prof["emb_conv_row64"].launches += 1;        // ... to conv_row64.hip
   else if (conv_stream_applicable(e->dtype, a)) e->prof["emb_conv_stream"].launches += 1;     // ... to conv_stream.hip
   DScope sc(e, nm.c_str(), 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
   return conv2d(e->stream, e->dtype, a);

@@ -288,6 +288,10 @@ int act_amax_bf16(hipStream_t s, const void* in_bf16, size_t n, unsigned* amax);
 // stage takes it only with RVD_CONV_STREAM64=1: measured equal to the direct kernel there (52.4 vs 51.5 ms per hour of audio;
 // the 32-channel stage 53.3-55.2 vs 65.7-66.3 ms, profiles/r04_call16_fast_epilogue.txt).
 #define CONV_STREAM_DEFAULT 1
+// conv_row64.hip: the stride-1 3x3 convolutions of the 64-channel stage (bf16): weights in registers, accumulators = 8 consecutive
+// channels of a pixel per lane, swizzled patch, two workgroups per CU
+bool conv_row64_applicable(int dtype, const ConvArgs& a);
+int conv_row64(hipStream_t s, const ConvArgs& a);
 bool conv_stream_applicable(int dtype, const ConvArgs& a);
 int conv_stream(hipStream_t s, const ConvArgs& a);
 int conv_igemm(hipStream_t s, const ConvArgs& a);

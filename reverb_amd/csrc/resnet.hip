@@ -380,6 +380,7 @@ int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
   }
   if (p.B <= 0) return OK;
   if (conv_igemm_applicable(dtype, p)) return conv_igemm(s, p);     // only when the engine packed w_ig (RVD_CONV_IGEMM=1)
+  if (conv_row64_applicable(dtype, p)) return conv_row64(s, p);
   if (conv_stream_applicable(dtype, p)) return conv_stream(s, p);
   const int nt = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
   if (dtype == DT_BF16) {

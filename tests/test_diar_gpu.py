@@ -235,6 +235,7 @@ def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypat
     out, streamed, flops = {}, {}, {}
     monkeypatch.setenv("RVD_CONV_STREAM64", "1")            # the 64-channel stage too (opt-in: measured equal to the direct kernel)
     monkeypatch.setenv("RVD_CONV_BLOCK", "0")                # stage 1 as single convolutions (the default fuses its blocks: conv_block.hip)
+    monkeypatch.setenv("RVD_CONV_ROW64", "0")                # stage 2 on the kernel under test, not on conv_row64.hip
     for flag in ("0", "1", "2", "3", "17"):
         monkeypatch.setenv("RVD_CONV_STREAM", flag)
         eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
@@ -314,6 +315,29 @@ def test_trunk_stages_3_and_4_in_fp8(case, emb_case):
     assert cosw.min() > 0.995, cosw            # measured 0.99960; the bf16 engine: 0.99999
     eng.close()
 
+
+
+def test_row64_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
+    """conv_row64.hip (round 5, default for the stride-1 3x3 convolutions of the 64-channel stage: weights in registers, a lane's
+    accumulators = 8 consecutive channels of one pixel, swizzled patch, two workgroups per CU) against resnet.hip's direct kernel
+    (lab switch RVD_CONV_ROW64=0): same operand values, accumulation order (chunks outer, taps inner) and rounding points -- the
+    embeddings must be IDENTICAL; the counters prove which path ran.  The windows include the zero-padded tail window; 499 frames
+    = 8 full tiles of 62 + one of 3, 40 mel rows = 10 row tiles, with and without a residual."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, row64, flops = {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_ROW64", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        row64[flag] = eng.timing("emb_conv_row64")[2]
+        flops[flag] = eng.timing("emb_conv_64")[1]
+        eng.close()
+    assert row64["0"] == 0 and row64["1"] >= 7                     # the 7 stride-1 convolutions of stage 2, per trunk pass
+    assert flops["1"] == flops["0"] > 0
+    assert np.array_equal(out["0"], out["1"])
 
 
 def test_fused_basic_block_equals_two_convolutions(case, emb_case, monkeypatch, lab):
