@@ -2,7 +2,7 @@
 import torch, time
 torch.manual_seed(0)
 dev = "cuda"
-M = 72720
+M = 73728      # the first encode slice of the bench hour: 144 chunks x 512 frames
 for (N, K) in ((4096, 1024), (1024, 4096), (1024, 1024), (3072, 1024), (2048, 1024), (1024, 19456)):
     A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     W = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
