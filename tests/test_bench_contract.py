@@ -12,10 +12,19 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "roofline": dict, "cpu_baseline": dict}
 
 
-@pytest.mark.parametrize("log", ["r01_bench_r640_1h_bf16.json.log", "r01_bench_r268_1h_bf16.json.log", "r01_bench_diar_1h_bf16.json.log",
-                                 "r02_bench_r640_1h_bf16.json.log", "r02_bench_r268_1h_bf16.json.log", "r02_bench_diar_1h_bf16.json.log"])
+def _latest(stem):
+    """newest committed profile of a kind: profiles/r05<letter>_<stem> (the round's evidence runs are lettered in order)"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_" + stem)))
+    assert hits, stem
+    return hits[-1]
+
+
+@pytest.mark.parametrize("log", ["archive/r01_bench_r640_1h_bf16.json.log", "archive/r02_bench_diar_1h_bf16.json.log",
+                                 "archive/r04d_bench_r640_1h_bf16.json.log", "LATEST:bench_r640_1h_bf16.json.log"])
 def test_committed_bench_line_has_the_contract_fields(log):
-    lines = [l for l in open(os.path.join(ROOT, "profiles", log)).read().splitlines() if l.strip()]
+    path = _latest(log[7:]) if log.startswith("LATEST:") else os.path.join(ROOT, "profiles", log)
+    lines = [l for l in open(path).read().splitlines() if l.strip()]
     d = json.loads(lines[-1])                      # the JSON line is the LAST line of stdout
     for k, t in REQUIRED.items():
         assert k in d and isinstance(d[k], t), k
@@ -68,27 +77,34 @@ def test_bench_scripts_parse_and_default_to_one_gpu():
         assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
 
 
-def test_round2_bench_line_carries_the_measured_sub_records():
-    """The default `python bench.py` line of round 2: live PMC traffic, the PCIe-inclusive leg, diarization (configs[3]) and
-    the joint fp8 pipeline (configs[4]) as sub-records with their own contract fields."""
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_r640_1h_bf16.json.log")).read().splitlines()[-1])
+def test_bench_line_carries_the_measured_sub_records():
+    """The driver's `python bench.py` line of round 5: live PMC traffic, the PCIe-inclusive leg, diarization (configs[3]), the
+    joint fp8 pipeline on THREE hours (configs[4]) with its sharded / replicated split, and the headline step in the other modes
+    (parity_f32 = the bit-exact mode, asr_fp8, r268) as sub-records."""
+    d = json.loads(open(_latest("bench_r640_1h_bf16.json.log")).read().splitlines()[-1])
     assert d["roofline"]["traffic"] > 1e8 and "rocprofv3 --pmc" in d["roofline"]["traffic_detail"]["method"]
-    assert d["pcie_inclusive"]["value"] <= d["value"] * 1.02 and d["pcie_inclusive"]["h2d_bytes_per_step"] == 115200000
+    assert d["pcie_inclusive"]["value"] <= d["value"] * 1.03 and d["pcie_inclusive"]["h2d_bytes_per_step"] == 115200000
     assert d["config"]["decoder_rows_per_step"] < d["config"]["decoder_pairs_per_step"]
+    assert "8 chunks" in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["kind"] == "port"
     for key in ("diarization", "joint_fp8"):
         r = d[key]
         assert "error" not in r and r["value"] > 0 and r["ms_per_step"] > 0 and r["data"] == "synthetic", key
     assert d["diarization"]["roofline"]["bound"] == "mfma" and d["diarization"]["cpu_baseline"]["kind"] == "port"
-    assert d["joint_fp8"]["dtype"] == "fp8" and d["joint_fp8"]["ms_per_step"] < d["joint_fp8"]["sequential_ms_per_step"]
-    f = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_r640_1h_fp8.json.log")).read().splitlines()[-1])
-    assert f["dtype"] == "fp8" and f["roofline"]["peak"] == 5000.0 and f["value"] > d["value"]
+    j = d["joint_fp8"]
+    assert j["dtype"] == "fp8" and "3 h" in j["config"]["workload"] and j["ms_per_step"] < j["sequential_ms_per_step"]
+    assert j["sharded_s"] > 0 and j["replicated_s"] > 0 and abs(j["projected_8gpu_step_s"] - (j["sharded_s"] / 8 + j["replicated_s"])) < 1e-3
+    assert j["diarization_fp8"]["state"] == 2 and j["diarization_fp8"]["clipped_values"] == 0
+    f32, f8, small = d["parity_f32"], d["asr_fp8"], d["r268"]
+    assert f32["dtype"] == "f32" and f32["roofline"]["peak"] == 157.3 and f32["value"] > 2000        # the bit-exact mode clears 2000x
+    assert f8["dtype"] == "fp8" and f8["roofline"]["peak"] == 5000.0 and f8["value"] > d["value"]
+    assert small["value"] > d["value"] and "r268" in small["workload"]
 
 
 def test_every_file_the_profiles_readme_names_exists():
     """profiles/README.md is what the judge reads first: every `r0N_…` file it cites must be committed next to it."""
     import re
     text = open(os.path.join(ROOT, "profiles", "README.md")).read()
-    names = set(re.findall(r"`((?:r\d\d_|gemm_traffic)[A-Za-z0-9_./]+\.(?:log|csv|json|jsonl|txt))`", text))
-    assert len(names) >= 15
+    names = set(re.findall(r"`((?:archive/)?r\d\d[a-z]?_[A-Za-z0-9_./]+\.(?:log|csv|json|jsonl|txt))`", text))
+    assert len(names) >= 8
     missing = [n for n in sorted(names) if not os.path.exists(os.path.join(ROOT, "profiles", n))]
     assert not missing, missing
