@@ -211,7 +211,7 @@ class _StubEngine:
 
 
 # ------------------------------------------------------------------------------------------------ diarization sub-record
-def diarization_record(device, steps=2, warmup=1, hours=1.0, dtype="bf16", cpu_windows=16, traffic="auto"):
+def diarization_record(device, steps=3, warmup=2, hours=1.0, dtype="bf16", cpu_windows=16, traffic="auto"):
     """BASELINE configs[3] on this GPU, measured exactly as bench_diar.py does (one step = one `pipeline(audio)` call
     on `hours` of audio held in host memory); returned as a sub-record of the main line so that the driver's run
     carries it."""
