@@ -13,6 +13,10 @@
 // The epilogue is conv_kernel's: 16-row slabs transposed through LDS, bias + residual + ReLU, full 128-byte runs of
 // channels per pixel into the bordered output.
 //
+// Measured and not kept (round 5, profiles/r05_call11_igemm_small_tiles.txt): 128 x 128 tiles of four waves, 64 KiB of stages, TWO
+// workgroups per CU -- the remedy that paid for the 32- / 64-channel stages: 64.2-64.7 vs 65.0-65.3 ms for the 128-channel stage,
+// 24.4-24.8 vs 25.0 ms for the 256-channel one (-1 %): this loop is paced by its stage fill, not by what overlaps what on a CU.
+//
 // STATUS (round 2): the default for the 128- and 256-channel stages (diar_engine.hip packs the second weight layout unless
 // RVD_CONV_IGEMM=0); tests/test_diar_gpu.py compares it with resnet.hip's direct kernel.  Tried and not kept: the
 // row-contiguous read-back + up-front residual prefetch that helped gemm2's fp32 epilogue (no change here: bf16 output and
