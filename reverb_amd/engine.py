@@ -304,6 +304,7 @@ class Engine:
         t = C.c_int32(0)
         check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
         self.batch, self.enc_frames, self.beam, self.topk = B, int(t.value), int(beam), k
+        self._last_encode = (feats, lens, int(beam), float(blank_penalty), int(first_chunk), int(T0))     # for joint_decode's retry
 
     # -------------------------------------------------------------------------------- streaming encoder
     def stream_begin(self):
@@ -466,8 +467,16 @@ class Engine:
         """`joint_decoding` (search.py:450-496): time-synchronous joint CTC / attention beam search of the last encoded batch
         (encode(..., topk=int(pre_beam_ratio * beam)) first).  DecodeResult: tokens, joint score, start frame and confidence
         per token -- the fields the reference fills -- plus `end_times`."""
-        check(self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus)),
-              "rvb_joint_decode")
+        rc = self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus))
+        if rc == -5 and self.topk < 64 and getattr(self, "_last_encode", None) is not None:
+            # RVB_E_UNSUPPORTED here = a frame holds a longer run of log-probs that tie EXACTLY with the pre-beam threshold than
+            # the kept top-k covers (the reference compares the whole row, beam_search_timesync.py:268-270).  Rather than fail
+            # the decode after all the work is done (ADVICE r4), encode the batch again keeping the kernel's maximum of 64
+            # log-probs per frame and search once more; only a run longer than that is refused.
+            feats, lens, beam, blank_penalty, first_chunk, T0 = self._last_encode
+            self.encode(feats, lens, beam, blank_penalty, first_chunk, T0, topk=64)
+            rc = self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus))
+        check(rc, "rvb_joint_decode")
         T = max(self.enc_frames, 1)
         tok = np.empty(T, np.int32); st = np.empty(T, np.int32); en = np.empty(T, np.int32); cf = np.empty(T, np.float64)
         res = []

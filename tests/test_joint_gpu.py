@@ -86,3 +86,35 @@ def test_joint_decoding_needs_enough_topk():
     with pytest.raises(RvbError, match="pre-beam"):
         eng.joint_decode(0.3, 0.5)
     eng.close()
+
+
+def test_joint_decoding_retries_with_more_logprobs_on_a_long_run_of_exact_ties():
+    """a run of more than 8 log-probs tying EXACTLY with the pre-beam threshold used to fail the whole decode
+    (RVB_E_UNSUPPORTED) after all the work was done.  A model whose CTC head gives 25 tokens the same logit in every frame
+    (zero weight rows, equal biases: bit-equal in the reference and in the f32 engine) puts such a run at the threshold of every
+    frame; the engine now encodes the batch again keeping 64 log-probs per frame and must return what the oracle -- which, like
+    the reference, compares the whole row with the threshold (beam_search_timesync.py:268-270) -- returns."""
+    import torch
+    from oracle import model_ref as M, search_ref as S
+    case = JointCase("joint_tiny")
+    sd = dict(case.sd)
+    w, b = np.array(sd["ctc.ctc_lo.weight"], np.float32), np.array(sd["ctc.ctc_lo.bias"], np.float32)
+    w[20:45] = 0.0
+    b[20:45] = 20.0                       # above every other token of this model: the top 25 of every frame tie exactly
+    sd["ctc.ctc_lo.weight"], sd["ctc.ctc_lo.bias"] = w, b
+    beam, ctc_weight, bonus = 4, 0.5, 0.5
+    tsd, cat = M.to_torch_sd(sd), torch.tensor(case.cat)
+    with torch.no_grad():
+        enc, mask = M.encoder_forward(tsd, case.cfg, torch.from_numpy(case.x), torch.from_numpy(case.lens), cat)
+        lp = M.ctc_logprobs(tsd, enc)
+    lens = mask.squeeze(1).sum(1)
+    assert int((lp[0, 0] == lp[0, 0, 20]).sum()) >= 25                     # the run of exact ties is really there
+    want = S.joint_decoding(tsd, case.cfg, enc, lens, lp, ctc_weight, beam, 1.5, bonus, cat)
+    eng = Engine(case.cfg, sd, dtype="f32", device=0, max_chunks=4, chunk_frames=case.chunk, cat_embs=case.cat)
+    eng.encode(case.x, case.lens, beam, topk=int(1.5 * beam) + 8)           # 14 per frame: 8 spare for ties, the run has 25
+    got = eng.joint_decode(ctc_weight, bonus, 1.5)
+    assert eng.topk == 64                                                   # the retry happened
+    for g, wnt in zip(got, want):
+        assert list(g.tokens) == list(wnt.tokens) and list(g.times) == list(wnt.times)
+        assert abs(g.score - wnt.score) <= 2e-2 + 1e-3 * abs(wnt.score)
+    eng.close()
