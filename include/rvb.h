@@ -96,6 +96,13 @@ int rvb_get_waveform(rvb_engine* e, float* out, int64_t* n_samples);
  * call only enqueues the kernel (rvb_encode is ordered behind it on the engine's stream); with a host buffer it returns
  * when the copy has landed. */
 int64_t rvb_num_frames(int64_t n_samples);
+/* ReverbASR.compute_feats with front-end settings OTHER than the model's 80 bins / 25 ms / 10 ms (cli/reverb.py:119-146 passes
+ * num_mel_bins, frame_length, frame_shift straight to kaldi.fbank; its own default is 23 bins): stand-alone, not bound to an engine.
+ * wave: mono waveform at 16 kHz on the int16 scale (what `.to(torch.float)` of the loaded file holds), host memory; feats_out
+ * [n_frames][num_mel_bins] (NULL: only *n_frames is set).  Supported: frame_length 16.1 .. 32 ms (Kaldi pads the window to the
+ * next power of two: the 512-point FFT of the hot path), any frame_shift, 1 .. 128 bins, dither 0; RVB_E_UNSUPPORTED otherwise. */
+int rvb_compute_feats(int device, const float* wave, int64_t n_samples, int num_mel_bins, double frame_length_ms,
+                      double frame_shift_ms, float* feats_out, int64_t* n_frames);
 int rvb_upload_pcm(rvb_engine* e, const int16_t* pcm, int64_t n_samples);
 /* Page-locked host memory for the audio reader (what `torchaudio.load` fills in the reference, cli/reverb.py:128):
  * PCM decoded straight into such a buffer reaches HBM at the PCIe rate (115 MB per hour of audio in ~2 ms);

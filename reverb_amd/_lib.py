@@ -61,6 +61,7 @@ SIGNATURES = {
     "rvb_load_tensor": (C.c_int, [_eng, C.c_char_p, _f32p, _i64p, C.c_int]),
     "rvb_finalize": (C.c_int, [_eng, _f32p, C.c_int]),
     "rvb_num_frames": (C.c_int64, [C.c_int64]),
+    "rvb_compute_feats": (C.c_int, [C.c_int, _f32p, C.c_int64, C.c_int, C.c_double, C.c_double, _f32p, _i64p]),
     "rvb_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
     "rvb_upload_pcm_async": (C.c_int, [_eng, _i16p, C.c_int64]),
     "rvb_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),

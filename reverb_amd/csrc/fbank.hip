@@ -13,6 +13,7 @@
 #include <cmath>
 #include <vector>
 
+#include "../../include/rvb.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -196,6 +197,135 @@ void resample_taps(int sample_rate, int target, std::vector<float>* ker, int* or
   *orig_out = orig; *new_out = nw; *width_out = width; *K_out = K;
 }
 
+// ------------------------------------------------------------------------------------------------
+// compute_feats with OTHER front-end settings (cli/reverb.py:119-146 takes any num_mel_bins / frame_length / frame_shift; the
+// model's own configuration is the kernel above).  Same algorithm with the three sizes as arguments: window of 257 .. 512
+// samples (frame_length 16.1 .. 32 ms at 16 kHz: Kaldi pads to the next power of two, i.e. the same 512-point FFT), any shift,
+// up to 128 mel bins.  Not on the hot path: host tables are built per call, the waveform comes from the host as float.
+struct FbankAny { int win, shift, nmel; };
+__global__ __launch_bounds__(256) void fbank_any_kernel(const float* __restrict__ wave, int64_t n_frames, float* __restrict__ feats,
+                                                        FbankTables t, FbankAny g) {
+  __shared__ float s_re[4][NFFT];
+  __shared__ float s_im[4][NFFT];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t frame = (int64_t)blockIdx.x * 4 + w;
+  const bool live = frame < n_frames;
+  float* re = s_re[w];
+  float* im = s_im[w];
+  float x[8];
+  float sum = 0.f;
+  const float* src = wave + frame * g.shift;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    x[i] = (live && j < g.win) ? src[j] : 0.f;
+    sum += x[i];
+  }
+  const float mean = wave_sum(sum) / (float)g.win;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    if (j < g.win) im[j] = x[i] - mean;
+  }
+  __syncthreads();
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    float v = 0.f;
+    if (j < g.win) v = (im[j] - 0.97f * im[j > 0 ? j - 1 : 0]) * t.window[j];
+    y[i] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    re[__brev((unsigned)j) >> 23] = y[i];
+    im[j] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < 9; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = lane + 64 * q;
+      const int j = b & (half - 1);
+      const int i0 = ((b >> s) << (s + 1)) + j;
+      const int i1 = i0 + half;
+      const int tw = j << (8 - s);
+      const float wr = t.twiddle[2 * tw], wi = t.twiddle[2 * tw + 1];
+      const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+      const float tr = wr * br - wi * bi;
+      const float ti = wr * bi + wi * br;
+      re[i0] = ar + tr; im[i0] = ai + ti;
+      re[i1] = ar - tr; im[i1] = ai - ti;
+    }
+    __syncthreads();
+  }
+  float pw[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + 64 * i;
+    pw[i] = (j < NBIN) ? re[j] * re[j] + im[j] * im[j] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + 64 * i;
+    if (j < NBIN) re[j] = pw[i];
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = lane + 64 * i;
+      if (m < g.nmel) {
+        const int lo = t.mel_lo[m], hi = t.mel_hi[m];
+        const float* wrow = t.mel_w + (size_t)m * NBIN;
+        float acc = 0.f;
+        for (int b = lo; b < hi; ++b) acc += re[b] * wrow[b];
+        feats[frame * g.nmel + m] = logf(fmaxf(acc, 1.1920928955078125e-07f));
+      }
+    }
+  }
+}
+
+// Kaldi mel banks / povey window / FFT twiddles for (win samples, nmel bins) at 16 kHz with a 512-point FFT
+// (oracle/fbank_ref.py restates torchaudio's; engine.hip make_fbank_tables is the 400 / 80 instance)
+void fbank_host_tables(int win, int nmel, std::vector<float>* window, std::vector<float>* tw, std::vector<float>* melw,
+                       std::vector<int32_t>* lo, std::vector<int32_t>* hi) {
+  const double PI = 3.14159265358979323846;
+  window->resize(win); tw->resize(2 * 256); melw->assign((size_t)nmel * NBIN, 0.f);
+  lo->assign(nmel, NBIN); hi->assign(nmel, 0);
+  for (int i = 0; i < win; ++i) (*window)[i] = (float)std::pow(0.5 - 0.5 * std::cos(2.0 * PI * i / (win - 1)), 0.85);
+  for (int k = 0; k < 256; ++k) { (*tw)[2 * k] = (float)std::cos(2.0 * PI * k / NFFT); (*tw)[2 * k + 1] = (float)(-std::sin(2.0 * PI * k / NFFT)); }
+  auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+  const double mlo = mel(20.0), mhi = mel(8000.0), delta = (mhi - mlo) / (nmel + 1);
+  for (int m = 0; m < nmel; ++m) {
+    const double left = mlo + m * delta, center = left + delta, right = center + delta;
+    for (int b = 0; b < NFFT / 2; ++b) {
+      const double mf = mel(16000.0 / NFFT * b);
+      const double up = (mf - left) / (center - left), down = (right - mf) / (right - center);
+      const double wgt = std::max(0.0, std::min(up, down));
+      if (wgt > 0.0) {
+        (*melw)[(size_t)m * NBIN + b] = (float)wgt;
+        (*lo)[m] = std::min((*lo)[m], b); (*hi)[m] = std::max((*hi)[m], b + 1);
+      }
+    }
+    if ((*hi)[m] == 0) (*lo)[m] = 0;
+  }
+}
+
+int fbank_any(hipStream_t s, const float* wave, int64_t n_frames, float* feats, const FbankTables& t, int win, int shift, int nmel) {
+  if (n_frames <= 0) return OK;
+  const FbankAny g{win, shift, nmel};
+  hipLaunchKernelGGL(fbank_any_kernel, dim3(cdiv(n_frames, 4)), dim3(256), 0, s, wave, n_frames, feats, t, g);
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 __global__ __launch_bounds__(256) void round_i16_kernel(const float* __restrict__ x, int64_t n, int16_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (int16_t)__builtin_rintf(fminf(fmaxf(x[i], -32768.f), 32767.f));
@@ -208,3 +338,40 @@ int round_to_i16(hipStream_t s, const float* x, int64_t n, int16_t* out) {
 }
 
 }  // namespace rvb
+
+// ReverbASR.compute_feats with front-end settings other than the model's (cli/reverb.py:119-146): see include/rvb.h
+extern "C" int rvb_compute_feats(int device, const float* wave, int64_t n_samples, int num_mel_bins, double frame_length_ms,
+                                 double frame_shift_ms, float* feats_out, int64_t* n_frames) {
+  using namespace rvb;
+  if (!n_frames || (!wave && n_samples > 0) || n_samples < 0) { set_error("rvb_compute_feats: bad argument"); return E_ARG; }
+  const int win = (int)(16000.0 * frame_length_ms * 0.001), shift = (int)(16000.0 * frame_shift_ms * 0.001);
+  if (win <= 256 || win > 512 || shift < 1 || num_mel_bins < 1 || num_mel_bins > 128) {
+    set_error("rvb_compute_feats: supported are frame_length 16.1 .. 32 ms (a 512-point FFT at 16 kHz), frame_shift >= 1 sample, 1 .. 128 mel bins");
+    return E_UNSUPPORTED;
+  }
+  const int64_t nf = n_samples < win ? 0 : 1 + (n_samples - win) / shift;
+  *n_frames = nf;
+  if (!feats_out || nf == 0) return OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { set_error("rvb_compute_feats: no HIP device (this library has no CPU fallback)"); return E_HIP; }
+  RVB_HIP_CHECK(hipSetDevice(device));
+  std::vector<float> window, tw, melw;
+  std::vector<int32_t> lo, hi;
+  fbank_host_tables(win, num_mel_bins, &window, &tw, &melw, &lo, &hi);
+  void *dwave = nullptr, *dwin = nullptr, *dtw = nullptr, *dmel = nullptr, *dlo = nullptr, *dhi = nullptr, *dout = nullptr;
+  auto up = [](void** d, const void* h, size_t bytes) { return hipMalloc(d, bytes) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+  int rc = OK;
+  if (!up(&dwave, wave, (size_t)n_samples * 4) || !up(&dwin, window.data(), window.size() * 4) || !up(&dtw, tw.data(), tw.size() * 4) ||
+      !up(&dmel, melw.data(), melw.size() * 4) || !up(&dlo, lo.data(), lo.size() * 4) || !up(&dhi, hi.data(), hi.size() * 4) ||
+      hipMalloc(&dout, (size_t)nf * num_mel_bins * 4) != hipSuccess) {
+    set_error("rvb_compute_feats: device allocation / upload failed"); rc = E_NOMEM;
+  }
+  if (rc == OK) {
+    const FbankTables t{(const float*)dwin, (const float*)dtw, (const float*)dmel, (const int*)dlo, (const int*)dhi};
+    rc = fbank_any(nullptr, (const float*)dwave, nf, (float*)dout, t, win, shift, num_mel_bins);
+    if (rc == OK && hipDeviceSynchronize() != hipSuccess) { set_error("rvb_compute_feats: kernel failed"); rc = E_HIP; }
+    if (rc == OK && hipMemcpy(feats_out, dout, (size_t)nf * num_mel_bins * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("rvb_compute_feats: download failed"); rc = E_HIP; }
+  }
+  for (void* q : {dwave, dwin, dtw, dmel, dlo, dhi, dout}) if (q) (void)hipFree(q);
+  return rc;
+}

@@ -170,11 +170,26 @@ class ReverbASR:
 
     def compute_feats(self, audio_file: str, resample_rate: int = 16000, num_mel_bins=23, frame_length=25,
                       frame_shift=10, dither=0.0):
-        """(1, frames, num_mel_bins) float32 tensor; the same features stay resident in HBM."""
-        if (num_mel_bins, frame_length, frame_shift, dither) != (80, 25, 10, 0.0):
-            raise NotImplementedError("the device fbank is built for 80 bins / 25 ms / 10 ms / no dither")
+        """(1, frames, num_mel_bins) float32 tensor.  With the model's own settings (80 / 25 / 10) the same features stay resident
+        in HBM for the decode that follows; any other setting (the reference passes them straight to kaldi.fbank, and its own
+        default is 23 bins) goes through the stand-alone `rvb_compute_feats`."""
+        if dither != 0.0:
+            raise NotImplementedError("dither is random noise: the device fbank computes dither = 0.0 (what the Reverb recipe uses)")
         self.engine.upload_pcm(*self._load_pcm(audio_file, resample_rate))
-        _, feats = self.engine.fbank(return_feats=True)
+        if (num_mel_bins, frame_length, frame_shift) == (80, 25, 10):
+            _, feats = self.engine.fbank(return_feats=True)
+            return _torch().from_numpy(feats).unsqueeze(0)
+        import ctypes as C
+        from ._lib import check, fptr
+        wave = np.ascontiguousarray(self.engine.waveform(), np.float32)       # 16 kHz, int16 scale (resampled on the device if needed)
+        n = C.c_int64(0)
+        lib, dev = self.engine.lib, int(getattr(self.engine, "device_index", 0) or 0)
+        check(lib.rvb_compute_feats(dev, fptr(wave), wave.size, int(num_mel_bins), float(frame_length), float(frame_shift), None, C.byref(n)),
+              "rvb_compute_feats")
+        feats = np.empty((n.value, int(num_mel_bins)), np.float32)
+        if n.value:
+            check(lib.rvb_compute_feats(dev, fptr(wave), wave.size, int(num_mel_bins), float(frame_length), float(frame_shift), fptr(feats),
+                                        C.byref(n)), "rvb_compute_feats")
         return _torch().from_numpy(feats).unsqueeze(0)
 
     def feats_batcher(self, infeats, chunk_size: int, batch_size: int) -> Generator[Tuple, None, None]:

@@ -134,3 +134,15 @@ def test_diarization_fails_loudly_without_gpu():
     from reverb_amd.diar_engine import DiarEngine
     with pytest.raises(_lib.RvbError, match="no HIP device"):
         DiarEngine(synth_diar.make_diar_config(), {}, dtype="f32")
+
+
+def test_compute_feats_refuses_what_the_kernel_does_not_cover():
+    """host-side argument checks of rvb_compute_feats (no GPU needed for the frame count or the refusals)"""
+    lib = _lib.load()
+    n = ctypes.c_int64(-1)
+    x = np.zeros(16000, np.float32)
+    assert lib.rvb_compute_feats(0, _lib.fptr(x), x.size, 23, 25.0, 10.0, None, ctypes.byref(n)) == 0 and n.value == 98
+    assert lib.rvb_compute_feats(0, _lib.fptr(x), x.size, 80, 32.0, 8.0, None, ctypes.byref(n)) == 0 and n.value == 1 + (16000 - 512) // 128
+    for bins, flen, fshift in ((80, 10.0, 10.0), (80, 40.0, 10.0), (200, 25.0, 10.0), (80, 25.0, 0.0)):
+        assert lib.rvb_compute_feats(0, _lib.fptr(x), x.size, bins, flen, fshift, None, ctypes.byref(n)) == -5      # RVB_E_UNSUPPORTED
+        assert b"rvb_compute_feats" in lib.rvb_last_error()
