@@ -7,6 +7,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("RVB_LAB", "1")                 # the policy is selected through lab switches: bind librvb_test.so
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np                                    # noqa: E402
