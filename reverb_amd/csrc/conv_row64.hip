@@ -13,19 +13,20 @@
 //     9 taps x 2 chunks x 2 n-tiles x 16 B = 144 VGPRs; LDS holds pixels only;
 //   * the 16-byte chunks of a pixel's 64-byte channel chunk are XOR-swizzled with bit 2 of the pixel index (source side of the
 //     LDS-DMA), so a ds_read_b128 of 16 consecutive pixels covers all 64 banks once;
-//   * 4 waves and ONE patch buffer per workgroup (49 KB of LDS, 2 waves per SIMD): TWO workgroups per CU fill each other's
-//     barriers and DMA waits; no prefetch across tiles.
+//   * 4 waves per workgroup (49 KB of LDS, 2 waves per SIMD): TWO workgroups per CU fill each other's barriers and waits.
 //
-// Geometry: a workgroup owns 4 output rows of one window and walks tiles of 62 frames (patch 6 rows x 64 pixels, stored as two
-// chunk planes [chunk][row][pixel][64 B] of 24 KiB).  Wave w: channel half w & 1, output rows 2 (w >> 1) and + 1 = 8 m-tiles of
-// 16 pixels, in two halves of four (32 accumulator + 32 fragment registers live at a time); per (chunk, tap) 4 fragment reads and
-// 8 MFMAs.  Every pixel fragment is read by two waves (the two channel halves).
-// Iteration: residual loads of the first half; 18 (chunk, tap) steps; epilogue + stores; the same for the second half; barrier
-// (the patch is free); LDS-DMA of the next patch; `s_waitcnt vmcnt(0)`; barrier.
+// Geometry: a workgroup owns 4 output rows of one window and walks tiles of 30 frames (patch 6 rows x 32 pixels, stored as two
+// chunk planes [chunk][row][pixel][64 B] of 12 KiB; TWO patch buffers = 49 KB of LDS).  Wave w: channel half w & 1, output rows
+// 2 (w >> 1) and + 1, two 16-pixel m-tiles each = 4 m-tiles, one accumulator set; per (chunk, tap) 4 fragment reads and 8 MFMAs.
+// Every pixel fragment is read by two waves (the two channel halves).
+// Iteration: LDS-DMA of the NEXT tile's patch into the other buffer; residual loads; 18 (chunk, tap) steps; `s_waitcnt vmcnt(0)`
+// (this wave's pieces of the next patch and the residual vectors: both requested a tile of MFMAs ago); epilogue with stores that
+// are younger than that wait and hidden from the compiler's, so nothing ever waits for them; ONE barrier.
 //
-// Measured (profiles/r05_call10_conv_row64.txt, same box A/B): the 64-channel stage 51.6-52.2 -> 43.3-43.4 ms per hour of audio
-// (4.9 us per tile against an HBM floor of about 3.5; what is left is the patch exchange -- barrier, DMA, wait, barrier -- that
-// only the CU's other workgroup covers).
+// Measured (same box A/B, profiles/r05_call10_conv_row64.txt, r05_call14_conv_row64_narrow.txt): the 64-channel stage 51.6-52.5 ms
+// per hour of audio on the direct kernel -> 43.3-43.8 ms in this kernel's first form (62-frame tiles, ONE patch buffer: barrier,
+// DMA, wait, barrier at the end of every tile, covered only by the CU's other workgroup) -> **39.1 ms** with 30-frame tiles and
+// two buffers (+3 % MFMA work for the narrower tiles, the DMA latency under the tile's own MFMAs).
 //
 // Results: accumulation order (chunks outer, taps inner), operand values and rounding points are conv_kernel's: bit-identical
 // (tests/test_diar_gpu.py: test_row64_convolutions_equal_the_direct_kernel).
@@ -39,10 +40,7 @@ namespace rvb {
 
 namespace {
 
-constexpr int CR_OT = 62, CR_PT = 64, CR_PF = 6, CR_OF = 4, CR_NT = 64;
-constexpr int CR_ROW = CR_PT * 64;                  // one patch row of one chunk plane: 4 096 B
-constexpr int CR_PLANE = CR_PF * CR_ROW;            // 24 576 B
-constexpr int CR_LDS = 2 * CR_PLANE + 128;          // 128 B: the two pixels garbage m-tile positions read past the buffer
+constexpr int CR_PF = 6, CR_OF = 4, CR_NT = 64;
 
 typedef unsigned cr_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -54,28 +52,6 @@ __device__ inline void cr_mma(const uint4& w, const uint4& x, f32x4_t& c) {
 }
 __device__ inline unsigned cr_swz(unsigned g, unsigned c) { return g * 64u + ((c ^ (((g >> 2) & 1u) << 1)) << 4); }
 
-// four 1-KiB LDS-DMA pieces: one patch row of one chunk plane (4 KiB), 16 pixels per piece
-__device__ inline void cr_dma4(const unsigned (&off)[4], const void* sbase, unsigned lds0) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(lds0)
-      : "memory", "scc");
-}
 // one 16-byte store the compiler's waitcnt pass does not see: it waits for a store (vmcnt is one queue for loads and stores)
 // before the next m-tile's epilogue touches the registers the store read, i.e. it would drain every store one by one.  s_nop 1:
 // the TWO wait states gfx950 wants between a store of more than 8 bytes and a VALU write of its data registers
@@ -95,6 +71,29 @@ __device__ inline const char* cr_uniform(const char* q) {
 
 // RES / RELU are template parameters: with `if (p.res)` blocks in the body the compiler re-waits for the residual loads inside each
 // of them, and each such wait (counted against ITS loads only) also drains the hidden stores issued in between
+constexpr int CN_OT = 30, CN_PT = 32;
+constexpr int CN_ROW = CN_PT * 64;                  // 2 048 B
+constexpr int CN_PLANE = CR_PF * CN_ROW;            // 12 288 B
+constexpr int CN_BUF = 2 * CN_PLANE + 128;          // both chunk planes of a tile + the spill pad
+constexpr int CN_LDS = 2 * CN_BUF;
+
+// two 1-KiB LDS-DMA pieces: one patch row of one chunk plane (2 KiB), 16 pixels per piece
+__device__ inline void cr_dma2(const unsigned (&off)[2], const void* sbase, unsigned lds0) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(lds0)
+      : "memory", "scc");
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cr_smem[];
@@ -102,10 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int FP = p.Fi + 2, TP = p.Ti + 2;
-  const int tiles_f = (p.Fo + CR_OF - 1) / CR_OF, tiles_t = (p.To + CR_OT - 1) / CR_OT;
-
-  // workgroup -> (window, mel-row tile); each XCD (workgroup id mod 8) takes a contiguous run of the linear order, so that the
-  // workgroups that share halo rows run on the same L2 at about the same time (as conv_stream.hip)
+  const int tiles_f = (p.Fo + CR_OF - 1) / CR_OF, tiles_t = (p.To + CN_OT - 1) / CN_OT;
   int lin;
   {
     const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
@@ -115,15 +111,11 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
   const int tf = lin % tiles_f;
   const int b = lin / tiles_f;
   const int f0 = tf * CR_OF;
-
   const char* in_b = cr_uniform((const char*)p.in + (size_t)b * FP * TP * CR_NT * 2);
-  const char* res_b = (const char*)p.res + (size_t)b * FP * TP * CR_NT * 2;       // from the argument itself: global (not flat) loads
+  const char* res_b = (const char*)p.res + (size_t)b * FP * TP * CR_NT * 2;
   char* out_b = (char*)p.out + (size_t)b * FP * TP * CR_NT * 2;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cr_smem;
 
-  // ---- DMA coordinates: the 12 (row, chunk) lines of a patch, 3 per wave: line q = 3 w + i -> row q >> 1, chunk q & 1 (bordered row
-  // f0 + row, clamped).  The LDS image is lane-linear, so the chunk swizzle is applied to the SOURCE: LDS position (pixel, chunk')
-  // receives global chunk chunk' ^ 2 [pixel bit 2]; within a piece pixel = lane >> 2, so that bit is lane bit 4
   unsigned lineoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -132,25 +124,21 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
   }
   const int ppx = lane >> 2;
   const unsigned piece_b = (unsigned)((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
-  auto issue = [&](int tt) __attribute__((always_inline)) {
-    const int t0 = tt * CR_OT;
-    unsigned px[4];
+  auto issue = [&](int tt) __attribute__((always_inline)) {          // 6 pieces per wave
+    const int t0 = tt * CN_OT;
+    unsigned px[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) px[g] = (unsigned)min(t0 + g * 16 + ppx, TP - 1) * (CR_NT * 2) + piece_b;
+    for (int g = 0; g < 2; ++g) px[g] = (unsigned)min(t0 + g * 16 + ppx, TP - 1) * (CR_NT * 2) + piece_b;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int q = wave * 3 + i;
-      unsigned off[4];
+      unsigned off[2];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) off[g] = lineoff[i] + px[g];
-      cr_dma4(off, in_b, __builtin_amdgcn_readfirstlane(lds_base + (q & 1) * CR_PLANE + (q >> 1) * CR_ROW));
+      for (int g = 0; g < 2; ++g) off[g] = lineoff[i] + px[g];
+      cr_dma2(off, in_b, __builtin_amdgcn_readfirstlane(lds_base + (tt & 1) * CN_BUF + (q & 1) * CN_PLANE + (q >> 1) * CN_ROW));
     }
   };
   issue(0);
-
-  // ---- this wave's half of the output channels, its weights in registers: lane (li, lg) supplies, for n-tile j, the row of channel
-  // half * 32 + (li >> 2) * 8 + j * 4 + (li & 3), k chunk lg of input-channel chunk c (global layout [tap][chunk][64][64 B]); its 8
-  // channels are then half * 32 + lg * 8 .. + 7 (accumulator (j, r) is channel + j * 4 + r)
   const int half = wave & 1, rpair = wave >> 1;
   uint4 w[9][2][2];
   float bias_r[8];
@@ -170,13 +158,12 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
       bias_r[0] = b0.x; bias_r[1] = b0.y; bias_r[2] = b0.z; bias_r[3] = b0.w; bias_r[4] = b1.x; bias_r[5] = b1.y; bias_r[6] = b1.z; bias_r[7] = b1.w;
     }
   }
-  // fragment offsets of the wave's first m-tile (patch row 2 rpair, pixel li) per column shift; the next m-tile is + 1 024 B, the
-  // next patch row + CR_ROW (= four m-tiles), the other chunk plane + CR_PLANE: all immediates, none changes the swizzle
+  // m-tile m of the wave = patch row 2 rpair + (m >> 1), pixels 16 (m & 1) ..: with two m-tiles per row, consecutive m-tiles are
+  // again 1 024 B apart
   unsigned aoff[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) aoff[kw] = cr_swz((unsigned)(2 * rpair * CR_PT + li + kw), lg);
+  for (int kw = 0; kw < 3; ++kw) aoff[kw] = cr_swz((unsigned)(2 * rpair * CN_PT + li + kw), lg);
   cr_wait_all();
-  // the weights are in their registers as far as the compiler is concerned (no pending load is carried into the loop)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -188,78 +175,73 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
   __syncthreads();
 
   for (int tt = 0; tt < tiles_t; ++tt) {
-    const int t0 = tt * CR_OT;
+    const int t0 = tt * CN_OT;
+    if (tt + 1 < tiles_t) issue(tt + 1);       // into the other buffer: its readers (tile tt - 1) are behind the last barrier
+    cr_u32x4 rp[4];
+    unsigned frow_off[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {              // output row 2 rpair + h: four m-tiles
-      const int fo = f0 + 2 * rpair + h;
-      const unsigned frow_off = (unsigned)(min(fo, p.Fo - 1) + 1) * TP;
-      cr_u32x4 rp[4];
-      if constexpr (RES) {
+    for (int h = 0; h < 2; ++h) frow_off[h] = (unsigned)(min(f0 + 2 * rpair + h, p.Fo - 1) + 1) * TP;
+    if constexpr (RES) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const unsigned t = (unsigned)min(t0 + m * 16 + li, p.To - 1) + 1;
-          rp[m] = *(const cr_u32x4*)(res_b + ((size_t)(frow_off + t) * CR_NT + half * 32 + lg * 8) * 2);
-        }
+      for (int m = 0; m < 4; ++m) {
+        const unsigned t = (unsigned)min(t0 + (m & 1) * 16 + li, p.To - 1) + 1;
+        rp[m] = *(const cr_u32x4*)(res_b + ((size_t)(frow_off[m >> 1] + t) * CR_NT + half * 32 + lg * 8) * 2);
       }
-      f32x4_t acc[4][2];
+    }
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const char* img = cr_smem + (tt & 1) * CN_BUF;
+    uint4 xf[2][4];
+    auto read_frags = [&](int step, int buf) __attribute__((always_inline)) {      // step = chunk * 9 + tap: chunks outer, taps inner
+      const int c = step / 9, tap = step - c * 9, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xf[buf][m] = *(const uint4*)(img + aoff[kw] + m * 1024 + kh * CN_ROW + c * CN_PLANE);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      const int cur = step & 1, c = step / 9, tap = step - c * 9;
+      if (step + 1 < 18) read_frags(step + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const char* img = cr_smem + h * CR_ROW;
-      uint4 xf[2][4];
-      auto read_frags = [&](int step, int buf) __attribute__((always_inline)) {      // step = chunk * 9 + tap: chunks outer, taps inner
-        const int c = step / 9, tap = step - c * 9, kh = tap / 3, kw = tap - kh * 3;
+        for (int j = 0; j < 2; ++j) cr_mma(w[tap][c][j], xf[cur][m], acc[m][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // this wave's pieces of the next patch (requested a whole tile of MFMAs ago) and the residual vectors have landed; the stores
+    // below are younger than this wait, so nothing ever waits for them
+    cr_wait_all();
+    if constexpr (RES) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xf[buf][m] = *(const uint4*)(img + aoff[kw] + m * 1024 + kh * CR_ROW + c * CR_PLANE);
-      };
-      read_frags(0, 0);
+      for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(rp[m]));
+    }
 #pragma unroll
-      for (int step = 0; step < 18; ++step) {
-        const int cur = step & 1, c = step / 9, tap = step - c * 9;
-        if (step + 1 < 18) read_frags(step + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 4; ++m) {
+      float v[8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) cr_mma(w[tap][c][j], xf[cur][m], acc[m][j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int e = 0; e < 8; ++e) v[e] = acc[m][e >> 2][e & 3] + bias_r[e];
       if constexpr (RES) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(rp[m]));        // consumed here, not inside the store predicates
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[m][e >> 2][e & 3] + bias_r[e];
-        if constexpr (RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __uint_as_float(rp[m][e] << 16);
-            v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
-          }
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += __uint_as_float(rp[m][e] << 16);
+          v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
         }
-        if constexpr (RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        const int o = m * 16 + li, t = t0 + o;
-        if (o < CR_OT && t < p.To && fo < p.Fo)
-          cr_store16(out_b + ((size_t)(frow_off + t + 1) * CR_NT + half * 32 + lg * 8) * 2,
-                     make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])));
       }
+      if constexpr (RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      const int o = (m & 1) * 16 + li, t = t0 + o, fo = f0 + 2 * rpair + (m >> 1);
+      if (o < CN_OT && t < p.To && fo < p.Fo)
+        cr_store16(out_b + ((size_t)(frow_off[m >> 1] + t + 1) * CR_NT + half * 32 + lg * 8) * 2,
+                   make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])));
     }
-    if (tt + 1 < tiles_t) {
-      cr_wait_lds();
-      __builtin_amdgcn_s_barrier();            // every wave has read the patch
-      asm volatile("" ::: "memory");
-      issue(tt + 1);
-      cr_wait_all();
-      __builtin_amdgcn_s_barrier();            // the next patch is visible
-      asm volatile("" ::: "memory");
-    }
+    __builtin_amdgcn_s_barrier();              // every wave's pieces of the next patch are in; this tile's buffer is free
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -276,11 +258,11 @@ template <bool RES, bool RELU>
 static int launch_row64(hipStream_t s, const ConvArgs& p) {
   static bool attr_set = false;
   if (!attr_set) {
-    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv_row64_kernel<RES, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_LDS));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv_row64_kernel<RES, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, CN_LDS));
     attr_set = true;
   }
   const int64_t blocks = (int64_t)p.B * cdiv(p.Fo, CR_OF);
-  hipLaunchKernelGGL((conv_row64_kernel<RES, RELU>), dim3((unsigned)blocks), dim3(256), CR_LDS, s, p);
+  hipLaunchKernelGGL((conv_row64_kernel<RES, RELU>), dim3((unsigned)blocks), dim3(256), CN_LDS, s, p);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -322,7 +322,7 @@ def test_row64_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch,
     accumulators = 8 consecutive channels of one pixel, swizzled patch, two workgroups per CU) against resnet.hip's direct kernel
     (lab switch RVD_CONV_ROW64=0): same operand values, accumulation order (chunks outer, taps inner) and rounding points -- the
     embeddings must be IDENTICAL; the counters prove which path ran.  The windows include the zero-padded tail window; 499 frames
-    = 8 full tiles of 62 + one of 3, 40 mel rows = 10 row tiles, with and without a residual."""
+    = 16 full tiles of 30 + one of 19, 40 mel rows = 10 row tiles, with and without a residual."""
     from reverb_amd.diar_engine import DiarEngine
     out, row64, flops = {}, {}, {}
     for flag in ("0", "1"):
