@@ -1,49 +1,46 @@
 // A whole stride-1 BasicBlock of the ResNet34 trunk's 32-channel stage in ONE kernel (bf16):
 //
 //     mid = relu(conv3x3_a(x) + b_a)          kept in LDS, never written to HBM
-//     out = relu(conv3x3_b(mid) + b_b + x)    the residual x comes out of the input patch that is in LDS anyway
+//     out = relu(conv3x3_b(mid) + b_b + x)    the residual x comes out of the input rows that are in LDS anyway
 //
 // Why (round 5; VERDICT r4 "next" #2): as two conv_stream launches a block moves five tensor passes through HBM (x read, mid
 // written, mid read, x read again as the residual, out written) for 37 kFLOP per pixel: 281 GB per hour of audio at 5.2 TB/s --
-// that form IS bound by HBM (profiles/r05_call7_conv_block_counters.txt).  Here x is read once (8 patch rows for 4 output rows, the
-// 4 halo rows served by the L2: 1.03 x the plane from HBM) and out written once: 113 GB per hour.
+// that form IS bound by HBM (profiles/r05_call7_conv_block_counters.txt).  Here x is read once and out written once.
 //
-// Geometry (unbordered coordinates; the tensors carry a one-pixel zero border, element (f, t) sits at bordered (f + 1, t + 1)):
-//   workgroup = 256 threads = 4 waves, owns output rows f0 .. f0+3 of one window and walks tiles of 60 frames, t0 = 60 tt
-//   patch  8 rows x 64 pixels x 64 B: bordered rows f0-1 .. f0+6, bordered columns t0-1 .. t0+62 (clamped into the plane: what the
-//          clamp changes only feeds mid positions outside the image, and those are set to zero); ONE buffer
-//   mid    6 rows x 64 pixels: rows f0-1 .. f0+4, columns t0-1 .. t0+62 (columns 62, 63 are never used); ZERO outside the image --
-//          the zero border the second convolution sees in the unfused path
-//   conv_a 24 m-tiles of 16 pixels, 6 per wave (two halves of three);  conv_b output row w, 4 m-tiles (two halves of two)
-//   LDS    patch 32 768 + mid 24 576 (+ pads) = 57 600 B and 248 VGPRs: TWO workgroups per CU, two waves per SIMD
+// Structure (the "band" form): a workgroup of 4 waves owns a 60-frame BAND of one window and walks DOWN its rows, three output rows
+// per step, with the input rows and the mid rows in two 8-row rings in LDS (64 pixels x 64 B per row; 2 x 32 KiB).  A step brings
+// three NEW input rows (LDS-DMA, requested a step ahead), computes the three NEW mid rows and three output rows; wave w owns the
+// 16-pixel column strip w of both convolutions (cb_slide).  No row of either convolution is computed twice, every input row is
+// fetched once, ONE barrier per step; 65.8 KB of LDS and 240 VGPRs: two workgroups per CU.
+//   bordered rows: input row pb = f + 1 (0 and F + 1 are the zero border); mid row mb = f + 1, ZERO for mb < 1 or mb > F -- the zero
+//   border the second convolution sees in the unfused path; columns: patch column c = bordered column t0 - 1 + c, mid column c =
+//   frame t0 - 1 + c (ZERO outside [0, T)), output o = frame t0 + o (o < 60)
+//   step k = -1 .. K - 1 (K = ceil(F / 3)):   conv_a -> mid rows 3k + 2 .. 3k + 4 from input rows 3k + 1 .. 3k + 5
+//                                             conv_b -> output rows (bordered) 3k + 1 .. 3k + 3 from mid rows 3k .. 3k + 4     (k >= 0)
+//                                             LDS-DMA of input rows 3k + 6 .. 3k + 8 (step k + 1's new rows) at the top of step k
+//   rings: row r lives in slot r & 7.  While a step reads input rows 3k + 1 .. 3k + 5, rows 3k + 6 .. 3k + 8 land: eight consecutive
+//   rows, eight slots; a wave that is past the barrier and already writes mid rows 3k + 5 .. 3k + 7 (step k + 1) beside one that still
+//   reads 3k .. 3k + 4: eight again.  Rows outside the tensor are clamped for the DMA; what they feed is zeroed or never stored.
 //
 // What makes it fast (each measured on the way, bit-identical throughout; "ms" = the stage per hour of audio, two launches: 54-56):
 //   * operand roles swapped: A = weights (M = channels), B = pixels (N = pixels), and the weight ROWS a lane supplies are chosen
 //     so that accumulator row (lane >> 4) * 4 + r of n-tile j is channel (lane >> 4) * 8 + j * 4 + r: a lane ends up holding 8
-//     CONSECUTIVE channels of ONE pixel -- exactly the 16 bytes it writes (to mid in LDS, or to the output in HBM: a wave stores
-//     1 KiB contiguous).  The first form (pixels x channels accumulators through a per-wave LDS slab, 61 LDS cycles per m-tile,
-//     weights and slabs in LDS: 61 ms, SLOWER than two launches) showed that these stages are bound by their LDS operations once
-//     HBM is out of the way;
-//   * both weight sets live in REGISTERS (2 x 9 taps x 2 n-tiles x 16 B per lane = 144 VGPRs), loaded once per workgroup: LDS holds
-//     only pixels, and no fragment of a weight is ever re-read;
+//     CONSECUTIVE channels of ONE pixel -- exactly the 16 bytes it writes (to mid in LDS, or to the output in HBM).  The first form
+//     (pixels x channels accumulators through a per-wave LDS slab, weights and slabs in LDS: 61 ms, SLOWER than two launches)
+//     showed that these stages are bound by their LDS operations once HBM is out of the way;
+//   * both weight sets live in REGISTERS (2 x 9 taps x 2 n-tiles x 16 B per lane = 144 VGPRs), loaded once per workgroup;
 //   * the 16-byte chunks of a pixel are XOR-swizzled with bit 2 of the pixel index (chunk ^= 2 for pixels 4-7 mod 8), on the
-//     LDS-DMA's source side for the patch and on the write side for mid: the plain [pixel][64 B] layout serves a ds_read_b128
-//     with a 2-way bank conflict in every lane group (lanes {0-3, 12-15} of a group sit 12 pixels = 768 B = 0 mod 256 apart);
-//     bank-conflict cycles 44 % -> 10 % of the LDS-active cycles.  Together: 42.5-43.0 ms (8 waves, two patch buffers, all waves in
-//     the same phase, two barriers per tile);
-//   * the same with the two convolutions as ROLES of different waves one tile apart (one barrier per tile): 42.8 ms -- equal; with
-//     the patches requested two tiles ahead by the role-A waves: 45.4 ms -- slower (profiles/r05_call5_*, r05_call8_*).  Neither
-//     phase serialisation inside a workgroup nor the prefetch distance was what was left: a tile took 3.0 us of which 1.2 us are
-//     MFMA time (MFMA busy 41 %, waves 33 % issuing / 43 % stalled at issue / 24 % parked, 3.25 VALU instructions per MFMA);
-//   * what did help is the ordinary remedy: FOUR waves and ONE patch buffer per workgroup, so that two workgroups share a CU and
-//     fill each other's barriers, DMA waits and VALU phases -- no prefetch across tiles at all: **39.3-39.5 ms**
-//     (profiles/r05_call9_conv_block_two_workgroups.txt).
-//
-// Iteration k (tile k of the walk):
-//   conv_a on the patch; bias + ReLU + zeroing; mid written; the wave's residual vectors read out of the patch; barrier B (mid
-//   visible, the patch free); LDS-DMA of patch k+1 into the patch buffer; conv_b on mid; `s_waitcnt vmcnt(0)` (this wave's pieces of
-//   patch k+1 have landed; the stores of tile k-1, issued a tile ago, have drained) and barrier A (patch k+1 visible, mid free);
-//   epilogue in registers: bias + residual + ReLU, one 16-byte store per lane and m-tile, draining under iteration k+1.
+//     LDS-DMA's source side for the input rows and on the write side for mid: the plain [pixel][64 B] layout serves a ds_read_b128
+//     with a 2-way bank conflict in every lane group; bank-conflict cycles 44 % -> 10 % of the LDS-active cycles.  Together, on
+//     tiles of 4 rows x 60 frames (8 waves, two patch buffers): 42.5-43.0 ms;
+//   * the two convolutions as ROLES of different waves one tile apart: 42.8 ms -- equal; patches two tiles ahead: 45.4 -- slower
+//     (profiles/r05_call5_*, r05_call8_*): neither phase serialisation inside a workgroup nor the prefetch distance was what was left;
+//   * FOUR waves and ONE patch buffer per workgroup, so that two workgroups share a CU and fill each other's barriers, DMA waits
+//     and VALU phases: 39.3-39.5 ms (profiles/r05_call9_conv_block_two_workgroups.txt);
+//   * column strips sliding down the rows of the tile (a fragment read once per input row instead of once per tap: 42 fragment reads
+//     per tile and wave instead of 90): 37.7 ms -- the LDS reads were no longer what bound it (profiles/r05_call15_*);
+//   * what did: the tile's halo.  Four output rows need six mid rows, 64 columns give 60 outputs: 1.33 x the block's MFMAs.  Walking
+//     down a band computes every row once (64 / 60 = 1.07 x): **30.8-31.0 ms** (profiles/r05_call16_conv_block_band.txt).
 //
 // Results: operand values, accumulation order (taps 0..8, one 32-channel K step each) and rounding points (mid and out rounded to
 // bf16 after bias / residual / ReLU in fp32) are those of two conv_stream / conv_kernel launches
@@ -58,12 +55,11 @@ namespace rvb {
 
 namespace {
 
-constexpr int CB_OT = 60, CB_PT = 64, CB_PF = 8, CB_MF = 6, CB_OF = 4, CB_NT = 32;
-constexpr int CB_ROW = CB_PT * 64;                   // one patch / mid row: 4 096 B
-constexpr int CB_PATCH = CB_PF * CB_ROW;             // 32 768 B
-constexpr int CB_MID = CB_MF * CB_ROW;               // 24 576 B
-constexpr int CB_OFF_MID = CB_PATCH + 128;              // 128 B: the two pixels garbage m-tile positions read past a buffer
-constexpr int CB_LDS = CB_OFF_MID + CB_MID + 128;
+constexpr int CB_OT = 60, CB_PT = 64, CB_NT = 32;         // output frames per band, patch / mid pixels per row, channels
+constexpr int CB_ROW = CB_PT * 64;                      // one patch / mid row: 4 096 B
+constexpr int CBB_R = 3, CBB_RING = 8;                  // output rows per step; rows per ring
+constexpr int CBB_OFF_MID = CBB_RING * CB_ROW + 128;    // 128 B: the two pixels the last strip reads past a ring's last row
+constexpr int CBB_LDS = CBB_OFF_MID + CBB_RING * CB_ROW + 128;
 
 typedef unsigned cb_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -78,28 +74,6 @@ __device__ inline void cb_mma(const uint4& w, const uint4& x, f32x4_t& c) {
 // byte offset of (pixel g, 16-byte chunk c) in a [pixel][64 B] image whose chunks are swizzled with bit 2 of the pixel index
 __device__ inline unsigned cb_swz(unsigned g, unsigned c) { return g * 64u + ((c ^ (((g >> 2) & 1u) << 1)) << 4); }
 
-// four 1-KiB LDS-DMA pieces: one patch row (4 KiB), 16 pixels per piece; per-lane 32-bit byte offsets from a scalar base
-__device__ inline void cb_dma4(const unsigned (&off)[4], const void* sbase, unsigned lds0) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(lds0)
-      : "memory", "scc");
-}
 __device__ inline void cb_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 __device__ inline void cb_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ inline const char* cb_uniform(const char* q) {
@@ -108,82 +82,96 @@ __device__ inline const char* cb_uniform(const char* q) {
   return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-// 9 taps of one convolution for NM consecutive m-tiles of this wave.  w: the weight fragments (registers); img: patch or mid at the
-// wave's first m-tile; a[kw]: this lane's swizzled byte offset at column shift kw, row shift 0.  The next m-tile is 16 pixels =
-// 1 024 B further (m-tiles are numbered along rows and a row is four of them), a row further down is + CB_ROW; neither changes
-// bit 2 of the pixel index, so the swizzle is the same and both are immediate offsets of the read.  The pixel fragments of
-// tap + 1 are read before the MFMAs of tap are issued.
-template <int NM>
-__device__ inline void cb_conv9(const uint4 (&w)[9][2], const char* img, const unsigned (&a)[3], f32x4_t (&acc)[NM][2]) {
-  uint4 xf[2][NM];
-  auto read_frags = [&](int tap, int buf) __attribute__((always_inline)) {
-    const int kh = tap / 3, kw = tap - kh * 3;
+__device__ inline void cb_dma1(unsigned off, const void* sbase, unsigned lds0) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off), "s"(sbase), "s"(lds0)
+      : "memory");
+}
+
+// One convolution for NR consecutive output rows of this wave's column strip, sliding down NR + 2 input rows of a ring (input row i
+// of the slide is ring row row0 + i).  The fragment of input row i at column shift kw is the operand of tap (kh, kw) of output row
+// i - kh for kh = 0, 1, 2: read ONCE, used for up to three output rows.  Every output still accumulates its taps in the order 0 .. 8
+// (row i - kh meets input row i at tap row kh, and rows arrive in order).  w: the weight fragments (registers); a[kw]: this lane's
+// swizzled byte offset at column shift kw in row 0 of the ring; done(r, acc) runs when row r has its last tap, between the MFMAs of
+// the rows that are still open.
+template <int NR, typename Done>
+__device__ inline void cb_slide(const uint4 (&w)[9][2], const char* ring, const unsigned (&a)[3], int row0, Done&& done) {
+  f32x4_t acc[NR][2];
+  uint4 xf[2][3];
+  auto read_row = [&](int i, int buf) __attribute__((always_inline)) {
+    const unsigned ro = (unsigned)((row0 + i) & (CBB_RING - 1)) * CB_ROW;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) xf[buf][m] = *(const uint4*)(img + a[kw] + m * 1024 + kh * CB_ROW);
+    for (int kw = 0; kw < 3; ++kw) xf[buf][kw] = *(const uint4*)(ring + (a[kw] + ro));
   };
+  read_row(0, 0);
 #pragma unroll
-  for (int m = 0; m < NM; ++m)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  read_frags(0, 0);
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int cur = tap & 1;
-    if (tap + 1 < 9) read_frags(tap + 1, cur ^ 1);
+  for (int i = 0; i < NR + 2; ++i) {
+    const int cur = i & 1;
+    if (i + 1 < NR + 2) read_row(i + 1, cur ^ 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < NM; ++m)
+    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) cb_mma(w[tap][j], xf[cur][m], acc[m][j]);
+      for (int kh = 2; kh >= 0; --kh) {
+        const int r = i - kh;
+        if (r < 0 || r >= NR) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (kh == 0 && kw == 0) acc[r][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          cb_mma(w[kh * 3 + kw][j], xf[cur][kw], acc[r][j]);
+        }
+      }
     __builtin_amdgcn_sched_barrier(0);
+    if (i >= 2) done(i - 2, acc[i - 2]);
   }
 }
 
-
-__global__ __launch_bounds__(256, 2) void conv_block32_kernel(ConvBlockArgs p, int tsplit) {
+__global__ __launch_bounds__(256, 2) void conv_block32_kernel(ConvBlockArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cb_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int FP = p.F + 2, TP = p.T + 2;
-  const int tiles_f = (p.F + CB_OF - 1) / CB_OF, tiles_t = (p.T + CB_OT - 1) / CB_OT;
-  const int per = (tiles_t + tsplit - 1) / tsplit;
+  const int bands = (p.T + CB_OT - 1) / CB_OT;
   int lin;
   {
     const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int sp = lin % tsplit;
-  const int tf = (lin / tsplit) % tiles_f;
-  const int b = lin / (tsplit * tiles_f);
-  const int f0 = tf * CB_OF;
-  const int tt0 = sp * per, tt1 = min(tiles_t, tt0 + per);
-  const int n_tiles = tt1 - tt0;
-  if (n_tiles <= 0) return;
+  const int band = lin % bands;
+  const int b = lin / bands;
+  const int t0 = band * CB_OT;
   const char* in_b = cb_uniform((const char*)p.in + (size_t)b * FP * TP * CB_NT * 2);
   char* out_b = (char*)p.out + (size_t)b * FP * TP * CB_NT * 2;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cb_smem;
 
-  // wave w brings patch rows 2 w and 2 w + 1 (8 pieces); chunk swizzle on the source side as in the 8-wave kernel
-  const unsigned rowoff0 = (unsigned)(min(max(f0 - 1 + 2 * wave, 0), FP - 1) * TP) * (CB_NT * 2);
-  const unsigned rowoff1 = (unsigned)(min(max(f0 + 2 * wave, 0), FP - 1) * TP) * (CB_NT * 2);
+  // a step's 12 pieces (3 rows x 4 groups of 16 pixels): wave w brings pieces 3 w .. 3 w + 2; the column part of their source
+  // offsets never changes (the band is fixed), the row part is uniform
   const int ppx = lane >> 2;
   const unsigned piece_b = (unsigned)((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
-  auto issue = [&](int k) __attribute__((always_inline)) {
-    const int t0 = (tt0 + k) * CB_OT;
-    unsigned px[4], off[4];
+  unsigned colterm[3];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) px[g] = (unsigned)min(max(t0 - 1 + g * 16 + ppx, 0), TP - 1) * (CB_NT * 2) + piece_b;
-    const unsigned dst = lds_base + 2 * wave * CB_ROW;
+  for (int i = 0; i < 3; ++i) {
+    const int g = (wave * 3 + i) & 3;
+    colterm[i] = (unsigned)min(max(t0 - 1 + g * 16 + ppx, 0), TP - 1) * (CB_NT * 2) + piece_b;
+  }
+  auto issue = [&](int k) __attribute__((always_inline)) {          // the new patch rows of step k: 3 k + 3 .. 3 k + 5
 #pragma unroll
-    for (int g = 0; g < 4; ++g) off[g] = rowoff0 + px[g];
-    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(dst));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) off[g] = rowoff1 + px[g];
-    cb_dma4(off, in_b, __builtin_amdgcn_readfirstlane(dst + CB_ROW));
+    for (int i = 0; i < 3; ++i) {
+      const int q = wave * 3 + i, pb = CBB_R * k + 3 + (q >> 2);
+      const unsigned rowterm = (unsigned)(min(pb, FP - 1) * TP) * (CB_NT * 2);
+      cb_dma1(colterm[i] + rowterm, in_b, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(pb & (CBB_RING - 1)) * CB_ROW + (unsigned)(q & 3) * 1024));
+    }
   };
-  issue(0);
+  issue(-1);
   uint4 wa[9][2], wb[9][2];
   float ba_r[8], bb_r[8];
   {
@@ -202,68 +190,60 @@ __global__ __launch_bounds__(256, 2) void conv_block32_kernel(ConvBlockArgs p, i
     ba_r[0] = a0.x; ba_r[1] = a0.y; ba_r[2] = a0.z; ba_r[3] = a0.w; ba_r[4] = a1.x; ba_r[5] = a1.y; ba_r[6] = a1.z; ba_r[7] = a1.w;
     bb_r[0] = b0.x; bb_r[1] = b0.y; bb_r[2] = b0.z; bb_r[3] = b0.w; bb_r[4] = b1.x; bb_r[5] = b1.y; bb_r[6] = b1.z; bb_r[7] = b1.w;
   }
-  unsigned aoff[3], boff[3];
+  unsigned soff[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    aoff[kw] = cb_swz((unsigned)(wave * 6 * 16 + li + kw), lg);
-    boff[kw] = cb_swz((unsigned)(wave * CB_PT + li + kw), lg);
-  }
-  const unsigned moff = cb_swz((unsigned)(wave * 6 * 16 + li), lg);
-  const unsigned roff = cb_swz((unsigned)((wave + 2) * CB_PT + li + 2), lg);
+  for (int kw = 0; kw < 3; ++kw) soff[kw] = cb_swz((unsigned)(wave * 16 + li + kw), lg);
+  const unsigned moff = cb_swz((unsigned)(wave * 16 + li), lg);
+  const unsigned roff = cb_swz((unsigned)(wave * 16 + li + 2), lg);
   const char* patch = cb_smem;
-  char* mid = cb_smem + CB_OFF_MID;
-  const int fo = f0 + wave;
-  const unsigned frow_off = (unsigned)(min(fo, p.F - 1) + 1) * TP;
+  char* mid = cb_smem + CBB_OFF_MID;
+  const int o = wave * 16 + li;
+  const int tm = t0 - 1 + o;                                // the mid column's frame
+  const bool tm_in = tm >= 0 && tm < p.T;
+  const int t = t0 + o;
+  const bool t_ok = o < CB_OT && t < p.T;
+  const int K = (p.F + CBB_R - 1) / CBB_R;
   cb_wait_all();
   __syncthreads();
 
-  for (int k = 0; k < n_tiles; ++k) {
-    const int t0 = (tt0 + k) * CB_OT;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x4_t acc[3][2];
-      cb_conv9<3>(wa, patch + h * 3 * 1024, aoff, acc);
-#pragma unroll
-      for (int mm = 0; mm < 3; ++mm) {
-        const int m = h * 3 + mm, idx = wave * 6 + m;
-        const int f = f0 - 1 + (idx >> 2), t = t0 - 1 + (idx & 3) * 16 + li;
-        const bool inside = f >= 0 && f < p.F && t >= 0 && t < p.T;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[mm][e >> 2][e & 3] + ba_r[e], 0.f) : 0.f;
-        *(uint4*)(mid + moff + m * 1024) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-      }
-    }
-    cb_u32x4 rp[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) rp[m] = *(const cb_u32x4*)(patch + roff + m * 1024);
-    cb_wait_lds();
-    __builtin_amdgcn_s_barrier();                      // B: mid visible, the patch is free
-    asm volatile("" ::: "memory");
-    if (k + 1 < n_tiles) issue(k + 1);
-    f32x4_t acc2[2][2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) cb_conv9<2>(wb, mid + h * 2 * 1024, boff, acc2[h]);
-    cb_wait_all();
-    __builtin_amdgcn_s_barrier();                      // A: patch k+1 visible, mid free
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
+  for (int k = -1; k < K; ++k) {
+    if (k + 1 < K) issue(k + 1);
+    const int m0 = CBB_R * k + 2;                           // first new mid row
+    cb_slide<CBB_R>(wa, patch, soff, m0 - 1, [&](int r, f32x4_t (&acc)[2]) __attribute__((always_inline)) {
+      const int mb = m0 + r;
+      const bool inside = tm_in && mb >= 1 && mb <= p.F;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc2[m >> 1][m & 1][e >> 2][e & 3] + bb_r[e];
+      for (int e = 0; e < 8; ++e) v[e] = inside ? fmaxf(acc[e >> 2][e & 3] + ba_r[e], 0.f) : 0.f;
+      *(uint4*)(mid + (moff + (unsigned)(mb & (CBB_RING - 1)) * CB_ROW)) =
+          make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+    });
+    const int ob0 = CBB_R * k + 1;                          // first output row (bordered) of the step
+    cb_u32x4 rp[CBB_R];
+    if (k >= 0) {
+#pragma unroll
+      for (int q = 0; q < CBB_R; ++q) rp[q] = *(const cb_u32x4*)(patch + (roff + (unsigned)((ob0 + q) & (CBB_RING - 1)) * CB_ROW));
+    }
+    cb_wait_all();                                     // mid written, residuals read, this wave's pieces of the next rows landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (k < 0) continue;
+    cb_slide<CBB_R>(wb, mid, soff, ob0 - 1, [&](int q, f32x4_t (&acc)[2]) __attribute__((always_inline)) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[e >> 2][e & 3] + bb_r[e];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[2 * e] += __uint_as_float(rp[m][e] << 16);
-        v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
+        v[2 * e] += __uint_as_float(rp[q][e] << 16);
+        v[2 * e + 1] += __uint_as_float(rp[q][e] & 0xffff0000u);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      const int o = m * 16 + li, t = t0 + o;
-      if (o < CB_OT && t < p.T && fo < p.F)
-        *(uint4*)(out_b + ((size_t)(frow_off + t + 1) * CB_NT + lg * 8) * 2) =
+      const int ob = ob0 + q;
+      if (t_ok && ob <= p.F)
+        *(uint4*)(out_b + ((size_t)((unsigned)ob * TP + t + 1) * CB_NT + lg * 8) * 2) =
             make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-    }
+    });
   }
 }
 
@@ -278,15 +258,14 @@ bool conv_block32_applicable(int dtype, int cin, int cmid, int cout, int stride_
 
 int conv_block32(hipStream_t s, const ConvBlockArgs& a) {
   if (a.B <= 0) return OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv_block32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS));
-    attr_set = true;
+  static bool attr_b = false;
+  if (!attr_b) {
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv_block32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CBB_LDS));
+    attr_b = true;
   }
-  const int tsplit = 1;
-  const int64_t blocks = (int64_t)a.B * cdiv(a.F, CB_OF) * tsplit;
-  if (blocks >= ((int64_t)1 << 31)) { set_error("conv_block32: too many workgroups"); return E_ARG; }
-  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)blocks), dim3(256), CB_LDS, s, a, tsplit);
+  const int64_t wgs = (int64_t)a.B * cdiv(a.T, CB_OT);
+  if (wgs >= ((int64_t)1 << 31)) { set_error("conv_block32: too many workgroups"); return E_ARG; }
+  hipLaunchKernelGGL(conv_block32_kernel, dim3((unsigned)wgs), dim3(256), CBB_LDS, s, a);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace rvb {
@@ -69,13 +70,14 @@ __device__ inline void cg_pin(uint4& a, uint4& b) {
 
 // SC: the block's projection shortcut rides in this convolution's K loop (ConvArgs::in2; its own instantiation, so that the plain
 // form keeps its registers: the 256-channel tile sits at 254 VGPRs)
-template <int BN, bool SC = false>
+template <int BN, bool SC = false, int BM = 256>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char cg_smem[];
   constexpr int BKB = 128, BKE = 64;
   constexpr int NWN = BN / 64, NWM = 8 / NWN;                 // waves along channels / pixels
-  constexpr int TM = 256 / NWM, FI = TM / 16, FJ = 4;         // wave tile TM pixels x 64 channels
-  constexpr int STAGE = (256 + BN) * BKB;
+  constexpr int TM = BM / NWM, FI = TM / 16, FJ = 4;          // wave tile TM pixels x 64 channels
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int AP = BM / 64, AR = BM / 8;                    // pixel pieces (8 rows each) / pixel rows per wave
   constexpr int WP = BN / 64;                                  // weight pieces (8 rows each) per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * 256, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BN;
   const bf16_t* __restrict__ in = (const bf16_t*)p.in;
   const bf16_t* __restrict__ w = (const bf16_t*)p.w_ig;
   const size_t ldw = (size_t)9 * Cin + (SC ? p.Cin2 : 0);      // weight row: 9 taps (+ the fused shortcut's channels)
@@ -102,11 +104,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
 
   // ---- DMA sources: wave w stages pixels [32w, 32w+32) and weight rows [8 WP w, +8 WP); source column swizzled
   const int lr = lane >> 3, lc = lane & 7;
-  const bf16_t* a_src[4];
+  const bf16_t* a_src[AP];
   const bf16_t* w_src[WP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + lr;
+  for (int i = 0; i < AP; ++i) {
+    const int row = wave * AR + i * 8 + lr;
     int m = m0 + row;
     if (m >= M) m = M - 1;                                     // clamped rows are computed and never stored
     const int b = m / (F * T), rem = m - b * (F * T);
@@ -130,18 +132,18 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
       const bf16_t* in2 = (const bf16_t*)p.in2;
       const int TP2 = p.Ti2 + 2, FP2 = p.Fi2 + 2, s2 = p.stride2, C2 = p.Cin2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + lr;
+      for (int i = 0; i < AP; ++i) {
+        const int row = wave * AR + i * 8 + lr;
         int m = m0 + row;
         if (m >= M) m = M - 1;
         const int b = m / (F * T), rem = m - b * (F * T);
         const int fo = rem / T, to = rem - fo * T;
         const bf16_t* src = in2 + ((size_t)(b * FP2 + s2 * fo + 1) * TP2 + s2 * to + 1) * C2 + j * BKE + (lc ^ ((row >> 1) & 7)) * 8;
-        cg_dma(src, dst + (wave * 32 + i * 8) * BKB);
+        cg_dma(src, dst + (wave * AR + i * 8) * BKB);
       }
       const size_t woff2 = (size_t)9 * Cin + (size_t)j * BKE;
 #pragma unroll
-      for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff2, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+      for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff2, dst + BM * BKB + (wave * (WP * 8) + i * 8) * BKB);
       return;
     }
     const int tap = kt / cpt, c0 = (kt - tap * cpt) * BKE;
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
     const size_t aoff = (size_t)(kh * TPi + kw) * Cin + c0;
     const size_t woff = (size_t)tap * Cin + c0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cg_dma(a_src[i] + aoff, dst + (wave * 32 + i * 8) * BKB);
+    for (int i = 0; i < AP; ++i) cg_dma(a_src[i] + aoff, dst + (wave * AR + i * 8) * BKB);
 #pragma unroll
-    for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff, dst + 256 * BKB + (wave * (WP * 8) + i * 8) * BKB);
+    for (int i = 0; i < WP; ++i) cg_dma(w_src[i] + woff, dst + BM * BKB + (wave * (WP * 8) + i * 8) * BKB);
   };
 
   f32x4_t acc[FI][FJ];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   roff[0] = ((0 + lgrp) ^ ((frow >> 1) & 7)) << 4;
   roff[1] = ((4 + lgrp) ^ ((frow >> 1) & 7)) << 4;
   const int a_off = (wr * TM + frow) * BKB;
-  const int b_off = 256 * BKB + (wc * 64 + frow) * BKB;
+  const int b_off = BM * BKB + (wc * 64 + frow) * BKB;
   const int nk = nk9 + (SC ? p.Cin2 / BKE : 0), nq = 2 * nk;      // nk >= 9
   uint4 fa[2][FI], fb[2][FJ];
   auto read_slice = [&](auto bufc, int q) __attribute__((always_inline)) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(ConvArgs p) {
   std::integral_constant<int, 1> b1;
   issue(0);
   issue(1);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + WP) : "memory");     // stage 0 = the older group of 4 + WP pieces
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + WP) : "memory");    // stage 0 = the older group of AP + WP pieces
   __syncthreads();
   read_slice(b0, 0);
   block(b0, 1);
@@ -530,20 +532,29 @@ int launch_igemm8(hipStream_t st, const ConvArgs& p) {
   return OK;
 }
 
-template <int BN, bool SC>
+template <int BN, bool SC, int BM = 256>
 int launch_igemm(hipStream_t st, const ConvArgs& p) {
-  const int lds = 2 * (256 + BN) * 128;
-  auto kern = conv_igemm_kernel<BN, SC>;
+  const int lds = 2 * (BM + BN) * 128;
+  auto kern = conv_igemm_kernel<BN, SC, BM>;
   static bool attr_set = false;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int64_t M = (int64_t)p.B * p.Fo * p.To;
-  const int64_t tiles = ((M + 255) / 256) * (p.Cout / BN);
+  const int64_t tiles = ((M + BM - 1) / BM) * (p.Cout / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, p);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
+}
+
+// 128-channel stage: 512-pixel tiles (wave tile 128 pixels x 64 channels, the 256-channel tile's) when the launch still fills the
+// chip several times over (lab: RVD_IGEMM_BM)
+bool igemm_wide_tile(const ConvArgs& p) {
+  const char* e = lab_env("RVD_IGEMM_BM");              // lab: 256 = never; 512 = always (tests: small launches too)
+  const int bm = e ? atoi(e) : 0;
+  if (bm == 256) return false;
+  return bm == 512 || (int64_t)p.B * p.Fo * p.To >= (int64_t)512 * 1024;
 }
 
 }  // namespace
@@ -555,6 +566,8 @@ bool conv_igemm_applicable(int dtype, const ConvArgs& p) {
   if (p.stride == 1) return p.Fo == p.Fi && p.To == p.Ti;
   return p.stride == 2 && p.Fo == (p.Fi - 1) / 2 + 1 && p.To == (p.Ti - 1) / 2 + 1;      // Conv2d(k 3, stride 2, pad 1)
 }
+
+bool conv_igemm_wide(const ConvArgs& p) { return p.Cout % 256 != 0 && !p.in2 && igemm_wide_tile(p); }
 
 bool conv_igemm8_applicable(int dtype, const ConvArgs& p) {
   if (!(dtype == DT_BF16 && p.in8 != nullptr && p.w8 != nullptr && p.w8_scale != nullptr && p.taps == 9 && p.Cin % 128 == 0 &&
@@ -571,8 +584,9 @@ int conv_igemm8(hipStream_t s, const ConvArgs& p) {
 
 int conv_igemm(hipStream_t s, const ConvArgs& p) {
   if (p.B <= 0) return OK;
-  if (p.in2) return p.Cout % 256 == 0 ? launch_igemm<256, true>(s, p) : launch_igemm<128, true>(s, p);
-  return p.Cout % 256 == 0 ? launch_igemm<256, false>(s, p) : launch_igemm<128, false>(s, p);
+  if (p.Cout % 256 == 0) return p.in2 ? launch_igemm<256, true>(s, p) : launch_igemm<256, false>(s, p);
+  if (conv_igemm_wide(p)) return launch_igemm<128, false, 512>(s, p);      // (with the fused shortcut the wide tile spills)
+  return p.in2 ? launch_igemm<128, true>(s, p) : launch_igemm<128, false>(s, p);
 }
 
 }  // namespace rvb

@@ -16,19 +16,22 @@
 //   * 4 waves per workgroup (49 KB of LDS, 2 waves per SIMD): TWO workgroups per CU fill each other's barriers and waits.
 //
 // Geometry: a workgroup owns 4 output rows of one window and walks tiles of 30 frames (patch 6 rows x 32 pixels, stored as two
-// chunk planes [chunk][row][pixel][64 B] of 12 KiB; TWO patch buffers = 49 KB of LDS).  Wave w: channel half w & 1, output rows
-// 2 (w >> 1) and + 1, two 16-pixel m-tiles each = 4 m-tiles, one accumulator set; per (chunk, tap) 4 fragment reads and 8 MFMAs.
-// Every pixel fragment is read by two waves (the two channel halves).
-// Iteration: LDS-DMA of the NEXT tile's patch into the other buffer; residual loads; 18 (chunk, tap) steps; `s_waitcnt vmcnt(0)`
-// (this wave's pieces of the next patch and the residual vectors: both requested a tile of MFMAs ago); epilogue with stores that
-// are younger than that wait and hidden from the compiler's, so nothing ever waits for them; ONE barrier.
+// chunk planes [chunk][row][pixel][64 B] of 12 KiB; TWO patch buffers = 49 KB of LDS).  Wave w = channel half w & 1 x the 16-pixel
+// column strip w >> 1, all FOUR output rows; it slides down the six patch rows once per channel chunk.  The fragment of input row i
+// at column shift kw is the operand of tap (kh, kw) of output row i - kh for kh = 0, 1, 2: read once, used for up to three rows --
+// 2 x 18 fragment reads per tile and wave for 144 MFMAs.  Every pixel fragment is read by two waves (the two channel halves).
+// Iteration: LDS-DMA of the NEXT tile's patch into the other buffer; residual loads; the two slides; when the first output row has
+// its last tap: `s_waitcnt vmcnt(0)` (this wave's pieces of the next patch and the residual vectors, both requested most of a tile of
+// MFMAs ago); the epilogue of row r between the MFMAs of the rows still open, with stores that are younger than that wait and
+// hidden from the compiler's, so nothing ever waits for them; ONE barrier.
 //
-// Measured (same box A/B, profiles/r05_call10_conv_row64.txt, r05_call14_conv_row64_narrow.txt): the 64-channel stage 51.6-52.5 ms
-// per hour of audio on the direct kernel -> 43.3-43.8 ms in this kernel's first form (62-frame tiles, ONE patch buffer: barrier,
-// DMA, wait, barrier at the end of every tile, covered only by the CU's other workgroup) -> **39.1 ms** with 30-frame tiles and
-// two buffers (+3 % MFMA work for the narrower tiles, the DMA latency under the tile's own MFMAs).
+// Measured (same box A/B, profiles/r05_call10_conv_row64.txt, r05_call14_*, r05_call15_*): the 64-channel stage 51.6-52.5 ms per hour
+// of audio on the direct kernel -> 43.3-43.8 ms in this kernel's first form (62-frame tiles, ONE patch buffer: barrier, DMA, wait,
+// barrier at the end of every tile, covered only by the CU's other workgroup) -> 39.1 ms with 30-frame tiles and two buffers (+3 %
+// MFMA work for the narrower tiles, the DMA latency under the tile's own MFMAs; wave = channel half x two rows, a fragment read per
+// tap: 72 reads per tile and wave) -> **37.0-38.0 ms** with the column strips (half the LDS reads: a small gain -- not what bounds it).
 //
-// Results: accumulation order (chunks outer, taps inner), operand values and rounding points are conv_kernel's: bit-identical
+// Results: accumulation order (chunks outer, taps inner: rows arrive in order, so every output still sees taps 0 .. 8 of chunk 0, then of chunk 1), operand values and rounding points are conv_kernel's: bit-identical
 // (tests/test_diar_gpu.py: test_row64_convolutions_equal_the_direct_kernel).
 #include <algorithm>
 #include <cstdlib>
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
     }
   };
   issue(0);
-  const int half = wave & 1, rpair = wave >> 1;
+  const int half = wave & 1, col = wave >> 1;
   uint4 w[9][2][2];
   float bias_r[8];
   {
@@ -158,11 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
       bias_r[0] = b0.x; bias_r[1] = b0.y; bias_r[2] = b0.z; bias_r[3] = b0.w; bias_r[4] = b1.x; bias_r[5] = b1.y; bias_r[6] = b1.z; bias_r[7] = b1.w;
     }
   }
-  // m-tile m of the wave = patch row 2 rpair + (m >> 1), pixels 16 (m & 1) ..: with two m-tiles per row, consecutive m-tiles are
-  // again 1 024 B apart
   unsigned aoff[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) aoff[kw] = cr_swz((unsigned)(2 * rpair * CN_PT + li + kw), lg);
+  for (int kw = 0; kw < 3; ++kw) aoff[kw] = cr_swz((unsigned)(col * 16 + li + kw), lg);
   cr_wait_all();
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -173,73 +174,79 @@ __global__ __launch_bounds__(256, 2) void conv_row64_kernel(ConvArgs p) {
       w[tap][c][0] = make_uint4(x[0], x[1], x[2], x[3]); w[tap][c][1] = make_uint4(y[0], y[1], y[2], y[3]);
     }
   __syncthreads();
+  const int o = col * 16 + li;
 
   for (int tt = 0; tt < tiles_t; ++tt) {
     const int t0 = tt * CN_OT;
     if (tt + 1 < tiles_t) issue(tt + 1);       // into the other buffer: its readers (tile tt - 1) are behind the last barrier
+    const int t = t0 + o;
+    const unsigned tcl = (unsigned)min(t, p.To - 1) + 1;
     cr_u32x4 rp[4];
-    unsigned frow_off[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) frow_off[h] = (unsigned)(min(f0 + 2 * rpair + h, p.Fo - 1) + 1) * TP;
     if constexpr (RES) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const unsigned t = (unsigned)min(t0 + (m & 1) * 16 + li, p.To - 1) + 1;
-        rp[m] = *(const cr_u32x4*)(res_b + ((size_t)(frow_off[m >> 1] + t) * CR_NT + half * 32 + lg * 8) * 2);
-      }
+      for (int q = 0; q < 4; ++q)
+        rp[q] = *(const cr_u32x4*)(res_b + ((size_t)((unsigned)(min(f0 + q, p.Fo - 1) + 1) * TP + tcl) * CR_NT + half * 32 + lg * 8) * 2);
     }
+    const bool t_ok = o < CN_OT && t < p.To;
     f32x4_t acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const char* img = cr_smem + (tt & 1) * CN_BUF;
-    uint4 xf[2][4];
-    auto read_frags = [&](int step, int buf) __attribute__((always_inline)) {      // step = chunk * 9 + tap: chunks outer, taps inner
-      const int c = step / 9, tap = step - c * 9, kh = tap / 3, kw = tap - kh * 3;
+    uint4 xf[2][3];
+    auto read_row = [&](int step, int buf) __attribute__((always_inline)) {      // step = chunk * 6 + input row
+      const int c = step / CR_PF, i = step - c * CR_PF;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) xf[buf][m] = *(const uint4*)(img + aoff[kw] + m * 1024 + kh * CN_ROW + c * CN_PLANE);
+      for (int kw = 0; kw < 3; ++kw) xf[buf][kw] = *(const uint4*)(img + aoff[kw] + i * CN_ROW + c * CN_PLANE);
     };
-    read_frags(0, 0);
+    read_row(0, 0);
 #pragma unroll
-    for (int step = 0; step < 18; ++step) {
-      const int cur = step & 1, c = step / 9, tap = step - c * 9;
-      if (step + 1 < 18) read_frags(step + 1, cur ^ 1);
+    for (int step = 0; step < 2 * CR_PF; ++step) {
+      const int cur = step & 1, c = step / CR_PF, i = step - c * CR_PF;
+      if (step + 1 < 2 * CR_PF) read_row(step + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cr_mma(w[tap][c][j], xf[cur][m], acc[m][j]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // this wave's pieces of the next patch (requested a whole tile of MFMAs ago) and the residual vectors have landed; the stores
-    // below are younger than this wait, so nothing ever waits for them
-    cr_wait_all();
-    if constexpr (RES) {
+        for (int kh = 2; kh >= 0; --kh) {
+          const int r = i - kh;
+          if (r < 0 || r >= CR_OF) continue;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(rp[m]));
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc[m][e >> 2][e & 3] + bias_r[e];
-      if constexpr (RES) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] += __uint_as_float(rp[m][e] << 16);
-          v[2 * e + 1] += __uint_as_float(rp[m][e] & 0xffff0000u);
+          for (int j = 0; j < 2; ++j) {
+            if (c == 0 && kh == 0 && kw == 0) acc[r][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            cr_mma(w[kh * 3 + kw][c][j], xf[cur][kw], acc[r][j]);
+          }
         }
-      }
-      if constexpr (RELU) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 1 && i >= 2) {
+        const int q = i - 2;
+        if (q == 0) {
+          // this wave's pieces of the next patch (requested most of a tile of MFMAs ago) and the residual vectors have landed; the
+          // stores below are younger than this wait, so nothing ever waits for them
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (RES) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(rp[m]));
+          }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[q][e >> 2][e & 3] + bias_r[e];
+        if constexpr (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(rp[q][e] << 16);
+            v[2 * e + 1] += __uint_as_float(rp[q][e] & 0xffff0000u);
+          }
+        }
+        if constexpr (RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const int fo = f0 + q;
+        if (t_ok && fo < p.Fo)
+          cr_store16(out_b + ((size_t)((unsigned)(fo + 1) * TP + t + 1) * CR_NT + half * 32 + lg * 8) * 2,
+                     make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])));
       }
-      const int o = (m & 1) * 16 + li, t = t0 + o, fo = f0 + 2 * rpair + (m >> 1);
-      if (o < CN_OT && t < p.To && fo < p.Fo)
-        cr_store16(out_b + ((size_t)(frow_off[m >> 1] + t + 1) * CR_NT + half * 32 + lg * 8) * 2,
-                   make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])));
     }
+    cr_wait_lds();
     __builtin_amdgcn_s_barrier();              // every wave's pieces of the next patch are in; this tile's buffer is free
     asm volatile("" ::: "memory");
   }

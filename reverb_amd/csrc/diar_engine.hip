@@ -551,7 +551,10 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
   a.stride = c.stride; a.taps = c.taps; a.relu = relu;
   a.w_ig = c.w_ig.p;
   const std::string nm = std::string(c.taps == 1 ? "emb_conv_sc" : (c.stride == 2 ? "emb_conv_s2_" : "emb_conv_")) + (c.taps == 1 ? "" : std::to_string(c.cout));
-  if (conv_igemm_applicable(e->dtype, a)) e->prof["emb_conv_igemm"].launches += 1;    // how many went to conv_gemm.hip
+  if (conv_igemm_applicable(e->dtype, a)) {
+    e->prof["emb_conv_igemm"].launches += 1;                                             // how many went to conv_gemm.hip
+    if (conv_igemm_wide(a)) e->prof["emb_conv_igemm_wide"].launches += 1;
+  }
   else if (conv_row64_applicable(e->dtype, a)) e->prof["emb_conv_row64"].launches += 1;        // ... to conv_row64.hip
   else if (conv_stream_applicable(e->dtype, a)) e->prof["emb_conv_stream"].launches += 1;     // ... to conv_stream.hip
   DScope sc(e, nm.c_str(), 2.0 * (double)B * dq.F * dq.T * c.cout * c.cin * c.taps);
@@ -625,7 +628,22 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
         x = out; dx = d; xi = oi;
         continue;
       }
-      RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+      bool sc_done = false;
+      if (Bk.has_sc && !Bk.c2.w_ig_sc.p &&
+          conv_s2sc_applicable(e->dtype, Bk.c1.cin, Bk.c1.cout, Bk.c1.stride, Bk.c1.taps, Bk.sc.cin, Bk.sc.cout, Bk.sc.stride, Bk.sc.taps, dx.F, dx.T, d.F, d.T)) {
+        // the stride-2 convolution and the projection shortcut of the block that opens the 64-channel stage: one pass over x (conv_s2.hip)
+        ConvS2Args a{};
+        a.in = x; a.w = Bk.c1.w.p; a.bias = Bk.c1.b.as<float>(); a.wsc = Bk.sc.w.p; a.bsc = Bk.sc.b.as<float>();
+        a.out = tmp; a.sc = e->act[li][3].p;
+        a.B = B; a.Fi = dx.F; a.Ti = dx.T; a.Fo = d.F; a.To = d.T;
+        e->prof["emb_conv_s2sc"].launches += 1;
+        { DScope sc(e, ("emb_conv_s2_" + std::to_string(Bk.c1.cout)).c_str(),
+                    2.0 * (double)B * d.F * d.T * Bk.c1.cout * ((double)Bk.c1.cin * 9 + Bk.sc.cin));
+          RVD_TRY(conv_s2sc(e->stream, a)); }
+        sc_done = true;
+      } else {
+        RVD_TRY(run_conv(e, Bk.c1, x, dx, nullptr, tmp, d, B, 1));
+      }
       if (f8blk && e->emb_f8_state == 1)
         RVD_TRY(act_amax_bf16(e->stream, tmp, (size_t)B * (d.F + 2) * (d.T + 2) * d.C, e->d_amax8.as<unsigned>() + ((li - 2) * 8 + (int)bi) * 2));
       if (Bk.has_sc && Bk.c2.w_ig_sc.p) {        // the projection shortcut inside the second convolution's K loop (RVD_CONV_SC_FUSE=1)
@@ -646,7 +664,7 @@ int run_trunk(rvd_engine* e, int B, const void** trunk_out) {
       }
       const void* res = x;
       if (Bk.has_sc) {
-        RVD_TRY(run_conv(e, Bk.sc, x, dx, nullptr, e->act[li][3].p, d, B, 0));
+        if (!sc_done) RVD_TRY(run_conv(e, Bk.sc, x, dx, nullptr, e->act[li][3].p, d, B, 0));
         res = e->act[li][3].p;
       }
       RVD_TRY(run_conv(e, Bk.c2, tmp, d, res, out, d, B, 1));

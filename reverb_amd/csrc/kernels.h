@@ -273,9 +273,24 @@ struct ConvBlockArgs {
 };
 bool conv_block32_applicable(int dtype, int cin, int cmid, int cout, int stride_a, int stride_b, int taps_a, int taps_b, int F, int T);
 int conv_block32(hipStream_t s, const ConvBlockArgs& a);
+// conv_s2.hip: the block that opens the 64-channel stage in one kernel (bf16): out = relu(conv3x3_s2(in) + bias), sc = conv1x1_s2(in) + bsc
+struct ConvS2Args {
+  const void* in;      // bf16 [B][Fi+2][Ti+2][32]
+  const void* w;       // bf16 [9][1][64][32] (conv2d's layout)
+  const float* bias;   // [64]
+  const void* wsc;     // bf16 [1][1][64][32]
+  const float* bsc;    // [64]
+  void* out;           // bf16 [B][Fo+2][To+2][64]
+  void* sc;            // bf16 [B][Fo+2][To+2][64]
+  int B, Fi, Ti, Fo, To;
+};
+bool conv_s2sc_applicable(int dtype, int cin, int cout, int stride, int taps, int sc_cin, int sc_cout, int sc_stride, int sc_taps,
+                          int Fi, int Ti, int Fo, int To);
+int conv_s2sc(hipStream_t s, const ConvS2Args& a);
 // conv_gemm.hip: 3x3 stride-1 convolution as an implicit GEMM on the LDS-DMA loop (bf16, Cin % 64 == 0, Cout % 128 == 0);
 // conv2d() routes to it when a.w_ig is set
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
+bool conv_igemm_wide(const ConvArgs& a);                        // ... and on the 512-pixel tile (128-channel stage)
 bool conv_igemm8_applicable(int dtype, const ConvArgs& a);      // fp8 operands (a.in8 != null)
 int conv_igemm8(hipStream_t s, const ConvArgs& a);
 // resnet.hip (round 4 candidate): e4m3 copy of a bf16 activation tensor at one scale (value = fp8 * scale), and the running

@@ -224,6 +224,24 @@ def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monk
         assert cosw.min() > 0.995, (flag, cosw)
 
 
+def test_wide_implicit_gemm_tile_equals_the_narrow_one(case, emb_case, monkeypatch, lab):
+    """The 128-channel stage on 512-pixel tiles (wave tile 128 x 64, default for launches of >= 512 Ki pixels) against the
+    256-pixel tile: the K order of every output is the same, so the embeddings are IDENTICAL; the counter proves which ran."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, wide = {}, {}
+    for bm in ("256", "512"):
+        monkeypatch.setenv("RVD_IGEMM_BM", bm)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[bm] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        wide[bm] = eng.timing("emb_conv_igemm_wide")[2]
+        eng.close()
+    assert wide["256"] == 0 and wide["512"] >= 10, wide      # 11 stride-1 convolutions of stage 3 (one carries the shortcut) + the stride-2 one
+    assert np.array_equal(out["256"], out["512"])
+
+
 def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
     """conv_stream.hip (the stride-1 convolutions of the 32- and 64-channel stages as a stream of tiles per workgroup: weights
     resident in LDS, patches by LDS-DMA ahead of the MFMAs, counted vmcnt) against resnet.hip's one-tile-per-workgroup kernel:
@@ -271,7 +289,7 @@ def test_projection_shortcut_fused_into_the_second_convolution(case, emb_case, m
         sc[flag] = eng.timing("emb_conv_sc")[2]
         eng.close()
     assert fused["0"] == 0 and fused["1"] >= 2                # stages 3 and 4, per trunk pass
-    assert sc["1"] == sc["0"] - fused["1"] > 0                # stage 2's shortcut (64 output channels) stays a kernel of its own
+    assert sc["1"] == sc["0"] - fused["1"] == 0               # (stage 2's shortcut is written by conv_s2.hip beside the stride-2 convolution)
     active = emb_case["masks"].sum(1) > 0
     a, b, want = out["0"][active], out["1"][active], emb_case["want"][active]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
@@ -336,6 +354,30 @@ def test_row64_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch,
         flops[flag] = eng.timing("emb_conv_64")[1]
         eng.close()
     assert row64["0"] == 0 and row64["1"] >= 7                     # the 7 stride-1 convolutions of stage 2, per trunk pass
+    assert flops["1"] == flops["0"] > 0
+    assert np.array_equal(out["0"], out["1"])
+
+
+def test_stride2_opener_equals_the_two_launches(case, emb_case, monkeypatch, lab):
+    """conv_s2.hip (round 5, default): the stride-2 3x3 convolution (32 -> 64 channels) and the 1x1 / stride-2 projection shortcut
+    of the block that opens the 64-channel stage in ONE pass over the block's input (de-interleaved patch planes, both outputs
+    written by the same kernel) against two launches of resnet.hip's direct kernel (lab switch RVD_CONV_S2SC=0): same operand
+    values, accumulation order (taps 0 .. 8) and rounding points -- the embeddings must be IDENTICAL; the counters prove which
+    path ran and that the FLOPs credited are the same (stride-2 convolution + shortcut).  998 -> 499 frames = 16 tiles of 31 +
+    one of 3, 80 -> 40 mel rows; the windows include the zero-padded tail window."""
+    from reverb_amd.diar_engine import DiarEngine
+    out, fused, flops = {}, {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_CONV_S2SC", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        eng.reset_timings(); eng.set_profiling(True)
+        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
+        eng.set_profiling(False)
+        fused[flag] = eng.timing("emb_conv_s2sc")[2]
+        flops[flag] = eng.timing("emb_conv_s2_64")[1] + eng.timing("emb_conv_sc")[1]
+        eng.close()
+    assert fused["0"] == 0 and fused["1"] >= 1
     assert flops["1"] == flops["0"] > 0
     assert np.array_equal(out["0"], out["1"])
 
