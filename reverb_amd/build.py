@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librvb.so")
 OUT_TEST = os.path.join(HERE, "librvb_test.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "conv_block.hip", "conv_row64.hip", "conv_s2.hip", "conv_flat.hip", "linkage.hip", "diar_engine.hip", "comm.hip", "search.cpp", "audio.cpp"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "conv_block.hip", "conv_row64.hip", "conv_s2.hip", "linkage.hip", "diar_engine.hip", "comm.hip", "search.cpp", "audio.cpp"]
 TEST_SOURCES = ["test_api.hip", ("engine.hip", "engine_testapi", ["-DRVB_TEST_API"])]      # (source, object stem, extra flags)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -17,6 +17,12 @@
 // workgroups per CU -- the remedy that paid for the 32- / 64-channel stages: 64.2-64.7 vs 65.0-65.3 ms for the 128-channel stage,
 // 24.4-24.8 vs 25.0 ms for the 256-channel one (-1 %): this loop is paced by its stage fill, not by what overlaps what on a CU.
 //
+// Measured and not kept (round 5, profiles/r05_call18_conv_flat_not_kept.txt): the same convolutions over the FLAT pixel index of the
+// bordered tensor (tap (kh, kw) of pixel m is pixel m + (kh - 1)(T + 2) + (kw - 1): a tile's 512 + 2 (T + 2) + 2 pixels resident in
+// LDS for all nine taps, persistent workgroups, a third of this loop's LDS-DMA requests per MFMA).  The image fits only for
+// T + 2 <= 127 -- the 256-channel stage; the 128-channel stage's 20 x 250 maps would need 2 x 65 KB of pixels beside 48 KB of
+// weights -- and there the border positions a flat tile has to compute are 1.22 x the MFMAs: 26.6 ms against 25.4 here.
+//
 // STATUS (round 2): the default for the 128- and 256-channel stages (diar_engine.hip packs the second weight layout unless
 // RVD_CONV_IGEMM=0); tests/test_diar_gpu.py compares it with resnet.hip's direct kernel.  Tried and not kept: the
 // row-contiguous read-back + up-front residual prefetch that helped gemm2's fp32 epilogue (no change here: bf16 output and

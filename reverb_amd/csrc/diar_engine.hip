@@ -18,7 +18,7 @@ namespace {
 struct LstmLayer { Linear ih; DevBuf whh; int in_pad = 0; };
 constexpr int SINC_K = 251, SINC_STRIDE = 10, CONV_K = 5;
 // ResNet34 trunk: conv weights packed [tap][Cin/CK][Cout][CK] with BatchNorm folded in
-struct ConvW { DevBuf w, b, w_ig, w_fl; int cin = 0, cout = 0, taps = 9, stride = 1;      // w_ig: conv_gemm.hip's layout (optional)
+struct ConvW { DevBuf w, b, w_ig; int cin = 0, cout = 0, taps = 9, stride = 1;      // w_ig: conv_gemm.hip's layout (optional)
                DevBuf w_ig_sc, b_sc;
                DevBuf w8, w8s; };            // RVD_EMB_FP8=1: e4m3 copy [cout][9][cin] + per-output-channel scales (conv_igemm8_kernel)      // second convolution of a block with a projection shortcut: w_ig rows + the shortcut's, summed biases
 struct ResBlock { ConvW c1, c2, sc; bool has_sc = false; };
@@ -403,25 +403,6 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
   // [cout][tap][cin].  Validated on hardware in round 2 (tests/test_diar_gpu.py: both kernels against the oracle and
   // against each other; 806 / 1150 TFLOP/s vs 555-598 for the direct kernel); RVD_CONV_IGEMM=0 selects the direct kernel.
   // Round 4: the stride-2 convolutions that open stages 3 and 4 go there too (RVD_CONV_IGEMM=1: stride 1 only, as in round 2).
-  // conv_flat.hip (round 5) for the stride-1 3x3 convolutions of the 128- / 256-channel stages: third weight layout
-  // [cout / 128][cin / 32][tap][128 rows in the order the MFMA fragments want them][32 cin]
-  {
-    const char* fl = lab_env("RVD_CONV_FLAT");
-    if (!(fl && atoi(fl) == 0) && e->dtype == DT_BF16 && k == 3 && stride == 1 && cin % 64 == 0 && cout % 128 == 0) {
-      const int nc = cin / 32, nt = cout / 128;
-      std::vector<float> pf((size_t)cout * taps * cin);
-      for (int tn = 0; tn < nt; ++tn)
-        for (int cc = 0; cc < nc; ++cc)
-          for (int t = 0; t < taps; ++t)
-            for (int rho = 0; rho < 128; ++rho) {
-              const int o = tn * 128 + conv_flat_channel_of_row(rho);
-              const float sc = g->data[o] / std::sqrt(v->data[o] + 1e-5f);
-              float* dst = pf.data() + ((((size_t)tn * nc + cc) * taps + t) * 128 + rho) * 32;
-              for (int ci = 0; ci < 32; ++ci) dst[ci] = w->data[((size_t)o * cin + cc * 32 + ci) * taps + t] * sc;
-            }
-      RVD_TRY(pack_T(e, c.w_fl, pf.data(), pf.size()));
-    }
-  }
   const char* ig = lab_env("RVD_CONV_IGEMM");
   const int ig_mode = ig ? atoi(ig) : 2;
   if (ig_mode != 0 && e->dtype == DT_BF16 && k == 3 && (stride == 1 || (stride == 2 && ig_mode >= 2)) && cin % 64 == 0 && cout % 128 == 0) {
@@ -569,10 +550,8 @@ int run_conv(rvd_engine* e, const ConvW& c, const void* in, const StageDims& di,
   a.B = B; a.Fi = di.F; a.Ti = di.T; a.Cin = c.cin; a.Fo = dq.F; a.To = dq.T; a.Cout = c.cout;
   a.stride = c.stride; a.taps = c.taps; a.relu = relu;
   a.w_ig = c.w_ig.p;
-  a.w_fl = c.w_fl.p;
   const std::string nm = std::string(c.taps == 1 ? "emb_conv_sc" : (c.stride == 2 ? "emb_conv_s2_" : "emb_conv_")) + (c.taps == 1 ? "" : std::to_string(c.cout));
-  if (conv_flat_applicable(e->dtype, a)) e->prof["emb_conv_flat"].launches += 1;           // ... to conv_flat.hip
-  else if (conv_igemm_applicable(e->dtype, a)) {
+  if (conv_igemm_applicable(e->dtype, a)) {
     e->prof["emb_conv_igemm"].launches += 1;                                             // how many went to conv_gemm.hip
     if (conv_igemm_wide(a)) e->prof["emb_conv_igemm_wide"].launches += 1;
   }
@@ -857,7 +836,7 @@ void rvd_destroy(rvd_engine* e) {
   for (auto* b : ebufs) b->release();
   for (auto& st : e->stages)
     for (auto& blk : st)
-      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); cw->w_fl.release(); cw->w_ig_sc.release(); cw->b_sc.release(); cw->w8.release(); cw->w8s.release(); }
+      for (ConvW* cw : {&blk.c1, &blk.c2, &blk.sc}) { cw->w.release(); cw->b.release(); cw->w_ig.release(); cw->w_ig_sc.release(); cw->b_sc.release(); cw->w8.release(); cw->w8s.release(); }
   for (auto& row : e->act) for (auto& b : row) b.release();
   (void)hipStreamDestroy(e->stream);
   delete e;

@@ -258,8 +258,6 @@ struct ConvArgs {
   float out8_inv_scale;
   unsigned* amax8;
   unsigned* sat8;         // += values of the fp8 output clipped at 448
-  // conv_flat.hip (round 5): bf16 [Cout/128][Cin/32][9][128 rows in fragment order][32] (BN folded), or null
-  const void* w_fl;
 };
 int conv2d(hipStream_t s, int dtype, const ConvArgs& a);
 // conv_block.hip: a whole stride-1 BasicBlock of 32 channels in one kernel (bf16): out = relu(conv_b(relu(conv_a(in) + ba)) + bb + in),
@@ -293,12 +291,6 @@ int conv_s2sc(hipStream_t s, const ConvS2Args& a);
 // conv2d() routes to it when a.w_ig is set
 bool conv_igemm_applicable(int dtype, const ConvArgs& a);
 bool conv_igemm_wide(const ConvArgs& a);
-// conv_flat.hip: the stride-1 3x3 convolutions of the 128- / 256-channel stages over the flat index of the bordered tensor, the
-// tile's pixels resident in LDS for all nine taps; conv2d() routes to it when a.w_fl is set and the launch is large enough
-bool conv_flat_applicable(int dtype, const ConvArgs& a);
-int conv_flat(hipStream_t s, const ConvArgs& a);
-// row rho of conv_flat's weight image of a 128-channel tile -> output channel within the tile
-inline int conv_flat_channel_of_row(int rho) { return (rho >> 6) * 64 + (((rho >> 4) & 3) >> 1) * 32 + ((rho & 15) >> 2) * 8 + (((rho >> 4) & 3) & 1) * 4 + (rho & 3); }                        // ... and on the 512-pixel tile (128-channel stage)
 bool conv_igemm8_applicable(int dtype, const ConvArgs& a);      // fp8 operands (a.in8 != null)
 int conv_igemm8(hipStream_t s, const ConvArgs& a);
 // resnet.hip (round 4 candidate): e4m3 copy of a bf16 activation tensor at one scale (value = fp8 * scale), and the running

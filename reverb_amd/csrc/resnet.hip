@@ -379,7 +379,6 @@ int conv2d(hipStream_t s, int dtype, const ConvArgs& p) {
     return E_UNSUPPORTED;
   }
   if (p.B <= 0) return OK;
-  if (conv_flat_applicable(dtype, p)) return conv_flat(s, p);       // only when the engine packed w_fl
   if (conv_igemm_applicable(dtype, p)) return conv_igemm(s, p);     // only when the engine packed w_ig (RVD_CONV_IGEMM=1)
   if (conv_row64_applicable(dtype, p)) return conv_row64(s, p);
   if (conv_stream_applicable(dtype, p)) return conv_stream(s, p);

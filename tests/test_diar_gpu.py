@@ -242,35 +242,6 @@ def test_wide_implicit_gemm_tile_equals_the_narrow_one(case, emb_case, monkeypat
     assert np.array_equal(out["256"], out["512"])
 
 
-def test_flat_convolutions_against_the_implicit_gemm(case, emb_case, monkeypatch, lab):
-    """conv_flat.hip (round 5, default for large launches; RVD_CONV_FLAT=2 forces it for these few windows): the stride-1 3x3
-    convolutions of the 128- and 256-channel stages over the flat index of the bordered tensor, a tile's pixels resident in LDS for
-    all nine taps, against conv_gemm.hip's implicit GEMM (RVD_CONV_FLAT=0).  The two differ in fp32 summation order only (chunks
-    outer / taps outer): the embeddings agree far tighter than either does with the fp32 oracle; the counters prove which ran.
-    17 tiles of 512 flat pixels cover 3 windows of 22 x 127 (the last one ragged); the 256-channel stage runs two channel tiles."""
-    from reverb_amd.diar_engine import DiarEngine
-    out, flat, flops = {}, {}, {}
-    for flag in ("0", "2"):
-        monkeypatch.setenv("RVD_CONV_FLAT", flag)
-        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
-        eng.upload(case["pcm"])
-        eng.reset_timings(); eng.set_profiling(True)
-        out[flag] = eng.embed(emb_case["wins"], emb_case["masks"])
-        eng.set_profiling(False)
-        flat[flag] = eng.timing("emb_conv_flat")[2]
-        flops[flag] = eng.timing("emb_conv_128")[1] + eng.timing("emb_conv_256")[1]
-        eng.close()
-    assert flat["0"] == 0 and flat["2"] >= 10 + 4, flat         # stage 3: conv1 / conv2 of blocks 1-5; stage 4: of blocks 1-2
-    assert flops["0"] == flops["2"] > 0
-    active = emb_case["masks"].sum(1) > 0
-    a, b, want = out["0"][active], out["2"][active], emb_case["want"][active]
-    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-    assert cos.min() > 0.9995, cos
-    cosw = (b * want).sum(1) / (np.linalg.norm(b, axis=1) * np.linalg.norm(want, axis=1))
-    assert cosw.min() > 0.995, cosw
-    _record(test="flat_convolutions", cos_vs_igemm_min=float(cos.min()), cos_vs_oracle_min=float(cosw.min()))
-
-
 def test_streamed_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
     """conv_stream.hip (the stride-1 convolutions of the 32- and 64-channel stages as a stream of tiles per workgroup: weights
     resident in LDS, patches by LDS-DMA ahead of the MFMAs, counted vmcnt) against resnet.hip's one-tile-per-workgroup kernel:
