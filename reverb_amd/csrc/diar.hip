@@ -30,8 +30,9 @@ int pcm_to_float(hipStream_t s, const int16_t* pcm, int64_t n, float* out, int64
 // waves that hide the LDS latency have to come from inside it (320 threads: 16.5 ms per hour of audio)
 static constexpr int SC_SLOTS = 24, SC_FT = 8 * SC_SLOTS, SC_NF = 80, SC_KS = 251, SC_THREADS = (SC_NF / 2) * SC_SLOTS;
 
+template <typename O>
 __global__ __launch_bounds__(SC_THREADS) void sinc_conv_kernel(const float* __restrict__ wave, const float* __restrict__ filt,
-                                                               float* __restrict__ craw, int64_t n_frames, int nf,
+                                                               O* __restrict__ craw, int64_t n_frames, int nf,
                                                                int ksize, int stride) {
   extern __shared__ __attribute__((aligned(16))) float sc_smem[];
   float* sf = sc_smem;                       // [nf][ksize]
@@ -70,24 +71,113 @@ __global__ __launch_bounds__(SC_THREADS) void sinc_conv_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (t + i < n_frames) {
-        craw[(t + i) * nf + f] = av[i];
-        if (two) craw[(t + i) * nf + f + HALF] = bv[i];
+        craw[(t + i) * nf + f] = Cvt<O>::from_f32(av[i]);
+        if (two) craw[(t + i) * nf + f + HALF] = Cvt<O>::from_f32(bv[i]);
       }
   }
 }
 
-int sinc_conv(hipStream_t s, const float* wave, const float* filt, float* craw, int64_t n_frames, int nf, int ksize,
+// The same filter bank on the fp32 matrix pipe (round 5): frames x taps x filters is a GEMM whose A operand is a Toeplitz view of the
+// waveform -- v_mfma_f32_32x32x2_f32 takes ONE float per lane for A (frame l & 31, k-slot l >> 5) and one for B (filter l & 31, the
+// same k-slot), is exact fp32 (an fmaf chain) and runs at the fp32 VECTOR peak, but without the operand traffic of the VALU form
+// above (per 8 FMAs that one issues 6 LDS reads: it is LDS-bound at a third of the fp32 peak).  The two k-slots of an MFMA are
+// taps j and j + 126, so that a lane walks CONSECUTIVE samples / weights: one 8-byte LDS read of each per two MFMAs.
+// Workgroup = 8 waves, 1 024 frames; wave w owns frames [128 w, 128 w + 128) as four 32-frame tiles x three 32-filter tiles
+// (filters 80 .. 95 are zero rows).  Accumulation order: (0, 126), (1, 127), ... -- not the tap order of the VALU form (fp32 both;
+// the oracle bound of the segmentation tests is 2e-3 on the SincNet output).
+static constexpr int SM_WAVES = 8, SM_TPW = 4, SM_FT = 32 * SM_TPW * SM_WAVES, SM_NFP = 96, SM_KH = 126, SM_KP = 2 * SM_KH;
+typedef __attribute__((ext_vector_type(16))) float sm_f32x16;
+
+template <typename O>
+__global__ __launch_bounds__(64 * SM_WAVES) void sinc_mfma_kernel(const float* __restrict__ wave, const float* __restrict__ filt,
+                                                                   O* __restrict__ craw, int64_t n_frames, int nf, int ksize, int stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm_smem[];
+  float* sw = sm_smem;                        // [96][252]: filter rows, taps 251 (and rows >= nf) zero
+  float* sx = sm_smem + SM_NFP * SM_KP;       // [(SM_FT - 1) * stride + 252]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * SM_FT;
+  const int nsamp = (SM_FT - 1) * stride + SM_KP;
+  const int64_t last = (n_frames - 1) * stride + ksize;   // samples available
+  for (int i = tid; i < SM_NFP * SM_KP; i += 64 * SM_WAVES) {
+    const int f = i / SM_KP, k = i - f * SM_KP;
+    sw[i] = (f < nf && k < ksize) ? filt[f * ksize + k] : 0.0f;
+  }
+  for (int i = tid; i < nsamp; i += 64 * SM_WAVES) {
+    const int64_t g = t0 * stride + i;
+    sx[i] = g < last ? wave[g] : 0.0f;
+  }
+  __syncthreads();
+  const int r = lane & 31, kk = lane >> 5;
+#pragma unroll 1
+  for (int tt = 0; tt < SM_TPW; ++tt) {
+    const int fr0 = (wv * SM_TPW + tt) * 32;
+    if (t0 + fr0 >= n_frames) break;
+    const float* xa = sx + (fr0 + r) * stride + kk * SM_KH;
+    const float* wb = sw + r * SM_KP + kk * SM_KH;
+    sm_f32x16 acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+#pragma unroll 3
+    for (int j = 0; j < SM_KH; j += 2) {
+      const float2 a2 = *(const float2*)(xa + j);
+      float2 b2[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) b2[n] = *(const float2*)(wb + n * 32 * SM_KP + j);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
+    }
+    // D[frame][filter]: lane = filter l & 31 of the n-tile, frames 8 (e >> 2) + 4 (l >> 5) + (e & 3)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int f = n * 32 + r;
+      if (f >= nf) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t t = t0 + fr0 + 8 * (e >> 2) + 4 * kk + (e & 3);
+        if (t < n_frames) craw[t * nf + f] = Cvt<O>::from_f32(acc[n][e]);
+      }
+    }
+  }
+}
+
+int sinc_conv(hipStream_t s, int dtype, const float* wave, const float* filt, void* craw, int64_t n_frames, int nf, int ksize,
               int stride) {
   if (nf > SC_NF || ksize > SC_KS || stride < 1 || stride > 16) { set_error("sinc_conv: unsupported filter bank shape"); return E_UNSUPPORTED; }
   if (n_frames <= 0) return OK;
+  {
+    const char* e = lab_env("RVD_SINC_MFMA");            // lab: 0 = the VALU form (until round 5)
+    if (!(e && atoi(e) == 0) && nf <= SM_NFP && ksize <= SM_KP && (stride % 2) == 0) {
+      const size_t lds = (size_t)(SM_NFP * SM_KP + (SM_FT - 1) * stride + SM_KP) * sizeof(float);
+      static bool attr_m = false;
+      if (!attr_m) {
+        RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_m = true;
+      }
+      if (lds <= 160 * 1024) {
+        const dim3 grid((unsigned)cdiv(n_frames, (int64_t)SM_FT)), block(64 * SM_WAVES);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(sinc_mfma_kernel<bf16_t>, grid, block, lds, s, wave, filt, (bf16_t*)craw, n_frames, nf, ksize, stride);
+        else hipLaunchKernelGGL(sinc_mfma_kernel<float>, grid, block, lds, s, wave, filt, (float*)craw, n_frames, nf, ksize, stride);
+        RVB_HIP_CHECK(hipGetLastError());
+        return OK;
+      }
+    }
+  }
   const size_t lds = (size_t)(SC_NF * SC_KS + (SC_FT - 1) * 16 + SC_KS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_conv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)sinc_conv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(sinc_conv_kernel, dim3(cdiv(n_frames, SC_FT)), dim3(SC_THREADS), lds, s, wave, filt, craw, n_frames,
-                     nf, ksize, stride);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(sinc_conv_kernel<bf16_t>, dim3(cdiv(n_frames, SC_FT)), dim3(SC_THREADS), lds, s, wave, filt, (bf16_t*)craw, n_frames, nf, ksize, stride);
+  else
+    hipLaunchKernelGGL(sinc_conv_kernel<float>, dim3(cdiv(n_frames, SC_FT)), dim3(SC_THREADS), lds, s, wave, filt, (float*)craw, n_frames, nf, ksize, stride);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -153,20 +243,21 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(PoolNormArgs p) {
   const int TP = p.frames_in / 3;
 
   float a = 0.f, off = 0.f;
-  const float* cr = nullptr;
+  const T* cr = nullptr;
   const T* x = nullptr;
   if (FIRST) {
     const float mean = p.stats[2 * w], rstd = p.stats[2 * w + 1];
     a = p.wn_gamma * rstd;
     if (active) off = (p.wn_beta - a * mean) * p.fsum[c];
-    cr = p.craw + (p.craw_frame0 + (int64_t)w * p.craw_frames_per_step) * p.C + c;
+    cr = (const T*)p.craw + (p.craw_frame0 + (int64_t)w * p.craw_frames_per_step) * p.C + c;
   } else {
     x = (const T*)p.x + (size_t)w * p.rows_in * p.ld_in + c;
   }
   auto pooled = [&](int tp) -> float {
     if (FIRST) {
-      const float* q = cr + (size_t)(3 * tp) * p.C;
-      const float v0 = fabsf(fmaf(a, q[0], off)), v1 = fabsf(fmaf(a, q[p.C], off)), v2 = fabsf(fmaf(a, q[2 * p.C], off));
+      const T* q = cr + (size_t)(3 * tp) * p.C;
+      const float v0 = fabsf(fmaf(a, Cvt<T>::to_f32(q[0]), off)), v1 = fabsf(fmaf(a, Cvt<T>::to_f32(q[p.C]), off)),
+                  v2 = fabsf(fmaf(a, Cvt<T>::to_f32(q[2 * p.C]), off));
       return fmaxf(v0, fmaxf(v1, v2));
     } else {
       const T* q = x + (size_t)(3 * tp) * p.ld_in;

@@ -310,7 +310,7 @@ int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
   { DScope sc(e, "pool_norm");
     pn.x = nullptr; pn.frames_in = e->f1; pn.C = NF; pn.ld_out = NF;
     pn.gamma = e->norm[0].g.as<float>(); pn.beta = e->norm[0].b.as<float>(); pn.out = e->a1.p;
-    pn.craw = e->craw.as<float>(); pn.craw_frame0 = first * (c.step_samples / SINC_STRIDE);
+    pn.craw = e->craw.p; pn.craw_frame0 = first * (c.step_samples / SINC_STRIDE);
     pn.craw_frames_per_step = c.step_samples / SINC_STRIDE;
     pn.stats = e->stats.as<float>(); pn.fsum = e->fsum.as<float>(); pn.wn_gamma = e->wn_gamma; pn.wn_beta = e->wn_beta;
     RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
@@ -920,11 +920,11 @@ static int prepare_audio(rvd_engine* e, int64_t n) {
   e->n_pad = (e->n_windows - 1) * c.step_samples + c.window_samples;
   e->craw_frames = (e->n_pad - SINC_K) / SINC_STRIDE + 1;
   RVD_TRY(e->wave.ensure((size_t)e->n_pad * 4));
-  RVD_TRY(e->craw.ensure((size_t)e->craw_frames * c.sinc_filters * 4));
+  RVD_TRY(e->craw.ensure((size_t)e->craw_frames * c.sinc_filters * dt_size(e->dtype)));
   { DScope sc(e, "pcm_to_float");
     RVD_TRY(pcm_to_float(e->stream, e->pcm.as<int16_t>(), n, e->wave.as<float>(), e->n_pad)); }
   { DScope sc(e, "sinc_conv", 2.0 * (double)e->craw_frames * c.sinc_filters * SINC_K);
-    RVD_TRY(sinc_conv(e->stream, e->wave.as<float>(), e->filt.as<float>(), e->craw.as<float>(), e->craw_frames, c.sinc_filters,
+    RVD_TRY(sinc_conv(e->stream, e->dtype, e->wave.as<float>(), e->filt.as<float>(), e->craw.p, e->craw_frames, c.sinc_filters,
                       SINC_K, SINC_STRIDE)); }
   if (e->has_emb) {
     // hamming log-mel of the zero-extended file, shared by all windows (frame j of window w = frame w*step/160 + j)

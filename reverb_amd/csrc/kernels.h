@@ -189,8 +189,9 @@ namespace rvb {
 int pcm_to_float(hipStream_t s, const int16_t* pcm, int64_t n, float* out, int64_t n_pad);
 
 // Sinc band-pass bank on the raw waveform, shared by every window that overlaps a frame:
-// craw[t][f] = sum_k wave[stride*t + k] * filt[f][k]        fp32 [n_frames][nf], nf <= 80, ksize <= 251
-int sinc_conv(hipStream_t s, const float* wave, const float* filt, float* craw, int64_t n_frames, int nf,
+// craw[t][f] = sum_k wave[stride*t + k] * filt[f][k]        T [n_frames][nf] (fp32 accumulation; the bf16 engine stores bf16: the
+// tensor is read twice by every window that covers a frame -- 10 windows -- in pool_norm), nf <= 80, ksize <= 251
+int sinc_conv(hipStream_t s, int dtype, const float* wave, const float* filt, void* craw, int64_t n_frames, int nf,
               int ksize, int stride);
 
 // per window (start = (first+w)*step samples, `len` samples): stats[w] = {mean, 1/sqrt(var+eps)} (biased var)
@@ -208,7 +209,7 @@ struct PoolNormArgs {
   int W;
   // first block (x == null): value = | a*(craw[frame0 + t][c] - mean*fsum[c]) + b*fsum[c] |, a = wn_gamma*rstd,
   // i.e. the sinc conv of the instance-normalised window, from the shared raw conv
-  const float* craw; int64_t craw_frame0; int craw_frames_per_step;
+  const void* craw /* T */; int64_t craw_frame0; int craw_frames_per_step;
   const float* stats; const float* fsum; float wn_gamma, wn_beta;
 };
 int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a);

@@ -78,6 +78,24 @@ def test_segmentation_f32_matches_oracle(case):
     eng.close()
 
 
+def test_sinc_filter_bank_on_the_matrix_pipe_equals_the_vector_form(case, monkeypatch, lab):
+    """diar.hip sinc_mfma_kernel (round 5, default: frames x taps x filters on v_mfma_f32_32x32x2_f32, exact fp32, taps paired
+    (j, j + 126)) against the VALU form (lab switch RVD_SINC_MFMA=0, taps in order): fp32 both, only the summation order
+    differs -- the SincNet output (three layers further down) agrees to 1e-4 of its scale."""
+    from reverb_amd.diar_engine import DiarEngine
+    taps = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVD_SINC_MFMA", flag)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="f32")
+        W = eng.upload(case["pcm"])
+        eng.segment()
+        taps[flag] = eng.tap("sincnet", W)
+        eng.close()
+    scale = np.abs(taps["0"]).max()
+    assert np.abs(taps["0"] - taps["1"]).max() < 1e-4 * scale, np.abs(taps["0"] - taps["1"]).max() / scale
+    assert np.abs(taps["1"] - case["taps"]["sincnet"]).max() < 2e-3
+
+
 def test_segmentation_f32_batching_is_invariant(case):
     from reverb_amd.diar_engine import DiarEngine
     eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="f32")
