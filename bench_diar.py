@@ -100,13 +100,20 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
     # de-duplicate the tiles: +-3 LSB of noise, so that no two windows (and no two embeddings) are bit-identical
     pcm = (pcm.astype(np.int32) + np.random.default_rng(7 + rank).integers(-3, 4, size=n)).clip(-32768, 32767).astype(np.int16)
 
-    def step():
+    def step(resident=True):
+        # one recording through the whole pipeline.  Single GPU: the samples are resident in HBM when the timed region starts (the
+        # bench contract; the ASR step's convention) -- rvd_rerun_resident runs the front end (waveform, sinc filter bank, fbank)
+        # on them again; `pcie_inclusive` below is the same step with the 115 MB/h upload from pageable host memory inside it.
         if use_dist:
             return diarize_sharded(pipe, pcm, device, uri="bench")
-        return pipe({"waveform": pcm, "sample_rate": 16000, "uri": "bench"})
+        t = time.perf_counter()
+        classes, emb = pipe.networks(pcm, resident=resident)
+        ann = pipe.finish(classes, emb, "bench")
+        pipe.timings["total"] = time.perf_counter() - t
+        return ann
 
-    for _ in range(warmup):
-        step()
+    for _ in range(max(warmup, 1)):
+        step(resident=False)            # (the first of these uploads the recording)
     eng = pipe.engine
     eng.reset_timings(); eng.set_profiling(True)
     comm = None
@@ -137,6 +144,16 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
     eng.set_profiling(False)
+    pcie = None
+    if not use_dist:
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(2):
+            step(resident=False)
+        torch.cuda.synchronize()
+        dp = (time.perf_counter() - tp) / 2
+        pcie = {"value": round(hours * 3600 / dp, 2), "ms_per_step": round(dp * 1e3, 2), "h2d_bytes_per_step": int(n) * 2,
+                "host_memory": "pageable (numpy array handed to rvd_upload_pcm)", "steps": 2}
     out = None
     if rank == 0:
         conv = [eng.timing(k) for k in CONV_KEYS]
@@ -158,6 +175,9 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
                          "flops_per_launch": round(fl / max(launches, 1), 1)},
             "stage_ms_per_step": {k: round(eng.timing(k)[0] / steps, 3) for k in STAGE_KEYS},
             "host_s_last_step": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()},
+            "input": ("int16 PCM resident in HBM when the timed region starts; the step re-runs the whole front end on it"
+                      if not use_dist else "every rank uploads its slice inside the step"),
+            "pcie_inclusive": pcie,
         }
         out["cpu_baseline"] = cpu_baseline(cfg, seg_sd, emb_sd, pcm, cpu_windows) if (world == 1 and cpu_windows > 0) else None
     eng.close()

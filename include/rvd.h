@@ -68,6 +68,11 @@ int rvd_frames_per_window(const rvd_engine* e);
 
 /* 16-bit mono PCM at cfg.sample_rate -> HBM; evaluates the sinc filter bank once for all windows */
 int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n_samples);
+/* the recording of the last rvd_upload_pcm is still resident in HBM: run its front end again (everything rvd_upload_pcm does
+ * behind the copy -- waveform, sinc filter bank, embedding fbank).  For callers that keep a recording on the device and for
+ * bench_diar.py, whose timed step starts from HBM-resident samples as the ASR bench's does (the reference has no counterpart:
+ * pyannote re-reads the file, diarization/infer_pyannote3.0.py:37). */
+int rvd_rerun_resident(rvd_engine* e);
 /* pyannote's `Audio` resamples every file to the model's rate (torchaudio.functional.resample with its defaults = the kernel of
  * the ASR front end, rvb_upload_pcm_rate): int16 mono PCM at `sample_rate` -> int16 at cfg.sample_rate, on the device.
  * out == NULL: only *n_out is written; otherwise *n_out holds the capacity of `out` on entry, the length on return. */

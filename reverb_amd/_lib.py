@@ -130,6 +130,7 @@ TEST_SIGNATURES = {
     "rvb_test_rownorm": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
                                    C.c_int, C.c_int]),
     "rvb_test_conv_block32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
+    "rvb_test_conv_s2sc": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_conv1": (C.c_int, [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_conv_igemm_fp8": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, _f32p, _f32p, _f32p]),
@@ -187,6 +188,7 @@ DIAR_SIGNATURES = {
     "rvd_num_windows": (C.c_int64, [_eng, C.c_int64]),
     "rvd_frames_per_window": (C.c_int, [_eng]),
     "rvd_upload_pcm": (C.c_int, [_eng, _i16p, C.c_int64]),
+    "rvd_rerun_resident": (C.c_int, [_eng]),
     "rvd_resample_pcm": (C.c_int, [_eng, _i16p, C.c_int64, C.c_int, _i16p, _i64p]),
     "rvd_segment": (C.c_int, [_eng, C.c_int64, C.c_int, _f32p]),
     "rvd_get_classes": (C.c_int, [_eng, C.POINTER(C.c_uint8)]),

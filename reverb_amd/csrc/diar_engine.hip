@@ -881,6 +881,13 @@ int rvd_upload_pcm(rvd_engine* e, const int16_t* pcm, int64_t n) {
   return prepare_audio(e, n);
 }
 
+int rvd_rerun_resident(rvd_engine* e) {
+  if (!e) { set_error("rvd_rerun_resident: null engine"); return E_ARG; }
+  if (e->n_samples <= 0 || !e->pcm.p) { set_error("rvd_rerun_resident: upload audio first"); return E_STATE; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  return prepare_audio(e, e->n_samples);
+}
+
 // pyannote's Audio resamples every file to the model's rate with torchaudio.functional.resample (its defaults: the kernel
 // of the ASR front end, rvb_upload_pcm_rate).  The resampled waveform comes back as int16 -- both networks of this engine start
 // from int16 PCM, and the host shards a recording by samples at the model's rate -- i.e. rounded by at most half an LSB (-96 dB).

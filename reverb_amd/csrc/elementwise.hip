@@ -67,12 +67,26 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) xin[kh * 3 + kw] = in[kh * F0 + 2 * f1 + kw];
         float o[8];
+        if constexpr (sizeof(T) == 4) {
+          // f32 engine: multiply and add rounded separately, as since round 1 (its token-exact goldens were produced with these)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float acc = br[c];
+          for (int c = 0; c < 8; ++c) {
+            float acc = br[c];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) acc += wr[c][k] * xin[k];
-          o[c] = fmaxf(acc, 0.f);
+            for (int k = 0; k < 9; ++k) acc += wr[c][k] * xin[k];
+            o[c] = fmaxf(acc, 0.f);
+          }
+        } else {
+          // bf16 / fp8 engines: two channels per v_pk_fma_f32 (36 packed FMAs per 8 channels; the separate form compiled to 36
+          // v_pk_mul_f32 + 64 v_add_f32 and the kernel sat between its VALU work and its 14.4 GB of stores)
+          typedef float c1_f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int c = 0; c < 8; c += 2) {
+            c1_f32x2 acc = {br[c], br[c + 1]};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = __builtin_elementwise_fma((c1_f32x2){wr[c][k], wr[c + 1][k]}, (c1_f32x2){xin[k], xin[k]}, acc);
+            o[c] = fmaxf(acc.x, 0.f); o[c + 1] = fmaxf(acc.y, 0.f);
+          }
         }
         T* dst = orow + (size_t)f1 * d + cg * 8;
         if (amax) {

@@ -18,6 +18,8 @@ int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float*
                      int silu, const float* add, float* out, int out_f32, int M, int d);
 /* conv_block.hip (a whole 32-channel BasicBlock per launch) on host floats, unbordered NHWC in / out, torch weight layout */
 int rvb_test_conv_block32(const float* x, const float* wa, const float* ba, const float* wb, const float* bb, float* out, int B, int F, int T);
+// conv_s2.hip on a plane of its own: x [B][Fi][Ti][32], w [64][32][3][3], wsc [64][32] -> out = relu(conv3x3 stride 2) and sc = conv1x1 stride 2, [B][Fo][To][64]
+int rvb_test_conv_s2sc(const float* x, const float* w, const float* b, const float* wsc, const float* bsc, float* out, float* sc, int B, int Fi, int Ti);
 int rvb_test_conv1(int dtype, const float* feats, const float* mean, const float* istd, const float* w,
                    const float* b, float* out, int B, int T0, int F0, int d);
 /* round-4 candidate: the fp8 implicit-GEMM convolution (csrc/conv_gemm.hip conv_igemm8_kernel) on host floats, see test_api.hip */

@@ -165,6 +165,53 @@ int rvb_test_conv_block32(const float* x, const float* wa, const float* ba, cons
   return OK;
 }
 
+int rvb_test_conv_s2sc(const float* x, const float* w, const float* b, const float* wsc, const float* bsc, float* out, float* sc, int B, int Fi, int Ti) {
+  T_TRY(need_gpu());
+  if (!x || !w || !b || !wsc || !bsc || !out || !sc || B < 1 || Fi < 1 || Ti < 1) { set_error("rvb_test_conv_s2sc: bad argument"); return E_ARG; }
+  const int Fo = (Fi - 1) / 2 + 1, To = (Ti - 1) / 2 + 1;
+  const int FPi = Fi + 2, TPi = Ti + 2, FPo = Fo + 2, TPo = To + 2;
+  const size_t ni = (size_t)B * FPi * TPi * 32, no = (size_t)B * FPo * TPo * 64;
+  std::vector<bf16_t> xb(ni, 0);
+  for (int bb = 0; bb < B; ++bb)
+    for (int f = 0; f < Fi; ++f)
+      for (int t = 0; t < Ti; ++t)
+        for (int c = 0; c < 32; ++c) xb[(((size_t)bb * FPi + f + 1) * TPi + t + 1) * 32 + c] = f32_to_bf16(x[(((size_t)bb * Fi + f) * Ti + t) * 32 + c]);
+  std::vector<bf16_t> pw((size_t)9 * 64 * 32), ps((size_t)64 * 32);      // [o][ci][kh][kw] -> [tap][1][o][ci];  [o][ci] as it is
+  for (int o = 0; o < 64; ++o)
+    for (int ci = 0; ci < 32; ++ci) {
+      for (int t = 0; t < 9; ++t) pw[((size_t)t * 64 + o) * 32 + ci] = f32_to_bf16(w[((size_t)o * 32 + ci) * 9 + t]);
+      ps[(size_t)o * 32 + ci] = f32_to_bf16(wsc[(size_t)o * 32 + ci]);
+    }
+  Dev dx, dw, ds, db, dbs, dout, dsc;
+  T_TRY(up_raw(dx, xb.data(), ni * 2)); T_TRY(up_raw(dw, pw.data(), pw.size() * 2)); T_TRY(up_raw(ds, ps.data(), ps.size() * 2));
+  T_TRY(up_raw(db, b, 64 * 4)); T_TRY(up_raw(dbs, bsc, 64 * 4));
+  T_TRY(dout.alloc(no * 2 + 256)); RVB_HIP_CHECK(hipMemset(dout.p, 0, no * 2 + 256));
+  T_TRY(dsc.alloc(no * 2 + 256)); RVB_HIP_CHECK(hipMemset(dsc.p, 0, no * 2 + 256));
+  if (!conv_s2sc_applicable(DT_BF16, 32, 64, 2, 9, 32, 64, 2, 1, Fi, Ti, Fo, To)) { set_error("rvb_test_conv_s2sc: switched off (RVD_CONV_S2SC=0)"); return E_STATE; }
+  ConvS2Args a{};
+  a.in = dx.p; a.w = dw.p; a.bias = (const float*)db.p; a.wsc = ds.p; a.bsc = (const float*)dbs.p; a.out = dout.p; a.sc = dsc.p;
+  a.B = B; a.Fi = Fi; a.Ti = Ti; a.Fo = Fo; a.To = To;
+  T_TRY(conv_s2sc(nullptr, a));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<bf16_t> ob(no), sb(no);
+  RVB_HIP_CHECK(hipMemcpy(ob.data(), dout.p, no * 2, hipMemcpyDeviceToHost));
+  RVB_HIP_CHECK(hipMemcpy(sb.data(), dsc.p, no * 2, hipMemcpyDeviceToHost));
+  for (int bb = 0; bb < B; ++bb)
+    for (int f = 0; f < FPo; ++f)
+      for (int t = 0; t < TPo; ++t)
+        for (int c = 0; c < 64; ++c) {
+          const size_t at = (((size_t)bb * FPo + f) * TPo + t) * 64 + c;
+          if (f == 0 || f == FPo - 1 || t == 0 || t == TPo - 1) {
+            // the zero border of both output planes must be untouched (the next convolution relies on it)
+            if (ob[at] != 0 || sb[at] != 0) { set_error("rvb_test_conv_s2sc: the kernel wrote into the zero border"); return E_STATE; }
+          } else {
+            const size_t o = (((size_t)bb * Fo + f - 1) * To + t - 1) * 64 + c;
+            out[o] = bf16_to_f32(ob[at]); sc[o] = bf16_to_f32(sb[at]);
+          }
+        }
+  return OK;
+}
+
 int rvb_test_glu_dwconv(int dtype, const float* G, const float* pw1_bias, const float* dw_w, const float* dw_b,
                         const int32_t* lens, float* out, int B, int T, int d, int K, int causal, const float* hist,
                         int hist_rows) {

@@ -92,6 +92,11 @@ class DiarEngine:
         self.n_windows = self.num_windows(pcm.shape[0])
         return self.n_windows
 
+    def rerun_resident(self) -> int:
+        """The recording of the last upload() is still in HBM: its front end again (what upload() does behind the copy)."""
+        _check(self.lib.rvd_rerun_resident(self._h), "rvd_rerun_resident")
+        return self.n_windows
+
     # ------------------------------------------------------------------ networks
     def segment(self, first: int = 0, n: Optional[int] = None, batch: int = 4096) -> np.ndarray:
         """log-probabilities over the powerset classes, [n, frames, classes]."""

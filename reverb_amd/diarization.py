@@ -585,7 +585,7 @@ class SpeakerDiarization:
         """run-length view of `classes` (built once per recording: networks() hands it to finish() through `_pre`)"""
         return ClassRuns(classes, self.cfg["step_samples"] / self.cfg["sample_rate"], self.cfg["window_samples"] / self.cfg["sample_rate"])
 
-    def networks(self, pcm: np.ndarray, prepare_finish: bool = True):
+    def networks(self, pcm: np.ndarray, prepare_finish: bool = True, resident: bool = False):
         """The GPU part on one recording (or one rank's slice of it): argmax powerset classes per window frame
         (uint8 [W, frames]) and one embedding per active (window, local speaker) pair (float32 [W, 3, dim], NaN
         where the speaker is inactive).  `prepare_finish=False` (the sharded path: finish() will see the gathered
@@ -593,7 +593,7 @@ class SpeakerDiarization:
         import time
         eng = self.engine
         t0 = time.perf_counter()
-        W = eng.upload(pcm)
+        W = eng.rerun_resident() if resident else eng.upload(pcm)             # resident: `pcm` went up with an earlier call
         t1 = time.perf_counter()
         classes = eng.segment_classes()                                       # argmax on the GPU
         t2 = time.perf_counter()

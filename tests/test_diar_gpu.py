@@ -108,6 +108,23 @@ def test_segmentation_f32_batching_is_invariant(case):
     eng.close()
 
 
+def test_rerun_resident_reproduces_the_upload(case):
+    """rvd_rerun_resident (the timed step of bench_diar.py starts from HBM-resident samples): the front end run again on the
+    recording that is already on the device gives the same windows and bit-identical segmentation output; before any upload
+    it is refused."""
+    from reverb_amd.diar_engine import DiarEngine
+    from reverb_amd._lib import RvbError
+    eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="f32")
+    with pytest.raises(RvbError):
+        eng.rerun_resident()
+    W = eng.upload(case["pcm"])
+    a = eng.segment()
+    assert eng.rerun_resident() == W
+    b = eng.segment()
+    assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_segmentation_bf16_close_to_oracle(case):
     from reverb_amd.diar_engine import DiarEngine
     eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
@@ -425,13 +442,13 @@ def test_fused_basic_block_equals_two_convolutions(case, emb_case, monkeypatch, 
 
 
 def test_fused_basic_block_on_ragged_shapes(lib):
-    """The fused block through librvb_test.so's hook on planes whose height is not a multiple of 4 and whose width is not a
-    multiple of 60 (partial row tiles, a partial last time tile, a single tile), against fp64 on the bf16-rounded operands with
+    """The fused block through librvb_test.so's hook on planes whose height is not a multiple of 3 (the rows of a step) and whose
+    width is not a multiple of 60 (a partial last band, a single band, fewer rows than a step), against fp64 on the bf16-rounded operands with
     the intermediate rounded to bf16 as the kernel (and the unfused path) rounds it."""
     from reverb_amd import _lib
     from util import bf16_round, f32
     rng = np.random.default_rng(5)
-    for B, F, T in ((2, 6, 61), (1, 9, 130), (1, 3, 17), (1, 4, 60)):
+    for B, F, T in ((2, 6, 61), (1, 9, 130), (1, 3, 17), (1, 4, 60), (1, 1, 5), (1, 2, 64), (1, 7, 121)):
         x = bf16_round(f32(np.abs(rng.standard_normal((B, F, T, 32)))))
         wa = bf16_round(f32(rng.standard_normal((32, 32, 3, 3)) / 12.0))
         wb = bf16_round(f32(rng.standard_normal((32, 32, 3, 3)) / 12.0))
@@ -454,6 +471,33 @@ def test_fused_basic_block_on_ragged_shapes(lib):
 
 
 # ------------------------------------------------------------------------------------ clustering on the GPU
+def test_stride2_opener_on_ragged_shapes(lib):
+    """conv_s2.hip through librvb_test.so's hook on planes of odd and even height / width (partial row tiles, a partial last time
+    tile, a single tile, one row), against fp64 on the bf16-rounded operands; the hook also checks the zero borders."""
+    from reverb_amd import _lib
+    from util import bf16_round, f32
+    rng = np.random.default_rng(6)
+    for B, Fi, Ti in ((2, 8, 62), (1, 9, 125), (1, 3, 17), (1, 1, 2), (1, 16, 63), (1, 5, 130)):
+        Fo, To = (Fi - 1) // 2 + 1, (Ti - 1) // 2 + 1
+        x = bf16_round(f32(rng.standard_normal((B, Fi, Ti, 32))))
+        w = bf16_round(f32(rng.standard_normal((64, 32, 3, 3)) / 12.0))
+        wsc = bf16_round(f32(rng.standard_normal((64, 32)) / 4.0))
+        b, bsc = f32(rng.standard_normal(64) * 0.1), f32(rng.standard_normal(64) * 0.1)
+        out, sc = np.zeros((B, Fo, To, 64), np.float32), np.zeros((B, Fo, To, 64), np.float32)
+        _lib.check(lib.rvb_test_conv_s2sc(_lib.fptr(x), _lib.fptr(w), _lib.fptr(b), _lib.fptr(wsc), _lib.fptr(bsc), _lib.fptr(out), _lib.fptr(sc), B, Fi, Ti))
+        xp = np.zeros((B, Fi + 2, Ti + 2, 32))
+        xp[:, 1:-1, 1:-1] = x
+        want = np.zeros((B, Fo, To, 64))
+        for kh in range(3):
+            for kw in range(3):
+                want += np.einsum("bftc,oc->bfto", xp[:, kh:kh + 2 * Fo:2, kw:kw + 2 * To:2][:, :Fo, :To], w[:, :, kh, kw].astype(np.float64))
+        want = np.maximum(want + b, 0.0)
+        wsc_ = np.einsum("bftc,oc->bfto", x[:, ::2, ::2].astype(np.float64), wsc.astype(np.float64)) + bsc
+        for got, ref in ((out, want), (sc, wsc_)):
+            err = np.abs(got - ref)
+            assert err.max() < 1e-2 * max(1.0, np.abs(ref).max()), (B, Fi, Ti, err.max())
+
+
 @pytest.mark.parametrize("n,d,seed", [(2, 8, 0), (3, 4, 1), (257, 16, 2), (1500, 256, 3), (3100, 64, 4)])
 def test_centroid_linkage_matches_scipy(case, n, d, seed):
     """scipy is what pyannote itself calls; it is installed on the GPU box, so the kernel is pinned to it.  n > 1024: several
