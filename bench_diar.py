@@ -144,6 +144,11 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
     eng.set_profiling(False)
+    # the kernel timings and FLOP counts of the timed steps: read BEFORE the pcie_inclusive steps below (the engine keeps counting
+    # FLOPs and launches with profiling off)
+    conv = [eng.timing(k) for k in CONV_KEYS]
+    stage_ms = {k: round(eng.timing(k)[0] / steps, 3) for k in STAGE_KEYS}
+    host_s = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()}
     pcie = None
     if not use_dist:
         torch.cuda.synchronize()
@@ -156,7 +161,6 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
                 "host_memory": "pageable (numpy array handed to rvd_upload_pcm)", "steps": 2}
     out = None
     if rank == 0:
-        conv = [eng.timing(k) for k in CONV_KEYS]
         ms, fl, launches = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
         ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
         out = {
@@ -173,8 +177,8 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
                          "kernel": "rvb::conv_kernel / conv_igemm_kernel (all ResNet34 3x3/1x1 convolutions of the timed steps, rank 0)",
                          "launches": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                          "flops_per_launch": round(fl / max(launches, 1), 1)},
-            "stage_ms_per_step": {k: round(eng.timing(k)[0] / steps, 3) for k in STAGE_KEYS},
-            "host_s_last_step": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipe.timings.items()},
+            "stage_ms_per_step": stage_ms,
+            "host_s_last_step": host_s,
             "input": ("int16 PCM resident in HBM when the timed region starts; the step re-runs the whole front end on it"
                       if not use_dist else "every rank uploads its slice inside the step"),
             "pcie_inclusive": pcie,
