@@ -5,7 +5,10 @@
 //             (S f + kh, S t + kw) of the bordered tensor (S = stride): one 128-byte run per pixel, no im2col buffer, no
 //             register staging.  Round 4: the two stride-2 convolutions that open stages 3 and 4 (64 -> 128, 128 -> 256) run
 //             here too -- on the direct kernel they were the 512-VGPR + scratch instantiations (24 ms per hour of audio)
-//   columns = output channels, weights [Cout][9][Cin] (BatchNorm folded), tile 256 pixels x 128 or 256 channels
+//   columns = output channels, weights [Cout][9][Cin] (BatchNorm folded), tile 256 pixels x 256 channels or (round 5) 512 pixels x
+//             128 channels: either way 8 waves of 128 pixels x 64 channels.  The 128-channel stage ran on 256 x 128 tiles until then
+//             (wave tile 64 x 64: a third more LDS fragment bytes per MFMA, at the LDS port's limit): 65.5 -> 60.9 ms per hour
+//             (profiles/r05_call15_strips_igemm512.txt); the variant with the fused shortcut stays on 256 pixels (it spills at 512)
 //
 // Main loop and gather measured in scripts/micro/gemm_lab.hip ("conv" mode, exact against a naive convolution):
 // 855 TFLOP/s for the 128-channel stage and 1193 for the 256-channel stage, against 555-598 for the direct
