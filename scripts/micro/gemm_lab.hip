@@ -75,8 +75,8 @@ template <int PPW> __device__ inline void wait_groups(int groups) {
   else wait_vm<3 * PPW>();
 }
 
-template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA, int STORE>
-__global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA, int STORE, int BN = 256, int OCC = 1>
+__global__ __launch_bounds__(NWM* NWN * 64, OCC) void gemm_lab(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                            float* __restrict__ C, int M, int N, int K, int phases) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NWM * NWN;
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
   constexpr int BKE = BKB / 2;           // bf16 elements
   constexpr int CPR = BKB / 16;          // 16-byte columns per row: 8 or 4
   constexpr int RPI = 64 / CPR;          // rows one DMA instruction covers: 8 or 16
-  constexpr int STAGE = 512 * BKB;       // 256 rows of A then 256 rows of W
-  constexpr int PPW = 512 / RPI / NW;    // DMA pieces per wave per stage
-  constexpr int TM = 256 / NWM, TN = 256 / NWN, FI = TM / 16, FJ = TN / 16;
+  constexpr int STAGE = (256 + BN) * BKB;       // 256 rows of A then BN rows of W
+  constexpr int PPW = (256 + BN) / RPI / NW;    // DMA pieces per wave per stage
+  static_assert(PPW * RPI * NW == 256 + BN, "pieces must divide among the waves");
+  constexpr int TM = 256 / NWM, TN = BN / NWN, FI = TM / 16, FJ = TN / 16;
   static_assert(3 * PPW <= 63, "vmcnt is a 6-bit counter");
   static_assert(NST >= 2 && NST <= 4, "stages");
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
     const int kilocycles = phase * (K / 64) * 1260 / phases / 1024;
     for (int i = 0; i < kilocycles; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 clocks
   }
-  const int tiles_n = N / 256;
+  const int tiles_n = N / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   {   // XCD-aware bijective tile order (as gemm2): consecutive tiles of one XCD share the A panel
@@ -112,25 +113,25 @@ __global__ __launch_bounds__(NWM* NWN * 64) void gemm_lab(const uint16_t* __rest
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * BN;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   // swizzle: LDS[row][c] = G[row][c ^ swz(row)] (16-byte columns): the 16 lanes of a fragment read (16 consecutive
   // rows, one logical column) then touch 16 distinct 16-byte slots of a 256-byte bank row
   auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
-  // ---- DMA sources: the first NW/2 waves stage A, the others W; piece i of a wave = image rows [first + i*RPI, +RPI)
-  const bool isA = wave < NW / 2;
-  const int first = (wave % (NW / 2)) * PPW * RPI;       // first tile row this wave stages (within A's or W's 256)
+  // ---- DMA sources: the stage image is 256 rows of A then BN rows of W; wave w stages its PPW consecutive pieces of RPI rows
   const int lr = lane / CPR, lc = lane % CPR;
   const uint16_t* src[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int row = first + i * RPI + lr;
+    const int irow = (wave * PPW + i) * RPI + lr;          // row of the image
+    const bool isA = irow < 256;
+    const int row = isA ? irow : irow - 256;
     const uint16_t* base = isA ? A + (size_t)(m0 + row) * K : W + (size_t)(n0 + row) * K;
     src[i] = base + (lc ^ swz(row)) * 8;
   }
-  const unsigned lds_wave = lds_base + (isA ? 0 : 256 * BKB) + first * BKB;
+  const unsigned lds_wave = lds_base + wave * PPW * RPI * BKB;
   auto issue = [&](int kt) __attribute__((always_inline)) {
     const unsigned dst = lds_wave + (kt % NST) * STAGE;
 #pragma unroll
@@ -1154,13 +1155,13 @@ static int conv_run(int reps) {
   return 0;
 }
 
-struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int, int); int threads, lds, store, persistent, phases; };
+struct Variant { const char* name; void (*kern)(const uint16_t*, const uint16_t*, float*, int, int, int, int); int threads, lds, store, persistent, phases; int bn = 256; };
 
-template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0, int STORE = 1> Variant make(const char* name, int phases = 0) {
-  auto k = gemm_lab<NWM, NWN, KSUBS, NST, PIPE, AMMA, STORE>;
-  const int lds = NST * 512 * 64 * KSUBS;
+template <int NWM, int NWN, int KSUBS, int NST, int PIPE, int AMMA = 0, int STORE = 1, int BN = 256, int OCC = 1> Variant make(const char* name, int phases = 0) {
+  auto k = gemm_lab<NWM, NWN, KSUBS, NST, PIPE, AMMA, STORE, BN, OCC>;
+  const int lds = NST * (256 + BN) * 64 * KSUBS;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  return {name, k, NWM * NWN * 64, lds, STORE, 0, phases};
+  return {name, k, NWM * NWN * 64, lds, STORE, 0, phases, BN};
 }
 
 int main(int argc, char** argv) {
@@ -1190,6 +1191,8 @@ int main(int argc, char** argv) {
   vs.push_back(make<2, 4, 2, 2, 1>("8w pipelined  first wave in 8 phases", 8));
   vs.push_back(make<2, 4, 2, 2, 0>("8w simple     first wave in 4 phases", 4));
   if (argc > 2) vs.erase(vs.begin() + 2, vs.begin() + 10);      // short run: skip the 4-wave / BK32 variants
+  const bool tile_mode = argc > 2 && std::string(argv[2]) == "tile";
+  if (tile_mode) vs.erase(vs.begin() + 2, vs.end());            // the two baselines + the phase loops + the 256 x 128 tiles below
   if (argc > 2 && std::string(argv[2]) == "phase") vs.erase(vs.begin() + 2, vs.end());   // the two baselines + the phase-interleaved loops
   {
     auto addph = [&](const char* name, auto kern, int nslot) {
@@ -1204,7 +1207,16 @@ int main(int argc, char** argv) {
     addph("phases 10 slots stagger            ", gemm_ph<10, 1, 0, 1>, 10);
     addph("phases  6 slots stagger prio       ", gemm_ph<6, 1, 1, 1>, 6);
   }
-  if (!(argc > 2 && std::string(argv[2]) == "phase")) vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
+  if (!(argc > 2 && std::string(argv[2]) == "phase") && !tile_mode) vs.push_back(make<2, 2, 1, 3, 1, 1>("4w 128x128 BK32 3st pipelined     "));
+  if (tile_mode) {
+    // VERDICT r4, "next" 3 (d): the 256 x 128 tile of FOUR waves (2 x 2 of 128 x 64, the wave tile of the 8-wave kernels), 64-byte
+    // rows and three 24-KiB stages = 72 KiB: TWO workgroups per CU, each filling the other's barriers, first-stage wait and epilogue
+    vs.push_back(make<2, 2, 1, 3, 1, 0, 1, 128, 2>("4w 256x128 BK32 3st pipelined 2/CU"));
+    vs.push_back(make<2, 2, 1, 3, 0, 0, 1, 128, 2>("4w 256x128 BK32 3st simple    2/CU"));
+    vs.push_back(make<2, 2, 1, 2, 1, 0, 1, 128, 2>("4w 256x128 BK32 2st pipelined 2/CU"));
+    vs.push_back(make<2, 2, 2, 2, 1, 0, 1, 128, 1>("4w 256x128 BK64 2st pipelined 1/CU"));
+    vs.push_back(make<2, 4, 2, 2, 1, 0, 1, 128, 1>("8w 256x128 BK64 2st pipelined     "));
+  }
 
   struct Shape { int M, N, K; };
   const Shape shapes[] = {{90112, 1024, 1024}, {90112, 4096, 1024}, {90112, 1024, 4096}, {90112, 1024, 19456}};
@@ -1223,8 +1235,8 @@ int main(int argc, char** argv) {
     std::vector<float> ref((size_t)2 * CHK * N), got((size_t)2 * CHK * N);
     CHECK(hipMemcpy(ref.data(), R, ref.size() * 4, hipMemcpyDeviceToHost));
     printf("M=%d N=%d K=%d\n", M, N, K);
-    const int tiles = (M / 256) * (N / 256);
     for (const Variant& v : vs) {
+      const int tiles = (M / 256) * (N / v.bn);
       CHECK(hipMemset(C, 0xff, (size_t)M * N * 4));
       const int grid = v.persistent ? (tiles < ncu ? tiles : ncu) : tiles;
       hipLaunchKernelGGL(v.kern, dim3(grid), dim3(v.threads), v.lds, 0, A, W, C, M, N, K, v.persistent ? v.store : v.phases);
