@@ -441,6 +441,7 @@ __global__ __launch_bounds__(NTH) void linkage_kernel(int getenv_prof, double* _
 // the last word of every entry, every WAVE polling the 16 tag words itself instead of thread 0 polling one arrival counter.
 // Exact, but 256 polling waves on 16 cache lines slow the writers down more than the saved round trip is worth: 111-122 ms
 // instead of 94-97 ms at n = 9 200, 531 instead of 422 ms at n = 27 000, 92 instead of 74 ms in the pipeline.
+// (MB_NT = 512, round 5: local minima unchanged, merge pass -14 %, publish + barrier +22 % -- 63.9-69.0 instead of 60.6 ms per hour; kept at 1024)
 static constexpr int MB_G = 16, MB_NT = 1024;
 // Eager validation right after a merge of the stale rows whose bound is within 5 % of the merged distance (to save the extra
 // round they would cost when they reach the top): measured and switched off -- on high-dimensional noise 33 rows per merge
