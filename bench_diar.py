@@ -164,34 +164,37 @@ def run(device, rank=0, world=1, dist=None, steps=3, warmup=1, hours=1.0, dtype=
         # Throughput of a service that diarizes recording after recording: two engines alternate, and the clustering + host part of
         # recording i (a helper thread; its merge loop on 4 workgroups, as in the joint pipeline) runs UNDER the networks of
         # recording i + 1.  Reported beside `value`, which stays the sequential step.
-        from concurrent.futures import ThreadPoolExecutor
-        pipe2 = D.SpeakerDiarization(cfg, seg_sd, emb_sd, None, dtype=dtype).to(device)
-        pipes = (pipe, pipe2)
-        c2, e2 = pipe2.networks(pcm)                       # uploads the recording to the second engine; warms it
-        pipe2.finish(c2, e2, "bench")
-        for q in pipes:
-            q.engine.set_linkage_workgroups(4)
-        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rvd-finish")
-        torch.cuda.synchronize()
-        tq = time.perf_counter()
-        fut = None
-        for i in range(pipeline_steps):
-            q = pipes[i & 1]
-            ci, ei = q.networks(pcm, resident=True)
-            if fut is not None:
-                fut.result()
-            fut = pool.submit(q.finish, ci, ei, "bench")
-        ann_p = fut.result()
-        torch.cuda.synchronize()
-        dq = (time.perf_counter() - tq) / pipeline_steps
-        pool.shutdown()
-        for q in pipes:
-            q.engine.set_linkage_workgroups(0)
-        pipelined = {"value": round(hours * 3600 / dq, 2), "ms_per_step": round(dq * 1e3, 2), "steps": pipeline_steps,
-                     "turns": len(ann_p), "how": "two engines alternate; clustering (4 workgroups) + host part of recording i on a helper "
-                                                 "thread under the networks of recording i + 1; samples resident"}
-        pipe2.engine.close()
-        pipe2._engine = None
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            pipe2 = D.SpeakerDiarization(cfg, seg_sd, emb_sd, None, dtype=dtype).to(device)
+            pipes = (pipe, pipe2)
+            c2, e2 = pipe2.networks(pcm)                       # uploads the recording to the second engine; warms it
+            pipe2.finish(c2, e2, "bench")
+            for q in pipes:
+                q.engine.set_linkage_workgroups(4)
+            pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rvd-finish")
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            fut = None
+            for i in range(pipeline_steps):
+                q = pipes[i & 1]
+                ci, ei = q.networks(pcm, resident=True)
+                if fut is not None:
+                    fut.result()
+                fut = pool.submit(q.finish, ci, ei, "bench")
+            ann_p = fut.result()
+            torch.cuda.synchronize()
+            dq = (time.perf_counter() - tq) / pipeline_steps
+            pool.shutdown()
+            for q in pipes:
+                q.engine.set_linkage_workgroups(0)
+            pipelined = {"value": round(hours * 3600 / dq, 2), "ms_per_step": round(dq * 1e3, 2), "steps": pipeline_steps,
+                         "turns": len(ann_p), "how": "two engines alternate; clustering (4 workgroups) + host part of recording i on a helper "
+                                                     "thread under the networks of recording i + 1; samples resident"}
+            pipe2.engine.close()
+            pipe2._engine = None
+        except Exception as ex:          # a sub-record must not cost the line its headline
+            pipelined = {"error": f"{type(ex).__name__}: {ex}"}
     out = None
     if rank == 0:
         ms, fl, launches = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
