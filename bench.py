@@ -212,9 +212,9 @@ class _StubEngine:
 
 # ------------------------------------------------------------------------------------------------ diarization sub-record
 def diarization_record(device, steps=3, warmup=2, hours=1.0, dtype="bf16", cpu_windows=16, traffic="auto"):
-    """BASELINE configs[3] on this GPU, measured exactly as bench_diar.py does (one step = one `pipeline(audio)` call
-    on `hours` of audio held in host memory); returned as a sub-record of the main line so that the driver's run
-    carries it."""
+    """BASELINE configs[3] on this GPU, measured exactly as bench_diar.py does (one step = the whole pipeline on `hours` of
+    audio whose samples are resident in HBM; `pcie_inclusive` and `pipelined` beside it); returned as a sub-record of the main
+    line so that the driver's run carries it."""
     import bench_diar
     return bench_diar.run(device, rank=0, world=1, dist=None, steps=steps, warmup=warmup, hours=hours, dtype=dtype,
                           cpu_windows=cpu_windows, traffic=traffic)
