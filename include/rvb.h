@@ -314,6 +314,10 @@ int rvb_comm_destroy(rvb_engine* e);
 int rvb_set_profiling(rvb_engine* e, int level);
 int rvb_reset_timings(rvb_engine* e);
 int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, int64_t* launches);
+/* ALGORITHMIC HBM bytes launched under `name` since the last reset ("gemm" / "gemm_fp8" only): every operand of a GEMM once --
+ * A (the NHWC activation once for the implicit convolution), W, bias, C, the fp32 residual.  What `roofline.traffic` (PMC) is
+ * compared with. */
+int rvb_get_timing_bytes(rvb_engine* e, const char* name, double* bytes);
 
 /* Word error counts of a hypothesis against a reference, both as word-id sequences (host code, no GPU): minimal Levenshtein
  * alignment, counts = {errors, substitutions, deletions, insertions} -- the numbers `fstalign wer` logs as bestWER and

@@ -109,6 +109,11 @@ int rvd_set_linkage_workgroups(rvd_engine* e, int workgroups);
  * scales, index ((stage - 2) * 8 + block) * 2 + {0: first convolution's output, 1: block output}; *clipped (nullable) = values that
  * did not fit e4m3 at those scales so far. */
 int rvd_get_emb_fp8(rvd_engine* e, int32_t* state, float* scales, int32_t* n, uint32_t* clipped);
+/* Install the 32 activation scales (layout as rvd_get_emb_fp8) and make the fp8 path active at once: every later trunk pass runs on
+ * e4m3 operands at these scales, no bf16 calibration pass.  How the ranks of a sharded run agree on ONE quantisation of the
+ * recording (reverb_amd/dist.py diarize_sharded: each rank calibrates on its windows, the element-wise maximum is installed
+ * everywhere and the windows are embedded again), as rvb_set_fp8_scales does on the ASR side.  The clip counter restarts. */
+int rvd_set_emb_fp8_scales(rvd_engine* e, const float* scales, int32_t n);
 
 int rvd_set_profiling(rvd_engine* e, int enabled);
 int rvd_reset_timings(rvd_engine* e);

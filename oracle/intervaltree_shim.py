@@ -106,17 +106,62 @@ def reference_available() -> bool:
     return os.path.isfile(REFERENCE_FILE)
 
 
+# The REAL package, when this machine happens to hold it (this image has intervaltree==3.1.0 under a conda
+# python's site-packages, not importable by the interpreter the tests run in; it is pure Python and needs `sortedcontainers`,
+# which is installed).  It is loaded from where it lies, by path -- nothing of it is copied, no sys.path change.
+REAL_SITE = os.environ.get("REVERB_REAL_INTERVALTREE", "/opt/conda/lib/python3.9/site-packages")
+_REAL = []
+
+
+def real_intervaltree():
+    """The genuine `intervaltree` module (3.1.0), or None.  With it the live pin runs the reference function against the
+    very data structure it was written for; the stand-in classes above remain for machines without it (the GPU box)."""
+    if _REAL:
+        return _REAL[0]
+    mod = None
+    try:
+        import intervaltree as mod          # installed for this interpreter after all
+    except ImportError:
+        init = os.path.join(REAL_SITE, "intervaltree", "__init__.py")
+        meta = os.path.join(REAL_SITE, "intervaltree-3.1.0.dist-info")
+        if os.path.isfile(init) and os.path.isdir(meta):
+            saved = {n: m for n, m in sys.modules.items() if n == "intervaltree" or n.startswith("intervaltree.")}
+            try:
+                import sortedcontainers  # noqa: F401 -- the package's one dependency
+                spec = importlib.util.spec_from_file_location("intervaltree", init, submodule_search_locations=[os.path.dirname(init)])
+                mod = importlib.util.module_from_spec(spec)
+                sys.modules["intervaltree"] = mod
+                spec.loader.exec_module(mod)
+            except Exception:
+                mod = None
+            finally:
+                for n in [n for n in sys.modules if n == "intervaltree" or n.startswith("intervaltree.")]:
+                    del sys.modules[n]
+                sys.modules.update(saved)
+    _REAL.append(mod)
+    return mod
+
+
+def tree_classes():
+    """(IntervalTree, Interval, "real 3.1.0" | "stand-in"): the real package's classes when present, else this module's."""
+    real = real_intervaltree()
+    if real is not None:
+        return real.IntervalTree, real.Interval, "real intervaltree " + getattr(real, "__version__", "3.1.0")
+    return IntervalTree, Interval, "stand-in"
+
+
 class _StandIns:
     """`intervaltree` = this module's classes, `pyannote.database.util.load_rttm` = `load_rttm`, for the span of a `with`."""
     NAMES = ("intervaltree", "pyannote", "pyannote.database", "pyannote.database.util")
 
-    def __init__(self, load_rttm=None):
+    def __init__(self, load_rttm=None, real=True):
         self.load_rttm = load_rttm
+        self.real = real            # hand the reference the real package's classes when this machine has them
 
     def __enter__(self):
         self.saved = {n: sys.modules.get(n) for n in self.NAMES}
         it = types.ModuleType("intervaltree")
-        it.IntervalTree, it.Interval = IntervalTree, Interval
+        it.IntervalTree, it.Interval, _ = tree_classes() if self.real else (IntervalTree, Interval, None)
         sys.modules["intervaltree"] = it
         for n in self.NAMES[1:]:
             m = types.ModuleType(n)
@@ -133,11 +178,12 @@ class _StandIns:
                 sys.modules[n] = m
 
 
-def load_reference_module():
-    """The reference's assign_words2speakers.py, executed unmodified against the stand-ins above."""
+def load_reference_module(real=True):
+    """The reference's assign_words2speakers.py, executed unmodified against the real intervaltree (when present and `real`)
+    or the stand-ins above."""
     if not reference_available():
         raise RuntimeError("reference not present at %s" % REFERENCE_FILE)
-    with _StandIns():
+    with _StandIns(real=real):
         spec = importlib.util.spec_from_file_location("_reference_assign_words2speakers", REFERENCE_FILE)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

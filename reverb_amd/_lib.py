@@ -120,6 +120,7 @@ SIGNATURES = {
     "rvb_set_profiling": (C.c_int, [_eng, C.c_int]),
     "rvb_reset_timings": (C.c_int, [_eng]),
     "rvb_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),
+    "rvb_get_timing_bytes": (C.c_int, [_eng, C.c_char_p, _f64p]),
     "rvb_wer_counts": (C.c_int, [_i32p, C.c_int64, _i32p, C.c_int64, _i64p]),
 }
 
@@ -198,6 +199,7 @@ DIAR_SIGNATURES = {
     "rvd_centroid_linkage": (C.c_int, [_eng, _f64p, C.c_int, C.c_int, _f64p]),
     "rvd_set_linkage_workgroups": (C.c_int, [_eng, C.c_int]),
     "rvd_get_emb_fp8": (C.c_int, [_eng, _i32p, _f32p, _i32p, C.POINTER(C.c_uint32)]),
+    "rvd_set_emb_fp8_scales": (C.c_int, [_eng, _f32p, C.c_int32]),
     "rvd_set_profiling": (C.c_int, [_eng, C.c_int]),
     "rvd_reset_timings": (C.c_int, [_eng]),
     "rvd_get_timing": (C.c_int, [_eng, C.c_char_p, _f64p, _f64p, _i64p]),

@@ -526,6 +526,10 @@ StageDims stage_dims(const rvd_engine* e, int li) {
 
 int ensure_emb_workspace(rvd_engine* e, int B) {
   if (B <= e->act_cap) return OK;
+  // lab hook (librvb_test.so only): pretend that more than RVD_FAKE_NOMEM_ABOVE windows do not fit, to exercise the retry below
+  if (const char* f = lab_env("RVD_FAKE_NOMEM_ABOVE")) {
+    if (B > atoi(f)) { set_error("hipMalloc refused (RVD_FAKE_NOMEM_ABOVE)"); return E_NOMEM; }
+  }
   const size_t ts = dt_size(e->dtype);
   for (int li = 0; li < 4; ++li) {
     const StageDims d = stage_dims(e, li);
@@ -704,8 +708,9 @@ int embed_impl(rvd_engine* e, const int64_t* win, const float* mask, int n, floa
     const int B = (int)uniq.size(), ni = i1 - i0;
     {
       const int rc = ensure_emb_workspace(e, B);
-      if (rc == E_NOMEM && EMB_BATCH > 16) {        // the activations of B windows do not fit beside what else lives on this GPU:
-        e->emb_batch = EMB_BATCH / 2;               // fewer windows per pass from here on, same results
+      if (rc == E_NOMEM && B > 1) {                 // the activations of B windows do not fit beside what else lives on this GPU:
+        e->emb_batch = std::max(1, std::min(EMB_BATCH, B) / 2);   // fewer windows per pass from here on, same results (ADVICE r4;
+                                                    // r5: halve what was ASKED FOR, so that every retry really shrinks)
         for (auto& row : e->act) for (auto& b : row) b.release();
         for (auto& row : e->act8) for (auto& b : row) b.release();
         e->act_cap = 0;
@@ -1061,6 +1066,19 @@ int rvd_get_emb_fp8(rvd_engine* e, int32_t* state, float* scales, int32_t* n, ui
       RVB_HIP_CHECK(hipStreamSynchronize(e->stream));
     }
   }
+  return OK;
+}
+
+int rvd_set_emb_fp8_scales(rvd_engine* e, const float* scales, int32_t n) {
+  if (!e || !scales || n != 32) { set_error("rvd_set_emb_fp8_scales: engine, 32 scales"); return E_ARG; }
+  if (!e->emb_fp8) { set_error("rvd_set_emb_fp8_scales: not an fp8 engine"); return E_STATE; }
+  for (int i = 0; i < 32; ++i)
+    if (!(scales[i] > 0.f) || !std::isfinite(scales[i])) { set_error("rvd_set_emb_fp8_scales: scales must be positive and finite"); return E_ARG; }
+  RVB_HIP_CHECK(hipSetDevice(e->device));
+  RVD_TRY(e->d_sat8.ensure(4));
+  RVB_HIP_CHECK(hipMemsetAsync(e->d_sat8.p, 0, 4, e->stream));
+  e->scale8.assign(scales, scales + 32);
+  e->emb_f8_state = 2;
   return OK;
 }
 

@@ -61,7 +61,7 @@ struct Decoder {
   bool kv_ready = false;      // the layers' kvmem hold the current batch (rvb_prepare_rescoring or the first decoder pass)
 };
 
-struct ProfEntry { double ms = 0, flops = 0; int64_t launches = 0; };
+struct ProfEntry { double ms = 0, flops = 0, bytes = 0; int64_t launches = 0; };
 
 struct RescoreResult {
   int best = 0;

@@ -28,6 +28,8 @@ int DevBuf::ensure(size_t n) {
   hipError_t err = hipMalloc(&p, n);
   if (err != hipSuccess) {
     p = nullptr;
+    (void)hipGetLastError();      // HIP's thread-local last error is sticky: a caller that retries with a smaller size must not
+                                  // trip over this failure at its next hipGetLastError() check
     set_error("hipMalloc of " + std::to_string(n) + " bytes failed: " + hipGetErrorString(err));
     return E_NOMEM;
   }
@@ -41,9 +43,9 @@ void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 // ------------------------------------------------------------------------------------ profiling
 struct Scope {
   rvb_engine* e; hipEvent_t a = nullptr, b = nullptr; std::string name;
-  Scope(rvb_engine* e_, const char* n, double flops = 0.0) : e(e_), name(n) {
+  Scope(rvb_engine* e_, const char* n, double flops = 0.0, double bytes = 0.0) : e(e_), name(n) {
     auto& pe = e->prof[name];
-    pe.launches += 1; pe.flops += flops;
+    pe.launches += 1; pe.flops += flops; pe.bytes += bytes;
     if (e->profiling == 0 || (e->profiling == 2 && name != "gemm" && name != "gemm_fp8")) return;
     auto get = [&]() { hipEvent_t ev; if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
     a = get(); b = get();
@@ -238,6 +240,15 @@ static int reset_f8sat(rvb_engine* e) {
   return OK;
 }
 
+// ALGORITHMIC HBM bytes of one GEMM launch: every operand once -- A [M,K] (the NHWC activation once for the implicit
+// convolution, not its 9-fold gather), W [N,K], bias, C [M,N] written once, the fp32 residual read once
+static double gemm_alg_bytes(const rvb_engine* e, const GemmArgs& g) {
+  const double es = g.in_fp8 ? 1.0 : (double)dt_size(e->dtype);
+  const double a = g.conv ? (double)(g.M / (g.cT2 * g.cF2)) * g.cT1 * g.cF1 * g.cC * es : (double)g.M * g.K * es;
+  const double c = (double)g.M * g.N * (g.out_fp8 ? 1.0 : (g.out_f32 ? 4.0 : (double)dt_size(e->dtype)));
+  return a + (double)g.N * g.K * es + (g.bias ? 4.0 * g.N : 0.0) + c + (g.res ? 4.0 * (double)g.M * g.N : 0.0);
+}
+
 static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void* C, int ldc, int M, bool out_f32,
                     float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
   GemmArgs g;
@@ -245,7 +256,7 @@ static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void
   g.A = A; g.W = L.w.p; g.bias = L.b.as<float>(); g.res = res; g.C = C;
   g.M = M; g.N = L.out; g.K = L.in; g.lda = lda; g.ldw = L.in; g.ldc = ldc; g.ldres = ldres;
   g.alpha = alpha; g.act = act; g.out_f32 = out_f32 ? 1 : 0;
-  Scope sc(e, "gemm", 2.0 * M * (double)L.out * L.in);
+  Scope sc(e, "gemm", 2.0 * M * (double)L.out * L.in, gemm_alg_bytes(e, g));
   return gemm(e->stream, e->dtype, g);
 }
 // out8 / out2_8 > 0: that output is fp8 bytes of value / scale (the calibrated per-tensor scale of the GEMM that reads it)
@@ -276,7 +287,7 @@ static int run_gemm8(rvb_engine* e, const void* A8, int lda, const Linear& L, vo
   g.alpha = alpha; g.act = act; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.in_fp8 = 1;
   g.a_scale = a_scale; g.w_scale = L.wscale.as<float>(); g.out_inv_scale = 1.f / out_scale;
   if (!L.w8.p) { set_error("fp8 GEMM on a layer without fp8 weights"); return E_STATE; }
-  Scope sc(e, "gemm_fp8", 2.0 * M * (double)L.out * L.in);
+  Scope sc(e, "gemm_fp8", 2.0 * M * (double)L.out * L.in, gemm_alg_bytes(e, g));
   return gemm(e->stream, e->dtype, g);
 }
 
@@ -759,7 +770,7 @@ static int encode_impl(rvb_engine* e, const float* feats, int64_t first_chunk, c
       g.M = nb * T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
       g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
       if (f8c2) { g.W = e->conv2.w8.p; g.in_fp8 = 1; g.a_scale = e->f8_x1; g.w_scale = e->conv2.wscale.as<float>(); }
-      Scope sc(e, f8c2 ? "gemm_fp8" : "gemm", 2.0 * g.M * (double)g.N * g.K);
+      Scope sc(e, f8c2 ? "gemm_fp8" : "gemm", 2.0 * g.M * (double)g.N * g.K, gemm_alg_bytes(e, g));
       RVB_TRY(gemm(e->stream, e->dtype, g));
     }
     RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, m, true, std::sqrt((float)d)));
@@ -893,7 +904,7 @@ static int stream_chunk_impl(rvb_engine* e, const float* feats, int T0, int requ
     g.A = e->X1.p; g.W = e->conv2.w.p; g.bias = e->conv2.b.as<float>(); g.C = e->X2.p;
     g.M = T2 * F2; g.N = d; g.K = 9 * d; g.lda = d; g.ldw = 9 * d; g.ldc = d;
     g.alpha = 1.f; g.act = ACT_RELU; g.conv = 1; g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = d;
-    Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K);
+    Scope sc(e, "gemm", 2.0 * g.M * (double)g.N * g.K, gemm_alg_bytes(e, g));
     RVB_TRY(gemm(e->stream, e->dtype, g));
   }
   RVB_TRY(run_gemm(e, e->X2.p, F2 * d, e->embed_out, e->x.p, d, M, true, std::sqrt((float)d)));
@@ -2450,6 +2461,12 @@ int rvb_get_timing(rvb_engine* e, const char* name, double* ms, double* flops, i
   auto it = e->prof.find(name);
   ProfEntry pe; if (it != e->prof.end()) pe = it->second;
   if (ms) *ms = pe.ms; if (flops) *flops = pe.flops; if (launches) *launches = pe.launches;
+  return OK;
+}
+int rvb_get_timing_bytes(rvb_engine* e, const char* name, double* bytes) {
+  if (!e || !name || !bytes) return E_ARG;
+  auto it = e->prof.find(name);
+  *bytes = it != e->prof.end() ? it->second.bytes : 0.0;
   return OK;
 }
 

@@ -161,6 +161,11 @@ class DiarEngine:
         _check(self.lib.rvd_get_emb_fp8(self._h, C.byref(st), fptr(sc), C.byref(n), C.byref(cl)), "rvd_get_emb_fp8")
         return int(st.value), sc, int(cl.value)
 
+    def set_emb_fp8_scales(self, scales: np.ndarray) -> None:
+        """install the 32 activation scales and activate the fp8 trunk (rvd_set_emb_fp8_scales): no calibration pass follows"""
+        sc = np.ascontiguousarray(scales, np.float32).reshape(-1)
+        _check(self.lib.rvd_set_emb_fp8_scales(self._h, fptr(sc), len(sc)), "rvd_set_emb_fp8_scales")
+
     def centroid_linkage(self, X: np.ndarray) -> np.ndarray:
         """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") on the GPU (fp64)."""
         X = np.ascontiguousarray(X, dtype=np.float64)

@@ -522,6 +522,7 @@ class SpeakerDiarization:
         self.dtype = dtype
         self.device_index: Optional[int] = None
         self._engine = None
+        self._emb_fp8_scales = None          # fp8 trunk scales agreed on by the ranks of a sharded run (dist.share_emb_fp8_scales)
         self.timings: Dict[str, float] = {}
 
     # pyannote API --------------------------------------------------------------------------------
@@ -553,6 +554,8 @@ class SpeakerDiarization:
         if self._engine is None:
             from .diar_engine import DiarEngine
             self._engine = DiarEngine(self.cfg, self._seg_sd, self._emb_sd, dtype=self.dtype, device=self.device_index or 0)
+            if self._emb_fp8_scales is not None:      # a rank that had no window when the scales were shared
+                self._engine.set_emb_fp8_scales(self._emb_fp8_scales)
         return self._engine
 
     def _load(self, file) -> Tuple[np.ndarray, str]:

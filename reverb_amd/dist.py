@@ -310,9 +310,92 @@ def default_comm(engine):
         import torch
         if os.environ.get("RVB_COMM") != "cabi" or not torch.cuda.is_available():
             return None
+    if _COMM_FALLBACK is not None:                 # an earlier attempt of this process failed on some rank: torch.distributed
+        return None
     if _DEFAULT_COMM is None or not _DEFAULT_COMM.handle:
-        _DEFAULT_COMM = RvbComm.from_torch_group(_device_of(engine))
+        _DEFAULT_COMM = _create_comm_or_agree_on_fallback(_device_of(engine))
     return _DEFAULT_COMM
+
+
+_COMM_FALLBACK = None      # why librvb's RCCL communicator is not used by this process (None = it is, or was never tried)
+_COMM_INIT_HUNG = False    # a thread of this process is still inside ncclCommInitRank (the caller should leave with os._exit)
+
+
+def comm_fallback_reason():
+    """None, or the reason every rank of this job exchanges through torch.distributed instead of librvb's RCCL binding."""
+    return _COMM_FALLBACK
+
+
+def comm_init_hung() -> bool:
+    return _COMM_INIT_HUNG
+
+
+def _create_comm_or_agree_on_fallback(device: int):
+    """Create the process-wide RvbComm, or -- when that fails on ANY rank -- make every rank fall back to torch.distributed
+    together (`ncclCommInitRank` across processes first runs on the driver's scaling box, and a failure
+    there used to raise and kill `bench.py --gpus 8`).  Steps, in lockstep on every rank: (1) the id travels over the torch
+    group and rvb_comm_create runs in a helper thread with a deadline (RVB_COMM_INIT_TIMEOUT, default 120 s: an init that
+    hangs counts as failed); (2) preflight: one 1-KB device-to-device all-gather under a 30 s collective timeout, so that the
+    first collective of the timed region cannot be the first ever; (3) the ranks all-gather (ok, reason) over the torch
+    group; unless every rank is fine, every rank frees its communicator, records the reason (comm_fallback_reason), logs it
+    to stderr and returns None -- the callers then gather through torch.distributed (the rendezvous group: gloo on host
+    buffers, or torch's own RCCL communicator)."""
+    import os
+    import sys
+    import threading
+    import torch.distributed as dist
+    global _COMM_FALLBACK, _COMM_INIT_HUNG
+    comm, reason = None, None
+    box = {}
+
+    if dist.get_world_size() == 1:
+        return RvbComm.from_torch_group(device)      # one rank: nothing to wait for, nothing to agree on
+    ident = [RvbComm.unique_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(ident, src=0)         # (torch collectives stay on the calling thread: its current device)
+
+    def create():
+        try:
+            box["comm"] = RvbComm(device, dist.get_world_size(), dist.get_rank(), ident[0])
+        except BaseException as ex:          # noqa: BLE001 -- whatever it is, the ranks must hear about it
+            box["error"] = f"{type(ex).__name__}: {ex}"
+
+    t = threading.Thread(target=create, name="rvb_comm_create", daemon=True)
+    t.start()
+    t.join(float(os.environ.get("RVB_COMM_INIT_TIMEOUT", "120")))
+    if t.is_alive():
+        _COMM_INIT_HUNG = True
+        reason = "rvb_comm_create did not return within RVB_COMM_INIT_TIMEOUT"
+    elif "error" in box:
+        reason = box["error"]
+    else:
+        comm = box["comm"]
+        try:
+            try:
+                comm.set_timeout(30.0)
+            except Exception:                 # an RCCL build without ncclCommAbort refuses timeouts: preflight without one
+                pass
+            comm.time_all_gather(1024, iters=1)
+            try:
+                comm.set_timeout(0.0)
+            except Exception:
+                pass
+        except Exception as ex:
+            reason = f"preflight all-gather failed: {type(ex).__name__}: {ex}"
+    votes = [None] * dist.get_world_size()
+    dist.all_gather_object(votes, reason)
+    bad = [(r, v) for r, v in enumerate(votes) if v is not None]
+    if not bad:
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:
+            pass
+    _COMM_FALLBACK = "; ".join(f"rank {r}: {v}" for r, v in bad)
+    sys.stderr.write("reverb_amd.dist: librvb's RCCL communicator is not usable (" + _COMM_FALLBACK +
+                     "); every rank exchanges through torch.distributed (" + dist.get_backend() + ") instead\n")
+    sys.stderr.flush()
+    return None
 
 
 def _device_of(engine) -> int:
@@ -384,13 +467,14 @@ def share_fp8_scales(engine, n_frames: int, chunk_size: int, beam_size: int, dev
     engines that are calibrated already (scales stick to an engine across recordings)."""
     if getattr(engine, "dtype", None) != "fp8" or not hasattr(engine, "fp8_scales"):
         return
-    vector = getattr(engine, "fp8_scale_vector", engine.fp8_scales)      # with conv1's output scale (ADVICE r4); stubs: blocks only
+    has_vec = hasattr(engine, "fp8_scale_vector")        # with conv1's output scale (ADVICE r4); stubs: blocks only
+    vector = engine.fp8_scale_vector if has_vec else engine.fp8_scales
     mine = vector()
     if mine is None and n_frames > 0:
         engine.decode_resident(n_frames, ["ctc_greedy_search"], chunk_size, beam_size, 0.0, 0.0)      # bf16 pass, records max |.|
         mine = vector()
     nb = int(engine.cfg.num_blocks)
-    send = np.zeros(1 + nb * 7 + (1 if vector is not engine.fp8_scales else 0), np.float32)
+    send = np.zeros(1 + nb * 7 + (1 if has_vec else 0), np.float32)      # (ADVICE r5: `vector is not engine.fp8_scales` was always true)
     if mine is not None:
         send[0] = 1.0
         send[1:] = mine.reshape(-1)
@@ -398,6 +482,33 @@ def share_fp8_scales(engine, n_frames: int, chunk_size: int, beam_size: int, dev
     have = host[:, 0] > 0
     if have.any():
         engine.set_fp8_scales(host[have, 1:].max(axis=0))
+
+
+def share_emb_fp8_scales(pipeline, device) -> bool:
+    """The diarization counterpart of share_fp8_scales: the embedding trunk of an fp8 pipeline calibrates its 32 activation
+    scales on the first windows it sees (that pass runs in bf16).  On the first sharded recording of a pipeline every rank
+    reports the scales it holds (none: a rank without windows has no engine), the element-wise maximum is installed
+    everywhere (rvd_set_emb_fp8_scales; kept on the pipeline for engines created later) and True is returned -- the caller
+    embeds its windows again, so ONE quantisation feeds the clustering whatever the world size.  Whether the collective
+    runs depends on the pipeline's dtype and on how many sharded calls it has seen ONLY -- the same on every rank."""
+    if getattr(pipeline, "dtype", None) != "fp8" or getattr(pipeline, "_emb_fp8_scales", None) is not None:
+        return False
+    eng = getattr(pipeline, "_engine", None)
+    send = np.zeros(33, np.float32)
+    if eng is not None and hasattr(eng, "emb_fp8"):
+        state, scales, _ = eng.emb_fp8()
+        if state == 2:
+            send[0] = 1.0
+            send[1:] = scales
+    idx = getattr(pipeline, "device_index", None)
+    host = gather_words(send.view(np.int32), device, default_comm(idx if idx is not None else device)).view(np.float32)
+    have = host[:, 0] > 0
+    if not have.any():
+        return False              # nobody embedded anything (no active speaker anywhere): try again on the next recording
+    pipeline._emb_fp8_scales = host[have, 1:].max(axis=0).astype(np.float32)
+    if eng is not None and hasattr(eng, "set_emb_fp8_scales"):
+        eng.set_emb_fp8_scales(pipeline._emb_fp8_scales)
+    return True
 
 
 class CollectiveFailed(RuntimeError):
@@ -700,6 +811,11 @@ def diarize_sharded(pipeline, pcm: np.ndarray, device, uri=None, timeout: float 
         return classes, emb
 
     classes, emb = run_windows(w0, w1)
+    if not _KNOWN_DEAD and share_emb_fp8_scales(pipeline, device):
+        # fp8 trunk, first recording of these engines: the pass above calibrated each rank on its own windows (and ran its first
+        # trunk pass in bf16); now that every rank holds the same scales, embed the windows again so that ONE quantisation feeds
+        # the clustering whatever the world size.  Once per engine: calibrated engines skip both steps.
+        classes, emb = run_windows(w0, w1)
     kmax = max(b - a for a, b in ranges)
     comm = None
     if not _KNOWN_DEAD:

@@ -304,7 +304,11 @@ class Engine:
         t = C.c_int32(0)
         check(self.lib.rvb_encoder_frames(self.handle, C.byref(t)))
         self.batch, self.enc_frames, self.beam, self.topk = B, int(t.value), int(beam), k
-        self._last_encode = (feats, lens, int(beam), float(blank_penalty), int(first_chunk), int(T0))     # for joint_decode's retry
+        # joint_decode's tie retry encodes the batch again; only an encode that asked for joint decoding's pre-beam (topk) and
+        # so may be followed by joint_decode keeps its arguments, and joint_decode drops them when it is done (every encode pinned
+        # hundreds of MB of features for the engine's lifetime)
+        self._last_encode = ((feats, lens, int(beam), float(blank_penalty), int(first_chunk), int(T0))
+                             if topk and k < 64 else None)      # feats None: the resident features (valid until the next upload)
 
     # -------------------------------------------------------------------------------- streaming encoder
     def stream_begin(self):
@@ -468,7 +472,8 @@ class Engine:
         (encode(..., topk=int(pre_beam_ratio * beam)) first).  DecodeResult: tokens, joint score, start frame and confidence
         per token -- the fields the reference fills -- plus `end_times`."""
         rc = self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus))
-        if rc == -5 and self.topk < 64 and getattr(self, "_last_encode", None) is not None:
+        if (rc == -5 and self.topk < 64 and getattr(self, "_last_encode", None) is not None
+                and b"tie exactly" in self.lib.rvb_last_error()):
             # RVB_E_UNSUPPORTED here = a frame holds a longer run of log-probs that tie EXACTLY with the pre-beam threshold than
             # the kept top-k covers (the reference compares the whole row, beam_search_timesync.py:268-270).  Rather than fail
             # the decode after all the work is done (ADVICE r4), encode the batch again keeping the kernel's maximum of 64
@@ -476,6 +481,7 @@ class Engine:
             feats, lens, beam, blank_penalty, first_chunk, T0 = self._last_encode
             self.encode(feats, lens, beam, blank_penalty, first_chunk, T0, topk=64)
             rc = self.lib.rvb_joint_decode(self.handle, self.beam, float(ctc_weight), float(pre_beam_ratio), float(length_bonus))
+        self._last_encode = None
         check(rc, "rvb_joint_decode")
         T = max(self.enc_frames, 1)
         tok = np.empty(T, np.int32); st = np.empty(T, np.int32); en = np.empty(T, np.int32); cf = np.empty(T, np.float64)
@@ -556,4 +562,6 @@ class Engine:
     def timing(self, name: str):
         ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
         check(self.lib.rvb_get_timing(self.handle, name.encode(), C.byref(ms), C.byref(fl), C.byref(n)))
-        return {"ms": ms.value, "flops": fl.value, "launches": n.value}
+        by = C.c_double(0)
+        check(self.lib.rvb_get_timing_bytes(self.handle, name.encode(), C.byref(by)))
+        return {"ms": ms.value, "flops": fl.value, "launches": n.value, "bytes": by.value}

@@ -225,8 +225,26 @@ def test_embedding_bf16_close_to_oracle(case, emb_case):
     want = emb_case["want"]
     active = emb_case["masks"].sum(1) > 0
     cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
-    assert cos[active].min() > 0.995, cos
+    assert cos[active].min() > 0.999, cos          # SURVEY 8(d)'s bar for embeddings; measured 0.99999
     eng.close()
+
+
+def test_embedding_retries_with_fewer_windows_when_the_workspace_does_not_fit(case, emb_case, monkeypatch, lab):
+    """the E_NOMEM retry of embed_impl (halve the windows per pass, release, regroup) was dead code -- HIP's sticky
+    last error failed the retried pass, and a request below the configured batch never shrank.  The lab hook
+    RVD_FAKE_NOMEM_ABOVE makes every workspace request of more than one window fail: the three windows of the case must
+    come out of three one-window passes, bit-identical to the one-pass run."""
+    from reverb_amd.diar_engine import DiarEngine
+    out = {}
+    for fake in (None, "1"):
+        if fake:
+            monkeypatch.setenv("RVD_FAKE_NOMEM_ABOVE", fake)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], emb_case["emb_sd"], dtype="bf16")
+        eng.upload(case["pcm"])
+        out[fake] = eng.embed(emb_case["wins"], emb_case["masks"])
+        assert (eng.emb_windows_per_pass() == 1) == bool(fake)
+        eng.close()
+    assert np.array_equal(out[None], out["1"])
 
 
 def test_implicit_gemm_convolutions_equal_the_direct_kernel(case, emb_case, monkeypatch, lab):
@@ -364,8 +382,8 @@ def test_trunk_stages_3_and_4_in_fp8(case, emb_case):
     cosw16 = (a * want).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(want, axis=1))
     _record(test="trunk_stages_3_and_4_in_fp8", cos_fp8_vs_bf16_min=float(cos.min()), cos_fp8_vs_bf16_mean=float(cos.mean()),
             cos_fp8_vs_fp32_oracle_min=float(cosw.min()), cos_bf16_vs_fp32_oracle_min=float(cosw16.min()), embeddings=int(active.sum()))
-    assert cos.min() > 0.995, cos              # measured 0.99960 (profiles/r05c_parity_metrics.jsonl)
-    assert cosw.min() > 0.995, cosw            # measured 0.99960; the bf16 engine: 0.99999
+    assert cos.min() > 0.999, cos              # SURVEY 8(d)'s bar; measured 0.99960 (profiles/r05h_parity_metrics.jsonl)
+    assert cosw.min() > 0.999, cosw            # measured 0.99960; the bf16 engine: 0.99999
     eng.close()
 
 

@@ -117,6 +117,68 @@ def test_all_gather_results_world2_gloo(row_words):
         assert first == (2 if row_words else 1) and second == 1
 
 
+class _FakeComm:
+    """RvbComm stand-in for the fallback test: creation / the preflight collective fail on the ranks the test names."""
+    fail_create, fail_preflight, closed = (), (), 0
+
+    def __init__(self, engine, world, rank, unique_id):
+        assert len(unique_id) == 128
+        if rank in _FakeComm.fail_create:
+            raise RuntimeError("ncclCommInitRank failed: unhandled system error")
+        self.world, self.rank, self.handle = world, rank, 1
+
+    @staticmethod
+    def unique_id():
+        return bytes(128)
+
+    def set_timeout(self, s):
+        pass
+
+    def time_all_gather(self, nbytes, iters=1):
+        if self.rank in _FakeComm.fail_preflight:
+            raise RuntimeError("rvb_comm_time_allgather: timed out")
+        return 0.01
+
+    def close(self):
+        _FakeComm.closed += 1
+        self.handle = None
+
+
+def _fallback_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RVB_COMM="cabi")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.is_available = lambda: True            # "a GPU box": default_comm goes for librvb's communicator
+    rdist.RvbComm = _FakeComm
+    _FakeComm.fail_create = (1,) if mode == "create" else ()
+    _FakeComm.fail_preflight = (0,) if mode == "preflight" else ()
+    comm = rdist.default_comm(0)
+    again = rdist.default_comm(0)                     # a later caller (the other engine) gets the same answer, no new attempt
+    merged = rdist.all_gather_results(_fake_results(rank), torch.device("cpu"), max_count=max(3 + 2 * r for r in range(world)), comm=comm) \
+        if comm is None else None
+    q.put((rank, comm is None, again is None, rdist.comm_fallback_reason(), _FakeComm.closed, [_row(h) for h in merged] if merged else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["create", "preflight", "fine"])
+def test_failed_rccl_init_on_one_rank_makes_every_rank_fall_back_together(mode):
+    """`rvb_comm_create` with world > 1 first runs on the driver's scaling box.  A failure on ANY
+    rank (creation, or the 1-KB preflight all-gather) must not raise and must not leave the ranks on different transports: all of
+    them free what they created, record the reason and gather through torch.distributed; with no failure all keep librvb's."""
+    got = _run_world2(_fallback_worker, (mode,))
+    want = [_row(h) for r in range(2) for h in _fake_results(r)]
+    for r in range(2):
+        is_none, again_none, reason, closed, rows = got[r]
+        if mode == "fine":
+            assert not is_none and not again_none and reason is None and closed == 0
+            continue
+        assert is_none and again_none and rows == want
+        assert ("rank 1: RuntimeError: ncclCommInitRank failed" in reason) if mode == "create" else ("rank 0: preflight all-gather failed" in reason)
+    # the rank whose own communicator was fine freed it
+    assert got[0 if mode == "create" else 1][3] == (1 if mode != "fine" else 0)
+
+
 # ------------------------------------------------------------------------------------------------ decode_sharded
 class _StubAsrEngine:
     """Stands in for the GPU engine: the result of a chunk is a pure function of the samples its frames cover, so the
@@ -370,6 +432,68 @@ def test_diarize_sharded_world2_gloo_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == want and got[1] == want
+
+
+class _StubFp8DiarEngine(_StubDiarEngine):
+    """fp8 trunk stand-in: the first embed call "calibrates" scales from this rank's own samples; installed scales win."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.scales, self.embed_calls, self.installed = None, 0, 0
+
+    def embed(self, wins, masks):
+        self.embed_calls += 1
+        if self.scales is None:
+            self.scales = np.full(32, 2.0 ** (int(np.abs(self.pcm).max()) % 5), np.float32)
+        return super().embed(wins, masks) + 1e-6 * self.scales[0]
+
+    def emb_fp8(self):
+        return (2 if self.scales is not None else 0), (self.scales if self.scales is not None else np.zeros(32, np.float32)), 0
+
+    def set_emb_fp8_scales(self, sc):
+        self.scales = np.asarray(sc, np.float32).copy()
+        self.installed += 1
+
+
+def _diar_fp8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from reverb_amd import synth_diar
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pcm = synth_diar.synth_conversation(33.4, seed=9)
+    pcm[: len(pcm) // 2] = (pcm[: len(pcm) // 2] // 2)          # the two halves calibrate to different ranges
+    pipe = _diar_pipeline()
+    pipe.dtype = "fp8"
+    pipe._engine = _StubFp8DiarEngine(pipe.cfg)
+    a1 = rdist.diarize_sharded(pipe, pcm, torch.device("cpu"), uri="talk")
+    calls1 = pipe._engine.embed_calls
+    a2 = rdist.diarize_sharded(pipe, pcm, torch.device("cpu"), uri="talk")
+    q.put((rank, pipe._emb_fp8_scales.tolist(), calls1, pipe._engine.embed_calls, pipe._engine.installed, _rttm(a1), _rttm(a2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_diarize_sharded_fp8_ranks_agree_on_one_set_of_trunk_scales():
+    """each rank of a sharded fp8 diarization calibrated its embedding scales on its own windows.  Now the first
+    sharded recording of a pipeline gathers the scales, installs the element-wise maximum everywhere and embeds again; the
+    second recording does neither."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diar_fp8_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sc0, c0, t0, i0, r0a, r0b), (_, sc1, c1, t1, i1, r1a, r1b) = got
+    assert sc0 == sc1 and len(sc0) == 32 and i0 == i1 == 1
+    assert c0 == c1 == 2 and t0 == t1 == 3                   # calibrate + re-embed on the first recording, one pass on the second
+    assert r0a == r1a == r0b == r1b
 
 
 def test_networks_host_overlap_keeps_results():

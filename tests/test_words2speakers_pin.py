@@ -73,12 +73,53 @@ def test_join_matches_the_reference_function_live():
     if not shim.reference_available():
         pytest.skip("reference checkout not present (GPU box): the golden pairs above are the pin")
     from oracle.gen_golden_words2speakers import make_case
+    # with the REAL intervaltree==3.1.0 when this machine holds it, else the stand-in classes
     ref = shim.load_reference_module()
+    Tree, Iv, which = shim.tree_classes()
     rng = random.Random(7)
     for idx in range(3, 25):
         c = make_case(rng, idx)
-        tree = shim.IntervalTree(shim.Interval(s, e, lab) for s, e, lab in c["turns"])
+        tree = Tree(Iv(s, e, lab) for s, e, lab in c["turns"])
         _check(c["turns"], c["words"], [ref.speaker_for_segment(s, d, tree) for s, d in c["words"]])
+
+
+def test_golden_pairs_hold_under_the_real_intervaltree_package():
+    """The golden speakers were generated through the stand-in; where the real package is on this disk, the unmodified
+    reference function is run again over the SAME golden pairs on the real `IntervalTree`: every answer must be one of the
+    tied-possible answers, and equal to the golden one wherever only one answer is possible.  Also: the stand-in and the
+    real tree return the same sets for random queries (so the stand-in is a faithful scan of the same intervals)."""
+    from oracle import intervaltree_shim as shim
+    real = shim.real_intervaltree()
+    if real is None or not shim.reference_available():
+        pytest.skip("no intervaltree==3.1.0 on this machine (or no reference checkout)")
+    ref = shim.load_reference_module(real=True)
+    doc = json.load(open(GOLDEN))
+    checked = 0
+    for c in doc["cases"]:
+        turns = _turn_list(c["turns"])
+        tree = real.IntervalTree(real.Interval(s, e, lab) for s, e, lab in turns)
+        for (s, d), want in zip(c["words"], c["speakers"]):
+            got = ref.speaker_for_segment(s, d, tree)
+            ok = _tied_answers(s, d, turns)
+            assert got in ok and (len(ok) > 1 or got == want), (s, d, got, want, ok)
+            checked += 1
+    assert checked == doc["pairs"]
+    rng = random.Random(3)
+    for _ in range(50):
+        ivs = []
+        for _ in range(rng.randrange(1, 30)):
+            a = round(rng.uniform(0, 50), 2)
+            ivs.append((a, a + round(rng.uniform(0.01, 8), 2), rng.choice("ABCD")))
+        rt = real.IntervalTree(real.Interval(*iv) for iv in ivs)
+        st = shim.IntervalTree(shim.Interval(*iv) for iv in ivs)
+        assert len(rt) == len(st)
+        for _ in range(40):
+            a = round(rng.uniform(-1, 60), 2)
+            b = a + rng.choice([0.0, 0.01, 1.0, 7.5])
+            assert {tuple(iv) for iv in rt[a:b]} == {tuple(iv) for iv in st[a:b]}
+            q = real.Interval(a, b + 0.01)
+            for iv in ivs:
+                assert real.Interval(*iv).distance_to(q) == shim.Interval(*iv).distance_to(shim.Interval(a, b + 0.01))
 
 
 def test_script_writes_the_stm_the_reference_script_writes(tmp_path):
