@@ -154,17 +154,18 @@ def cpu_baseline(cfg, sd, feats_chunks, lens, args):
     dt = time.perf_counter() - t0
     torch.set_num_threads(default)
     return {"value": round(frames * 0.01 / dt, 3), "unit": "RTFx (audio-sec/wall-sec)", "cores": cores, "kind": "port",
-            "sample": f"first {len(lens)} chunks ({frames * 0.01:.1f} s of audio) of the same workload, oracle "
-                      f"attention_rescoring fp32 batch 1, {dt:.1f} s wall; threads = best of "
-                      + (", ".join(f"{c}: {1e3 * t:.0f} ms" for c, t in probe.items()) if probe else str(cores)) + " on chunk 0"}
+            "sample": f"first {len(lens)} chunks ({frames * 0.01:.1f} s of audio) of the same workload, oracle port, "
+                      f"fp32 batch 1, {dt:.1f} s wall",
+            "threads_probe_ms_chunk0": {str(c): round(1e3 * t) for c, t in probe.items()}}
 
 
 # ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
-def pmc_traffic(sub, match, what):
+def pmc_traffic(sub, match, what, last=None):
     """HBM bytes per launch of the kernels whose name contains one of `match`, over one run of the command `sub`:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots, MI355X_MICROARCH.md); FETCH_SIZE
     doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B), both counters in units of 1024 B.
-    Returns a dict or None."""
+    `last` = N: only the LAST N matching dispatches of the run count (one steady-state step: a process's first step also
+    launches what only a first step does).  Returns a dict or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
@@ -185,15 +186,18 @@ def pmc_traffic(sub, match, what):
                         path = os.path.join(d, f)
             if r.returncode != 0 or path is None:
                 return None
-            tot, ids = 0.0, set()
+            per = {}                                   # dispatch id -> counter value (summed over the rows of one dispatch)
             with open(path) as fh:
                 for row in csv.DictReader(fh):
                     if any(m in row["Kernel_Name"] for m in match) and row["Counter_Name"] == counter:
-                        tot += float(row["Counter_Value"])
-                        ids.add(row["Dispatch_Id"])
-            if not ids:
+                        k = int(row["Dispatch_Id"])
+                        per[k] = per.get(k, 0.0) + float(row["Counter_Value"])
+            if not per:
                 return None
-            got[counter] = (tot * 1024.0, len(ids))
+            ids = sorted(per)
+            if last is not None:
+                ids = ids[-int(last):]
+            got[counter] = (sum(per[k] for k in ids) * 1024.0, len(ids))
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
         return None
     finally:
@@ -201,17 +205,18 @@ def pmc_traffic(sub, match, what):
     (f, nf), (w, nw) = got["FETCH_SIZE"], got["WRITE_SIZE"]
     return {"bytes_per_launch": round((2.0 * f) / nf + w / nw, 1), "read_bytes_per_launch": round(2.0 * f / nf, 1),
             "write_bytes_per_launch": round(w / nw, 1), "launches": nf,
-            "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over one step of {what}, nested "
+            "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over {what}, nested "
                       "in this run; FETCH_SIZE x2 (gfx950 wide-read correction), units of 1024 B"}
 
 
-def measure_traffic(args):
-    """HBM bytes per GEMM launch of this workload (one step of this same command under the two PMC passes)."""
-    sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--model", args.model,
+def measure_traffic(args, per_step):
+    """HBM bytes per GEMM launch of this workload: this same command (headline leg only) under the two PMC passes, one warm-up
+    step and one timed step; the last `per_step` GEMM dispatches -- the timed step's -- are what counts."""
+    sub = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "1", "--model", args.model,
            "--dtype", args.dtype, "--hours", str(args.hours), "--chunks-per-launch", str(args.chunks_per_launch),
            "--beam", str(args.beam), "--ctc-weight", str(args.ctc_weight), "--reverse-weight", str(args.reverse_weight),
            "--cpu-baseline-chunks", "0", "--no-profile", "--traffic", "off", "--no-diarization", "--no-pcie", "--no-variants"]
-    return pmc_traffic(sub, ("gemm",), "this command")
+    return pmc_traffic(sub, ("gemm",), "the last step of this command", last=per_step)
 
 
 # ------------------------------------------------------------------------------------------------ stub (CPU test hook)
@@ -605,8 +610,8 @@ def main():
     if rank == 0 and not STUB and world == 1:
         # the engine is closed and the GPU idle: nested measurements of the same workload
         if args.traffic == "auto" and out["roofline"] is not None and args.dtype != "fp8":
-            t = measure_traffic(args)
             per_step = out["roofline"]["launches"] // max(args.steps, 1)
+            t = measure_traffic(args, per_step)
             if t is not None and t["launches"] != per_step:
                 # the nested passes must have profiled exactly one step of THIS workload's GEMMs (a pass that
                 # also ran the variants averaged 3 731 launches instead of 333); anything else is not this kernel's traffic

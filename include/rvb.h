@@ -127,7 +127,10 @@ int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int6
  *   AIFF / AIFF-C  NONE / twos / sowt PCM 8 (signed in the file, handed on as uint8 = value + 128) / 16 / 24 / 32, fl32 / fl64, alaw / ulaw
  *   FLAC       (RFC 9639) <= 16 bits per sample: int16, left-justified; wider: int32, left-justified; frame CRC-8 / CRC-16
  *              and the STREAMINFO MD5 of the decoded PCM are verified (md5_checked = 1 when the file carries a signature)
- * MP3 / Ogg are refused by name (RVB_E_UNSUPPORTED); corrupt data is -6.
+ *   MPEG audio Layer III (MP3; MPEG-1, MPEG-2 and 2.5 sampling rates, mono / stereo / joint stereo, CRC checked when present): float32,
+ *              full scale 1.0; a leading Xing / Info / VBRI frame is skipped and the encoder delay / padding of a LAME-style tag are trimmed
+ *              the way FFmpeg (torchaudio's loader) trims them; free format and Layers I / II are refused by name
+ * Ogg is refused by name (RVB_E_UNSUPPORTED); corrupt data is -6.
  * rvb_audio_probe fills `info` only.  The decode calls write channel `channel` (or, with channel = -1, all channels
  * planar [channels][frames]) into `out` of `capacity` samples and return the frames per channel (< 0: error code).
  * flags: RVB_AUDIO_NO_MD5 skips the FLAC signature check (the loader of the reference does not check it either); bits 8..15 =
@@ -135,7 +138,7 @@ int rvb_fbank(rvb_engine* e, float* feats_out /* nullable [n_frames*80] */, int6
  * rvb_audio_decode_i16 serves the files whose native format is int16 (sample_format == RVB_SAMPLE_I16): the PCM can go
  * straight into a page-locked buffer for rvb_upload_pcm_rate; everything else goes through rvb_audio_decode_f32 and
  * rvb_upload_wave_f32. */
-enum { RVB_AUDIO_WAVE = 1, RVB_AUDIO_FLAC = 2, RVB_AUDIO_AIFF = 3 };
+enum { RVB_AUDIO_WAVE = 1, RVB_AUDIO_FLAC = 2, RVB_AUDIO_AIFF = 3, RVB_AUDIO_MP3 = 4 /* MPEG-1 / 2 / 2.5 audio Layer III: float32 */ };
 enum { RVB_AUDIO_NO_MD5 = 1 };
 enum { RVB_SAMPLE_U8 = 1, RVB_SAMPLE_I16 = 2, RVB_SAMPLE_I32 = 3, RVB_SAMPLE_F32 = 4, RVB_SAMPLE_F64 = 5 };
 typedef struct rvb_audio_info {

@@ -1,5 +1,6 @@
 """Audio file reader of the front end: `torchaudio.load(audio_file, normalize=False)` of the reference
-(asr/wenet/cli/reverb.py:128) for RIFF/WAVE and FLAC, decoded by librvb on the host (csrc/audio.cpp, include/rvb.h
+(asr/wenet/cli/reverb.py:128) for RIFF/WAVE, AIFF, FLAC and MP3 (MPEG audio Layer III, csrc/mp3.cpp: float32 in [-1, 1], as
+torchaudio returns it whatever `normalize` says), decoded by librvb on the host (csrc/audio.cpp, include/rvb.h
 `rvb_audio_*`).  normalize=False keeps the decoder's native sample format; the array returned here has the dtype
 and the values of the tensor torchaudio hands back (int16 for 16-bit PCM / A-law / mu-law / FLAC up to 16 bits,
 float32 holding the `.to(torch.float)` values for everything else -- uint8, left-justified int32, float)."""
@@ -12,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-CONTAINERS = {1: "wav", 2: "flac", 3: "aiff"}
+CONTAINERS = {1: "wav", 2: "flac", 3: "aiff", 4: "mp3"}
 SAMPLE_FORMATS = {1: "uint8", 2: "int16", 3: "int32", 4: "float32", 5: "float64"}
 
 

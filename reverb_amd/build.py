@@ -17,18 +17,36 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librvb.so")
 OUT_TEST = os.path.join(HERE, "librvb_test.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "conv_block.hip", "conv_row64.hip", "conv_s2.hip", "linkage.hip", "diar_engine.hip", "comm.hip", "search.cpp", "audio.cpp"]
+SOURCES = ["gemm.hip", "gemm2.hip", "attention.hip", "elementwise.hip", "softmax_topk.hip", "fbank.hip", "engine.hip", "diar.hip", "resnet.hip", "conv_gemm.hip", "conv_stream.hip", "conv_block.hip", "conv_row64.hip", "conv_s2.hip", "linkage.hip", "diar_engine.hip", "comm.hip", "search.cpp", "audio.cpp", "mp3.cpp"]
 TEST_SOURCES = ["test_api.hip", ("engine.hip", "engine_testapi", ["-DRVB_TEST_API"])]      # (source, object stem, extra flags)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-variable"]
 
 
-def _headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(HERE, "..", "include", "rvb.h"))
-    hs.append(os.path.join(HERE, "..", "include", "rvd.h"))
-    return hs
+def _headers(path=None, seen=None):
+    """The headers a source really includes (its `#include "..."` lines, followed recursively through csrc/ and include/): a change of
+    mp3.h rebuilds the three files that read it, not gemm2.hip's seven minutes of template instantiations."""
+    import re
+    if path is None:
+        hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        hs.append(os.path.join(HERE, "..", "include", "rvb.h"))
+        hs.append(os.path.join(HERE, "..", "include", "rvd.h"))
+        return hs
+    seen = set() if seen is None else seen
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return []
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for base in (os.path.dirname(path), CSRC, os.path.join(HERE, "..", "include"), os.path.join(HERE, "..")):
+            cand = os.path.normpath(os.path.join(base, name))
+            if os.path.isfile(cand):
+                if cand not in seen:
+                    seen.add(cand)
+                    _headers(cand, seen)
+                break
+    return sorted(seen)
 
 
 def _stale(target, deps):
@@ -44,7 +62,7 @@ def _compile(item):
     os.makedirs(bdir, exist_ok=True)
     obj = os.path.join(bdir, stem + ".o")
     path = os.path.join(CSRC, src)
-    if _stale(obj, [path] + _headers()):
+    if _stale(obj, [path] + _headers(path)):
         lang = ["-x", "hip"] if src.endswith(".hip") else []
         cmd = [HIPCC] + FLAGS + extra + lang + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

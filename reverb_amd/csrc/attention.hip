@@ -34,7 +34,7 @@ static constexpr int KT = 64;     // keys per tile
 // with the 16-byte pad rounds 1-3 used (row pitch 144 B = 9 bank quads) two lanes of every group meet in one quad (2-way
 // conflicts on every S-phase fragment read); a pitch of 2 mod 4 quads (pad 32: 96 / 160 / 224 / 288 B rows for dk 32 / 64 /
 // 96 / 128 in bf16) is conflict-free for that grouping.
-template <typename T, int DKP, bool HAS_POS, bool FOLD = false, int PADK = 32>
+template <typename T, int DKP, bool HAS_POS, int FOLD = 0, int PADK = 32>
 struct AttnLds {
   static constexpr bool BF = sizeof(T) == 2;
   static constexpr int ROW_K = DKP * (int)sizeof(T) + PADK;   // K / P rows (bytes)
@@ -51,7 +51,9 @@ struct AttnLds {
 
 // NW = waves per workgroup (16 queries each): 8 for the encoder and the cross attention (128-query blocks share a
 // staged key tile), 1 for the decoder's self attention over a hypothesis trie (a hypothesis owns a handful of rows).
-template <typename T, int DKP, bool HAS_POS, int NW, bool FOLD = false, int PADK = 32>
+// FOLD: 0 = two products; 1 = folded, K' = k + p formed while staging; 2 (round 6) = folded, `k` already holds K' (the qkv GEMM
+// wrote k + p, GemmArgs::rowadd): no positional rows are loaded, no additions -- the fold without the VALU work that made form 1 lose.
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32>
 __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   static_assert(!FOLD || (HAS_POS && sizeof(T) == 2), "the folded positional term is built for the bf16 encoder form");
   constexpr int QT = 16 * NW;
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       const int key = kt0 + r;
       const bool ok = i < KT * VPR && key < kvlen && c * VE < dk;
       rk[n] = make_uint4(0, 0, 0, 0); rv[n] = make_uint4(0, 0, 0, 0);
-      if constexpr (HAS_POS) rp[n] = make_uint4(0, 0, 0, 0);
+      if constexpr (HAS_POS && FOLD != 2) rp[n] = make_uint4(0, 0, 0, 0);
       if (ok) {
         const size_t krow = kvi ? (size_t)kvi[key] : (size_t)(ks + key);
         rk[n] = *(const uint4*)(K + krow * a.k_stride + head * dk + c * VE);
         rv[n] = *(const uint4*)(V + krow * a.v_stride + head * dk + c * VE);
-        if constexpr (HAS_POS) rp[n] = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
+        if constexpr (HAS_POS && FOLD != 2) rp[n] = *(const uint4*)(P + (size_t)key * a.p_stride + head * dk + c * VE);
       }
     }
   };
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
       const int i = tid + NT * n;
       if (i < KT * VPR) {
         const int r = i / VPR, c = i - r * VPR;
-        if constexpr (FOLD) {
+        if constexpr (FOLD == 1) {
           // K' = k + p: eight bf16 sums in fp32, rounded once
           const bf16_t* kk = (const bf16_t*)&rk[n];
           const bf16_t* pp = (const bf16_t*)&rp[n];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
           *(uint4*)(sK + r * L::ROW_K + c * 16) = o;
         } else {
           *(uint4*)(sK + r * L::ROW_K + c * 16) = rk[n];
-          if constexpr (HAS_POS) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
+          if constexpr (HAS_POS && !FOLD) *(uint4*)(sP + r * L::ROW_K + c * 16) = rp[n];
         }
         if constexpr (BF) {
           *(uint4*)(sV + r * L::ROW_V + c * 16) = rv[n];
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int DKP, bool HAS_POS, int NW, bool FOLD = false, int PADK = 32>
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
   using L = AttnLds<T, DKP, HAS_POS, FOLD, PADK>;
   static bool attr_set = false;
@@ -415,12 +417,13 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   const bool pos = a.p != nullptr;
   const int dk = a.dk;
   if constexpr (sizeof(T) == 2) {      // the folded positional term: bf16, dk <= 64, 128-query workgroups (the encoder's form)
-    if (pos && a.pos_bias != nullptr && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128)) return launch_attn<T, 64, true, 8, true>(s, a);
+    if (pos && a.pos_bias != nullptr && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128))
+      return a.k_prefolded ? launch_attn<T, 64, true, 8, 2>(s, a) : launch_attn<T, 64, true, 8, 1>(s, a);
     // A/B switch for the encoder's form (dk 33..64, 128-query workgroups, positional keys): RVB_ATTN_PADK=16 = the 144-byte row
     // pitch of rounds 1-3 (2-way bank conflicts on every S-phase fragment read: 10.41 vs 9.99 ms per hour, SQ_LDS_BANK_CONFLICT
     // 2.1e8 vs 0 on a quarter hour, profiles/r04_call7_attention_padk_pmc.txt); every other form uses the 32-byte pad
     static const int padk = lab_env("RVB_ATTN_PADK") ? atoi(lab_env("RVB_ATTN_PADK")) : 32;
-    if (pos && padk == 16 && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128)) return launch_attn<T, 64, true, 8, false, 16>(s, a);
+    if (pos && padk == 16 && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128)) return launch_attn<T, 64, true, 8, 0, 16>(s, a);
   }
 #define RVB_ATTN_CASE(D)                                                           \
   if (dk <= D) {                                                                   \
@@ -470,6 +473,10 @@ int attention(hipStream_t s, int dtype, const AttnArgs& a0) {
   const int ve = dtype == DT_BF16 ? 8 : 4;
   if (a.dk % ve || a.q_stride % ve || a.k_stride % ve || a.v_stride % ve || (a.p && a.p_stride % ve)) {
     set_error("attention: dk and row strides must be multiples of the 16-byte vector width");
+    return E_ARG;
+  }
+  if (a.k_prefolded && !(dtype == DT_BF16 && a.p && a.pos_bias && a.dk <= 64 && a.dk > 32 && (a.q_block == 0 || a.q_block == 128))) {
+    set_error("attention: pre-folded keys (k + p) are read by the folded bf16 encoder form only (33 <= dk <= 64, 128-query blocks, pos_bias table)");
     return E_ARG;
   }
   if ((a.bias_u == nullptr) != (a.bias_v == nullptr)) { set_error("attention: bias_u/bias_v must come together"); return E_ARG; }

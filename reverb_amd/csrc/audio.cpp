@@ -11,6 +11,7 @@
 //                                    and arrives as uint8 with the offset added (value + 128)
 //   FLAC <= 16 bits per sample       int16, left-justified      -> value << (16 - bps)
 //   FLAC  > 16 bits per sample       int32, left-justified      -> value << (32 - bps)
+//   MPEG audio Layer III (.mp3)      float32                    -> the decoder's output, full scale = 1.0 (csrc/mp3.cpp; round 6)
 // (the FFmpeg-backed loader of the torchaudio the reference pins: s16 / s32 / u8 / flt / dbl planar or packed
 // sample formats, nothing rescaled).  MP3 / Vorbis are lossy float decoders and are not built: rvb_audio_probe
 // names the container in its error.
@@ -32,6 +33,9 @@
 #include <vector>
 
 #include "../../include/rvb.h"
+
+#include <type_traits>
+#include "mp3.h"
 
 namespace rvb {
 void set_error(const std::string& msg);  // engine.hip: thread-local last error
@@ -787,9 +791,9 @@ int sniff(const uint8_t* d, size_t n) {
   const size_t off = n >= 10 && std::memcmp(d, "ID3", 3) == 0 ? skip_id3(d, n) : 0;
   if (n - off >= 4 && std::memcmp(d + off, "fLaC", 4) == 0) return RVB_AUDIO_FLAC;
   if (n - off >= 4 && std::memcmp(d + off, "OggS", 4) == 0) fail(E_UNSUPPORTED, "Ogg container (Vorbis / Opus): lossy codecs are not decoded here");
-  if (off > 0 || (n >= 2 && d[0] == 0xff && (d[1] & 0xe0) == 0xe0)) fail(E_UNSUPPORTED, "MPEG audio (MP3): lossy codecs are not decoded here");
+  if (off > 0 || (n >= 2 && d[0] == 0xff && (d[1] & 0xe0) == 0xe0)) return RVB_AUDIO_MP3;       // MPEG audio: csrc/mp3.cpp says which layers it takes
   if (n >= 12 && std::memcmp(d, "FORM", 4) == 0) fail(E_UNSUPPORTED, "IFF container other than AIFF / AIFF-C is not decoded here");
-  fail(E_DATA, "unrecognised audio container (RIFF/WAVE, RF64, AIFF and FLAC are decoded)");
+  fail(E_DATA, "unrecognised audio container (RIFF/WAVE, RF64, AIFF, FLAC and MPEG audio Layer III are decoded)");
 }
 
 template <typename Out>
@@ -839,6 +843,36 @@ int64_t decode(const uint8_t* d, size_t n, int channel, Out* out, int64_t capaci
         for (size_t i = 0; i < (size_t)info->frames; ++i) o[i] = (Out)wave_sample(w, wf, i, c);
     }
     return info->frames;
+  }
+  if (kind == RVB_AUDIO_MP3) {
+    // MPEG audio Layer III: float32, as torchaudio's (FFmpeg's float) decoder hands it on; encoder delay / padding of a LAME-style
+    // tag trimmed as FFmpeg trims them (mp3.cpp probe())
+    try {
+      rvb::mp3::Info mi;
+      int64_t frames;
+      if (!want) {
+        mi = rvb::mp3::probe(d, n);
+        frames = mi.samples;
+      } else {
+        if (i16) fail(E_UNSUPPORTED, "rvb_audio_decode_i16: the file's native sample format is not int16");
+        std::vector<float> tmp;
+        float* dst;
+        if (std::is_same<Out, float>::value) dst = (float*)out;
+        else { tmp.resize((size_t)std::max<int64_t>(capacity, 1)); dst = tmp.data(); }
+        frames = rvb::mp3::decode(d, n, channel, dst, capacity, &mi, nullptr, (flags >> 8) & 0xff);
+      }
+      info->container = RVB_AUDIO_MP3;
+      info->channels = mi.channels;
+      info->sample_rate = mi.sample_rate;
+      info->bits_per_sample = 0;                     // a lossy stream declares none
+      info->sample_format = RVB_SAMPLE_F32;
+      info->frames = mi.samples;
+      info->md5_checked = 0;
+      info->decode_threads = mi.decode_threads;
+      return frames;
+    } catch (const rvb::mp3::Error& e) {
+      fail(e.code, e.msg);
+    }
   }
   // FLAC: integer samples left-justified in the 16- or 32-bit word of the native sample format
   const FlacStream fs = flac_open(d, n);

@@ -522,6 +522,14 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   const unsigned grp = f8 ? e->f8_groups[lidx] : 0u;
   const bool f8_ffm = grp & 1u, f8_qkv = grp & 2u, f8_pw1 = grp & 4u, f8_pw2 = grp & 8u, f8_ff = (grp & 16u) && !L.is_lsl;
   const F8Scales sc8 = f8 ? e->f8[lidx] : F8Scales();
+  // Folded rel-pos attention with the fold done by the qkv GEMM (round 6): (q+u).k + (q+v).p = (q+u).(k+p) + (v-u).p; the GEMM's
+  // epilogue writes K' = k + p (positional key of the frame's place in its chunk, GemmArgs::rowadd) and the attention kernel
+  // (attention.hip FOLD 2) multiplies once per key tile and starts from the per-key constants (v-u).p built at load time.
+  // bf16 offline batches only (the streaming form caches k itself, and its positional rows move with the stream offset).
+  const char* prefold_env = lab_env("RVB_ATTN_PREFOLD");       // read per call (not cached): the A/B test flips it inside one process
+  const int prefold_on = prefold_env ? atoi(prefold_env) : 1;
+  const bool prefold = prefold_on && e->dtype == DT_BF16 && li < 0 && !f8_qkv && L.pos_bias.p != nullptr && dk > 32 && dk <= 64 &&
+                       T <= e->pe_rows && (d % 8) == 0;
   auto note = [&](int slot, const void* t, size_t n) -> int {
     return cal ? amax_abs(e->stream, e->dtype, t, n, e->d_amax.as<float>() + (size_t)lidx * 8 + slot) : OK;
   };
@@ -545,7 +553,17 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   } else {
     RVB_TRY(run_norm(e, x, L.n_mha, e->xn.p, false, M, d));
     RVB_TRY(note(2, e->xn.p, (size_t)M * d));
-    RVB_TRY(run_gemm(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, false));
+    if (prefold) {       // the K third of the output is written as K' = k + p (one rounding), see `prefold` above
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = e->xn.p; g.W = L.qkv.w.p; g.bias = L.qkv.b.as<float>(); g.C = e->h.p;
+      g.M = M; g.N = 3 * d; g.K = d; g.lda = d; g.ldw = d; g.ldc = 3 * d; g.alpha = 1.f; g.act = ACT_NONE;
+      g.rowadd = L.pos_keys.p; g.rowadd_rows = T; g.rowadd_ld = d; g.rowadd_col0 = d; g.rowadd_cols = d;
+      Scope sc(e, "gemm", 2.0 * M * (double)g.N * g.K, gemm_alg_bytes(e, g));
+      RVB_TRY(gemm(e->stream, e->dtype, g));
+    } else {
+      RVB_TRY(run_gemm(e, e->xn.p, d, L.qkv, e->h.p, 3 * d, M, false));
+    }
   }
   {
     AttnArgs a;
@@ -556,6 +574,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     {   // bf16: positional term folded into per-key constants (RVB_ATTN_FOLD=1; default: the two-product form)
       static const int fold = lab_env("RVB_ATTN_FOLD") ? atoi(lab_env("RVB_ATTN_FOLD")) : 0;     // measured slower (10.3 -> 10.8 ms per hour): opt-in
       if (fold && L.pos_bias.p) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; }
+      if (prefold) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; a.k_prefolded = 1; }
     }
     a.q_stride = a.k_stride = a.v_stride = 3 * d; a.p_stride = d; a.o_stride = d;
     a.bias_u = L.bias_u.as<float>(); a.bias_v = L.bias_v.as<float>();

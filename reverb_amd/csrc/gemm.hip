@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         float v = acc[i][j][r] + bv;
         v = act_apply(v, p.act) * p.alpha;
         if (p.res) v += p.res[(size_t)row * p.ldres + col];
+        if (p.rowadd && col >= p.rowadd_col0 && col < p.rowadd_col0 + p.rowadd_cols)      // row-periodic bf16 addend (kernels.h)
+          v += bf16_to_f32(((const bf16_t*)p.rowadd)[(size_t)(row % p.rowadd_rows) * p.rowadd_ld + (col - p.rowadd_col0)]);
         C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
       }
     }
@@ -193,6 +195,10 @@ int gemm(hipStream_t s, int dtype, const GemmArgs& p) {
     return E_ARG;
   }
   if (p.M == 0) return OK;
+  if (p.rowadd && (dtype != DT_BF16 || p.out_f32 || p.in_fp8 || p.out_fp8 || p.rowadd_rows <= 0)) {
+    set_error("gemm: the row-periodic addend exists for bf16 operands and bf16 output only");
+    return E_UNSUPPORTED;
+  }
   if (p.in_fp8) {       // fp8 operands exist only on the LDS-DMA kernel
     if (!gemm2_applicable(dtype, p)) { set_error("gemm: fp8 operands need the bf16 engine, K % 128 == 0 and per-channel weight scales"); return E_ARG; }
     return gemm2(s, dtype, p);

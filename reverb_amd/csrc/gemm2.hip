@@ -813,13 +813,19 @@ __device__ inline const char* uniform_ptr(const char* q) {
 // (scripts/gemm_timeline.py) are gone.  The epilogue's slabs have their own LDS, so nothing waits for anything else.
 // PMODE 2 (round 4): the persistent LOOP without the cross-tile prefetch -- a workgroup per CU walks its tiles, every tile with
 // its own first-stage requests and waits; only the dispatch gap between two workgroups of a CU is gone.
-template <typename T, typename OutT, bool CONV, int PMODE = 0>
+template <typename T, typename OutT, bool CONV, int PMODE = 0, bool M32 = false>
 __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
+  // M32 (bf16, round 6): v_mfma_f32_32x32x16_bf16 on 32x32 accumulator blocks instead of v_mfma_f32_16x16x32_bf16 on 16x16
+  // fragments -- the same ring, phases, fragment bytes and read counts (a lane's 16-byte vector is 8 k-values of one of 32
+  // rows); a phase is 8 MFMAs of 32 cycles instead of 16 of ~17 (MI355X_MICROARCH.md: the 32x32x16 form is the one that
+  // reaches the matrix pipe's peak), i.e. half the issue slots next to the SIMD's other wave.
+  static_assert(!M32 || sizeof(T) == 2, "M32 is the bf16 form");
   constexpr bool PERSIST = PMODE != 0;        // one workgroup per CU walks tiles
   constexpr bool XPF = PMODE == 1;            // ... and the operand stream runs across tile edges
   static_assert(!(PERSIST && CONV), "the persistent form reuses the per-lane DMA offsets from tile to tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool F8 = std::is_same<T, fp8_t>::value;
+  constexpr bool B32 = F8 || M32;             // 32x32 accumulator blocks
   constexpr int BKE = ROW2 / (int)sizeof(T);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -976,8 +982,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 
   // 16x16 fragments: acc[i][j] = rows 16i.., cols 16j.. of the wave's 128x64 tile (C/D: col = lane&15, row = 4*(lane>>4)+r).
   // 32x32 blocks (fp8): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-  f32x4_t acc[F8 ? 1 : 8][F8 ? 1 : 4];
-  f32x16_t acc32[F8 ? 4 : 1][F8 ? 2 : 1];
+  f32x4_t acc[B32 ? 1 : 8][B32 ? 1 : 4];
+  f32x16_t acc32[B32 ? 4 : 1][B32 ? 2 : 1];
   const bool res_acc = !p.res_epilogue && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
                        ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
   // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
@@ -1003,7 +1009,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     // the wave's 128 x 64 residual sub-tile, 4 rows x 256 B per instruction; bf16: all 32 vectors in flight together (they
     // land in the accumulator registers themselves); fp8: two halves of 16 (the 16-register accumulator blocks cannot
     // alias the staging vectors, and 128 + 128 registers do not exist)
-    constexpr int NPART = F8 ? 2 : 1, QP = 32 / NPART;
+    constexpr int NPART = B32 ? 2 : 1, QP = 32 / NPART;
 #pragma unroll
     for (int part = 0; part < NPART; ++part) {
       f32x4_t rv[QP];
@@ -1019,7 +1025,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4_t*)(tb + (q * 4 + lr4) * P_SROW + lc4 * 4) = rv[ii * 4 + q];
         __builtin_amdgcn_wave_barrier();
-        if constexpr (F8) {
+        if constexpr (B32) {
           const int bi = i >> 1, hh = i & 1;
           const int r32 = 4 * (lane >> 5), c32 = lane & 31;
 #pragma unroll
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
       }
     }
   } else {
-    if constexpr (F8) {
+    if constexpr (B32) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1063,11 +1069,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // fragment addressing (as gemm2_kernel).  bf16: lane = (row 0..15, 16-byte column group 0..3 of the 64-byte k32 slice), a
   // fragment set is [16-row fragment][k32 slice].  fp8: lane = (row 0..31, half g); the lane's 32 bytes of a k64 slice are
   // the 16-byte columns 2g, 2g+1; a set is [32-row block x k64 slice][column].
-  const int frow = F8 ? (lane & 31) : (lane & 15), lgrp = F8 ? (lane >> 5) : (lane >> 4);
+  // bf16 M32: lane = (row 0..31, half g); MFMA u = 0..3 of the K step takes the 16-byte column 2u + g of the 128-byte row;
+  // a set is [32-row block x k-half][MFMA of the half] with the same four offsets (ro0, rh0 | ro1, rh1) as fp8's.
+  const int frow = B32 ? (lane & 31) : (lane & 15), lgrp = B32 ? (lane >> 5) : (lane >> 4);
   const int swz = (frow >> 1) & 7;
   const int ro0 = F8 ? ((0 * 4 + 2 * lgrp) ^ swz) << 4 : ((0 * 4 + lgrp) ^ swz) << 4;
   const int ro1 = F8 ? ((1 * 4 + 2 * lgrp) ^ swz) << 4 : ((1 * 4 + lgrp) ^ swz) << 4;
-  const int rh0 = ((0 * 4 + 2 * lgrp + 1) ^ swz) << 4, rh1 = ((1 * 4 + 2 * lgrp + 1) ^ swz) << 4;     // fp8: second column
+  const int rh0 = F8 ? ((0 * 4 + 2 * lgrp + 1) ^ swz) << 4 : ((0 * 4 + 2 + lgrp) ^ swz) << 4;      // fp8: second column; M32: second MFMA
+  const int rh1 = F8 ? ((1 * 4 + 2 * lgrp + 1) ^ swz) << 4 : ((1 * 4 + 2 + lgrp) ^ swz) << 4;
   const int a_off = (wr * 64 + frow) * ROW2;       // in an A half-tile: rows wr*64 + 16 i (32 bi) + frow
   const int b_off = (wc * 32 + frow) * ROW2;       // in a B half-tile: rows wc*32 + 16 j + frow
   // A set: k-half 0 / 1 = the first / second 64 bytes of the 128-byte row.  bf16: [16-row fragment i]; fp8: [32-row block
@@ -1076,7 +1085,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   auto read_a_half = [&](auto halfc, uint4 (&f)[4], int slot) __attribute__((always_inline)) {
     constexpr int hf = decltype(halfc)::value;
     const char* sp = smem + slot * P_HT + a_off;
-    if constexpr (F8) {
+    if constexpr (B32) {
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi) {
         f[bi * 2 + 0] = *(const uint4*)(sp + bi * 4096 + (hf ? ro1 : ro0));
@@ -1092,8 +1101,12 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   auto read_b_khalf = [&](auto sc, uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
     constexpr int sk = decltype(sc)::value;
     const char* sp = smem + slot * P_HT + b_off;
+    if constexpr (B32) {      // [k-half][MFMA of the half]
+      f[sk][0] = *(const uint4*)(sp + (sk ? ro1 : ro0)); f[sk][1] = *(const uint4*)(sp + (sk ? rh1 : rh0));
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) f[j][sk] = *(const uint4*)(sp + j * 2048 + (sk ? ro1 : ro0));
+      for (int j = 0; j < 2; ++j) f[j][sk] = *(const uint4*)(sp + j * 2048 + (sk ? ro1 : ro0));
+    }
   };
   auto read_b = [&](uint4 (&f)[2][2], int slot) __attribute__((always_inline)) {
     const char* sp = smem + slot * P_HT + b_off;
@@ -1118,6 +1131,18 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
           const i32x8_t b8 = __builtin_bit_cast(i32x8_t, (Pair{fb[sl][0], fb[sl][1]}));
           acc32[ai * 2 + bi][bj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc32[ai * 2 + bi][bj], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
+    } else if constexpr (M32) {
+      // 8 MFMAs: k-half sl, MFMA uu of the half, the two 32-row blocks alternating (an accumulator is touched every second MFMA)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi) {
+            const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, sl ? ahi[bi * 2 + uu] : alo[bi * 2 + uu]);
+            const bf16x8_t b8 = __builtin_bit_cast(bf16x8_t, fb[sl][uu]);
+            acc32[ai * 2 + bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc32[ai * 2 + bi][bj], 0, 0, 0);
+          }
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -1256,6 +1281,19 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
       for (int e = 0; e < CPL; ++e) scv[e] = col0 + e < p.N ? p.a_scale * p.w_scale[col0 + e] : 0.0f;
     }
     const bool seg_full = col0 + CPL <= p.N;
+    // Row-periodic bf16 addend (GemmArgs::rowadd; bf16 output only): `ra_any` = this tile touches its column range, `ra_vec` =
+    // this lane's whole 8-column segment lies inside it and is one aligned 16-byte vector of the addend's row
+    constexpr bool RA_OK = sizeof(OutT) == 2 && !F8;
+    const bool ra_any = RA_OK && p.rowadd != nullptr && n0 < p.rowadd_col0 + p.rowadd_cols && n0 + B2N > p.rowadd_col0;
+    const bool ra_tile = ra_any && n0 >= p.rowadd_col0 && n0 + B2N <= p.rowadd_col0 + p.rowadd_cols && (p.rowadd_ld & 7) == 0 &&
+                         ((p.rowadd_col0 - n0) & 7) == 0 && ((size_t)p.rowadd & 15) == 0;      // every lane's segment is such a vector
+    const int ra_t0 = ra_any ? (m0 + wr * 128) % p.rowadd_rows : 0;       // addend row of the wave's first output row
+    auto ra_row = [&](int local) __attribute__((always_inline)) -> int {      // addend row of output row m0 + wr*128 + local
+      int t = ra_t0 + local;
+      if (t >= p.rowadd_rows) { t -= p.rowadd_rows; if (t >= p.rowadd_rows) t %= p.rowadd_rows; }
+      return t;
+    };
+    const bf16_t* ra_base = (const bf16_t*)p.rowadd + (col0 - p.rowadd_col0);
     // The residual of a tile whose residual is added HERE (p.res_epilogue, or whenever it cannot start out in the
     // accumulators): a ring of RING slabs' worth of 16-byte vectors per lane, requested that far ahead of the slab that
     // consumes them -- the K loop's fragment registers are dead by now, so 16 vectors (64 registers) fit next to the
@@ -1281,7 +1319,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_wave_barrier();
-        if constexpr (F8) {
+        if constexpr (B32) {
           // rows [16i, 16i+16) of the wave tile = half hh = i&1 of block row bi = i>>1: registers 8hh .. 8hh+7
           const int bi = i >> 1, hh = i & 1;
           const int r32 = 4 * (lane >> 5), c32 = lane & 31;
@@ -1326,6 +1364,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
                 v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
               }
             }
+            if constexpr (RA_OK) {
+              if (ra_any) {
+                const bf16_t* ar = ra_base + (size_t)ra_row(i * 16 + srow) * p.rowadd_ld;
+#pragma unroll
+                for (int e = 0; e < CPL; ++e)
+                  if (col0 + e >= p.rowadd_col0 && col0 + e < p.rowadd_col0 + p.rowadd_cols) v[e] += bf16_to_f32(ar[e]);
+              }
+            }
             if constexpr (sizeof(OutT) == 1) {
               const float qs = p.out_inv_scale;
               if (p.sat) {      // saturation counter of this fp8 tensor (rvb_get_fp8_saturation)
@@ -1356,6 +1402,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
             for (int e = 0; e < CPL && col0 + e < p.N; ++e) {
               float o = v[e];
               if (p.res && !res_acc) o += p.res[(size_t)row * p.ldres + col0 + e];
+              if constexpr (RA_OK) {
+                if (ra_any && col0 + e >= p.rowadd_col0 && col0 + e < p.rowadd_col0 + p.rowadd_cols)
+                  o += bf16_to_f32(ra_base[(size_t)ra_row(i * 16 + srow) * p.rowadd_ld + e]);
+              }
               if constexpr (sizeof(OutT) == 1) cp[e] = (OutT)(pack4_fp8(o * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
               else cp[e] = Cvt<OutT>::from_f32(o);
             }
@@ -1374,8 +1424,21 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     // invisible to the waitcnt pass: without a residual the loop contains no vector-memory wait at all; with one the
     // compiler sees loads only and counts them in order (two slabs' worth stay in flight), which is conservative by
     // exactly the interleaved stores -- a slab's worth of stores drains underneath the next slab instead of in front of it.
-    auto finish_fast = [&](auto actf, auto resc) {
+    auto finish_fast = [&](auto actf, auto resc, auto addc) {
       constexpr bool HR = decltype(resc)::value;
+      constexpr bool RA = decltype(addc)::value && RA_OK;       // the row-periodic addend, one 16-byte vector per lane and pass
+      // requested RING slabs ahead like the residual: a load waited for right where it is issued would also wait for every store
+      // issued before it (one in-order queue)
+      uint4 aring[RA ? RING : 1][RA ? NQ : 1];
+      auto add_issue = [&](int i, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          aring[RA ? slot : 0][RA ? q : 0] = *(const uint4*)(ra_base + (size_t)ra_row(i * 16 + q * RPP + orow) * p.rowadd_ld);
+      };
+      if constexpr (RA) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) add_issue(i, i);
+      }
       auto res_issue_f = [&](int i, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -1391,7 +1454,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_wave_barrier();
-        if constexpr (F8) {
+        if constexpr (B32) {
           const int bi = i >> 1, hh = i & 1;
           const int r32 = 4 * (lane >> 5), c32 = lane & 31;
 #pragma unroll
@@ -1431,6 +1494,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
               v[c4 * 4 + 0] += tt.x; v[c4 * 4 + 1] += tt.y; v[c4 * 4 + 2] += tt.z; v[c4 * 4 + 3] += tt.w;
             }
           }
+          if constexpr (RA) {
+            const uint4 av = aring[i % RING][q];
+            v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xffff0000u);
+            v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xffff0000u);
+            v[4] += __uint_as_float(av.z << 16); v[5] += __uint_as_float(av.z & 0xffff0000u);
+            v[6] += __uint_as_float(av.w << 16); v[7] += __uint_as_float(av.w & 0xffff0000u);
+          }
           OutT* cp = C + (size_t)(m0 + wr * 128 + i * 16 + srow) * p.ldc + col0;
           if constexpr (sizeof(OutT) == 1) {
             const float qs = p.out_inv_scale;
@@ -1455,13 +1525,19 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         if constexpr (HR) {
           if (i + RING < 8) res_issue_f(i + RING, i % RING);
         }
+        if constexpr (RA) {
+          if (i + RING < 8) add_issue(i + RING, i % RING);
+        }
       }
     };
     const bool hr = p.res != nullptr && !res_acc;
-    const bool fast = full && (p.fast_epilogue & (hr ? 2 : 1));
+    // a tile that the addend's column range cuts through takes the generic loop (per-element range checks)
+    const bool fast = full && (p.fast_epilogue & (hr ? 2 : 1)) && (!ra_any || (ra_tile && !hr));
     auto run = [&](auto actf) __attribute__((always_inline)) {
       if (fast) {
-        if (hr) finish_fast(actf, std::true_type()); else finish_fast(actf, std::false_type());
+        if (hr) finish_fast(actf, std::true_type(), std::false_type());
+        else if (ra_any) finish_fast(actf, std::false_type(), std::true_type());
+        else finish_fast(actf, std::false_type(), std::false_type());
       } else {
         finish_v(actf);
       }
@@ -1473,7 +1549,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     return;
   }
   // unaligned output / residual rows: element-wise stores
-  if constexpr (F8) {
+  if constexpr (B32) {
     auto finish32 = [&](auto actf) {
 #pragma unroll
       for (int bi = 0; bi < 4; ++bi)
@@ -1481,13 +1557,18 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         for (int bj = 0; bj < 2; ++bj) {
           const int col = n0 + wc * 64 + bj * 32 + (lane & 31);
           const float bvv = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
-          const float sc = col < p.N ? p.a_scale * p.w_scale[col] : 0.f;
+          float sc = 1.f;
+          if constexpr (F8) sc = col < p.N ? p.a_scale * p.w_scale[col] : 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row >= p.M || col >= p.N) continue;
             float v = actf(acc32[bi][bj][r] * sc + bvv) * p.alpha;
             if (p.res && !res_acc) v += p.res[(size_t)row * p.ldres + col];
+            if constexpr (sizeof(OutT) == 2 && !F8) {
+              if (p.rowadd && col >= p.rowadd_col0 && col < p.rowadd_col0 + p.rowadd_cols)
+                v += bf16_to_f32(((const bf16_t*)p.rowadd)[(size_t)(row % p.rowadd_rows) * p.rowadd_ld + (col - p.rowadd_col0)]);
+            }
             if constexpr (sizeof(OutT) == 1) C[(size_t)row * p.ldc + col] = (OutT)(pack4_fp8(v * p.out_inv_scale, 0.f, 0.f, 0.f) & 0xffu);
             else C[(size_t)row * p.ldc + col] = Cvt<OutT>::from_f32(v);
           }
@@ -1519,6 +1600,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
           if (!full && col >= p.N) continue;
           float v = actf(acc[i][j][r] + bv[j]) * p.alpha;
           if (rrow) v += rrow[col];
+          if constexpr (sizeof(OutT) == 2) {
+            if (p.rowadd && col >= p.rowadd_col0 && col < p.rowadd_col0 + p.rowadd_cols)
+              v += bf16_to_f32(((const bf16_t*)p.rowadd)[(size_t)(row % p.rowadd_rows) * p.rowadd_ld + (col - p.rowadd_col0)]);
+          }
           crow_p[col] = Cvt<OutT>::from_f32(v);
         }
       }
@@ -1539,14 +1624,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   }      // tiles of this workgroup
 }
 
-template <typename T, typename OutT, bool CONV>
+template <typename T, typename OutT, bool CONV, bool M32 = false>
 static int launch2p(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
   static int ncu = 0;
-  auto kern = gemm2p_kernel<T, OutT, CONV, 0>;
+  auto kern = gemm2p_kernel<T, OutT, CONV, 0, M32>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
-    if constexpr (!CONV && std::is_same<T, bf16_t>::value) {
+    if constexpr (!CONV && !M32 && std::is_same<T, bf16_t>::value) {
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
     }
@@ -1558,7 +1643,7 @@ static int launch2p(hipStream_t s, const GemmArgs& p) {
     attr_set = true;
   }
   const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
-  if constexpr (!CONV && std::is_same<T, bf16_t>::value) {
+  if constexpr (!CONV && !M32 && std::is_same<T, bf16_t>::value) {
     // persistent forms: full tiles only, and at least two tiles per CU; bit 4 = with the cross-tile prefetch, bit 12 = loop only
     if ((g_gemm2_flags & (16 | 4096)) && ncu >= 8 && p.M % B2M == 0 && p.N % B2N == 0 && tiles >= 2 * ncu && p.K >= 4 * (ROW2 / 2)) {
       if (g_gemm2_flags & 16) hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, 1>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
@@ -1629,6 +1714,7 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //          gemm2p_kernel): with the bit set every tile runs the generic epilogue, as until round 4
 //   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
 //   bit 12 the persistent LOOP without cross-tile prefetch (gemm2p_kernel PMODE 2): removes the dispatch gap only
+//   bit 13 (round 6) the phase-interleaved loop on v_mfma_f32_32x32x16_bf16 (gemm2p_kernel M32): 8 MFMAs of 32 cycles per phase
 #ifndef GEMM2_STAGGER_DEFAULT
 #define GEMM2_STAGGER_DEFAULT 1
 #endif
@@ -1641,6 +1727,10 @@ static void gemm2_opts_from_env() {
 int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   gemm2_opts_from_env();
   GemmArgs p = p0;
+  if (p.rowadd && (dtype != DT_BF16 || p.in_fp8 || p.out_f32 || p.out_fp8 || (g_gemm2_flags & (1 | 4)))) {
+    set_error("gemm2: the row-periodic addend exists on the phase-interleaved bf16 kernel with bf16 output only");
+    return E_UNSUPPORTED;
+  }
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;
   p.prio = (g_gemm2_flags >> 1) & 1;
   p.res_epilogue = ((g_gemm2_flags >> 5) & 1) ^ 1;
@@ -1692,6 +1782,10 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
     if (g_gemm2_flags & 1) {
       if (p.out_f32) return p.conv ? launch2<bf16_t, float, true, true>(s, p) : launch2<bf16_t, float, false, true>(s, p);
       return p.conv ? launch2<bf16_t, bf16_t, true, true>(s, p) : launch2<bf16_t, bf16_t, false, true>(s, p);
+    }
+    if (!(g_gemm2_flags & 4) && (g_gemm2_flags & 8192)) {     // the phase-interleaved loop on 32x32x16 MFMAs (round 6)
+      if (p.out_f32) return p.conv ? launch2p<bf16_t, float, true, true>(s, p) : launch2p<bf16_t, float, false, true>(s, p);
+      return p.conv ? launch2p<bf16_t, bf16_t, true, true>(s, p) : launch2p<bf16_t, bf16_t, false, true>(s, p);
     }
     if (!(g_gemm2_flags & 4)) {     // the phase-interleaved loop (default)
       if (p.out_f32) return p.conv ? launch2p<bf16_t, float, true>(s, p) : launch2p<bf16_t, float, false>(s, p);

@@ -37,6 +37,12 @@ struct GemmArgs {
   const float* w_scale;   // [N]
   unsigned* sat;          // out_fp8: += the values clipped at +-448 (device counter, nullable)
   long long* dbg;         // test hook (rvb_test_gemm_timeline): per workgroup {start, stage 0 landed, main loop done, end} in 10 ns ticks + HW ids
+  // Row-periodic addend (bf16 engine, bf16 output; round 6): C[m][n] += rowadd[m % rowadd_rows][n - rowadd_col0] for the columns
+  // rowadd_col0 <= n < rowadd_col0 + rowadd_cols, added in fp32 after bias / activation / alpha, before the one rounding to bf16.
+  // The qkv GEMM of an encoder block uses it to write K' = k + p (p = the layer's positional keys, one row per frame of a chunk),
+  // which is what the folded form of the rel-pos attention reads (attention.hip FOLD 2).  null = none.
+  const void* rowadd;     // bf16 [rowadd_rows][rowadd_ld]
+  int rowadd_rows, rowadd_ld, rowadd_col0, rowadd_cols;
 };
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
 // gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)
@@ -174,6 +180,7 @@ struct AttnArgs {
   // (pos_bias_v - pos_bias_u)[head] . p[j][head] * log2(e) / sqrt(dk) for positional row j of `p` (same row offset as `p`); null = two products
   const float* pos_bias;
   int pos_bias_stride;
+  int k_prefolded;       // with pos_bias: `k` already holds K' = k + p (written by the qkv GEMM, GemmArgs::rowadd): nothing to add while staging
 };
 // builds that table for positional keys P [rows, p_stride] (bf16): out fp32 [heads][rows]
 int attention_pos_bias(hipStream_t s, const void* P, int rows, int p_stride, const float* bias_u, const float* bias_v, int heads, int dk,

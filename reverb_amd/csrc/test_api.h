@@ -51,6 +51,20 @@ int rvb_test_logsoftmax_topk(const float* logits, int M, int V, int k, float bla
                              float* topk_val, int32_t* topk_idx, float* logp);
 int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target, float* out);
 /* fp8 (e4m3) GEMM / LayerNorm-to-fp8 of the RVB_FP8 mode on host floats (operands quantised as the engine does) */
+/* bf16 GEMM with bf16 output and the row-periodic addend of GemmArgs::rowadd (round 6): C[m][n] = A.W^T + bias (+ add[m % add_rows][n - add_col0]
+ * for add_col0 <= n < add_col0 + add_cols); add is fp32 on the host, rounded to bf16 on the way up (what the engine's positional keys are) */
+int rvb_test_gemm_rowadd(const float* A, const float* W, const float* bias, const float* add, float* C, int M, int N, int K,
+                         int add_rows, int add_col0, int add_cols);
+/* csrc/mp3.cpp (round 6).  decode: as rvb_audio_decode_f32 + the stream facts (info9: version, channels, rate, audio frames, samples per
+ * frame, info frame, start skip, samples, kbit/s) and what the pass saw (stats12: granule-channels, Huffman data ending exactly on /
+ * before / past part2_3_length, CRCs checked / failed, frames without their reservoir bytes, short / mixed / M-S / intensity granules,
+ * largest main_data_begin).  hybrid / polyphase: one granule of the two synthesis stages on caller state.  window: D[512].
+ * huffman: table t of the standard (32 / 33 = count1 A / B) -> number of entries, (code, length) per symbol, linbits per table_select. */
+int64_t rvb_test_mp3_decode(const void* data, int64_t nbytes, int channel, float* out, int64_t capacity, int64_t* info9, int64_t* stats12, int threads);
+int rvb_test_mp3_hybrid(float* xr576, float* overlap576, int block_type, int mixed, float* out576);
+int rvb_test_mp3_polyphase(const float* sb576, float* vbuf1024, int* voff, float* pcm576);
+int rvb_test_mp3_window(float* out512);
+int rvb_test_mp3_huffman(int t, uint16_t* codes, uint8_t* lens, int32_t* linbits32);
 int rvb_test_gemm_fp8(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K,
                       float a_scale, float alpha, int act, int out_kind, float out_scale, float* a_deq, float* w_deq);
 int rvb_test_rownorm_fp8(const float* x, const float* gamma, const float* beta, float eps, int silu, int M, int d, float scale,

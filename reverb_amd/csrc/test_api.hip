@@ -1,6 +1,7 @@
 // rvb_test_*: raw kernel entry points used by tests/ (host buffers in, host buffers out).  Each one
 // uploads fp32 host data (rounded to the compute dtype with the same RNE conversion the engine
 // uses), launches exactly the kernel the engine launches, and downloads the result as fp32.
+#include "mp3.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -76,6 +77,53 @@ int rvb_test_gemm(int dtype, const float* A, const float* W, const float* bias, 
   T_TRY(gemm(nullptr, dtype, g));
   RVB_HIP_CHECK(hipDeviceSynchronize());
   return down_T(dC, dtype, f32out, C, (size_t)M * N);
+}
+
+int rvb_test_gemm_rowadd(const float* A, const float* W, const float* bias, const float* add, float* C, int M, int N, int K,
+                         int add_rows, int add_col0, int add_cols) {
+  T_TRY(need_gpu());
+  Dev dA, dW, dB, dP, dC;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  T_TRY(up_T(dA, DT_BF16, A, (size_t)M * K));
+  T_TRY(up_T(dW, DT_BF16, W, (size_t)N * K));
+  T_TRY(up_raw(dB, bias, (size_t)N * 4));
+  T_TRY(up_T(dP, DT_BF16, add, (size_t)add_rows * add_cols));
+  T_TRY(dC.alloc((size_t)M * N * 2));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.alpha = 1.f; g.act = ACT_NONE;
+  g.rowadd = dP.p; g.rowadd_rows = add_rows; g.rowadd_ld = add_cols; g.rowadd_col0 = add_col0; g.rowadd_cols = add_cols;
+  T_TRY(gemm(nullptr, DT_BF16, g));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dC, DT_BF16, false, C, (size_t)M * N);
+}
+
+int64_t rvb_test_mp3_decode(const void* data, int64_t nbytes, int channel, float* out, int64_t capacity, int64_t* info9, int64_t* stats12, int threads) {
+  try {
+    rvb::mp3::Info i;
+    rvb::mp3::Stats st;
+    const int64_t r = rvb::mp3::decode((const uint8_t*)data, (size_t)nbytes, channel, out, capacity, &i, &st, threads);
+    if (info9) { info9[0] = i.version; info9[1] = i.channels; info9[2] = i.sample_rate; info9[3] = i.audio_frames; info9[4] = i.samples_per_frame;
+                 info9[5] = i.has_info_frame; info9[6] = i.start_skip; info9[7] = i.samples; info9[8] = i.bitrate_kbps; }
+    if (stats12) { stats12[0] = st.granules; stats12[1] = st.huff_exact; stats12[2] = st.huff_short; stats12[3] = st.huff_overrun; stats12[4] = st.crc_checked;
+                   stats12[5] = st.crc_failed; stats12[6] = st.reservoir_missing; stats12[7] = st.short_granules; stats12[8] = st.mixed_granules;
+                   stats12[9] = st.ms_granules; stats12[10] = st.intensity_granules; stats12[11] = st.max_main_data_begin; }
+    return r;
+  } catch (const rvb::mp3::Error& e) {
+    set_error(e.msg);
+    return e.code;
+  }
+}
+int rvb_test_mp3_hybrid(float* xr, float* overlap, int block_type, int mixed, float* out) { rvb::mp3::hybrid_granule(xr, overlap, block_type, mixed, 2, out); return OK; }
+int rvb_test_mp3_polyphase(const float* sb, float* vbuf, int* voff, float* pcm) { rvb::mp3::polyphase_granule(sb, vbuf, voff, pcm); return OK; }
+int rvb_test_mp3_window(float* out512) { memcpy(out512, rvb::mp3::synthesis_window(), 512 * sizeof(float)); return OK; }
+int rvb_test_mp3_huffman(int t, uint16_t* codes, uint8_t* lens, int32_t* linbits32) {
+  const uint16_t* c = nullptr; const uint8_t* l = nullptr;
+  int lb[32];
+  const int n = rvb::mp3::huffman_table(t, &c, &l, lb);
+  if (linbits32) for (int i = 0; i < 32; ++i) linbits32[i] = lb[i];
+  if (n > 0) { memcpy(codes, c, 2 * (size_t)n); memcpy(lens, l, (size_t)n); }
+  return n;
 }
 
 int rvb_test_rownorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, int mode, int silu,

@@ -59,7 +59,7 @@ def test_gemm_epilogue(lib, dtype, act, alpha, use_res, out_f32):
         np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("flags,group_m", [(0, 0), (1, 0), (1, 8), (3, 4), (0, 8), (1, 3), (4, 8), (4, 0), (0, -2), (32, -2), (32, 0), (1024, -2), (2048, 0), (1025, 0)])
+@pytest.mark.parametrize("flags,group_m", [(0, 0), (1, 0), (1, 8), (3, 4), (0, 8), (1, 3), (4, 8), (4, 0), (0, -2), (32, -2), (32, 0), (1024, -2), (2048, 0), (1025, 0), (8192, -2), (8192, 0)])
 @pytest.mark.parametrize("M,N,K,act,alpha,use_res,out_f32", [
     (300, 200, 128, 0, 1.0, False, 1),        # one partial tile, aligned rows: LDS-transposed vector epilogue
     (513, 330, 192, 1, 1.0, False, 0),        # unaligned bf16 rows: element-wise epilogue, SiLU
@@ -101,6 +101,40 @@ def test_gemm2_tuning_switches_keep_results(lib, flags, group_m, M, N, K, act, a
         np.testing.assert_allclose(C, v, rtol=5e-5, atol=2e-4)
     else:
         np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)      # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("flags", [0, 8192, 1024])
+@pytest.mark.parametrize("M,N,K,rows,col0,cols", [
+    (1024, 768, 128, 512, 256, 256),      # the engine's form in small: q | k | v thirds, whole tiles inside the k third, rows = frames per chunk
+    (1536, 3072, 1024, 512, 1024, 1024),  # the r640 qkv GEMM (three chunks): twelve column tiles, four of them with the addend
+    (700, 520, 64, 300, 128, 200),        # ragged tiles, a column range that cuts through tiles, rows that wrap inside a tile
+    (130, 72, 64, 50, 8, 40),             # small: the 128x128 kernel
+    (1024, 512, 128, 97, 256, 256),       # a row period that is no multiple of anything
+])
+def test_gemm_row_periodic_addend(lib, flags, M, N, K, rows, col0, cols):
+    """GemmArgs::rowadd (round 6): the qkv GEMM of an encoder block writes K' = k + p -- p = the layer's positional keys, one bf16
+    row per frame of a chunk -- in its epilogue, in fp32 before the one rounding to bf16.  Against fp64 on every path: full tiles
+    (the epilogue with inline-asm stores and the prefetched addend ring), ragged tiles / a range cutting through a tile (the
+    generic loop), the small-shape kernel; on the 16x16x32 and the 32x32x16 form of the loop and with the fast epilogue off."""
+    rng = np.random.default_rng(M + N + rows)
+    A = rnd(BF16, rng.standard_normal((M, K)))
+    W = rnd(BF16, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    add = rnd(BF16, 3.0 * rng.standard_normal((rows, cols)))
+    C = np.full((M, N), np.nan, np.float32)
+    lib.rvb_test_set_gemm2_opts(flags, -2)
+    try:
+        _lib.check(lib.rvb_test_gemm_rowadd(fptr(A), fptr(W), fptr(bias), fptr(add), fptr(C), M, N, K, rows, col0, cols))
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+    v = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    v[:, col0:col0 + cols] += add[np.arange(M) % rows]
+    np.testing.assert_allclose(C, v, rtol=1e-2, atol=1e-2)            # one bf16 rounding of the output
+    # ... and nothing leaked outside the column range: there the result equals the plain GEMM's exactly
+    P = np.empty((M, N), np.float32)
+    _lib.check(lib.rvb_test_gemm(BF16, fptr(A), fptr(W), fptr(bias), None, fptr(P), M, N, K, 1.0, 0, 0, 0, 0, 0, 0, 0))
+    outside = np.ones(N, bool); outside[col0:col0 + cols] = False
+    assert np.array_equal(C[:, outside], P[:, outside])
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

@@ -179,6 +179,33 @@ def test_r640_chunk_against_reference(dtype):
     eng.close()
 
 
+def test_r640_attention_with_keys_prefolded_by_the_qkv_gemm_equals_the_two_product_form(monkeypatch, lab):
+    """Round 6: the bf16 encoder runs the rel-pos attention in its folded form, (q+u).(k+p) + (v-u).p, with K' = k + p written by
+    the qkv GEMM's epilogue (GemmArgs::rowadd) and the second product a per-key table.  Against the two-product form of rounds
+    1-5 (lab switch RVB_ATTN_PREFOLD=0) on the r640 chunk pair: the same mathematics with one rounding of k fewer and one
+    accumulation chain instead of two -- encoder outputs agree far tighter than either agrees with the fp32 reference, the top-1
+    CTC ids agree on all but a handful of near-tied frames, and the GEMM really wrote k + p (the K third of the qkv buffer differs
+    between the two runs by exactly the positional rows)."""
+    case = LongCase("r640_chunk")
+    x = np.concatenate([case.chunk_feats(c)[0] for c in range(2)])
+    lens = np.array(case.js["lens"], np.int32)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVB_ATTN_PREFOLD", flag)
+        eng = Engine(case.cfg, case.sd, dtype="bf16", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
+        eng.encode(x, lens, case.beam)
+        _, ti = eng.ctc_topk()
+        out[flag] = (eng.encoder_out().astype(np.float64), ti[:, :, 0].copy(), _tap_metrics(eng, case, 0, 0))
+        eng.close()
+    (e0, i0, m0), (e1, i1, m1) = out["0"], out["1"]
+    n = case.js["encoder_lens"]
+    cos = min(float((e0[b, :n[b]] * e1[b, :n[b]]).sum() / (np.linalg.norm(e0[b, :n[b]]) * np.linalg.norm(e1[b, :n[b]]))) for b in range(2))
+    agree = float(np.mean([np.mean(i0[b, :n[b]] == i1[b, :n[b]]) for b in range(2)]))
+    _record(case="r640_chunk", test="attention_prefold_vs_two_products", cos=cos, top1_agree=agree, two_products=m0, prefolded=m1)
+    assert cos > 0.99995 and agree > 0.98, (cos, agree)
+    assert m1["cos"] > BF16_COS and m1["logp_p99_abs"] <= BF16_LOGP_P99_ABS, m1
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_r640_one_hour_bench_workload_against_reference(dtype):
     """bench.py's step, checked: PCM -> device fbank -> decode_resident(176 chunks: slices of 144 + 32) -> attention
