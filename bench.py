@@ -118,8 +118,8 @@ def launch_ranks(n: int, argv, script: str = None) -> int:
 def cpu_baseline(cfg, sd, feats_chunks, lens, args):
     """The oracle (CPU restatement of the reference, plain torch fp32, batch 1 as the reference does,
     recognize_wav.py:60-64) timed on the host cores on a bounded sample of the same workload.  The reference gets its best
-    thread count: the first chunk is decoded once per candidate (8, 32, all cores; the first decode of
-    all is a discarded warm-up), the fastest candidate then decodes the whole sample."""
+    thread count: the first chunk is decoded once per candidate (8, 16, 32, 64 threads; the first decode
+    of all is a discarded warm-up), the fastest candidate then decodes the whole sample."""
     import torch
     from oracle import model_ref as M, search_ref as S
     tsd = M.to_torch_sd(sd)
@@ -132,7 +132,9 @@ def cpu_baseline(cfg, sd, feats_chunks, lens, args):
 
     ncpu = os.cpu_count() or 1
     default = torch.get_num_threads()
-    cands = sorted({c for c in (8, 32, ncpu) if c <= ncpu} | {min(default, ncpu)})
+    # candidates stop at 64 threads: on the 256-thread host of the GPU box one chunk took 1.5 s on 8 threads, 1.0 s on 32, 4.2 s on
+    # 128 and 174 s (!) on 256 (profiles/r06_call3_*): torch's intra-op pool thrashes on a batch-1 model far above its sweet spot
+    cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu})
     probe = {}
     if len(cands) > 1 and len(lens) > 1:
         torch.set_num_threads(cands[-1])

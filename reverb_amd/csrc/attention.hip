@@ -53,8 +53,11 @@ struct AttnLds {
 // staged key tile), 1 for the decoder's self attention over a hypothesis trie (a hypothesis owns a handful of rows).
 // FOLD: 0 = two products; 1 = folded, K' = k + p formed while staging; 2 (round 6) = folded, `k` already holds K' (the qkv GEMM
 // wrote k + p, GemmArgs::rowadd): no positional rows are loaded, no additions -- the fold without the VALU work that made form 1 lose.
-template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32>
-__global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
+// OCC: minimum waves per SIMD asked of the register allocator (1 = whatever the kernel needs).  The folded encoder form needs 94
+// VGPRs = two 8-wave workgroups per CU; OCC = 6 (lab switch RVB_ATTN_OCC=3: three workgroups per CU) squeezes it into 80 with 5 dwords
+// of scratch per lane.
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
   static_assert(!FOLD || (HAS_POS && sizeof(T) == 2), "the folded positional term is built for the bf16 encoder form");
   constexpr int QT = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,11 +398,11 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32>
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
   using L = AttnLds<T, DKP, HAS_POS, FOLD, PADK>;
   static bool attr_set = false;
-  auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD, PADK>;
+  auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD, PADK, OCC>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
     attr_set = true;
@@ -418,7 +421,11 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   const int dk = a.dk;
   if constexpr (sizeof(T) == 2) {      // the folded positional term: bf16, dk <= 64, 128-query workgroups (the encoder's form)
     if (pos && a.pos_bias != nullptr && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128))
+    {
+      static const int occ = lab_env("RVB_ATTN_OCC") ? atoi(lab_env("RVB_ATTN_OCC")) : 2;      // workgroups per CU asked for (lab A/B)
+      if (a.k_prefolded && occ == 3) return launch_attn<T, 64, true, 8, 2, 32, 6>(s, a);
       return a.k_prefolded ? launch_attn<T, 64, true, 8, 2>(s, a) : launch_attn<T, 64, true, 8, 1>(s, a);
+    }
     // A/B switch for the encoder's form (dk 33..64, 128-query workgroups, positional keys): RVB_ATTN_PADK=16 = the 144-byte row
     // pitch of rounds 1-3 (2-way bank conflicts on every S-phase fragment read: 10.41 vs 9.99 ms per hour, SQ_LDS_BANK_CONFLICT
     // 2.1e8 vs 0 on a quarter hour, profiles/r04_call7_attention_padk_pmc.txt); every other form uses the 32-byte pad

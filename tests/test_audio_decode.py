@@ -308,6 +308,44 @@ def test_front_end_reads_flac_and_wide_wav(tmp_path):
     assert ff.shape[1:] == want.shape and np.abs(ff[0] - want).max() < 5e-3
 
 
+@pytest.mark.gpu
+def test_front_end_transcribes_an_mp3(tmp_path):
+    """`reverb.transcribe("x.mp3")` -- the reference's own usage example (README.md:61-106) -- end to end: a 44.1 kHz joint-stereo
+    Layer III file (written by tests/mp3_writer.py, with an Info + LAME tag frame) is decoded on the host, channel 0 goes to the
+    device as float32 (what torchaudio.load hands the reference for an mp3, whatever `normalize` says), is resampled there and
+    transcribed; a float32 WAVE file holding the decoder's very samples gives bit-identical features and the same CTM."""
+    import mp3_tables as MT
+    import mp3_writer as Wr
+    from reverb_amd import synth
+    from reverb_amd.reverb import load_model
+    mdir = synth.write_model_dir(str(tmp_path / "m"), "tiny")
+    asr = load_model(mdir, gpu=0, dtype="f32", max_chunks=4)
+    pcm = synth.synth_audio(6.0, seed=3).astype(np.float64) / 32768.0
+    t = np.arange(int(6.0 * 44100)) / 44100.0
+    x = np.interp(t, np.arange(len(pcm)) / 16000.0, pcm)                                   # the 16 kHz test signal at 44.1 kHz
+    stereo = np.stack([x, 0.6 * x + 0.01 * np.sin(2 * np.pi * 500 * t)])
+    D = np.array(MT.D) / 65536.0
+    mp3 = str(tmp_path / "talk.mp3")
+    with open(mp3, "wb") as f:
+        f.write(Wr.Encoder(44100, 2, 192, D, mode=1, mode_ext=2, info_frame=(528, 700), plan=lambda g: Wr.GranuleCfg([0, 0, 1, 2, 3, 0][g % 6])).encode(stereo))
+    wave, info = audio.load_with_info(mp3)
+    assert info.container == "mp3" and info.channels == 2 and info.sample_rate == 44100 and wave.dtype == np.float32
+    assert info.frames == -(-len(t) // 1152) * 1152 - 1057 - (700 - 529)
+    snr = 10 * np.log10((x[3000:200000] ** 2).sum() / ((x[3000:200000] - wave[0][3000:200000]) ** 2).sum())
+    assert snr > 20, snr        # aligned with the input by the tag's delay (29 dB measured: 96 kbit/s per channel, random scale factors)
+    wav = str(tmp_path / "talk.wav")
+    with open(wav, "wb") as f:
+        f.write(wav_bytes(3, 1, 44100, 32, wave[0].astype("<f4").tobytes()))
+    f_mp3 = asr.compute_feats(mp3, num_mel_bins=80).numpy()
+    f_wav = asr.compute_feats(wav, num_mel_bins=80).numpy()
+    np.testing.assert_array_equal(f_mp3, f_wav)
+    ctm = asr.transcribe(mp3, mode="attention_rescoring", format="ctm")
+    assert ctm == asr.transcribe(wav, mode="attention_rescoring", format="ctm").replace("talk.wav", "talk.mp3") or \
+        [l.split()[2:] for l in ctm.split("\n")] == [l.split()[2:] for l in asr.transcribe(wav, mode="attention_rescoring", format="ctm").split("\n")]
+    assert len(ctm.split("\n")) >= 1 and isinstance(asr.transcribe(mp3), str)
+    asr.engine.close()
+
+
 # ----------------------------------------------------------------------------------------------------- RF64, AIFF / AIFF-C
 def ext80(x):
     """80-bit IEEE extended of a positive number (AIFF sample rates)"""
