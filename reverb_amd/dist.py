@@ -335,7 +335,7 @@ def _create_comm_or_agree_on_fallback(device: int):
     together (`ncclCommInitRank` across processes first runs on the driver's scaling box, and a failure
     there used to raise and kill `bench.py --gpus 8`).  Steps, in lockstep on every rank: (1) the id travels over the torch
     group and rvb_comm_create runs in a helper thread with a deadline (RVB_COMM_INIT_TIMEOUT, default 120 s: an init that
-    hangs counts as failed); (2) preflight: one 1-KB device-to-device all-gather under a 30 s collective timeout, so that the
+    hangs counts as failed); (2) preflight: one 1-KB all-gather (contents checked) under a 30 s collective timeout, so that the
     first collective of the timed region cannot be the first ever; (3) the ranks all-gather (ok, reason) over the torch
     group; unless every rank is fine, every rank frees its communicator, records the reason (comm_fallback_reason), logs it
     to stderr and returns None -- the callers then gather through torch.distributed (the rendezvous group: gloo on host
@@ -374,7 +374,9 @@ def _create_comm_or_agree_on_fallback(device: int):
                 comm.set_timeout(30.0)
             except Exception:                 # an RCCL build without ncclCommAbort refuses timeouts: preflight without one
                 pass
-            comm.time_all_gather(1024, iters=1)
+            got = comm.all_gather(np.full(256, comm.rank, np.int32))      # through comm_wait: honours the timeout (the timed form does not)
+            if [int(r[0]) for r in got] != list(range(comm.world)):
+                raise RuntimeError("the slots do not hold their ranks' words")
             try:
                 comm.set_timeout(0.0)
             except Exception:

@@ -13,15 +13,16 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 
 
 def _latest(stem):
-    """newest committed profile of a kind: profiles/r05<letter>_<stem> (the round's evidence runs are lettered in order)"""
+    """newest committed profile of a kind: profiles/r06<letter>_<stem> (the round's evidence runs are lettered in order)"""
     import glob
-    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_" + stem)))
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_" + stem)))
     assert hits, stem
     return hits[-1]
 
 
 @pytest.mark.parametrize("log", ["archive/r01_bench_r640_1h_bf16.json.log", "archive/r02_bench_diar_1h_bf16.json.log",
-                                 "archive/r04d_bench_r640_1h_bf16.json.log", "LATEST:bench_r640_1h_bf16.json.log"])
+                                 "archive/r04d_bench_r640_1h_bf16.json.log", "archive/r05h_bench_r640_1h_bf16.json.log",
+                                 "LATEST:bench_r640_1h_bf16.json.log", "LATEST:bench_diar_1h_bf16.json.log"])
 def test_committed_bench_line_has_the_contract_fields(log):
     path = _latest(log[7:]) if log.startswith("LATEST:") else os.path.join(ROOT, "profiles", log)
     lines = [l for l in open(path).read().splitlines() if l.strip()]
@@ -77,27 +78,40 @@ def test_bench_scripts_parse_and_default_to_one_gpu():
         assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
 
 
-def test_bench_line_carries_the_measured_sub_records():
-    """The driver's `python bench.py` line of round 5: live PMC traffic, the PCIe-inclusive leg, diarization (configs[3]), the
-    joint fp8 pipeline on THREE hours (configs[4]) with its sharded / replicated split, and the headline step in the other modes
-    (parity_f32 = the bit-exact mode, asr_fp8, r268) as sub-records."""
-    d = json.loads(open(_latest("bench_r640_1h_bf16.json.log")).read().splitlines()[-1])
-    assert d["roofline"]["traffic"] > 1e8 and "rocprofv3 --pmc" in d["roofline"]["traffic_detail"]["method"]
-    assert d["pcie_inclusive"]["value"] <= d["value"] * 1.03 and d["pcie_inclusive"]["h2d_bytes_per_step"] == 115200000
-    assert d["config"]["decoder_rows_per_step"] < d["config"]["decoder_pairs_per_step"]
-    assert "8 chunks" in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["kind"] == "port"
-    for key in ("diarization", "joint_fp8"):
-        r = d[key]
-        assert "error" not in r and r["value"] > 0 and r["ms_per_step"] > 0 and r["data"] == "synthetic", key
-    assert d["diarization"]["roofline"]["bound"] == "mfma" and d["diarization"]["cpu_baseline"]["kind"] == "port"
+def test_bench_line_is_compact_and_the_long_form_carries_the_sub_records():
+    """Round 6: the driver's record keeps about 1.5 KB of the line's tail, so stdout carries a COMPACT line (< 2 KB: the contract keys,
+    `roofline` and `cpu_baseline` as scalars, every sub-record as {value, ms_per_step, frac}, configs[3] and configs[4] last) and the
+    full record goes to gpurun_out/bench_long.json (committed as profiles/r06*_bench_long.json).  The PMC traffic belongs to the
+    headline's own GEMM launches: one step's worth, compared with the algorithmic bytes."""
+    raw = open(_latest("bench_r640_1h_bf16.json.log")).read().splitlines()[-1]
+    d = json.loads(raw)
+    assert len(raw) < 2048, len(raw)
+    assert list(d)[-3:-1] == ["diarization", "joint_fp8"] and d["long_form"].endswith("bench_long.json")
+    for key in ("pcie_inclusive", "parity_f32", "asr_fp8", "r268", "diarization", "joint_fp8"):
+        assert set(d[key]) >= {"value", "ms_per_step"} and d[key]["value"] > 0, key
+    r = d["roofline"]
+    assert r["traffic_launches"] == r["launches"] // d["steps"] == 333
+    assert 1.0 < r["traffic_over_algorithmic"] < 3.0 and abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - r["traffic_over_algorithmic"]) < 1e-2
+    assert 0.2 < r["step_frac"] < r["frac"] < 1.0
+    assert d["cpu_baseline"]["cores"] in (8, 16, 32, 64) and "8 chunks" in d["cpu_baseline"]["sample"]
     j = d["joint_fp8"]
-    assert j["dtype"] == "fp8" and "3 h" in j["config"]["workload"] and j["ms_per_step"] < j["sequential_ms_per_step"]
-    assert j["sharded_s"] > 0 and j["replicated_s"] > 0 and abs(j["projected_8gpu_step_s"] - (j["sharded_s"] / 8 + j["replicated_s"])) < 1e-3
-    assert j["diarization_fp8"]["state"] == 2 and j["diarization_fp8"]["clipped_values"] == 0
-    f32, f8, small = d["parity_f32"], d["asr_fp8"], d["r268"]
+    assert abs(j["projected_8gpu_step_s"] - (j["sharded_s"] / 8 + j["replicated_s"])) < 1e-3
+    # the long form: what round 5's 14 KB line held
+    L = json.load(open(_latest("bench_long.json")))
+    assert L["value"] == d["value"] and "rocprofv3 --pmc" in L["roofline"]["traffic_detail"]["method"]
+    assert L["pcie_inclusive"]["h2d_bytes_per_step"] == 115200000 and L["config"]["decoder_rows_per_step"] < L["config"]["decoder_pairs_per_step"]
+    for key in ("diarization", "joint_fp8"):
+        rr = L[key]
+        assert "error" not in rr and rr["value"] > 0 and rr["ms_per_step"] > 0 and rr["data"] == "synthetic", key
+    assert L["diarization"]["roofline"]["bound"] == "mfma" and L["diarization"]["cpu_baseline"]["kind"] == "port"
+    jj = L["joint_fp8"]
+    assert jj["dtype"] == "fp8" and "3 h" in jj["config"]["workload"] and jj["ms_per_step"] < jj["sequential_ms_per_step"]
+    assert jj["diarization_fp8"]["state"] == 2 and jj["diarization_fp8"]["clipped_values"] == 0
+    f32, f8, small = L["parity_f32"], L["asr_fp8"], L["r268"]
     assert f32["dtype"] == "f32" and f32["roofline"]["peak"] == 157.3 and f32["value"] > 2000        # the bit-exact mode clears 2000x
-    assert f8["dtype"] == "fp8" and f8["roofline"]["peak"] == 5000.0 and f8["value"] > d["value"]
-    assert small["value"] > d["value"] and "r268" in small["workload"]
+    assert f8["dtype"] == "fp8" and f8["roofline"]["peak"] == 5000.0 and f8["value"] > L["value"]
+    assert small["value"] > L["value"] and "r268" in small["workload"]
+    assert set(L["cpu_baseline"]["threads_probe_ms_chunk0"]) <= {"8", "16", "32", "64"}
 
 
 def test_every_file_the_profiles_readme_names_exists():
