@@ -68,10 +68,36 @@ class RvbASRModel:
             raise NotImplementedError("context biasing is out of scope")
         if blank_id != self.engine.cfg.blank_id:
             raise ValueError("blank_id differs from the model's ctc_blank_id")
-        if cat_embs is not None:
-            self.engine.set_cat_embs(np.asarray(cat_embs, dtype=np.float32))
         feats = speech.detach().cpu().numpy() if hasattr(speech, "detach") else np.asarray(speech)
         lens = speech_lengths.detach().cpu().numpy() if hasattr(speech_lengths, "detach") else np.asarray(speech_lengths)
+        if cat_embs is not None:
+            cat = cat_embs.detach().cpu().numpy() if hasattr(cat_embs, "detach") else np.asarray(cat_embs)
+            cat = np.asarray(cat, dtype=np.float32)
+            if cat.ndim == 2:
+                # per-utterance language weights (encoder_layer.py:378-390, decoder_layer.py: `cat_embs[:, i]` scales layer i's output
+                # of batch item b): the engine folds ONE weight vector into its language-specific layers (W = sum_i c_i W_i), so the
+                # batch is decoded group by group, one group per distinct row, and the results go back in the caller's order
+                if cat.shape[0] != feats.shape[0]:
+                    raise ValueError(f"cat_embs has {cat.shape[0]} rows for a batch of {feats.shape[0]}")
+                kw = dict(decoding_chunk_size=decoding_chunk_size, num_decoding_left_chunks=num_decoding_left_chunks, ctc_weight=ctc_weight,
+                          simulate_streaming=simulate_streaming, reverse_weight=reverse_weight, blank_id=blank_id,
+                          blank_penalty=blank_penalty, length_penalty=length_penalty)
+                rows, groups = {}, []
+                for b in range(cat.shape[0]):
+                    key = cat[b].tobytes()
+                    if key not in rows:
+                        rows[key] = len(groups)
+                        groups.append([])
+                    groups[rows[key]].append(b)
+                merged = {}
+                for idx in groups:
+                    part = self.decode(methods, feats[idx], lens[idx], beam_size, cat_embs=cat[idx[0]], **kw)
+                    for m, res in part.items():
+                        slot = merged.setdefault(m, [None] * cat.shape[0])
+                        for b, r in zip(idx, res):
+                            slot[b] = r
+                return merged
+            self.engine.set_cat_embs(cat)
         results = {}
         if simulate_streaming and decoding_chunk_size > 0:
             # asr_model.py:301-306: the encoder runs chunk by chunk with attention caches (encoder.py:343-402) on the whole
