@@ -5,7 +5,7 @@
 //
 // Why (round 5; VERDICT r4 "next" #2): as two conv_stream launches a block moves five tensor passes through HBM (x read, mid
 // written, mid read, x read again as the residual, out written) for 37 kFLOP per pixel: 281 GB per hour of audio at 5.2 TB/s --
-// that form IS bound by HBM (profiles/r05_call7_conv_block_counters.txt).  Here x is read once and out written once.
+// that form IS bound by HBM (profiles/archive/r05_call7_conv_block_counters.txt).  Here x is read once and out written once.
 //
 // Structure (the "band" form): a workgroup of 4 waves owns a 60-frame BAND of one window and walks DOWN its rows, three output rows
 // per step, with the input rows and the mid rows in two 8-row rings in LDS (64 pixels x 64 B per row; 2 x 32 KiB).  A step brings
@@ -34,13 +34,13 @@
 //     with a 2-way bank conflict in every lane group; bank-conflict cycles 44 % -> 10 % of the LDS-active cycles.  Together, on
 //     tiles of 4 rows x 60 frames (8 waves, two patch buffers): 42.5-43.0 ms;
 //   * the two convolutions as ROLES of different waves one tile apart: 42.8 ms -- equal; patches two tiles ahead: 45.4 -- slower
-//     (profiles/r05_call5_*, r05_call8_*): neither phase serialisation inside a workgroup nor the prefetch distance was what was left;
+//     (profiles/archive/r05_call5_*, r05_call8_*): neither phase serialisation inside a workgroup nor the prefetch distance was what was left;
 //   * FOUR waves and ONE patch buffer per workgroup, so that two workgroups share a CU and fill each other's barriers, DMA waits
-//     and VALU phases: 39.3-39.5 ms (profiles/r05_call9_conv_block_two_workgroups.txt);
+//     and VALU phases: 39.3-39.5 ms (profiles/archive/r05_call9_conv_block_two_workgroups.txt);
 //   * column strips sliding down the rows of the tile (a fragment read once per input row instead of once per tap: 42 fragment reads
-//     per tile and wave instead of 90): 37.7 ms -- the LDS reads were no longer what bound it (profiles/r05_call15_*);
+//     per tile and wave instead of 90): 37.7 ms -- the LDS reads were no longer what bound it (profiles/archive/r05_call15_*);
 //   * what did: the tile's halo.  Four output rows need six mid rows, 64 columns give 60 outputs: 1.33 x the block's MFMAs.  Walking
-//     down a band computes every row once (64 / 60 = 1.07 x): **30.8-31.0 ms** (profiles/r05_call16_conv_block_band.txt).
+//     down a band computes every row once (64 / 60 = 1.07 x): **30.8-31.0 ms** (profiles/archive/r05_call16_conv_block_band.txt).
 //
 // Results: operand values, accumulation order (taps 0..8, one 32-channel K step each) and rounding points (mid and out rounded to
 // bf16 after bias / residual / ReLU in fp32) are those of two conv_stream / conv_kernel launches

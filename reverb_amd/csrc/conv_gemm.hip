@@ -8,7 +8,7 @@
 //   columns = output channels, weights [Cout][9][Cin] (BatchNorm folded), tile 256 pixels x 256 channels or (round 5) 512 pixels x
 //             128 channels: either way 8 waves of 128 pixels x 64 channels.  The 128-channel stage ran on 256 x 128 tiles until then
 //             (wave tile 64 x 64: a third more LDS fragment bytes per MFMA, at the LDS port's limit): 65.5 -> 60.9 ms per hour
-//             (profiles/r05_call15_strips_igemm512.txt); the variant with the fused shortcut stays on 256 pixels (it spills at 512)
+//             (profiles/archive/r05_call15_strips_igemm512.txt); the variant with the fused shortcut stays on 256 pixels (it spills at 512)
 //
 // Main loop and gather measured in scripts/micro/gemm_lab.hip ("conv" mode, exact against a naive convolution):
 // 855 TFLOP/s for the 128-channel stage and 1193 for the 256-channel stage, against 555-598 for the direct
@@ -16,11 +16,11 @@
 // The epilogue is conv_kernel's: 16-row slabs transposed through LDS, bias + residual + ReLU, full 128-byte runs of
 // channels per pixel into the bordered output.
 //
-// Measured and not kept (round 5, profiles/r05_call11_igemm_small_tiles.txt): 128 x 128 tiles of four waves, 64 KiB of stages, TWO
+// Measured and not kept (round 5, profiles/archive/r05_call11_igemm_small_tiles.txt): 128 x 128 tiles of four waves, 64 KiB of stages, TWO
 // workgroups per CU -- the remedy that paid for the 32- / 64-channel stages: 64.2-64.7 vs 65.0-65.3 ms for the 128-channel stage,
 // 24.4-24.8 vs 25.0 ms for the 256-channel one (-1 %): this loop is paced by its stage fill, not by what overlaps what on a CU.
 //
-// Measured and not kept (round 5, profiles/r05_call18_conv_flat_not_kept.txt): the same convolutions over the FLAT pixel index of the
+// Measured and not kept (round 5, profiles/archive/r05_call18_conv_flat_not_kept.txt): the same convolutions over the FLAT pixel index of the
 // bordered tensor (tap (kh, kw) of pixel m is pixel m + (kh - 1)(T + 2) + (kw - 1): a tile's 512 + 2 (T + 2) + 2 pixels resident in
 // LDS for all nine taps, persistent workgroups, a third of this loop's LDS-DMA requests per MFMA).  The image fits only for
 // T + 2 <= 127 -- the 256-channel stage; the 128-channel stage's 20 x 250 maps would need 2 x 65 KB of pixels beside 48 KB of

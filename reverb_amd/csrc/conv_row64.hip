@@ -1,7 +1,7 @@
 // The stride-1 3x3 convolutions of the ResNet34 trunk's 64-channel stage (bf16), built from what conv_block.hip's history showed
 // for the 32-channel stage (round 5): these kernels are bound by their LDS operations and by what overlaps what on a CU, not by
 // the matrix pipe.  resnet.hip's conv_kernel<64> (the default until now) spent 36 % of its LDS-active cycles in bank conflicts and
-// ran at 3.2 TB/s of HBM traffic with the waves 30 % parked / 37 % stalled at issue (profiles/r05_call5_*.txt, call 6); the
+// ran at 3.2 TB/s of HBM traffic with the waves 30 % parked / 37 % stalled at issue (profiles/archive/r05_call5_*.txt, call 6); the
 // streamed form of round 4 (conv_stream.hip, 64 channels: one workgroup per CU) measured equal to it.
 //
 //   out = relu?(conv3x3(x) + b [+ res])        x, res, out: bordered NHWC [B][F+2][T+2][64], weights [tap][chunk][64][64 B]
@@ -25,7 +25,7 @@
 // MFMAs ago); the epilogue of row r between the MFMAs of the rows still open, with stores that are younger than that wait and
 // hidden from the compiler's, so nothing ever waits for them; ONE barrier.
 //
-// Measured (same box A/B, profiles/r05_call10_conv_row64.txt, r05_call14_*, r05_call15_*): the 64-channel stage 51.6-52.5 ms per hour
+// Measured (same box A/B, profiles/archive/r05_call10_conv_row64.txt, r05_call14_*, r05_call15_*): the 64-channel stage 51.6-52.5 ms per hour
 // of audio on the direct kernel -> 43.3-43.8 ms in this kernel's first form (62-frame tiles, ONE patch buffer: barrier, DMA, wait,
 // barrier at the end of every tile, covered only by the CU's other workgroup) -> 39.1 ms with 30-frame tiles and two buffers (+3 %
 // MFMA work for the narrower tiles, the DMA latency under the tile's own MFMAs; wave = channel half x two rows, a fragment read per

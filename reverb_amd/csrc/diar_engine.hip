@@ -434,7 +434,7 @@ int pack_conv_bn(rvd_engine* e, ConvW& c, const std::string& conv, const std::st
 }
 
 // Default since round 5 (measured: shortcut kernels 12.1 -> 5.2 ms per hour, the 256-channel stage 21.4 -> 25.0 ms, step 358-360
-// -> 355-359 ms, profiles/r05_call1.txt; and one rounding point fewer): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4
+// -> 355-359 ms, profiles/archive/r05_call1.txt; and one rounding point fewer): the 1x1 / stride-2 projection shortcut of the blocks that open stages 3 and 4
 // rides in the K loop of the block's second convolution (conv_gemm.hip, ConvArgs::in2) instead of being a kernel of its own whose
 // output is written, read back as the residual and rounded to bf16 on the way: rows [cout][9 cout + cin_sc], bias = b_2 + b_sc.
 int pack_fused_shortcut(rvd_engine* e, ResBlock& B, const std::string& p) {

@@ -382,7 +382,7 @@ def test_trunk_stages_3_and_4_in_fp8(case, emb_case):
     cosw16 = (a * want).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(want, axis=1))
     _record(test="trunk_stages_3_and_4_in_fp8", cos_fp8_vs_bf16_min=float(cos.min()), cos_fp8_vs_bf16_mean=float(cos.mean()),
             cos_fp8_vs_fp32_oracle_min=float(cosw.min()), cos_bf16_vs_fp32_oracle_min=float(cosw16.min()), embeddings=int(active.sum()))
-    assert cos.min() > 0.999, cos              # SURVEY 8(d)'s bar; measured 0.99960 (profiles/r05h_parity_metrics.jsonl)
+    assert cos.min() > 0.999, cos              # SURVEY 8(d)'s bar; measured 0.99960 (profiles/archive/r05h_parity_metrics.jsonl)
     assert cosw.min() > 0.999, cosw            # measured 0.99960; the bf16 engine: 0.99999
     eng.close()
 
