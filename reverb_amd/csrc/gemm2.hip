@@ -813,8 +813,19 @@ __device__ inline const char* uniform_ptr(const char* q) {
 // (scripts/gemm_timeline.py) are gone.  The epilogue's slabs have their own LDS, so nothing waits for anything else.
 // PMODE 2 (round 4): the persistent LOOP without the cross-tile prefetch -- a workgroup per CU walks its tiles, every tile with
 // its own first-stage requests and waits; only the dispatch gap between two workgroups of a CU is gone.
-template <typename T, typename OutT, bool CONV, int PMODE = 0, bool M32 = false>
+// PH2 (bf16, one tile per workgroup; round 6): the K step as TWO phases instead of four --
+//         X: (A0 x B0), (A0 x B1)    32 MFMAs    reads before it: A-h0 (both k-halves), B-h0, B-h1     16 ds_read_b128
+//         Y: (A1 x B1), (A1 x B0)    32 MFMAs    reads before it: A-h1                                  8
+//     i.e. four barriers per K step instead of eight: the 16-MFMA sections of the four-phase loop are 272 matrix-pipe cycles between
+//     two barriers that cost 60-120 cycles together (scripts/gemm_timeline.py: 1.31-1.48 us per K step against 0.86 of matrix pipe).
+//     64 fragment registers (one A set, two B sets; no prefetched k-half), the second wave row still one barrier behind the first.
+//     The ring becomes EIGHT slots with static addresses: half-tile ty of K step t lives in slot 4 (t & 1) + ty; X(t) requests the
+//     three half-tiles of X(t + 1) into the slots X(t - 1) left two phases ago, Y(t) the one of Y(t + 1); waits are vmcnt(6) / vmcnt(2)
+//     (everything but what the phase itself just requested).  128 KiB of ring: the epilogue's slabs reuse slot memory (nothing is in
+//     flight after the last K step, and every wave is past the last barrier).
+template <typename T, typename OutT, bool CONV, int PMODE = 0, bool M32 = false, bool PH2 = false>
 __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
+  static_assert(!PH2 || (sizeof(T) == 2 && !M32 && PMODE == 0), "PH2: bf16, 16x16x32 fragments, one tile per workgroup");
   // M32 (bf16, round 6): v_mfma_f32_32x32x16_bf16 on 32x32 accumulator blocks instead of v_mfma_f32_16x16x32_bf16 on 16x16
   // fragments -- the same ring, phases, fragment bytes and read counts (a lane's 16-byte vector is 8 k-values of one of 32
   // rows); a phase is 8 MFMAs of 32 cycles instead of 16 of ~17 (MI355X_MICROARCH.md: the 32x32x16 form is the one that
@@ -984,12 +995,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   // 32x32 blocks (fp8): acc32[bi][bj] = rows 32bi.., cols 32bj.. (C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
   f32x4_t acc[B32 ? 1 : 8][B32 ? 1 : 4];
   f32x16_t acc32[B32 ? 4 : 1][B32 ? 2 : 1];
-  const bool res_acc = !p.res_epilogue && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
-                       ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N
+  const bool res_acc = !PH2 && !p.res_epilogue && p.res != nullptr && p.act == ACT_NONE && p.alpha != 0.f && (p.N & 3) == 0 && (p.ldres & 3) == 0 &&
+                       ((size_t)p.res & 15) == 0;      // 16-byte residual vectors, whole inside N (PH2: its slabs share the ring's memory)
   // ---- prologue: half-tiles 0 .. P_LEAD-1 requested; then (optionally) the fp32 residual tile becomes the initial
   // accumulator: C = res + alpha * (A.W^T + bias) = alpha * (res / alpha + A.W^T + bias), see gemm2_kernel
   if constexpr (PMODE == 2) { s_cur = 0; s_rd = 1; s_st = P_LEAD; }      // every tile restarts the ring (all readers are past the K loop's last barrier)
-  if (first_tile || !XPF) {       // a later tile of a cross-prefetching workgroup found its first half-tiles requested by the tile before it
+  if constexpr (PH2) {
+    for (int h = 0; h < 4; ++h) stage(h, h);      // X(0) and Y(0): slots 0..3
+  } else if (first_tile || !XPF) {       // a later tile of a cross-prefetching workgroup found its first half-tiles requested by the tile before it
     for (int h = 0; h < P_LEAD && h < nh; ++h) stage(h, h);
   }
   if (res_acc) {
@@ -1059,7 +1072,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (first_tile || !XPF) {       // half-tiles 0 and 1 have landed (later tiles: the previous tile's last two phases waited for them)
+  if constexpr (PH2) {
+    wait_vm<2>();                   // X(0)'s three half-tiles have landed (Y(0)'s two pieces may still be in flight)
+  } else if (first_tile || !XPF) {       // half-tiles 0 and 1 have landed (later tiles: the previous tile's last two phases waited for them)
     const int infl = (nh < P_LEAD ? nh : P_LEAD) - 2;
     if (infl >= P_DEPTH) wait_vm<2 * P_DEPTH>(); else wait_vm<0>();
   }
@@ -1167,6 +1182,30 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
 
   std::integral_constant<int, 0> h0;
   std::integral_constant<int, 1> h1;
+  if constexpr (PH2) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // the second wave row runs one barrier behind the first from here on
+    std::integral_constant<int, 2> c2;
+    std::integral_constant<int, 3> c3;
+    // (one loop body with the slot group as a scalar: two parity copies of the body made hipcc rename the accumulators between them --
+    // 180 spilled VGPRs, and every scratch reload is a vector-memory operation whose wait drains the DMA queue)
+    for (int t = 0; t < nk; ++t) {
+      const int base = (t & 1) * 4, nb = 4 - base;
+      const bool nx = t + 1 < nk;
+      // ---- phase X: requests for X(t + 1), all of this phase's fragments, then "Y(t)'s half-tile has landed"
+      if (nx) { stage_ty(c0, t + 1, ak1, nb + 0); stage_ty(c1, t + 1, ak1, nb + 1); stage_ty(c2, t + 1, ak1, nb + 2); }
+      read_b_khalf(h0, fb0, base + 1); read_a_half(h0, fa_lo, base + 0); read_a_half(h1, fa_hi, base + 0); read_b_khalf(h1, fb0, base + 1);
+      read_b(fb1, base + 2);
+      if (nx) wait_vm<6>(); else wait_vm<0>();
+      mid(); mma_q(c0, c0, fa_lo, fa_hi, fb0); mma_q(c0, c1, fa_lo, fa_hi, fb1); end();
+      // ---- phase Y: the request for Y(t + 1), A1, then "X(t + 1)'s half-tiles have landed"
+      if (nx) stage_ty(c3, t + 1, ak1, nb + 3);
+      read_a_half(h0, fa_lo, base + 3); read_a_half(h1, fa_hi, base + 3);
+      if (nx) wait_vm<2>(); else wait_vm<0>();
+      mid(); mma_q(c1, c1, fa_lo, fa_hi, fb1); mma_q(c1, c0, fa_lo, fa_hi, fb0); end();
+      ak1 = ak2; ac1 = ac2;
+      advance(ak2, ac2);
+    }
+  } else {
   read_a_half(h0, fh, s_cur);
   if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind the first from here on
   int ph = 0;                       // phase counter (of this tile)
@@ -1253,6 +1292,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     if (nk >= 2) kstep(c1, std::integral_constant<int, 2>(), nk - 2);
     kstep(c1, c1, nk - 1);
   }
+  }      // !PH2
   if (wr == 0) __builtin_amdgcn_s_barrier();       // balances the stagger: every wave has executed the same number of barriers
   if (p.dbg && tid == 0) p.dbg[dbg_i * 6 + 2] = wall_clock64();
   auto epilogue = [&]() __attribute__((always_inline)) {
@@ -1265,7 +1305,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   const bool vec_ok = ((p.ldc * (int)sizeof(OutT)) % 16 == 0) && (((size_t)p.C & 15) == 0) &&
                       (p.res == nullptr || ((p.ldres % 4) == 0 && ((size_t)p.res & 15) == 0));
   if (vec_ok) {
-    char* slab = smem + P_NSLOT * P_HT + wave * (16 * P_SROW);
+    char* slab = smem + (PH2 ? 0 : P_NSLOT * P_HT) + wave * (16 * P_SROW);      // PH2: slot memory, idle by now
     constexpr int CPL = sizeof(OutT) == 4 ? 4 : (sizeof(OutT) == 2 ? 8 : 16);   // columns per lane
     constexpr int LPR = 64 / CPL;                                                // lanes per slab row
     constexpr int RPP = 64 / LPR;                                                // rows per pass
@@ -1624,14 +1664,14 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
   }      // tiles of this workgroup
 }
 
-template <typename T, typename OutT, bool CONV, bool M32 = false>
+template <typename T, typename OutT, bool CONV, bool M32 = false, bool PH2 = false>
 static int launch2p(hipStream_t s, const GemmArgs& p) {
   static bool attr_set = false;
   static int ncu = 0;
-  auto kern = gemm2p_kernel<T, OutT, CONV, 0, M32>;
+  auto kern = gemm2p_kernel<T, OutT, CONV, 0, M32, PH2>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
-    if constexpr (!CONV && !M32 && std::is_same<T, bf16_t>::value) {
+    if constexpr (!CONV && !M32 && !PH2 && std::is_same<T, bf16_t>::value) {
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
       RVB_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2p_kernel<T, OutT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
     }
@@ -1643,7 +1683,7 @@ static int launch2p(hipStream_t s, const GemmArgs& p) {
     attr_set = true;
   }
   const int tiles = cdiv(p.M, B2M) * cdiv(p.N, B2N);
-  if constexpr (!CONV && !M32 && std::is_same<T, bf16_t>::value) {
+  if constexpr (!CONV && !M32 && !PH2 && std::is_same<T, bf16_t>::value) {
     // persistent forms: full tiles only, and at least two tiles per CU; bit 4 = with the cross-tile prefetch, bit 12 = loop only
     if ((g_gemm2_flags & (16 | 4096)) && ncu >= 8 && p.M % B2M == 0 && p.N % B2N == 0 && tiles >= 2 * ncu && p.K >= 4 * (ROW2 / 2)) {
       if (g_gemm2_flags & 16) hipLaunchKernelGGL((gemm2p_kernel<T, OutT, false, 1>), dim3(ncu), dim3(512), GEMM2P_LDS, s, p);
@@ -1715,6 +1755,8 @@ bool gemm2_applicable(int dtype, const GemmArgs& p) {
 //   bit 11 residual tiles take the fast epilogue only where K is short (<= 2048 bf16 / 4096 fp8 elements)
 //   bit 12 the persistent LOOP without cross-tile prefetch (gemm2p_kernel PMODE 2): removes the dispatch gap only
 //   bit 13 (round 6) the phase-interleaved loop on v_mfma_f32_32x32x16_bf16 (gemm2p_kernel M32): 8 MFMAs of 32 cycles per phase
+//   bit 14 (round 6) two phases of 32 MFMAs per K step instead of four of 16 (gemm2p_kernel PH2): half the barriers; exact, 211 VGPRs, and
+//          SLOWER (kernel benchmark -2.4 %, the GEMMs of the bench hour 100.2 -> 105.7 ms): compiled with -DRVB_GEMM2_PH2 only
 #ifndef GEMM2_STAGGER_DEFAULT
 #define GEMM2_STAGGER_DEFAULT 1
 #endif
@@ -1783,6 +1825,12 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
       if (p.out_f32) return p.conv ? launch2<bf16_t, float, true, true>(s, p) : launch2<bf16_t, float, false, true>(s, p);
       return p.conv ? launch2<bf16_t, bf16_t, true, true>(s, p) : launch2<bf16_t, bf16_t, false, true>(s, p);
     }
+#ifdef RVB_GEMM2_PH2      // measured slower (profiles/r06_call7_gemm_two_phase_not_kept.txt): compiled only on request -- four instantiations, 3 min
+    if (!(g_gemm2_flags & 4) && (g_gemm2_flags & 16384) && p.res_epilogue) {     // two phases per K step (round 6, gemm2p_kernel PH2)
+      if (p.out_f32) return p.conv ? launch2p<bf16_t, float, true, false, true>(s, p) : launch2p<bf16_t, float, false, false, true>(s, p);
+      return p.conv ? launch2p<bf16_t, bf16_t, true, false, true>(s, p) : launch2p<bf16_t, bf16_t, false, false, true>(s, p);
+    }
+#endif
     if (!(g_gemm2_flags & 4) && (g_gemm2_flags & 8192) && !p.conv) {     // the phase-interleaved loop on 32x32x16 MFMAs (round 6: measured
       // slower, kept as the lab's comparison partner for the plain shapes only -- every instantiation costs 40 s of build time)
       return p.out_f32 ? launch2p<bf16_t, float, false, true>(s, p) : launch2p<bf16_t, bf16_t, false, true>(s, p);

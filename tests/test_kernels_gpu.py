@@ -158,6 +158,31 @@ def test_gemm_implicit_conv(lib, dtype, Cc, N):
     np.testing.assert_allclose(C, ref, rtol=5e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("flags", [0])
+@pytest.mark.parametrize("Cc,N,B,T1,F1", [(128, 260, 3, 41, 23), (64, 256, 2, 65, 39)])
+def test_gemm_implicit_conv_on_the_lds_dma_loops(lib, flags, Cc, N, B, T1, F1):
+    """the convolution gather of gemm2p_kernel (A rows addressed through the 3x3 stride-2 taps, 9 Cc / 64 K steps, the kernel-row jump
+    of the A offset), several row tiles, ragged edges, bf16 out (the two-phase form of the loop, flag bit 14 with -DRVB_GEMM2_PH2, passed the
+    same test in round 6 before it was measured slower and compiled out)"""
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    rng = np.random.default_rng(Cc + N)
+    x = rnd(BF16, rng.standard_normal((B, T1, F1, Cc)))
+    w = rnd(BF16, rng.standard_normal((N, Cc, 3, 3)) / math.sqrt(9 * Cc))
+    bias = f32(rng.standard_normal(N))
+    wp = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(N, 9 * Cc))
+    M = B * T2 * F2
+    C = np.full((M, N), np.nan, np.float32)
+    lib.rvb_test_set_gemm2_opts(flags, -2)
+    try:
+        _lib.check(lib.rvb_test_gemm(BF16, fptr(x), fptr(wp), fptr(bias), None, fptr(C), M, N, 9 * Cc, 1.0, 2, 0, 1, T1, F1, Cc, B))
+    finally:
+        lib.rvb_test_set_gemm2_opts(-1, -1)
+    ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2),
+                                                torch.from_numpy(w).double(), torch.from_numpy(bias).double(), stride=2))
+    ref = ref.permute(0, 2, 3, 1).reshape(M, N).numpy()
+    np.testing.assert_allclose(C, ref, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("mode,silu,use_add,out_f32,d", [(0, 0, False, 0, 64), (0, 1, False, 0, 640), (0, 0, True, 1, 1024),
                                                          (1, 1, False, 0, 96)])
