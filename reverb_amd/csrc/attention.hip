@@ -45,8 +45,8 @@ struct AttnLds {
   static constexpr int OFF_K = 0;
   static constexpr int OFF_P = OFF_K + KT * ROW_K;
   static constexpr int OFF_V = (HAS_POS && !FOLD) ? OFF_P + KT * ROW_K : OFF_P;     // no positional keys (or folded into K): no P tile
-  static constexpr int OFF_C = OFF_V + (BF ? KT : DKP) * ROW_V;          // FOLD: the tile's 64 per-key constants (fp32)
-  static constexpr int TOTAL = OFF_C + (FOLD ? KT * 4 : 0);
+  static constexpr int OFF_C = OFF_V + (BF ? KT : DKP) * ROW_V;          // FOLD: the (sequence, head)'s per-key constants (fp32), all of them: fold_kv_cap floats
+  static constexpr int TOTAL = OFF_C;                                     // (+ 4 * fold_kv_cap bytes at launch)
 };
 
 // NW = waves per workgroup (16 queries each): 8 for the encoder and the cross attention (128-query blocks share a
@@ -178,19 +178,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
   // bank, so whole groups of 4 keys are XOR-swizzled by the row's 8-dim block: key' = key ^ (((dim/VE)&7)<<2).
   constexpr int NV = (KT * VPR + NT - 1) / NT;
   uint4 rk[NV], rp[HAS_POS ? NV : 1], rv[NV];
-  float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);       // FOLD: threads 0..15 carry the tile's 64 per-key constants
-  const float* __restrict__ Cb = FOLD ? a.pos_bias + (size_t)head * a.pos_bias_stride : nullptr;
+  // FOLD: the head's per-key constants (v - u).p_j, ALL fold_kv_cap of them, go into LDS once per workgroup (round 6).  Until then
+  // 16 threads fetched the tile's 64 constants tile by tile -- `key + r < kvlen ? Cb[key + r] : 0`, which hipcc compiled into four
+  // exec-masked branches whose loads reused one address pair: `s_waitcnt vmcnt(0)` between them, four serialised memory round trips
+  // in wave 0 of EVERY tile with the whole workgroup waiting at the barrier behind it (that, not the arithmetic of the fold, is why
+  // round 4 measured the fold slower).  Keys past kvlen are masked to -inf below whatever constant they carry.
   char* sC = smem + L::OFF_C;
+  if constexpr (FOLD) {
+    const float* __restrict__ Cb = a.pos_bias + (size_t)head * a.pos_bias_stride;
+    const int last = a.pos_bias_stride - 1;
+    for (int j = tid; j < a.fold_kv_cap; j += NT) ((float*)sC)[j] = Cb[min(j, last)];
+  }
   auto gload = [&](int kt0) {
-    if constexpr (FOLD) {
-      if (tid < KT / 4) {
-        const int key = kt0 + 4 * tid;
-        float t4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t4[r] = key + r < kvlen ? Cb[key + r] : 0.f;
-        rc = make_float4(t4[0], t4[1], t4[2], t4[3]);
-      }
-    }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + NT * n;
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
     }
   };
   auto lstore = [&]() {
-    if constexpr (FOLD) { if (tid < KT / 4) *(float4*)(sC + tid * 16) = rc; }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + NT * n;
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       if constexpr (FOLD) {         // the accumulation starts from the keys' constants: fragment nf = keys 16 nf + 4 lgrp + r
-        const float4 c4 = *(const float4*)(sC + (nf * 16 + lgrp * 4) * 4);
+        const float4 c4 = *(const float4*)(sC + (kt0 + nf * 16 + lgrp * 4) * 4);
         s[nf] = (f32x4_t){c4.x, c4.y, c4.z, c4.w};
       } else {
         s[nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -404,13 +402,15 @@ static int launch_attn(hipStream_t s, const AttnArgs& a) {
   static bool attr_set = false;
   auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD, PADK, OCC>;
   if (!attr_set) {
-    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL + (FOLD ? 64 * 1024 : 0)));
     attr_set = true;
   }
   dim3 grid(cdiv(a.max_q, 16 * NW), a.heads, a.nseq);
   if (a.work) grid = dim3(a.n_work, a.heads, 1);
   if (grid.x == 0) return OK;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), L::TOTAL, s, a);
+  const int fold_bytes = FOLD ? a.fold_kv_cap * 4 : 0;
+  if (FOLD && (a.fold_kv_cap <= 0 || a.fold_kv_cap % 64 || fold_bytes > 64 * 1024)) { set_error("attention: folded form needs fold_kv_cap = a multiple of 64 keys, at most 16384"); return E_ARG; }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), L::TOTAL + fold_bytes, s, a);
   RVB_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -420,7 +420,7 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
   const bool pos = a.p != nullptr;
   const int dk = a.dk;
   if constexpr (sizeof(T) == 2) {      // the folded positional term: bf16, dk <= 64, 128-query workgroups (the encoder's form)
-    if (pos && a.pos_bias != nullptr && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128))
+    if (pos && a.pos_bias != nullptr && a.fold_kv_cap > 0 && dk <= 64 && dk > 32 && (a.q_block == 0 || a.q_block == 128))
     {
       static const int occ = lab_env("RVB_ATTN_OCC") ? atoi(lab_env("RVB_ATTN_OCC")) : 2;      // workgroups per CU asked for (lab A/B)
       if (a.k_prefolded && occ == 3) return launch_attn<T, 64, true, 8, 2, 32, 6>(s, a);
@@ -482,7 +482,7 @@ int attention(hipStream_t s, int dtype, const AttnArgs& a0) {
     set_error("attention: dk and row strides must be multiples of the 16-byte vector width");
     return E_ARG;
   }
-  if (a.k_prefolded && !(dtype == DT_BF16 && a.p && a.pos_bias && a.dk <= 64 && a.dk > 32 && (a.q_block == 0 || a.q_block == 128))) {
+  if (a.k_prefolded && !(dtype == DT_BF16 && a.p && a.pos_bias && a.fold_kv_cap > 0 && a.dk <= 64 && a.dk > 32 && (a.q_block == 0 || a.q_block == 128))) {
     set_error("attention: pre-folded keys (k + p) are read by the folded bf16 encoder form only (33 <= dk <= 64, 128-query blocks, pos_bias table)");
     return E_ARG;
   }

@@ -529,7 +529,7 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   const char* prefold_env = lab_env("RVB_ATTN_PREFOLD");       // read per call (not cached): the A/B test flips it inside one process
   const int prefold_on = prefold_env ? atoi(prefold_env) : 1;
   const bool prefold = prefold_on && e->dtype == DT_BF16 && li < 0 && !f8_qkv && L.pos_bias.p != nullptr && dk > 32 && dk <= 64 &&
-                       T <= e->pe_rows && (d % 8) == 0;
+                       T <= e->pe_rows && T <= 16384 && (d % 8) == 0;     // 16384: the keys whose constants the kernel holds in LDS
   auto note = [&](int slot, const void* t, size_t n) -> int {
     return cal ? amax_abs(e->stream, e->dtype, t, n, e->d_amax.as<float>() + (size_t)lidx * 8 + slot) : OK;
   };
@@ -573,8 +573,9 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
     a.p = L.pos_keys.p;
     {   // bf16: positional term folded into per-key constants (RVB_ATTN_FOLD=1; default: the two-product form)
       static const int fold = lab_env("RVB_ATTN_FOLD") ? atoi(lab_env("RVB_ATTN_FOLD")) : 0;     // measured slower (10.3 -> 10.8 ms per hour): opt-in
-      if (fold && L.pos_bias.p) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; }
-      if (prefold) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; a.k_prefolded = 1; }
+      const int cap = (T + 63) / 64 * 64;             // offline: every chunk's keys are its own T frames
+      if (fold && li < 0 && L.pos_bias.p && cap <= 16384) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; a.fold_kv_cap = cap; }
+      if (prefold && cap <= 16384) { a.pos_bias = L.pos_bias.as<float>(); a.pos_bias_stride = e->pe_rows; a.k_prefolded = 1; a.fold_kv_cap = cap; }
     }
     a.q_stride = a.k_stride = a.v_stride = 3 * d; a.p_stride = d; a.o_stride = d;
     a.bias_u = L.bias_u.as<float>(); a.bias_v = L.bias_v.as<float>();

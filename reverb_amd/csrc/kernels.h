@@ -180,6 +180,7 @@ struct AttnArgs {
   // (pos_bias_v - pos_bias_u)[head] . p[j][head] * log2(e) / sqrt(dk) for positional row j of `p` (same row offset as `p`); null = two products
   const float* pos_bias;
   int pos_bias_stride;
+  int fold_kv_cap;       // with pos_bias: keys whose constants the kernel keeps in LDS (a multiple of 64, >= every sequence's kv_len; <= 16384); 0 = do not fold
   int k_prefolded;       // with pos_bias: `k` already holds K' = k + p (written by the qkv GEMM, GemmArgs::rowadd): nothing to add while staging
 };
 // builds that table for positional keys P [rows, p_stride] (bf16): out fp32 [heads][rows]

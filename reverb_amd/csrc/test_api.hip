@@ -330,6 +330,9 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
     T_TRY(attention_pos_bias(nullptr, dp.p, p_rows, d, (const float*)du.p, (const float*)dvv.p, heads, dk, 1.44269504f / sqrtf((float)dk),
                              (float*)dc.p));
     a.pos_bias = (const float*)dc.p; a.pos_bias_stride = p_rows;
+    int mk = 0;
+    for (int i = 0; i < nseq; ++i) mk = kv_len[i] > mk ? kv_len[i] : mk;
+    a.fold_kv_cap = (mk + 63) / 64 * 64;
   }
   T_TRY(attention(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());
