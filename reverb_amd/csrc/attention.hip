@@ -56,10 +56,14 @@ struct AttnLds {
 // OCC: minimum waves per SIMD asked of the register allocator (1 = whatever the kernel needs).  The folded encoder form needs 94
 // VGPRs = two 8-wave workgroups per CU; OCC = 6 (lab switch RVB_ATTN_OCC=3: three workgroups per CU) squeezes it into 80 with 5 dwords
 // of scratch per lane.
-template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1>
+// MF: 16-query fragments per wave (round 6).  With MF = 2 a wave owns 32 queries: every K / V fragment it reads from LDS feeds two MFMAs,
+// a tile is staged and two barriers are passed for twice the work, and the second fragment's MFMAs are independent of the first
+// fragment's softmax -- the in-order wave has matrix work to issue beside its own VALU chain.
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1, int MF = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
   static_assert(!FOLD || (HAS_POS && sizeof(T) == 2), "the folded positional term is built for the bf16 encoder form");
-  constexpr int QT = 16 * NW;
+  static_assert(MF == 1 || FOLD == 2, "two fragments per wave: built for the prefolded encoder form");
+  constexpr int QT = 16 * NW * MF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AttnLds<T, DKP, HAS_POS, FOLD, PADK>;
   constexpr bool BF = sizeof(T) == 2;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
   // position of the sequence's first query among its keys (causal mask): 0 when queries and keys are the same rows;
   // a hypothesis that shares its first d tokens with an earlier one only computes rows d.. (rescoring trie)
   const int pos0 = a.q_pos0 ? a.q_pos0[seq] : 0;
-  const int* __restrict__ kvi = a.kv_index ? a.kv_index + ks : nullptr;   // key j lives in row kvi[j] instead of ks + j
+  const int* __restrict__ kvi = (MF == 1 && a.kv_index) ? a.kv_index + ks : nullptr;   // key j lives in row kvi[j] instead of ks + j (MF = 2: the encoder's form, no index list)
   const int dk = a.dk;
   const T* Q = (const T*)a.q;
   const T* K = (const T*)a.k;
@@ -116,16 +120,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
 
   const int lrow = lane & 15;          // operand row inside a fragment; in C layout: the column
   const int lgrp = lane >> 4;          // 16-byte vector of a 64-byte chunk; in C layout: rows 4*lgrp..+3
-  const int my_q = q0 + wave * 16 + lrow;        // the query this lane's accumulator column belongs to
+  int my_q[MF];                                   // the queries this lane's accumulator columns belong to
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) my_q[mf] = q0 + (wave * MF + mf) * 16 + lrow;
 
   // bf16: exp(x/sqrt(dk)) = exp2(x * log2(e)/sqrt(dk)); the factor is folded into the q operands
   const float qscale = BF ? 1.44269504f / a.sqrt_dk : 1.0f;
 
   // ---- query operands: this wave's 16 queries, biased copies (rows >= qlen are zero) ----
-  uint4 qu[NCH], qv[HAS_POS ? NCH : 1];
-  {
-    const bool rok = my_q < qlen;
-    const T* qp = Q + (size_t)(qs + (rok ? my_q : 0)) * a.q_stride + head * dk;
+  uint4 qu[MF][NCH], qv[HAS_POS ? NCH : 1];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const bool rok = my_q[mf] < qlen;
+    const T* qp = Q + (size_t)(qs + (rok ? my_q[mf] : 0)) * a.q_stride + head * dk;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int e0 = ch * KC + lgrp * VE;
@@ -143,19 +150,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
           ou[e] = Cvt<T>::from_f32(ok ? (qf + bu) * qscale : 0.f);
           ov[e] = Cvt<T>::from_f32(ok ? (qf + bvv) * qscale : 0.f);
         }
-        qu[ch] = *(uint4*)ou;
+        qu[mf][ch] = *(uint4*)ou;
         if constexpr (HAS_POS && !FOLD) qv[ch] = *(uint4*)ov;
       } else {
-        qu[ch] = raw;
+        qu[mf][ch] = raw;
         if constexpr (HAS_POS && !FOLD) qv[ch] = raw;
       }
     }
   }
 
-  f32x4_t o[NOF];                      // O^T: lane holds dims 16f + 4*lgrp + r of its query
+  f32x4_t o[MF][NOF];                  // O^T: lane holds dims 16f + 4*lgrp + r of its query
+  float m_run[MF], l_run[MF];
 #pragma unroll
-  for (int f = 0; f < NOF; ++f) o[f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+    for (int f = 0; f < NOF; ++f) o[mf][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    m_run[mf] = -INFINITY; l_run[mf] = 0.f;
+  }
 
   char* sK = smem + L::OFF_K;
   char* sP = smem + L::OFF_P;
@@ -245,107 +256,117 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
     if (kt0 + KT < kend) gload(kt0 + KT);       // in flight under the MFMAs / softmax below
 
     // ---- S^T = K.Qu^T (+ P.Qv^T): fragment nf holds keys 16nf + 4*lgrp + r of query lrow ----
-    f32x4_t s[4];
+    f32x4_t s[MF][4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      if constexpr (FOLD) {         // the accumulation starts from the keys' constants: fragment nf = keys 16 nf + 4 lgrp + r
-        const float4 c4 = *(const float4*)(sC + (kt0 + nf * 16 + lgrp * 4) * 4);
-        s[nf] = (f32x4_t){c4.x, c4.y, c4.z, c4.w};
-      } else {
-        s[nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        if constexpr (FOLD) {         // the accumulation starts from the keys' constants: fragment nf = keys 16 nf + 4 lgrp + r
+          const float4 c4 = *(const float4*)(sC + (kt0 + nf * 16 + lgrp * 4) * 4);
+          s[mf][nf] = (f32x4_t){c4.x, c4.y, c4.z, c4.w};
+        } else {
+          s[mf][nf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const uint4 ak = *(const uint4*)(sK + (nf * 16 + lrow) * L::ROW_K + ch * 64 + lgrp * 16);
-        Mma16<T>::run(ak, qu[ch], s[nf]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) Mma16<T>::run(ak, qu[mf][ch], s[mf][nf]);
         if constexpr (HAS_POS && !FOLD) {
           const uint4 ap = *(const uint4*)(sP + (nf * 16 + lrow) * L::ROW_K + ch * 64 + lgrp * 16);
-          Mma16<T>::run(ap, qv[ch], s[nf]);
+          Mma16<T>::run(ap, qv[ch], s[0][nf]);
         }
       }
     }
-    // ---- scale (f32 mode), mask (only tiles that need it), online softmax of this lane's query ----
-    if constexpr (!BF) {
+    // ---- scale (f32 mode), mask (only tiles that need it), online softmax of this lane's queries ----
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+    for (int mf = 0; mf < MF; ++mf) {
+      if constexpr (!BF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[nf][r] = s[nf][r] / a.sqrt_dk;
-    }
-    if (a.causal || cs > 0 || kt0 + KT > kvlen) {          // block-uniform
-      int lo = 0, hi = kvlen;
-      if (cs > 0) {
-        const int ci = my_q / cs;
-        hi = min(kvlen, (ci + 1) * cs);
-        if (a.left >= 0) lo = max((ci - a.left) * cs, 0);
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[mf][nf][r] = s[mf][nf][r] / a.sqrt_dk;
       }
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt0 + nf * 16 + lgrp * 4 + r;
-          if (key >= hi || key < lo || (a.causal && key > pos0 + my_q)) s[nf][r] = -INFINITY;
+      if (a.causal || cs > 0 || kt0 + KT > kvlen) {          // block-uniform
+        int lo = 0, hi = kvlen;
+        if (cs > 0) {
+          const int ci = my_q[mf] / cs;
+          hi = min(kvlen, (ci + 1) * cs);
+          if (a.left >= 0) lo = max((ci - a.left) * cs, 0);
         }
-    }
-    float mx = -INFINITY;
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+        for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nf][r]);
-    mx = rows_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    // Branch-free since round 4: while every key so far is masked for this query (m_new = -inf) the reference point is 0, so that
-    // exp(-inf - 0) = 0 gives the zeros the old "all masked" branch wrote by hand -- hipcc had turned that branch into 18
-    // register clears + an exec-masked block that EVERY tile executed.  al = exp(-inf) = 0 instead of 1 there, on o = l = 0.
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    float al, ps;
-    if constexpr (BF) {
-      // pairs: the subtraction and the running sum are packed (v_pk_add_f32); the sum's order differs from the scalar loop's
-      // in the last bit at most (bf16 engine only: its probabilities are rounded to bf16 right below)
-      typedef float f32x2_t __attribute__((ext_vector_type(2)));
-      al = __builtin_amdgcn_exp2f(m_run - m_use);
-      const f32x2_t mm = {m_use, m_use};
-      f32x2_t acc = {0.f, 0.f};
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt0 + nf * 16 + lgrp * 4 + r;
+            if (key >= hi || key < lo || (a.causal && key > pos0 + my_q[mf])) s[mf][nf][r] = -INFINITY;
+          }
+      }
+      float mx = -INFINITY;
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const f32x2_t dd = (f32x2_t){s[nf][r], s[nf][r + 1]} - mm;
-          const f32x2_t pp = {__builtin_amdgcn_exp2f(dd.x), __builtin_amdgcn_exp2f(dd.y)};
-          s[nf][r] = pp.x; s[nf][r + 1] = pp.y;
-          acc += pp;
-        }
-      ps = acc.x + acc.y;
-    } else {
-      al = expf(m_run - m_use);
-      ps = 0.f;
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[mf][nf][r]);
+      mx = rows_max(mx);
+      const float m_new = fmaxf(m_run[mf], mx);
+      // Branch-free since round 4: while every key so far is masked for this query (m_new = -inf) the reference point is 0, so that
+      // exp(-inf - 0) = 0 gives the zeros the old "all masked" branch wrote by hand -- hipcc had turned that branch into 18
+      // register clears + an exec-masked block that EVERY tile executed.  al = exp(-inf) = 0 instead of 1 there, on o = l = 0.
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      float al, ps;
+      if constexpr (BF) {
+        // pairs: the subtraction and the running sum are packed (v_pk_add_f32); the sum's order differs from the scalar loop's
+        // in the last bit at most (bf16 engine only: its probabilities are rounded to bf16 right below)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        al = __builtin_amdgcn_exp2f(m_run[mf] - m_use);
+        const f32x2_t mm = {m_use, m_use};
+        f32x2_t acc = {0.f, 0.f};
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+        for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float pv = expf(s[nf][r] - m_use); s[nf][r] = pv; ps += pv; }
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t dd = (f32x2_t){s[mf][nf][r], s[mf][nf][r + 1]} - mm;
+            const f32x2_t pp = {__builtin_amdgcn_exp2f(dd.x), __builtin_amdgcn_exp2f(dd.y)};
+            s[mf][nf][r] = pp.x; s[mf][nf][r + 1] = pp.y;
+            acc += pp;
+          }
+        ps = acc.x + acc.y;
+      } else {
+        al = expf(m_run[mf] - m_use);
+        ps = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float pv = expf(s[mf][nf][r] - m_use); s[mf][nf][r] = pv; ps += pv; }
+      }
+      ps = rows_sum(ps);
+      l_run[mf] = l_run[mf] * al + ps;
+      m_run[mf] = m_new;
+#pragma unroll
+      for (int f = 0; f < NOF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[mf][f][r] *= al;
     }
-    ps = rows_sum(ps);
-    l_run = l_run * al + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int f = 0; f < NOF; ++f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[f][r] *= al;
 
     // ---- O^T += V^T.P^T : the lane's own probabilities are its B operand; the k slot (lgrp, e) of a
     //      key chunk is assigned key 16nf + 4*lgrp + r, and V^T is read with the same assignment ----
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-      uint4 pb;
-      if constexpr (BF) {
-        const f32x4_t& x0 = s[2 * kc];
-        const f32x4_t& x1 = s[2 * kc + 1];
-        pb.x = pack2_bf16(x0[0], x0[1]);
-        pb.y = pack2_bf16(x0[2], x0[3]);
-        pb.z = pack2_bf16(x1[0], x1[1]);
-        pb.w = pack2_bf16(x1[2], x1[3]);
-      } else {
-        const f32x4_t& x0 = s[kc];
-        pb = make_uint4(__float_as_uint(x0[0]), __float_as_uint(x0[1]), __float_as_uint(x0[2]), __float_as_uint(x0[3]));
+      uint4 pb[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        if constexpr (BF) {
+          const f32x4_t& x0 = s[mf][2 * kc];
+          const f32x4_t& x1 = s[mf][2 * kc + 1];
+          pb[mf].x = pack2_bf16(x0[0], x0[1]);
+          pb[mf].y = pack2_bf16(x0[2], x0[3]);
+          pb[mf].z = pack2_bf16(x1[0], x1[1]);
+          pb[mf].w = pack2_bf16(x1[2], x1[3]);
+        } else {
+          const f32x4_t& x0 = s[mf][kc];
+          pb[mf] = make_uint4(__float_as_uint(x0[0]), __float_as_uint(x0[1]), __float_as_uint(x0[2]), __float_as_uint(x0[3]));
+        }
       }
 #pragma unroll
       for (int f = 0; f < NOF; ++f) {
@@ -366,46 +387,49 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_kernel(AttnArgs a) {
         } else {
           va = *(const uint4*)(vrow + ((16 * kc + 4 * lgrp) ^ swz) * 4);
         }
-        Mma16<T>::run(va, pb, o[f]);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) Mma16<T>::run(va, pb[mf], o[mf][f]);
       }
     }
     __syncthreads();
   }
 
   // ---- normalise and store: 4 consecutive dims per fragment ----
-  if (my_q < qlen) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    T* orow = (T*)a.out + (size_t)(qs + my_q) * a.o_stride + head * dk;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    if (my_q[mf] >= qlen) continue;
+    const float inv = l_run[mf] > 0.f ? 1.0f / l_run[mf] : 0.f;
+    T* orow = (T*)a.out + (size_t)(qs + my_q[mf]) * a.o_stride + head * dk;
 #pragma unroll
     for (int f = 0; f < NOF; ++f) {
       const int c0 = f * 16 + lgrp * 4;
       if (c0 + 4 <= dk && ((a.o_stride * (int)sizeof(T)) % (BF ? 8 : 16)) == 0) {
         if constexpr (BF) {
           uint2 pk;
-          pk.x = pack2_bf16(o[f][0] * inv, o[f][1] * inv);
-          pk.y = pack2_bf16(o[f][2] * inv, o[f][3] * inv);
+          pk.x = pack2_bf16(o[mf][f][0] * inv, o[mf][f][1] * inv);
+          pk.y = pack2_bf16(o[mf][f][2] * inv, o[mf][f][3] * inv);
           *(uint2*)(orow + c0) = pk;
         } else {
-          *(float4*)(orow + c0) = make_float4(o[f][0] * inv, o[f][1] * inv, o[f][2] * inv, o[f][3] * inv);
+          *(float4*)(orow + c0) = make_float4(o[mf][f][0] * inv, o[mf][f][1] * inv, o[mf][f][2] * inv, o[mf][f][3] * inv);
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (c0 + r < dk) orow[c0 + r] = Cvt<T>::from_f32(o[f][r] * inv);
+        for (int r = 0; r < 4; ++r) if (c0 + r < dk) orow[c0 + r] = Cvt<T>::from_f32(o[mf][f][r] * inv);
       }
     }
   }
 }
 
-template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1>
+template <typename T, int DKP, bool HAS_POS, int NW, int FOLD = 0, int PADK = 32, int OCC = 1, int MF = 1>
 static int launch_attn(hipStream_t s, const AttnArgs& a) {
   using L = AttnLds<T, DKP, HAS_POS, FOLD, PADK>;
   static bool attr_set = false;
-  auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD, PADK, OCC>;
+  auto kern = attn_kernel<T, DKP, HAS_POS, NW, FOLD, PADK, OCC, MF>;
   if (!attr_set) {
     RVB_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL + (FOLD ? 64 * 1024 : 0)));
     attr_set = true;
   }
-  dim3 grid(cdiv(a.max_q, 16 * NW), a.heads, a.nseq);
+  dim3 grid(cdiv(a.max_q, 16 * NW * MF), a.heads, a.nseq);
   if (a.work) grid = dim3(a.n_work, a.heads, 1);
   if (grid.x == 0) return OK;
   const int fold_bytes = FOLD ? a.fold_kv_cap * 4 : 0;
@@ -424,6 +448,13 @@ static int dispatch_attn(hipStream_t s, const AttnArgs& a) {
     {
       static const int occ = lab_env("RVB_ATTN_OCC") ? atoi(lab_env("RVB_ATTN_OCC")) : 2;      // workgroups per CU asked for (lab A/B)
       if (a.k_prefolded && occ == 3) return launch_attn<T, 64, true, 8, 2, 32, 6>(s, a);
+      // Two 16-query fragments per wave, 256 queries per workgroup, held to 128 VGPRs = two workgroups per CU (round 6; lab switch
+      // RVB_ATTN_MF=0 = one fragment per wave): 8.13 -> 7.25 ms per hour of audio.  Measured beside it and dropped
+      // (profiles/r06_call11_*, r06_call13_*): the same with 4 waves / 128 queries (149 VGPRs: 10.2 ms), with 8 waves at the
+      // allocator's own 133 VGPRs (one workgroup per CU: 9.2 ms), with 16 waves / 512 queries (8.17 ms), and softmax + P.V fragment by
+      // fragment in one basic block (8.55 ms: hipcc does not interleave the two chains and the V fragments are read twice).
+      static const int mfv = lab_env("RVB_ATTN_MF") ? atoi(lab_env("RVB_ATTN_MF")) : 1;
+      if (a.k_prefolded && a.work == nullptr && a.kv_index == nullptr && a.q_block == 0 && a.max_q > 128 && mfv != 0) return launch_attn<T, 64, true, 8, 2, 32, 4, 2>(s, a);
       return a.k_prefolded ? launch_attn<T, 64, true, 8, 2>(s, a) : launch_attn<T, 64, true, 8, 1>(s, a);
     }
     // A/B switch for the encoder's form (dk 33..64, 128-query workgroups, positional keys): RVB_ATTN_PADK=16 = the 144-byte row
