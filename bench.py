@@ -21,6 +21,7 @@ At N = 1 the same JSON line also carries
   joint_fp8         BASELINE configs[4] as a sub-record (bench_joint.py: 3 h recording, ASR + diarization with their fp8 GEMMs,
                     word->speaker join; carries sharded_s / replicated_s for the 8-GPU arithmetic)
   parity_f32, asr_fp8, r268   the headline step in the exact-parity mode, with fp8 GEMMs, and on the smaller planning point
+  two_streams                 the headline hour as two half-hour engines on two HIP streams (throughput of a service, no roofline)
   cpu_baseline      the oracle (CPU port of the reference) on the first chunks of the same workload
 """
 from __future__ import annotations
@@ -305,6 +306,62 @@ def asr_variant(local_rank, model, dtype, hours, beam, ctc_weight, reverse_weigh
     return rec
 
 
+def asr_two_streams(local_rank, model, dtype, hours, beam, ctc_weight, reverse_weight, steps=4, warmup=2, state=None):
+    """The headline hour as TWO engines with half of the chunks each, on their own HIP streams, driven by two host threads
+    (a service that decodes two recordings at a time).  The tile-count tails of the N = 1024 GEMMs (1 408 tiles on 256 CUs =
+    5.5 rounds), the lock-step epilogue bursts and the host's share of the search fill up with the other stream's work:
+    about 4 % more audio per second than one engine with the whole hour (profiles/r06_call10_*).  A sub-record, not the headline:
+    two streams share the GPU, so a GEMM launch's duration no longer measures the kernel (no per-launch roofline here)."""
+    import threading
+    import torch
+    from reverb_amd import synth
+    from reverb_amd.engine import Engine
+    chunk = 2051
+    seconds = hours * 3600.0 / 2
+    n_samples = int(round(seconds * 16000))
+    n_chunks = -(-(1 + (n_samples - 400) // 160) // chunk)
+    cfg, sd = state if state is not None else synth.calibrated_state_dict(model, 0)
+    engs = [Engine(cfg, sd, dtype=dtype, device=local_rank, max_chunks=n_chunks, chunk_frames=chunk) for _ in range(2)]
+    del sd
+    try:
+        for i, eng in enumerate(engs):
+            pcm = eng.pinned_pcm(n_samples)
+            pcm[:] = synth.synth_audio(seconds, seed=1234 + i)
+            eng.upload_pcm(pcm)
+        toks, errs = [0, 0], []
+
+        def work(i, k):
+            try:
+                for _ in range(k):
+                    hyps = engs[i].decode_resident(engs[i].fbank(), ["attention_rescoring"], chunk, beam, ctc_weight, reverse_weight)
+                    toks[i] = sum(len(h.tokens) for h in hyps["attention_rescoring"])
+            except Exception as ex:        # noqa: BLE001 -- reported by the caller's thread
+                errs.append(ex)
+
+        def run(k):
+            th = [threading.Thread(target=work, args=(i, k)) for i in range(2)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            if errs:
+                raise errs[0]
+            return time.perf_counter() - t0
+
+        run(max(warmup, 1))
+        dt = run(steps)
+    finally:
+        for eng in engs:
+            eng.close()
+    return {"value": round(2 * seconds * steps / dt, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(dt / steps * 1e3, 2),
+            "steps": steps, "warmup": max(warmup, 1), "dtype": dtype, "tokens_per_step": int(sum(toks)),
+            "workload": f"the headline hour as two engines x {n_chunks} chunks, one HIP stream and one host thread each",
+            "note": "throughput of two concurrent half-hour recordings; per-launch kernel durations overlap, so no roofline object"}
+
+
 # ------------------------------------------------------------------------------------------------ the line
 def write_long_form(out):
     """The full record (every sub-record with its stage tables, methods and notes) goes to gpurun_out/bench_long.json (or
@@ -356,7 +413,7 @@ def compact(out, long_path=None):
     line["cpu_baseline"] = dict(cb, sample=cb["sample"][:130]) if cb else None
     if out.get("xgmi_allgather"):
         line["xgmi_allgather"] = {k: out["xgmi_allgather"][k] for k in ("bytes_per_rank", "ms", "busbw_GBps")}
-    for k in ("pcie_inclusive", "parity_f32", "asr_fp8", "r268"):
+    for k in ("pcie_inclusive", "two_streams", "parity_f32", "asr_fp8", "r268"):
         if out.get(k) is not None:
             line[k] = _brief(out[k])
     if out.get("diarization") is not None:
@@ -651,6 +708,10 @@ def main():
                                            state=state if model == args.model else None, **kw)
                 except Exception as ex:
                     out[key] = {"error": f"{type(ex).__name__}: {ex}"}
+            try:
+                out["two_streams"] = asr_two_streams(local_rank, args.model, args.dtype, state=state, **kw)
+            except Exception as ex:
+                out["two_streams"] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in the C stdout buffer: get it out first,
