@@ -26,6 +26,35 @@ def seeds():
             b"FORM" + struct.pack(">I", 17) + b"AIFF" + b"ANNO" + struct.pack(">I", 5) + b"hello"]
 
 
+def mp3_seeds():
+    """Layer III streams of tests/mp3_writer.py (MPEG-1 / 2 / 2.5, joint stereo, block switching, CRC, reservoir) + the real file;
+    the synthesis window the encoder's analysis needs is read from the lab library (built by `python -m reverb_amd.build`)."""
+    import ctypes as C
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import mp3_writer as Wr
+    G = Wr.GranuleCfg
+    lib = C.CDLL(os.path.join(here, "reverb_amd", "librvb_test.so"))
+    w = np.zeros(512, np.float32)
+    lib.rvb_test_mp3_window(w.ctypes.data_as(C.POINTER(C.c_float)))
+    w = w.astype(np.float64)
+    rng = np.random.default_rng(5)
+    bt = lambda g: [0, 0, 1, 2, 2, 3, 0, 1, 2, 3][g % 10]
+
+    def sig(n, nch):
+        t = np.arange(n)
+        return np.stack([0.1 * np.sin(0.05 * (c + 1) * t) + 0.02 * rng.standard_normal(n) for c in range(nch)])
+
+    out = [Wr.Encoder(44100, 2, 128, w, mode=1, mode_ext=2, plan=lambda g: G(bt(g))).encode(sig(1152 * 4, 2)),
+           Wr.Encoder(48000, 1, 96, w, scfsi=True, crc=True, seed=2).encode(sig(1152 * 4, 1)),
+           Wr.Encoder(22050, 2, 64, w, plan=lambda g: G(bt(g), bt(g) != 0 and g % 2 == 0), seed=3).encode(sig(576 * 6, 2)),
+           Wr.Encoder(8000, 1, 32, w, plan=lambda g: G(bt(g)), seed=4).encode(sig(576 * 6, 1)),
+           Wr.Encoder(44100, 1, 64, w, bit_share=lambda f: 0.25 if f % 3 else 3.0, seed=7).encode(sig(1152 * 6, 1))]
+    real = open(os.path.join(here, "tests", "golden", "mathjax_invalid_keypress.mp3"), "rb").read()
+    out.append(real)                 # 43 frames: enough for decode() to split it over up to 5 threads
+    return [bytes(x) for x in out]
+
+
 def _riff(body):
     return b"RIFF" + struct.pack("<I", len(body)) + body
 
@@ -52,6 +81,8 @@ def mutate(d, rng):
 def main():
     path, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40000
     rng, base = np.random.default_rng(1), seeds()
+    if os.environ.get("FUZZ_MP3", "1") != "0":
+        base = base + mp3_seeds()
     with open(path, "wb") as f:
         for it in range(n):
             d = mutate(base[it % len(base)], rng)
