@@ -300,10 +300,125 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(PoolNormArgs p) {
   }
 }
 
+// bf16, 16-byte vectors (round 6): thread = (group of 8 channels, slot); the scalar form above issues one 2-byte load per channel and
+// pooled frame (three per pooled value, twice: statistics, then output) and is bound by load issue -- 5.2 ms per hour for the first
+// layer, whose 18 GB of (cached) reads would take 3 ms at the HBM rate.  Same arithmetic per element; the fp64 partial sums of a
+// channel are added over slots in a fixed order (another order than the scalar form's: 1e-16 relative on the statistics).
+template <bool FIRST>
+__global__ __launch_bounds__(256) void pool_norm_vec_kernel(PoolNormArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double pnv_red[];       // [2][nslots][CG * 8]
+  __shared__ float s_scale[128], s_shift[128];
+  const int w = blockIdx.x;
+  const int ldi = FIRST ? p.C : p.ld_in;               // input row stride (elements)
+  const int CG = p.ld_out / 8;                          // channel groups of 8 (ld_out covers C)
+  const int nslots = 256 / CG;
+  const int g = threadIdx.x % CG, slot = threadIdx.x / CG;
+  const bool active = slot < nslots;
+  const int TP = p.frames_in / 3;
+  const int c0 = g * 8;
+
+  float a = 0.f, off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) off[e] = 0.f;
+  const bf16_t* src;
+  if (FIRST) {
+    const float mean = p.stats[2 * w], rstd = p.stats[2 * w + 1];
+    a = p.wn_gamma * rstd;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) off[e] = (c0 + e < p.C) ? (p.wn_beta - a * mean) * p.fsum[c0 + e] : 0.f;
+    src = (const bf16_t*)p.craw + (p.craw_frame0 + (int64_t)w * p.craw_frames_per_step) * p.C + c0;
+  } else {
+    src = (const bf16_t*)p.x + (size_t)w * p.rows_in * p.ld_in + c0;
+  }
+  auto pooled = [&](int tp, float (&v)[8]) {
+    const bf16_t* q = src + (size_t)(3 * tp) * ldi;
+    const uint4 r0 = *(const uint4*)q, r1 = *(const uint4*)(q + ldi), r2 = *(const uint4*)(q + 2 * ldi);
+    const bf16_t* b0 = (const bf16_t*)&r0;
+    const bf16_t* b1 = (const bf16_t*)&r1;
+    const bf16_t* b2 = (const bf16_t*)&r2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (FIRST) {
+        const float v0 = fabsf(fmaf(a, bf16_to_f32(b0[e]), off[e])), v1 = fabsf(fmaf(a, bf16_to_f32(b1[e]), off[e])),
+                    v2 = fabsf(fmaf(a, bf16_to_f32(b2[e]), off[e]));
+        v[e] = fmaxf(v0, fmaxf(v1, v2));
+      } else {
+        v[e] = fmaxf(bf16_to_f32(b0[e]), fmaxf(bf16_to_f32(b1[e]), bf16_to_f32(b2[e])));
+      }
+    }
+  };
+  double s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.0; ss[e] = 0.0; }
+  if (active)
+    for (int tp = slot; tp < TP; tp += nslots) {
+      float v[8];
+      pooled(tp, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += v[e]; ss[e] += (double)v[e] * v[e]; }
+    }
+  double* r_sum = pnv_red;
+  double* r_sq = pnv_red + nslots * CG * 8;
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r_sum[slot * CG * 8 + c0 + e] = s[e]; r_sq[slot * CG * 8 + c0 + e] = ss[e]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < CG * 8) {
+    const int c = threadIdx.x;
+    if (c < p.C) {
+      double ts = 0.0, tq = 0.0;
+      for (int k = 0; k < nslots; ++k) { ts += r_sum[k * CG * 8 + c]; tq += r_sq[k * CG * 8 + c]; }
+      const double mean = ts / TP;
+      double var = tq / TP - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+      const float gm = p.gamma[c] * rstd;
+      s_scale[c] = gm;
+      s_shift[c] = p.beta[c] - (float)mean * gm;
+    } else {
+      s_scale[c] = 0.f; s_shift[c] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = s_scale[c0 + e]; sh[e] = s_shift[c0 + e]; }
+  bf16_t* out = (bf16_t*)p.out + (size_t)w * TP * p.ld_out + c0;
+  for (int tp = slot; tp < TP; tp += nslots) {
+    float v[8];
+    pooled(tp, v);
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = fmaf(v[e], sc[e], sh[e]);
+      y = y > 0.f ? y : 0.01f * y;
+      o[e] = (c0 + e < p.C) ? f32_to_bf16(y) : f32_to_bf16(0.f);
+    }
+    *(uint4*)(out + (size_t)tp * p.ld_out) = *(const uint4*)o;
+  }
+}
+
 int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a) {
   if (a.W <= 0) return OK;
   if (a.ld_out > 128 || a.ld_out < a.C || a.C < 1) { set_error("pool_norm: channels must be <= ld_out <= 128"); return E_ARG; }
   const bool first = a.x == nullptr;
+  {
+    static const int vec = lab_env("RVD_POOLNORM_VEC") ? atoi(lab_env("RVD_POOLNORM_VEC")) : 1;      // lab: 0 = the scalar form
+    const int ldi = first ? a.C : a.ld_in;
+    const uintptr_t base = first ? (uintptr_t)a.craw : (uintptr_t)a.x;
+    if (vec && dtype == DT_BF16 && (ldi % 8) == 0 && (a.ld_out % 8) == 0 && a.ld_out >= 8 && (base % 16) == 0 && ((uintptr_t)a.out % 16) == 0 &&
+        (!first || ((a.craw_frame0 * a.C) % 8 == 0 && ((int64_t)a.craw_frames_per_step * a.C) % 8 == 0)) &&
+        (first || ((size_t)a.rows_in * a.ld_in) % 8 == 0)) {
+      const int CG = a.ld_out / 8, nslots = 256 / CG;
+      const size_t lds = (size_t)2 * nslots * CG * 8 * sizeof(double);
+      if (first) hipLaunchKernelGGL((pool_norm_vec_kernel<true>), dim3(a.W), dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((pool_norm_vec_kernel<false>), dim3(a.W), dim3(256), lds, s, a);
+      RVB_HIP_CHECK(hipGetLastError());
+      return OK;
+    }
+  }
   if (dtype == DT_BF16) {
     if (first) hipLaunchKernelGGL((pool_norm_kernel<bf16_t, true>), dim3(a.W), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((pool_norm_kernel<bf16_t, false>), dim3(a.W), dim3(256), 0, s, a);
