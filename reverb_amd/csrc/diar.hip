@@ -430,6 +430,142 @@ int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a) {
   return OK;
 }
 
+// ------------------------------------------------------------------------------------ SincNet conv layers 2 and 3 (kernel 5, 60 filters)
+// out[m][n] = bias[n] + sum_{k < 5 CIN} A[m * CIN + k] * W[n][k]: row m of the im2col matrix is frames m .. m + 4 of the activation
+// tensor [rows][CIN], which are contiguous -- no im2col buffer.  As a GEMM this is [19 M x 400] x [400 x 64]: too thin for the 256 x 256
+// tile (three quarters of its columns idle) and, at K = 400, not a multiple of its K step; on the generic 128 x 128 kernel it ran at
+// 160 TFLOP/s, 6 ms per hour for layer 2.  Here: persistent workgroups (8 waves), the 64 x (5 CIN) weight matrix resident in LDS, 256
+// frames per tile staged through registers into one of two LDS buffers (rows padded so that 16 rows hit 16 different bank groups) while
+// the previous tile is multiplied; wave = 64 frames x 32 filters (v_mfma_f32_16x16x32_bf16, the weights as the A operand so that a lane
+// ends up with four consecutive filters of one frame: 8-byte stores).  K = 400 is 12.5 MFMA steps: the lanes of the last half step feed zeros.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv1d5_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ out, int64_t M) {
+  constexpr int K = 5 * CIN, KS = (K + 31) / 32, KP = KS * 32;
+  constexpr int WS = KP * 2 + 16;                 // weight row pitch (bytes): an odd multiple of 16 mod 256
+  constexpr int RS = CIN * 2 + 16;                // frame row pitch (bytes): 176 / 144, odd multiples of 16
+  constexpr int TM = 256, ROWS = TM + 4;
+  constexpr int VPR = CIN / 8;                    // 16-byte vectors per frame
+  constexpr int NV = (ROWS * VPR + 511) / 512;
+  static_assert((WS / 16) % 2 == 1 && (RS / 16) % 2 == 1, "bank-conflict-free pitches");
+  extern __shared__ __attribute__((aligned(16))) char c5_smem[];
+  char* sW = c5_smem;                             // [64][WS]
+  char* sA = c5_smem + 64 * WS;                   // [2][ROWS][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, lgrp = lane >> 4;
+  // weights -> LDS (zero beyond K)
+  for (int i = tid; i < 64 * (KP / 8); i += 512) {
+    const int n = i / (KP / 8), v = i - n * (KP / 8);
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (v * 8 < K) w = *(const uint4*)(Wt + (size_t)n * K + v * 8);
+    *(uint4*)(sW + n * WS + v * 16) = w;
+  }
+  const int64_t ntiles = (M + TM - 1) / TM;
+  uint4 ra[NV];
+  auto gload = [&](int64_t tile) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * 512;
+      const int r = v / VPR, c = v - r * VPR;
+      int64_t row = tile * TM + r;
+      row = row < M + 3 ? row : M + 3;            // the buffer holds M + 8 rows; what lies past M feeds only the rows nobody reads
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (v < ROWS * VPR) ra[i] = *(const uint4*)(A + row * CIN + c * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * 512;
+      if (v < ROWS * VPR) { const int r = v / VPR, c = v - r * VPR; *(uint4*)(sA + (size_t)buf * ROWS * RS + r * RS + c * 16) = ra[i]; }
+    }
+  };
+  // this lane's byte offset inside its frame row for MFMA step ks (k = 32 ks + 8 lgrp: frame k / CIN, channel k % CIN)
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) { const int k = 32 * ks + 8 * lgrp; koff[ks] = (k / CIN) * RS + (k % CIN) * 2; }
+  const int wm = wave >> 1, wn = wave & 1;        // wave: frames [64 wm, +64), filters [32 wn, +32)
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = bias[wn * 32 + j * 16 + lgrp * 4 + r];
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) gload(tile);
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    lstore(buf);
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){bv[j][0], bv[j][1], bv[j][2], bv[j][3]};
+    const char* ab = sA + (size_t)buf * ROWS * RS + (wm * 64 + lrow) * RS;
+    const char* wb = sW + (wn * 32 + lrow) * WS + lgrp * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 wf[2], af[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *(const uint4*)(wb + j * 16 * WS + ks * 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const uint4*)(ab + i * 16 * RS + koff[ks]);
+        if (K % 32 != 0 && ks == KS - 1 && 32 * ks + 8 * lgrp >= K) af[i] = make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          union U { uint4 u; bf16x8_t v; } ua, ub;
+          ua.u = wf[j]; ub.u = af[i];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+        }
+    }
+    // D^T fragment (i, j): lane = frame 16 i + lrow, filters 16 j + 4 lgrp + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = tile * TM + wm * 64 + i * 16 + lrow;
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint2 pk;
+          pk.x = pack2_bf16(acc[i][j][0], acc[i][j][1]);
+          pk.y = pack2_bf16(acc[i][j][2], acc[i][j][3]);
+          *(uint2*)(out + m * 64 + wn * 32 + j * 16 + lgrp * 4) = pk;
+        }
+      }
+    }
+  }
+}
+
+int conv1d5(hipStream_t s, int dtype, const void* A, int cin, const void* W, const float* bias, void* out, int64_t M) {
+  if (dtype != DT_BF16 || (cin != 80 && cin != 64)) { set_error("conv1d5: built for bf16 and 80 or 64 input channels"); return E_UNSUPPORTED; }
+  if (M <= 0) return OK;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    RVB_HIP_CHECK(hipGetDevice(&dev));
+    RVB_HIP_CHECK(hipGetDeviceProperties(&pr, dev));
+    ncu = pr.multiProcessorCount;
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv1d5_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RVB_HIP_CHECK(hipFuncSetAttribute((const void*)conv1d5_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  const int64_t ntiles = (M + 255) / 256;
+  const int grid = (int)std::min<int64_t>(ntiles, ncu);
+  if (cin == 80) {
+    const size_t lds = 64 * (13 * 64 + 16) + 2 * 260 * (160 + 16);
+    hipLaunchKernelGGL(conv1d5_kernel<80>, dim3(grid), dim3(512), lds, s, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)out, M);
+  } else {
+    const size_t lds = 64 * (10 * 64 + 16) + 2 * 260 * (128 + 16);
+    hipLaunchKernelGGL(conv1d5_kernel<64>, dim3(grid), dim3(512), lds, s, (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)out, M);
+  }
+  RVB_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
 // ------------------------------------------------------------------------------------ LSTM recurrence
 // One block = 16 windows x one direction, 4 waves; wave v owns hidden units [32v, 32v+32) and therefore the
 // four gate columns {q*128 + unit} of each: the i/f/g/o pre-activations of a (window, unit) pair land in

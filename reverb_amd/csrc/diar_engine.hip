@@ -209,6 +209,17 @@ int run_gemm(rvd_engine* e, const char* name, const void* A, int lda, const Line
   return gemm(e->stream, e->dtype, g);
 }
 
+// conv layers 2 / 3 of SincNet: the thin-GEMM kernel of diar.hip (bf16; lab: RVD_CONV1D5=0 = the generic GEMM)
+int run_sincnet_conv(rvd_engine* e, const void* A, int cin, const Linear& L, void* C, int ldc, int64_t M) {
+  static const int on = lab_env("RVD_CONV1D5") ? atoi(lab_env("RVD_CONV1D5")) : 1;
+  if (on && e->dtype == DT_BF16 && (cin == 80 || cin == 64) && L.out == 64 && ldc == 64 && L.in == 5 * cin && L.b.p) {
+    DScope sc(e, "sincnet_conv", 2.0 * (double)M * L.out * L.in);
+    return conv1d5(e->stream, e->dtype, A, cin, L.w.p, L.b.as<float>(), C, M);
+  }
+  return run_gemm(e, "sincnet_conv", A, cin, L, C, ldc, M, ACT_NONE);
+}
+
+
 int finalize_embedding(rvd_engine* e);
 
 int finalize_impl(rvd_engine* e) {
@@ -314,12 +325,12 @@ int segment_impl(rvd_engine* e, int64_t first, int W, float* logp_out) {
     pn.craw_frames_per_step = c.step_samples / SINC_STRIDE;
     pn.stats = e->stats.as<float>(); pn.fsum = e->fsum.as<float>(); pn.wn_gamma = e->wn_gamma; pn.wn_beta = e->wn_beta;
     RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
-  RVD_TRY(run_gemm(e, "sincnet_conv", e->a1.p, NF, e->conv2, e->c2.p, CP, R1, ACT_NONE));
+  RVD_TRY(run_sincnet_conv(e, e->a1.p, NF, e->conv2, e->c2.p, CP, R1));
   { DScope sc(e, "pool_norm");
     pn.x = e->c2.p; pn.rows_in = e->p1; pn.ld_in = CP; pn.frames_in = e->f2; pn.C = c.sinc_channels; pn.ld_out = CP;
     pn.gamma = e->norm[1].g.as<float>(); pn.beta = e->norm[1].b.as<float>(); pn.out = e->a2.p;
     RVD_TRY(pool_norm(e->stream, e->dtype, pn)); }
-  RVD_TRY(run_gemm(e, "sincnet_conv", e->a2.p, CP, e->conv3, e->c3.p, CP, R2, ACT_NONE));
+  RVD_TRY(run_sincnet_conv(e, e->a2.p, CP, e->conv3, e->c3.p, CP, R2));
   { DScope sc(e, "pool_norm");
     pn.x = e->c3.p; pn.rows_in = e->p2; pn.ld_in = CP; pn.frames_in = e->f3; pn.C = c.sinc_channels; pn.ld_out = CP;
     pn.gamma = e->norm[2].g.as<float>(); pn.beta = e->norm[2].b.as<float>(); pn.out = e->a3.p;

@@ -221,6 +221,9 @@ struct PoolNormArgs {
   const float* stats; const float* fsum; float wn_gamma, wn_beta;
 };
 int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a);
+// SincNet conv layers 2 / 3 (Conv1d kernel 5, 64 padded filters) straight from the [rows + 8][cin] activation tensor (bf16; cin 80 or 64):
+// out[m][0..63] = bias + W[64][5 cin] . A[m cin .. (m + 5) cin); W as pack_conv1d lays it out
+int conv1d5(hipStream_t s, int dtype, const void* A, int cin, const void* W, const float* bias, void* out, int64_t M);
 
 // One bidirectional LSTM layer's recurrence (hidden 128).  xproj T [W*T, 8H] = x.Wih^T + b_ih + b_hh for
 // (forward | reverse) gates i,f,g,o; whh T [2][4H][H]; out T [W*T, 2H].
