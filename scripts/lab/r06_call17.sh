@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call 17: the segmentation of the windows behind the first trunk pass on its own stream, underneath that pass (RVD_SEG_OVERLAP=1, default) against all windows first (0): segmentation tests + stage times
+# round 6, call 17: the segmentation of the windows behind the first trunk pass on its own stream, underneath that pass (RVD_SEG_OVERLAP=1, default) against all windows first (0): segmentation tests + stage times -- the code of this experiment is not in the tree (profiles/r06_call17_*)
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_call17; rm -rf $O; mkdir -p $O
 export PYTHONPATH=$R TMPDIR=/tmp
