@@ -572,7 +572,7 @@ int conv1d5(hipStream_t s, int dtype, const void* A, int cin, const void* W, con
 // the same lane of four accumulator fragments, so the cell update is lane-local.  The recurrent weights
 // (4H x H) stay in registers as MFMA B fragments for all 589 steps (bf16: 128 VGPRs per lane); h_t goes
 // through a double-buffered 4 KB LDS tile to become the next step's A operand; the input projection of
-// step t+1 is prefetched while step t runs.
+// step t+1 is prefetched while step t runs (its columns permuted at load time so that a lane reads one vector per window).
 template <typename T> struct GateMath;
 template <> struct GateMath<float> {
   __device__ static inline float sig(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -618,14 +618,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void lstm_kernel(const
   }
   const int ucol = 32 * wv + col;     // + 16*hf
   float xpv[4][2][4];
+  // the projection's columns come in the order this kernel reads them (diar_engine.hip: column 128 v + 8 c + 2 q + hf of a direction):
+  // a lane's eight starting values of a window and step are one 16-byte vector (two for fp32)
   auto load_xp = [&](int t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const T* xp = xproj + (xrow[r] + t) * (size_t)(8 * H) + dir * 4 * H + ucol;
+      const T* xp = xproj + (xrow[r] + t) * (size_t)(8 * H) + dir * 4 * H + 128 * wv + 8 * col;
+      T v8[8];
+      if constexpr (sizeof(T) == 2) { *(uint4*)v8 = *(const uint4*)xp; }
+      else { *(uint4*)v8 = *(const uint4*)xp; *(uint4*)(v8 + 4) = *(const uint4*)(xp + 4); }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) xpv[q][hf][r] = Cvt<T>::to_f32(xp[q * H + 16 * hf]);
+        for (int hf = 0; hf < 2; ++hf) xpv[q][hf][r] = Cvt<T>::to_f32(v8[2 * q + hf]);
     }
   };
 

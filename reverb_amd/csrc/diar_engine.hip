@@ -256,9 +256,14 @@ int finalize_impl(rvd_engine* e) {
       RVD_TRY(need(e, S + "lstm.weight_hh" + suf, (size_t)4 * H * H, &wh));
       RVD_TRY(need(e, S + "lstm.bias_ih" + suf, (size_t)4 * H, &bi));
       RVD_TRY(need(e, S + "lstm.bias_hh" + suf, (size_t)4 * H, &bh));
+      // The projection's output columns are laid out for the recurrence kernel (diar.hip lstm_kernel): the eight pre-activations
+      // one of its lanes starts a step from -- gates i, f, g, o of hidden units u and u + 16 -- are consecutive (one 16-byte load
+      // per window and step instead of eight 2-byte ones): gate q of unit 32 v + 16 hf + c -> column 128 v + 8 c + 2 q + hf.
       for (int r = 0; r < 4 * H; ++r) {
-        std::memcpy(&wih[((size_t)d * 4 * H + r) * in_pad], &wi->data[(size_t)r * in], (size_t)in * 4);
-        bias[(size_t)d * 4 * H + r] = bi->data[r] + bh->data[r];
+        const int q = r / H, u = r % H, v = u / 32, hf = (u % 32) / 16, cc = u % 16;
+        const int col = 128 * v + 8 * cc + 2 * q + hf;
+        std::memcpy(&wih[((size_t)d * 4 * H + col) * in_pad], &wi->data[(size_t)r * in], (size_t)in * 4);
+        bias[(size_t)d * 4 * H + col] = bi->data[r] + bh->data[r];
       }
       std::memcpy(&whh[(size_t)d * 4 * H * H], wh->data.data(), (size_t)4 * H * H * 4);
     }

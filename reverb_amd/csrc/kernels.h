@@ -225,8 +225,9 @@ int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a);
 // out[m][0..63] = bias + W[64][5 cin] . A[m cin .. (m + 5) cin); W as pack_conv1d lays it out
 int conv1d5(hipStream_t s, int dtype, const void* A, int cin, const void* W, const float* bias, void* out, int64_t M);
 
-// One bidirectional LSTM layer's recurrence (hidden 128).  xproj T [W*T, 8H] = x.Wih^T + b_ih + b_hh for
-// (forward | reverse) gates i,f,g,o; whh T [2][4H][H]; out T [W*T, 2H].
+// One bidirectional LSTM layer's recurrence (hidden 128).  xproj T [W*T, 8H] = x.Wih^T + b_ih + b_hh, per direction (forward | reverse)
+// 4H columns in the kernel's read order: gate q (i, f, g, o) of hidden unit 32 v + 16 hf + c is column 128 v + 8 c + 2 q + hf
+// (diar_engine.hip permutes W_ih / the biases accordingly); whh T [2][4H][H]; out T [W*T, 2H].
 int lstm_recurrence(hipStream_t s, int dtype, const void* xproj, const void* whh, void* out, int W, int T);
 
 // logp[r][:] = log_softmax(x[r].Wc^T + bc)   x T [M, ldx], Wc fp32 [C][in], C <= 16; cls[r] = argmax (nullable)
