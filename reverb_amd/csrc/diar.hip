@@ -405,7 +405,7 @@ int pool_norm(hipStream_t s, int dtype, const PoolNormArgs& a) {
   if (a.ld_out > 128 || a.ld_out < a.C || a.C < 1) { set_error("pool_norm: channels must be <= ld_out <= 128"); return E_ARG; }
   const bool first = a.x == nullptr;
   {
-    static const int vec = lab_env("RVD_POOLNORM_VEC") ? atoi(lab_env("RVD_POOLNORM_VEC")) : 1;      // lab: 0 = the scalar form
+    const int vec = lab_env("RVD_POOLNORM_VEC") ? atoi(lab_env("RVD_POOLNORM_VEC")) : 1;      // lab: 0 = the scalar form (read per call: the A/B test flips it)
     const int ldi = first ? a.C : a.ld_in;
     const uintptr_t base = first ? (uintptr_t)a.craw : (uintptr_t)a.x;
     if (vec && dtype == DT_BF16 && (ldi % 8) == 0 && (a.ld_out % 8) == 0 && a.ld_out >= 8 && (base % 16) == 0 && ((uintptr_t)a.out % 16) == 0 &&

@@ -211,7 +211,7 @@ int run_gemm(rvd_engine* e, const char* name, const void* A, int lda, const Line
 
 // conv layers 2 / 3 of SincNet: the thin-GEMM kernel of diar.hip (bf16; lab: RVD_CONV1D5=0 = the generic GEMM)
 int run_sincnet_conv(rvd_engine* e, const void* A, int cin, const Linear& L, void* C, int ldc, int64_t M) {
-  static const int on = lab_env("RVD_CONV1D5") ? atoi(lab_env("RVD_CONV1D5")) : 1;
+  const int on = lab_env("RVD_CONV1D5") ? atoi(lab_env("RVD_CONV1D5")) : 1;      // read per call: the A/B test flips it
   if (on && e->dtype == DT_BF16 && (cin == 80 || cin == 64) && L.out == 64 && ldc == 64 && L.in == 5 * cin && L.b.p) {
     DScope sc(e, "sincnet_conv", 2.0 * (double)M * L.out * L.in);
     return conv1d5(e->stream, e->dtype, A, cin, L.w.p, L.b.as<float>(), C, M);

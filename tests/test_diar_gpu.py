@@ -96,6 +96,31 @@ def test_sinc_filter_bank_on_the_matrix_pipe_equals_the_vector_form(case, monkey
     assert np.abs(taps["1"] - case["taps"]["sincnet"]).max() < 2e-3
 
 
+def test_sincnet_thin_gemm_and_vector_pool_norm_equal_the_forms_they_replaced(case, monkeypatch, lab):
+    """Round 6, bf16: SincNet's conv layers 2 / 3 on conv1d5 (weights resident in LDS, 256-frame tiles) against the generic GEMM
+    (RVD_CONV1D5=0) and pool_norm in 16-byte vectors against the scalar form (RVD_POOLNORM_VEC=0).  The same bf16 products summed in
+    another order (and fp64 statistics added in another order): the SincNet output, three bf16 roundings further down, agrees to
+    bf16 resolution, and both stay as close to the fp32 oracle as the bf16 segmentation test asks."""
+    from reverb_amd.diar_engine import DiarEngine
+    taps = {}
+    for conv, vec in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("RVD_CONV1D5", conv)
+        monkeypatch.setenv("RVD_POOLNORM_VEC", vec)
+        eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="bf16")
+        W = eng.upload(case["pcm"])
+        eng.segment()
+        taps[conv + vec] = eng.tap("sincnet", W)
+        eng.close()
+    ref = taps["00"]
+    scale = np.abs(ref).max()
+    for k in ("10", "01", "11"):
+        d = np.abs(taps[k] - ref)
+        assert d.max() < 0.03 * scale and d.mean() < 2e-3 * scale, (k, d.max() / scale, d.mean() / scale)
+    o = case["taps"]["sincnet"]
+    e_old, e_new = np.abs(ref - o).mean(), np.abs(taps["11"] - o).mean()
+    assert e_new < 1.1 * e_old + 1e-6, (e_old, e_new)
+
+
 def test_segmentation_f32_batching_is_invariant(case):
     from reverb_amd.diar_engine import DiarEngine
     eng = DiarEngine(case["cfg"], case["seg_sd"], dtype="f32")
