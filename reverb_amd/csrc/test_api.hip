@@ -300,7 +300,18 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
   const int d = heads * dk;
   Dev dq, dkk, dv, dp, du, dvv, dout, qs, ql, ks, kl;
   T_TRY(up_T(dq, dtype, q, (size_t)q_rows * d));
-  T_TRY(up_T(dkk, dtype, k, (size_t)kv_rows * d));
+  // bit 2 of `causal` (with bit 1, bf16): the keys go up PREFOLDED, K' = k + p[position of the key in its sequence] summed in fp32 and
+  // rounded once -- what the qkv GEMM's epilogue writes in the engine (GemmArgs::rowadd); the kernel then runs with k_prefolded
+  const bool prefolded = (causal & 6) == 6 && p && dtype == DT_BF16;
+  if (prefolded) {
+    std::vector<float> kp(k, k + (size_t)kv_rows * d);
+    for (int i = 0; i < nseq; ++i)
+      for (int j = 0; j < kv_len[i] && j < p_rows; ++j)
+        for (int c = 0; c < d; ++c) kp[(size_t)(kv_start[i] + j) * d + c] += p[(size_t)j * d + c];
+    T_TRY(up_T(dkk, dtype, kp.data(), (size_t)kv_rows * d));
+  } else {
+    T_TRY(up_T(dkk, dtype, k, (size_t)kv_rows * d));
+  }
   T_TRY(up_T(dv, dtype, v, (size_t)kv_rows * d));
   T_TRY(up_T(dp, dtype, p, (size_t)p_rows * d));
   T_TRY(up_raw(du, bias_u, (size_t)d * 4));
@@ -317,7 +328,7 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
   a.q_stride = a.k_stride = a.v_stride = a.p_stride = a.o_stride = d;
   a.bias_u = (const float*)du.p; a.bias_v = (const float*)dvv.p; a.out = dout.p;
   a.q_start = (const int*)qs.p; a.q_len = (const int*)ql.p; a.kv_start = (const int*)ks.p; a.kv_len = (const int*)kl.p;
-  // `causal`: bit 0 = causal mask; bits 8..19 = streaming chunk size (0 = off); bits 20..31 = left chunks + 1 (0 = all)
+  // `causal`: bit 0 = causal mask; bit 1 = folded positional term; bit 2 = ... with prefolded keys (see above); bits 8..19 = streaming chunk size (0 = off); bits 20..31 = left chunks + 1 (0 = all)
   a.nseq = nseq; a.heads = heads; a.dk = dk; a.causal = causal & 1; a.sqrt_dk = sqrtf((float)dk);
   a.chunk = (causal >> 8) & 0xfff; a.left = ((causal >> 20) & 0xfff) - 1;
   int mq = 0;
@@ -333,6 +344,7 @@ int rvb_test_attention(int dtype, const float* q, const float* k, const float* v
     int mk = 0;
     for (int i = 0; i < nseq; ++i) mk = kv_len[i] > mk ? kv_len[i] : mk;
     a.fold_kv_cap = (mk + 63) / 64 * 64;
+    a.k_prefolded = prefolded ? 1 : 0;
   }
   T_TRY(attention(nullptr, dtype, a));
   RVB_HIP_CHECK(hipDeviceSynchronize());

@@ -403,7 +403,7 @@ def _ref_attention(q, k, v, p, bu, bv, heads, dk, q_start, q_len, kv_start, kv_l
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("heads,dk,T,pos", [(2, 16, 100, True), (4, 64, 200, True), (2, 80, 130, True), (2, 32, 70, False)])
+@pytest.mark.parametrize("heads,dk,T,pos", [(2, 16, 100, True), (4, 64, 200, True), (2, 64, 517, True), (3, 48, 129, True), (2, 80, 130, True), (2, 32, 70, False)])
 def test_attention_encoder_form(lib, dtype, heads, dk, T, pos):
     """RelPositionMultiHeadedAttention scores (attention.py:378-399) with key-padding mask."""
     B = 3
@@ -434,6 +434,16 @@ def test_attention_encoder_form(lib, dtype, heads, dk, T, pos):
         np.testing.assert_allclose(out2, ref, rtol=tol, atol=tol)
         assert np.all(out2[2 * T:] == 0)
         assert not np.array_equal(out2, out)          # it really is the other kernel
+        # round 6: the same with K' = k + p handed over ready-made (bit 2: what the qkv GEMM's epilogue writes in the engine); from 129
+        # queries on this is the kernel with two 16-query fragments per wave and the per-key constants resident in LDS
+        out3 = np.empty_like(out)
+        _lib.check(lib.rvb_test_attention(dtype, fptr(q), fptr(k), fptr(v), fptr(p), fptr(bu), fptr(bv), fptr(out3), B * T, B * T, T,
+                                          heads, dk, iptr(starts), iptr(qlen), iptr(starts), iptr(kv_len), B, 6))
+        np.testing.assert_allclose(out3, ref, rtol=tol, atol=tol)
+        assert np.all(out3[2 * T:] == 0)
+        # the fold while staging forms the same K' (fp32 sum of the two bf16 values, one rounding) and a query's arithmetic does not
+        # depend on how many fragments its wave owns: the two kernels agree bit for bit
+        assert np.array_equal(out3, out2)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
