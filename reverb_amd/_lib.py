@@ -150,6 +150,7 @@ TEST_SIGNATURES = {
                                           _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_logsoftmax_topk": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _f32p]),
     "rvb_test_lse_gather": (C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _f32p]),
+    "rvb_test_gemm_glu": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]),
     "rvb_test_gemm_rowadd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rvb_test_mp3_decode": (C.c_int64, [C.c_char_p, C.c_int64, C.c_int, _f32p, C.c_int64, _i64p, _i64p, C.c_int]),
     "rvb_test_mp3_hybrid": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p]),

@@ -408,6 +408,8 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
   const int len = a.lens[b];
   const int lorder = K - 1;
   const T* G = (const T*)a.G;
+  const bool gated = a.gated != 0;                       // G is [B*T, d], gated by the pointwise GEMM's epilogue (ACT_GLU); vector path only
+  const size_t gstride = gated ? (size_t)a.d : (size_t)2 * a.d;
   // the two channels of a lane as one 2-wide vector: v_pk_fma_f32 does both FMAs of a tap in one instruction
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   f32x2_t wk[DW_KMAX];
@@ -435,9 +437,9 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
       const int cg = min(c0 + grp * VE, a.d - VE);
       const bool from_hist = a.causal && t < 0 && t >= -a.hist_rows;
       const T* gr = from_hist ? (const T*)a.hist + (size_t)(lorder + t) * 2 * a.d
-                              : G + ((size_t)b * a.T + min(max(t, 0), a.T - 1)) * 2 * a.d;
+                              : G + ((size_t)b * a.T + min(max(t, 0), a.T - 1)) * gstride;
       ra[it] = *(const uint4*)(gr + cg);
-      rb[it] = *(const uint4*)(gr + a.d + cg);
+      rb[it] = gated ? make_uint4(0, 0, 0, 0) : *(const uint4*)(gr + a.d + cg);
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -458,7 +460,8 @@ __global__ __launch_bounds__(DW_THREADS) void glu_dw_kernel(GluDwArgs a) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             const float a0 = Cvt<T>::to_f32(av[e]), b0 = Cvt<T>::to_f32(bvv[e]);
-            if constexpr (sizeof(T) == 2) g[e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b0));
+            if (gated) g[e] = a0;          // the pointwise GEMM's epilogue gated it (ACT_GLU)
+            else if constexpr (sizeof(T) == 2) g[e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b0));
             else g[e] = a0 / (1.0f + expf(-b0));
           }
         } else {
@@ -559,6 +562,9 @@ int glu_dwconv(hipStream_t s, int dtype, const GluDwArgs& a) {
   if (a.B <= 0 || a.T <= 0) return OK;
   if (a.K > DW_KMAX || a.K < 1 || (!a.causal && (a.K % 2) == 0) || (a.d % 2)) {
     set_error("glu_dwconv: kernel must be <= 31 (and odd unless causal), d even"); return E_ARG;
+  }
+  if (a.gated && (a.hist_rows > 0 || (a.d % (dtype == DT_BF16 ? 8 : 4)) != 0)) {
+    set_error("glu_dwconv: a gated input comes in whole 16-byte vectors and without a streaming history"); return E_ARG;
   }
   if (a.hist_rows > 0 && (!a.causal || a.B != 1 || a.hist_rows > a.K - 1 || !a.hist)) {
     set_error("glu_dwconv: a left-context history belongs to one causal stream"); return E_ARG;

@@ -39,6 +39,7 @@ struct LNorm { DevBuf g, b; float eps = 1e-5f; };
 
 struct EncLayer {
   Linear ffm1, ffm2, ff1, ff2, qkv, att_out, pw1, pw2, lsl;
+  Linear pw1_glu;             // bf16 engine: pw1 with its output rows interleaved (a_0, b_0, a_1, b_1, ...) for the GEMM's ACT_GLU epilogue
   DevBuf pos_keys;            // T [Tpos, d] = linear_pos(pe[:Tpos])
   DevBuf pos_bias;            // bf16 engine: fp32 [heads][Tpos], (pos_bias_v - pos_bias_u) . pos_keys * log2(e)/sqrt(dk) (attention.hip FOLD)
   DevBuf bias_u, bias_v;      // fp32 [h*dk]

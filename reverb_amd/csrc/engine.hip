@@ -245,10 +245,11 @@ static int reset_f8sat(rvb_engine* e) {
 static double gemm_alg_bytes(const rvb_engine* e, const GemmArgs& g) {
   const double es = g.in_fp8 ? 1.0 : (double)dt_size(e->dtype);
   const double a = g.conv ? (double)(g.M / (g.cT2 * g.cF2)) * g.cT1 * g.cF1 * g.cC * es : (double)g.M * g.K * es;
-  const double c = (double)g.M * g.N * (g.out_fp8 ? 1.0 : (g.out_f32 ? 4.0 : (double)dt_size(e->dtype)));
+  const double c = (double)g.M * (g.act == ACT_GLU ? g.N / 2 : g.N) * (g.out_fp8 ? 1.0 : (g.out_f32 ? 4.0 : (double)dt_size(e->dtype)));
   return a + (double)g.N * g.K * es + (g.bias ? 4.0 * g.N : 0.0) + c + (g.res ? 4.0 * (double)g.M * g.N : 0.0);
 }
 
+static constexpr int GLU_FUSE_DEFAULT = 1;      // pointwise_conv1 + GLU in the GEMM's epilogue (encoder_layer: lab switch RVB_GLU_FUSE)
 static int run_gemm(rvb_engine* e, const void* A, int lda, const Linear& L, void* C, int ldc, int M, bool out_f32,
                     float alpha = 1.f, int act = ACT_NONE, const float* res = nullptr, int ldres = 0) {
   GemmArgs g;
@@ -393,6 +394,19 @@ static int finalize_impl(rvb_engine* e, const float* cat, int ncat) {
       RVB_TRY(pack_concat(e, L.qkv, {p + ".self_attn.linear_q", p + ".self_attn.linear_k", p + ".self_attn.linear_v"}, d, d, true));
       RVB_TRY(pack_named_linear(e, L.att_out, p + ".self_attn.linear_out", d, d));
       RVB_TRY(pack_named_linear(e, L.pw1, p + ".conv_module.pointwise_conv1", 2 * d, d, true, true));
+      if (e->dtype == DT_BF16) {      // the same weights with rows (c, c + d) next to each other: columns 2c / 2c + 1 of the ACT_GLU GEMM
+        const HostTensor *tw, *tb;
+        RVB_TRY(need(e, p + ".conv_module.pointwise_conv1.weight", (size_t)2 * d * d, &tw));
+        RVB_TRY(need(e, p + ".conv_module.pointwise_conv1.bias", (size_t)2 * d, &tb));
+        std::vector<float> wi((size_t)2 * d * d), bi((size_t)2 * d);
+        for (int c = 0; c < d; ++c) {
+          memcpy(&wi[(size_t)(2 * c) * d], &tw->data[(size_t)c * d], (size_t)d * 4);
+          memcpy(&wi[(size_t)(2 * c + 1) * d], &tw->data[(size_t)(d + c) * d], (size_t)d * 4);
+          bi[2 * c] = tb->data[c]; bi[2 * c + 1] = tb->data[d + c];
+        }
+        RVB_TRY(pack_linear(e, L.pw1_glu, wi.data(), bi.data(), 2 * d, d, false));
+        RVB_HIP_CHECK(hipStreamSynchronize(e->stream));      // wi / bi go out of scope
+      }
       RVB_TRY(pack_named_linear(e, L.pw2, p + ".conv_module.pointwise_conv2", d, d, true, true));
       RVB_TRY(need(e, p + ".self_attn.pos_bias_u", d, &t));
       RVB_TRY(upload_f32(e, L.bias_u, t->data.data(), d));
@@ -605,16 +619,35 @@ static int encoder_layer(rvb_engine* e, EncLayer& L, int lidx, int M, int B, int
   }
   RVB_TRY(run_gemm(e, e->ao.p, d, L.att_out, x, d, M, true, 1.f, ACT_NONE, x, d));
   // convolution module: x += Conv(LN(x))                   encoder_layer.py:218-229, convolution.py:89-144
+  bool glu_fused = false;
   if (f8_pw1) {
     RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d, NORM_LN, 0, nullptr, nullptr, nullptr, sc8.in_pw1, 0.f, false, satp(3)));
     RVB_TRY(run_gemm8(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, sc8.in_pw1, 0));
   } else {
     RVB_TRY(run_norm(e, x, L.n_conv, e->xn.p, false, M, d));
     RVB_TRY(note(3, e->xn.p, (size_t)M * d));
-    RVB_TRY(run_gemm(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, false));
+    // pointwise_conv1 + GLU in one kernel (round 6): the GEMM runs on the interleaved copy of the weights and its epilogue stores
+    // a * sigmoid(b) -- half the bytes written here and read by the depthwise kernel, the gate computed once per element instead
+    // of once per staged element (halo rows twice).  Offline bf16 only (the streaming module caches pointwise OUTPUT rows).
+    {
+      const char* ge = lab_env("RVB_GLU_FUSE");      // read per call: the A/B test flips it inside one process
+      const int glu_on = ge ? atoi(ge) : GLU_FUSE_DEFAULT;
+      GemmArgs t;
+      memset(&t, 0, sizeof(t));
+      t.A = e->xn.p; t.W = L.pw1_glu.w.p; t.bias = L.pw1_glu.b.as<float>(); t.C = e->h.p; t.M = M; t.N = 2 * d; t.K = d; t.lda = d; t.ldw = d;
+      t.ldc = d; t.alpha = 1.f; t.act = ACT_GLU;
+      glu_fused = glu_on && li < 0 && L.pw1_glu.w.p != nullptr && !cal && gemm_glu_supported(e->dtype, t);
+      if (glu_fused) {
+        Scope sc(e, "gemm", 2.0 * M * (double)t.N * t.K, gemm_alg_bytes(e, t));
+        RVB_TRY(gemm(e->stream, e->dtype, t));
+      } else {
+        RVB_TRY(run_gemm(e, e->xn.p, d, L.pw1, e->h.p, 2 * d, M, false));
+      }
+    }
   }
   {
     GluDwArgs g;
+    g.gated = glu_fused ? 1 : 0;
     g.G = e->h.p; g.pw1_bias = L.pw1.b.as<float>(); g.dw_w = L.dw_w.as<float>(); g.dw_b = L.dw_b.as<float>();
     g.lens = e->cur_lens; g.out = e->dconv.as<float>(); g.B = B; g.T = T; g.d = d; g.K = e->cfg.cnn_kernel;
     g.causal = e->cfg.cnn_causal ? 1 : 0;
@@ -1965,7 +1998,7 @@ void rvb_destroy(rvb_engine* e) {
   auto rel_lin = [](Linear& l) { l.w.release(); l.b.release(); l.w8.release(); l.wscale.release(); };
   auto rel_n = [](LNorm& n) { n.g.release(); n.b.release(); };
   for (auto& L : e->enc) {
-    for (Linear* l : {&L.ffm1, &L.ffm2, &L.ff1, &L.ff2, &L.qkv, &L.att_out, &L.pw1, &L.pw2, &L.lsl}) rel_lin(*l);
+    for (Linear* l : {&L.ffm1, &L.ffm2, &L.ff1, &L.ff2, &L.qkv, &L.att_out, &L.pw1, &L.pw1_glu, &L.pw2, &L.lsl}) rel_lin(*l);
     for (LNorm* n : {&L.n_ffm, &L.n_mha, &L.n_conv, &L.n_ff, &L.n_final, &L.n_cnn}) rel_n(*n);
     L.pos_keys.release(); L.pos_bias.release(); L.bias_u.release(); L.bias_v.release(); L.dw_w.release(); L.dw_b.release();
   }

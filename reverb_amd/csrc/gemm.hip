@@ -199,6 +199,10 @@ int gemm(hipStream_t s, int dtype, const GemmArgs& p) {
     set_error("gemm: the row-periodic addend exists for bf16 operands and bf16 output only");
     return E_UNSUPPORTED;
   }
+  if (p.act == ACT_GLU) {     // pairs of columns gated in the epilogue: gemm2's phase-interleaved bf16 kernel only
+    if (g_gemm_variant == 1 || !gemm_glu_supported(dtype, p)) { set_error("gemm: ACT_GLU needs the bf16 LDS-DMA kernel (see gemm_glu_supported)"); return E_UNSUPPORTED; }
+    return gemm2(s, dtype, p);
+  }
   if (p.in_fp8) {       // fp8 operands exist only on the LDS-DMA kernel
     if (!gemm2_applicable(dtype, p)) { set_error("gemm: fp8 operands need the bf16 engine, K % 128 == 0 and per-channel weight scales"); return E_ARG; }
     return gemm2(s, dtype, p);

@@ -66,6 +66,14 @@ __device__ inline void store16_hidden(void* q, unsigned a, unsigned b, unsigned 
   const u32x4_t v = {a, b, c, d};
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
 }
+// ... and its 8-byte sibling (ACT_GLU: a lane's eight columns are four gated values)
+__device__ inline void store8_hidden(void* q, unsigned a, unsigned b) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t v = {a, b};
+  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+}
+// a * sigmoid(b) as glu_dw_kernel's bf16 staging computes it
+__device__ inline float glu_gate(float a, float b) { return a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * b)); }
 
 template <typename T, typename OutT, bool CONV, bool MMA32>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
@@ -1324,6 +1332,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
     // Row-periodic bf16 addend (GemmArgs::rowadd; bf16 output only): `ra_any` = this tile touches its column range, `ra_vec` =
     // this lane's whole 8-column segment lies inside it and is one aligned 16-byte vector of the addend's row
     constexpr bool RA_OK = sizeof(OutT) == 2 && !F8;
+    const bool glu = sizeof(OutT) == 2 && !F8 && p.act == ACT_GLU;      // gemm2() admits it on this kernel only (full column segments)
     const bool ra_any = RA_OK && p.rowadd != nullptr && n0 < p.rowadd_col0 + p.rowadd_cols && n0 + B2N > p.rowadd_col0;
     const bool ra_tile = ra_any && n0 >= p.rowadd_col0 && n0 + B2N <= p.rowadd_col0 + p.rowadd_cols && (p.rowadd_ld & 7) == 0 &&
                          ((p.rowadd_col0 - n0) & 7) == 0 && ((size_t)p.rowadd & 15) == 0;      // every lane's segment is such a vector
@@ -1429,12 +1438,19 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
               *(uint4*)cp = make_uint4(pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
                                        pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
             } else if constexpr (sizeof(OutT) == 2) {
-              uint4 o0;
-              o0.x = pack2_bf16(v[0], v[1]);
-              o0.y = pack2_bf16(v[2], v[3]);
-              o0.z = pack2_bf16(v[4], v[5]);
-              o0.w = pack2_bf16(v[6], v[7]);
-              *(uint4*)cp = o0;
+              if (glu) {        // (a, b) column pairs -> a * sigmoid(b), half as many columns
+                uint2 o0;
+                o0.x = pack2_bf16(glu_gate(v[0], v[1]), glu_gate(v[2], v[3]));
+                o0.y = pack2_bf16(glu_gate(v[4], v[5]), glu_gate(v[6], v[7]));
+                *(uint2*)(C + (size_t)row * p.ldc + (col0 >> 1)) = o0;
+              } else {
+                uint4 o0;
+                o0.x = pack2_bf16(v[0], v[1]);
+                o0.y = pack2_bf16(v[2], v[3]);
+                o0.z = pack2_bf16(v[4], v[5]);
+                o0.w = pack2_bf16(v[6], v[7]);
+                *(uint4*)cp = o0;
+              }
             } else {
               *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -1557,7 +1573,9 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs p) {
             store16_hidden(cp, pack4_fp8(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs), pack4_fp8(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs),
                            pack4_fp8(v[8] * qs, v[9] * qs, v[10] * qs, v[11] * qs), pack4_fp8(v[12] * qs, v[13] * qs, v[14] * qs, v[15] * qs));
           } else if constexpr (sizeof(OutT) == 2) {
-            store16_hidden(cp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+            if (glu) store8_hidden(C + (size_t)(m0 + wr * 128 + i * 16 + srow) * p.ldc + (col0 >> 1),
+                                   pack2_bf16(glu_gate(v[0], v[1]), glu_gate(v[2], v[3])), pack2_bf16(glu_gate(v[4], v[5]), glu_gate(v[6], v[7])));
+            else store16_hidden(cp, pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
           } else {
             store16_hidden(cp, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
           }
@@ -1711,6 +1729,11 @@ static int launch2(hipStream_t s, const GemmArgs& p) {
   return OK;
 }
 
+bool gemm_glu_supported(int dtype, const GemmArgs& p) {
+  return dtype == DT_BF16 && p.act == ACT_GLU && gemm2_applicable(dtype, p) && !p.in_fp8 && !p.out_fp8 && !p.out_f32 && !p.conv && p.res == nullptr &&
+         p.rowadd == nullptr && (p.N % 16) == 0 && p.ldc >= p.N / 2 && (p.ldc % 8) == 0 && ((size_t)p.C & 15) == 0 && p.alpha == 1.f;
+}
+
 bool gemm2_applicable(int dtype, const GemmArgs& p) {
   // fp8 with the convolution gather (round 4: conv2 of the subsampling, K = 9 d): the phase-interleaved loop, bf16 output
   if (p.in_fp8 && p.conv) return dtype == DT_BF16 && p.K % 128 == 0 && p.cC % 128 == 0 && p.ldw % 16 == 0 && p.M >= 1 && p.N >= 64 &&
@@ -1771,6 +1794,10 @@ int gemm2(hipStream_t s, int dtype, const GemmArgs& p0) {
   GemmArgs p = p0;
   if (p.rowadd && (dtype != DT_BF16 || p.in_fp8 || p.out_f32 || p.out_fp8 || (g_gemm2_flags & (1 | 4)))) {
     set_error("gemm2: the row-periodic addend exists on the phase-interleaved bf16 kernel with bf16 output only");
+    return E_UNSUPPORTED;
+  }
+  if (p.act == ACT_GLU && (!gemm_glu_supported(dtype, p) || (g_gemm2_flags & (1 | 4 | 16 | 4096 | 8192 | 16384)))) {
+    set_error("gemm2: ACT_GLU runs on the default phase-interleaved bf16 kernel only (bf16 output, no residual / addend / fp8, N % 16 == 0)");
     return E_UNSUPPORTED;
   }
   p.group_m = g_gemm2_group_m == GROUP_M_AUTO ? (p.K * (p.in_fp8 ? 1 : 2) >= 4096 ? 0 : 8) : g_gemm2_group_m;

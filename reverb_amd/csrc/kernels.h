@@ -8,6 +8,11 @@ namespace rvb {
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LRELU = 3 /* leaky_relu, slope 0.01 (gemm.hip kernel only) */ };
+// ACT_GLU (gemm2's phase-interleaved bf16 kernel only, round 6): the N output columns are (a, b) PAIRS -- column 2c = a_c, column
+// 2c + 1 = b_c (the caller interleaves the weight rows) -- and what is stored is the gated value a_c * sigmoid(b_c), N / 2 columns
+// per row at leading dimension ldc: the convolution module's pointwise_conv1 + GLU (convolution.py:107-111) in one kernel, half the
+// output bytes.  gemm_glu_supported() says whether a problem can run this way.
+enum { ACT_GLU = 4 };
 
 inline size_t dt_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
@@ -47,6 +52,7 @@ struct GemmArgs {
 int gemm(hipStream_t s, int dtype, const GemmArgs& a);
 // gemm2.hip: 256x256 LDS-DMA kernel for large shapes (K multiple of the 128-byte step)
 bool gemm2_applicable(int dtype, const GemmArgs& a);
+bool gemm_glu_supported(int dtype, const GemmArgs& a);
 int gemm2(hipStream_t s, int dtype, const GemmArgs& a);
 extern int g_gemm_variant;   // 0 = auto, 1 = always gemm.hip kernel, 2 = gemm2.hip whenever applicable
 extern int g_gemm2_flags, g_gemm2_group_m;   // gemm2.hip tuning switches (-1 = read RVB_GEMM2_FLAGS / RVB_GEMM2_GROUP_M or the defaults)
@@ -122,6 +128,7 @@ struct GluDwArgs {
   float* out;             // fp32 [B*T, d] (or bf16 when out_bf16)
   int B, T, d, K;
   int out_bf16 = 0;       // bf16 engine: the convolution-module norm that follows reads bf16 (NormArgs::x_bf16)
+  int gated = 0;          // G is [B*T, d], already gated (the pointwise GEMM ran with ACT_GLU): no gate arithmetic here
   int causal = 0;
   const void* hist = nullptr;   // T [K-1][2d], row K-2 = the frame just before this chunk (causal, B = 1)
   int hist_rows = 0;            // real frames in hist (its last hist_rows rows)

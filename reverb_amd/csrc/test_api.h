@@ -53,6 +53,7 @@ int rvb_test_lse_gather(const float* logits, int R, int V, const int32_t* target
 /* fp8 (e4m3) GEMM / LayerNorm-to-fp8 of the RVB_FP8 mode on host floats (operands quantised as the engine does) */
 /* bf16 GEMM with bf16 output and the row-periodic addend of GemmArgs::rowadd (round 6): C[m][n] = A.W^T + bias (+ add[m % add_rows][n - add_col0]
  * for add_col0 <= n < add_col0 + add_cols); add is fp32 on the host, rounded to bf16 on the way up (what the engine's positional keys are) */
+int rvb_test_gemm_glu(const float* A, const float* W, const float* bias, float* C, int M, int N, int K);
 int rvb_test_gemm_rowadd(const float* A, const float* W, const float* bias, const float* add, float* C, int M, int N, int K,
                          int add_rows, int add_col0, int add_cols);
 /* csrc/mp3.cpp (round 6).  decode: as rvb_audio_decode_f32 + the stream facts (info9: version, channels, rate, audio frames, samples per

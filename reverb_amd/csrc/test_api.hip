@@ -98,6 +98,25 @@ int rvb_test_gemm_rowadd(const float* A, const float* W, const float* bias, cons
   return down_T(dC, DT_BF16, false, C, (size_t)M * N);
 }
 
+// bf16 GEMM with the ACT_GLU epilogue: W rows / bias / output columns interleaved as the engine packs them (row 2c = a_c, 2c + 1 = b_c);
+// C [M, N / 2] = a * sigmoid(b)
+int rvb_test_gemm_glu(const float* A, const float* W, const float* bias, float* C, int M, int N, int K) {
+  T_TRY(need_gpu());
+  Dev dA, dW, dB, dC;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  T_TRY(up_T(dA, DT_BF16, A, (size_t)M * K));
+  T_TRY(up_T(dW, DT_BF16, W, (size_t)N * K));
+  T_TRY(up_raw(dB, bias, (size_t)N * 4));
+  T_TRY(dC.alloc((size_t)M * (N / 2) * 2));
+  g.A = dA.p; g.W = dW.p; g.bias = (const float*)dB.p; g.C = dC.p;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N / 2; g.alpha = 1.f; g.act = ACT_GLU;
+  if (!gemm_glu_supported(DT_BF16, g)) { set_error("rvb_test_gemm_glu: shape not supported by the ACT_GLU epilogue"); return E_UNSUPPORTED; }
+  T_TRY(gemm(nullptr, DT_BF16, g));
+  RVB_HIP_CHECK(hipDeviceSynchronize());
+  return down_T(dC, DT_BF16, false, C, (size_t)M * (N / 2));
+}
+
 int64_t rvb_test_mp3_decode(const void* data, int64_t nbytes, int channel, float* out, int64_t capacity, int64_t* info9, int64_t* stats12, int threads) {
   try {
     rvb::mp3::Info i;

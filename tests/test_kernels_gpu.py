@@ -137,6 +137,23 @@ def test_gemm_row_periodic_addend(lib, flags, M, N, K, rows, col0, cols):
     assert np.array_equal(C[:, outside], P[:, outside])
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 128), (1536, 2048, 1024), (700, 528, 64), (256, 64, 64)])
+def test_gemm_glu_epilogue(lib, M, N, K):
+    """ACT_GLU (round 6): pointwise_conv1 + GLU (convolution.py:107-111) in the GEMM's epilogue -- the weight rows interleaved so that
+    output columns 2c / 2c + 1 are the pair (a_c, b_c), stored: a_c * sigmoid(b_c), N / 2 columns.  Against fp64 on full tiles (inline-asm
+    8-byte stores) and on ragged ones (the generic loop: 700 rows, 528 columns)."""
+    rng = np.random.default_rng(M + N)
+    A = rnd(BF16, rng.standard_normal((M, K)))
+    W = rnd(BF16, rng.standard_normal((N, K)) / math.sqrt(K))
+    bias = f32(rng.standard_normal(N))
+    C = np.full((M, N // 2), np.nan, np.float32)
+    _lib.check(lib.rvb_test_gemm_glu(fptr(A), fptr(W), fptr(bias), fptr(C), M, N, K))
+    v = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    ref = v[:, 0::2] / (1.0 + np.exp(-v[:, 1::2]))
+    np.testing.assert_allclose(C, ref, rtol=1e-2, atol=1e-2)          # one bf16 rounding of the output, hardware exp2 / rcp in the gate
+
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("Cc,N", [(16, 24), (64, 72), (128, 260)])
 def test_gemm_implicit_conv(lib, dtype, Cc, N):

@@ -206,6 +206,33 @@ def test_r640_attention_with_keys_prefolded_by_the_qkv_gemm_equals_the_two_produ
     assert m1["cos"] > BF16_COS and m1["logp_p99_abs"] <= BF16_LOGP_P99_ABS, m1
 
 
+def test_r640_glu_in_the_pointwise_gemm_equals_the_two_kernel_form(monkeypatch, lab):
+    """Round 6: pointwise_conv1 + GLU of the convolution module in ONE kernel -- the GEMM runs on the interleaved copy of the weights
+    and its epilogue stores a * sigmoid(b) (ACT_GLU) -- against GEMM + gate-while-staging (lab switch RVB_GLU_FUSE=0).  The fused form
+    gates the fp32 accumulators and rounds once; the other rounds a and b to bf16 first: encoder outputs agree far tighter than either
+    agrees with the fp32 reference."""
+    case = LongCase("r640_chunk")
+    x = np.concatenate([case.chunk_feats(c)[0] for c in range(2)])
+    lens = np.array(case.js["lens"], np.int32)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RVB_GLU_FUSE", flag)
+        eng = Engine(case.cfg, case.sd, dtype="bf16", device=0, max_chunks=2, chunk_frames=case.chunk, cat_embs=case.cat)
+        eng.encode(x, lens, case.beam)
+        _, ti = eng.ctc_topk()
+        out[flag] = (eng.encoder_out().astype(np.float64), ti[:, :, 0].copy(), _tap_metrics(eng, case, 0, 0))
+        eng.close()
+    (e0, i0, m0), (e1, i1, m1) = out["0"], out["1"]
+    n = case.js["encoder_lens"]
+    cos = min(float((e0[b, :n[b]] * e1[b, :n[b]]).sum() / (np.linalg.norm(e0[b, :n[b]]) * np.linalg.norm(e1[b, :n[b]]))) for b in range(2))
+    agree = float(np.mean([np.mean(i0[b, :n[b]] == i1[b, :n[b]]) for b in range(2)]))
+    _record(case="r640_chunk", test="glu_fused_vs_two_kernels", cos=cos, top1_agree=agree, two_kernels=m0, fused=m1)
+    assert not np.array_equal(e0, e1)                     # it really is the other path
+    assert cos > 0.99995 and agree > 0.98, (cos, agree)
+    assert m1["cos"] > BF16_COS and m1["logp_p99_abs"] <= BF16_LOGP_P99_ABS, m1
+    assert m1["cos"] >= m0["cos"] - 2e-6, (m0["cos"], m1["cos"])      # one rounding fewer: not further from the fp32 reference
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_r640_one_hour_bench_workload_against_reference(dtype):
     """bench.py's step, checked: PCM -> device fbank -> decode_resident(176 chunks: slices of 144 + 32) -> attention
